@@ -1,0 +1,216 @@
+"""TEST INFRASTRUCTURE (build container only) -- generate tests/golden/*.npz by IMPORTING the
+reference's Python (via oracle/ref_import.py stubs) and running it on seeded inputs.
+
+    python -m oracle.gen_golden            # rewrites tests/golden/
+
+Fixtures are data only: inputs, (randomised) weights, expected outputs of the reference's own
+modules.  No reference source text is stored.  Reference call sites exercised:
+  embeddings  src/dprt/models/embeddings/sinusoidal.py:63-110,137-153
+  querent     src/dprt/models/queries/data_agnostic.py:126-172
+  ref points  src/dprt/models/fusers/mpfusion.py:617-696
+  MLFusion/MPFusion/IMPFusion  src/dprt/models/fusers/mpfusion.py:231-263,472-514,698-745
+  MSDeformAttn (python part)   src/dprt/models/layers/ms_deform_attn.py:138-217
+  head        src/dprt/models/heads/detection.py:252-275
+  loss        src/dprt/training/loss.py:17-60,234-373 ; bbox src/dprt/utils/bbox.py:4-163
+The MSDA *core* inside these fixtures is the oracle's grid_sample core (the reference has no CPU
+core; parity for that core is unpinned by the reference, see oracle/__init__.py).
+"""
+from __future__ import annotations
+
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from oracle import ref_import
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+CFG = "/root/reference/config/kradar.json"
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v))
+            for k, v in d.items()}
+
+
+def _randomise(module: torch.nn.Module, g: torch.Generator, scale: float = 0.05):
+    """Perturb every parameter so that nothing stays at its degenerate init (sampling_offsets.weight
+    and attention_weights.* are zero at init, ms_deform_attn.py:118,131-132)."""
+    with torch.no_grad():
+        for p in module.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * scale)
+
+
+def small_views(B: int, g: torch.Generator):
+    """Reduced 5-level pyramids (B,H,W,16) for the three views."""
+    shapes = {
+        "camera_mono": [(32, 57), (8, 15), (4, 8), (2, 4), (1, 2)],
+        "radar_bev": [(16, 7), (8, 4), (4, 2), (2, 1), (1, 1)],
+        "radar_front": [(5, 14), (3, 7), (2, 4), (1, 2), (1, 1)],
+    }
+    return OrderedDict(
+        (n, OrderedDict((str(i), torch.randn(B, h, w, 16, generator=g)) for i, (h, w) in enumerate(s)))
+        for n, s in shapes.items())
+
+
+def projections(B: int, g: torch.Generator):
+    """K-Radar-shaped T/P matrices (radar P from dataset.py:271-275,289-293)."""
+    f, cx, cy = 560.0, 640.0, 360.0
+    cam_p = torch.tensor([[cx, -f, 0, 0], [cy, 0, -f, 0], [1, 0, 0, 0], [0, 0, 0, 1.0]]).repeat(B, 1, 1)
+    cam_p = cam_p + (torch.rand(B, 4, 4, generator=g) * 10 - 5) * (cam_p != 0)
+    cam_t = torch.zeros(B, 4, 4)
+    rad_t = torch.eye(4).repeat(B, 1, 1)
+    rad_t[:, 0, 3] = torch.rand(B, generator=g) * 6 - 3
+    rad_t[:, 1, 3] = torch.rand(B, generator=g) * 2 - 1
+    bev_p = torch.tensor([[0, -1, 0, 53], [256 / 118.03710938, 0, 0, 0], [0, 0, 0, 1.0]]).repeat(B, 1, 1)
+    fr_p = torch.tensor([[0, -1, 0, 53], [0, 0, 1, 18], [0, 0, 0, 1.0]]).repeat(B, 1, 1)
+    shapes = [torch.tensor([[720, 1280]] * B), torch.tensor([[256, 107]] * B),
+              torch.tensor([[37, 107]] * B)]
+    return [(cam_t, cam_p), (rad_t, bev_p), (rad_t.clone(), fr_p)], shapes
+
+
+def main():
+    ref_import.install()
+    from dprt.models.embeddings import build_embedding
+    from dprt.models.fusers import build_fuser
+    from dprt.models.heads import build_head
+    from dprt.models.queries import build_querent
+    from dprt.training.loss import SetCriterion, focal_loss
+    from dprt.utils import bbox
+
+    os.makedirs(OUT, exist_ok=True)
+    cfg = json.load(open(CFG))
+    comp, m = cfg["computing"], cfg["model"]
+    g = torch.Generator().manual_seed(42)
+    B = 2
+
+    # (i) embeddings -----------------------------------------------------------------
+    emb = build_embedding(m["embeddings"]["camera_mono"]["name"],
+                          dict(comp | m["embeddings"]["camera_mono"]))
+    levels = OrderedDict((str(i), torch.randn(B, h, w, 16, generator=g))
+                         for i, (h, w) in enumerate([(7, 13), (4, 5), (3, 3), (2, 1), (1, 1)]))
+    ins = {f"in{k}": v.clone() for k, v in levels.items()}
+    outs = emb(levels)
+    np.savez(os.path.join(OUT, "embedding.npz"), **_np(ins), **_np({f"out{k}": v for k, v in outs.items()}))
+
+    # (ii) querent -------------------------------------------------------------------
+    qr = build_querent(m["querent"]["name"], dict(comp | m["querent"]))
+    center0 = qr({"x": torch.zeros(B, 3)})["center"]
+    np.savez(os.path.join(OUT, "querent.npz"), center=center0.numpy())
+
+    # (iii) reference points -----------------------------------------------------------
+    head = build_head(m["head"]["name"], dict(comp | m["head"]))
+    fcfg = dict(comp | m["fuser"])
+    fuser = build_fuser(m["fuser"]["name"], fcfg, head=head)
+    _randomise(fuser, g)
+    fuser.eval()
+    proj, shp = projections(B, g)
+    centers = center0 + torch.randn(B, 400, 3, generator=g) * 2.0
+    centers[0, 0] = torch.tensor([-5.0, 1.0, 0.5])      # behind the camera: w < 0 (App. E-4)
+    centers[0, 1] = torch.tensor([0.0, 2.0, 0.1])       # w == 0 for the camera
+    rp = {"centers": centers}
+    for v, ((t, p), s) in enumerate(zip(proj, shp)):
+        rp[f"t{v}"], rp[f"p{v}"], rp[f"shape{v}"] = t, p, s
+        rp[f"ref{v}"] = fuser.get_reference_points(centers.clone(), t, p, s)
+    np.savez(os.path.join(OUT, "refpoints.npz"), **_np(rp))
+
+    # (iv)/(v) fuser forward (eval) + one MLFusion / MPFusion ----------------------------
+    views = small_views(B, g)
+    sd = {k: v.detach().clone() for k, v in fuser.state_dict().items()}
+    fx = {f"sd/{k}": v for k, v in sd.items()}
+    for n, lv in views.items():
+        for k, v in lv.items():
+            fx[f"view/{n}/{k}"] = v
+    for v, ((t, p), s) in enumerate(zip(proj, shp)):
+        fx[f"t{v}"], fx[f"p{v}"], fx[f"shape{v}"] = t, p, s
+    fx["center0"] = center0
+    with torch.no_grad():
+        query = fuser.query.unsqueeze(0).repeat(B, 1, 1)
+        qpos = fuser.query_embedding.weight.unsqueeze(0).repeat(B, 1, 1)
+        refs = [fuser.get_reference_points(center0.clone(), t, p, s) for (t, p), s in zip(proj, shp)]
+        mp0 = fuser.mpfusion["fusion0"]
+        ml00 = mp0.ml_fusion_layers["ms_deform_attn0"]
+        fx["ml00_out"] = ml00(query, views["camera_mono"], refs[0], qpos)
+        fx["mp0_out"] = mp0(query, list(views.values()), refs, qpos)
+        out = fuser(batch=list(views.values()), shape=shp, projection=proj,
+                    out=OrderedDict(center=center0.clone()))
+    for k, v in out.items():
+        fx[f"out/{k}"] = v
+    np.savez_compressed(os.path.join(OUT, "fuser_small.npz"), **_np(fx))
+
+    # (ix) gradients with dropout 0 (train mode) ------------------------------------------
+    fcfg0 = dict(fcfg); fcfg0["dropout"] = 0.0
+    head0 = build_head(m["head"]["name"], dict(comp | m["head"]))
+    fuser0 = build_fuser(m["fuser"]["name"], fcfg0, head=head0)
+    fuser0.load_state_dict(sd)
+    fuser0.train()
+    views_g = OrderedDict((n, OrderedDict((k, v.clone().requires_grad_(True)) for k, v in lv.items()))
+                          for n, lv in views.items())
+    out = fuser0(batch=list(views_g.values()), shape=shp, projection=proj,
+                 out=OrderedDict(center=center0.clone()))
+    cot = {k: torch.randn(v.shape, generator=g) for k, v in out.items()}
+    loss = sum((out[k] * cot[k]).sum() for k in out)
+    loss.backward()
+    gx = {f"cot/{k}": v for k, v in cot.items()}
+    gx["loss"] = loss.detach()
+    for n, p in fuser0.named_parameters():
+        if p.grad is not None:
+            gx[f"grad/{n}"] = p.grad
+    for n, lv in views_g.items():
+        for k, v in lv.items():
+            gx[f"gview/{n}/{k}"] = v.grad
+    np.savez_compressed(os.path.join(OUT, "fuser_grads.npz"), **_np(gx))
+
+    # (vi) head -------------------------------------------------------------------------
+    hx = {f"sd/{k}": v for k, v in head.state_dict().items()}
+    _randomise(head, g, 0.3)
+    hx = {f"sd/{k}": v.detach().clone() for k, v in head.state_dict().items()}
+    x = torch.randn(B, 400, 16, generator=g)
+    hx["x"], hx["ref"] = x, center0
+    with torch.no_grad():
+        ho = head(x, OrderedDict(center=center0.clone()))
+    for k, v in ho.items():
+        hx[f"out/{k}"] = v
+    np.savez(os.path.join(OUT, "head.npz"), **_np(hx))
+
+    # (vii)/(viii) loss pieces ---------------------------------------------------------------
+    lx = {}
+    logits = torch.randn(1, 400, 2, generator=g) * 2
+    tgt1h = torch.zeros(1, 400, 2); tgt1h[..., 0] = 1; tgt1h[0, 5] = torch.tensor([0.0, 1.0])
+    lx["focal_in"], lx["focal_tgt"] = logits, tgt1h
+    lx["focal_out"] = focal_loss(logits, tgt1h)
+    M = 5
+    pred = {"class": logits, "center": torch.randn(1, 400, 3, generator=g) * 10,
+            "size": torch.rand(1, 400, 3, generator=g) * 4, "angle": torch.tanh(torch.randn(1, 400, 2, generator=g))}
+    yaw = torch.rand(1, M, generator=g) * 6.28 - 3.14
+    tgt = {"gt_class": torch.tensor([[0.0, 1.0]]).repeat(1, M, 1),
+           "gt_center": torch.randn(1, M, 3, generator=g) * 10,
+           "gt_size": torch.rand(1, M, 3, generator=g) * 3 + 1,
+           "gt_angle": torch.stack((torch.sin(yaw), torch.cos(yaw)), -1)}
+    i = torch.tensor([[3, 17, 42, 200, 399]]); j = torch.tensor([[2, 0, 4, 1, 3]])
+    crit = SetCriterion()
+    losses = crit(pred, tgt, indices=(i, j))
+    for k, v in pred.items():
+        lx[f"pred/{k}"] = v
+    for k, v in tgt.items():
+        lx[f"tgt/{k}"] = v
+    lx["i"], lx["j"] = i, j
+    for k, v in losses.items():
+        lx[f"loss/{k}"] = v
+    corners = bbox.get_box_corners(tgt["gt_center"], tgt["gt_size"], yaw)
+    lx["yaw"] = yaw
+    lx["corners"] = corners
+    c2 = bbox.get_box_corners(pred["center"][:, :7], pred["size"][:, :7],
+                              torch.atan2(pred["angle"][:, :7, 0], pred["angle"][:, :7, 1]))
+    lx["enclosing"] = bbox.get_minimum_enclosing_box_corners(c2, corners)
+    lx["enclosing_vol"] = bbox.get_box_volume_from_corners(lx["enclosing"].flatten(0, 2))
+    np.savez(os.path.join(OUT, "loss.npz"), **_np(lx))
+    print("golden fixtures written to", OUT)
+    for f in sorted(os.listdir(OUT)):
+        print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,165 @@
+"""Oracle vs golden vectors produced by the imported reference (oracle/gen_golden.py)."""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import dprt_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+FUSER_CFG = dict(i_iter=4, m_views=3, n_heads=[8, 8, 8], n_points=[4, 4, 4], activation="Mish")
+VIEWS = ("camera_mono", "radar_bev", "radar_front")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def close(a, b, rtol=1e-4, atol_scale=1e-5):
+    b = T(b) if not isinstance(b, torch.Tensor) else b
+    atol = atol_scale * max(float(b.abs().max()), 1e-6)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol)
+
+
+def test_embedding(golden):
+    g = golden("embedding.npz")
+    for k in "01234":
+        out = O.sinusoidal_embedding(T(g["in" + k]), num_feats=16, normalize=True)
+        close(out, g["out" + k], rtol=1e-6, atol_scale=1e-6)
+
+
+def test_querent(golden):
+    g = golden("querent.npz")
+    q = O.querent(2, [20, 20, 1], [4, -50, 0], [72, 50, 0])
+    close(q, g["center"], rtol=1e-6, atol_scale=1e-7)
+    assert abs(float(q[0, 0, 0]) - 2.5712) < 1e-3 and abs(float(q[0, 0, 1]) + 3.0642) < 1e-3
+
+
+def test_reference_points(golden):
+    g = golden("refpoints.npz")
+    for v in range(3):
+        ref = O.reference_points(T(g["centers"]), T(g[f"t{v}"]), T(g[f"p{v}"]), T(g[f"shape{v}"]))
+        close(ref, g[f"ref{v}"], rtol=1e-5, atol_scale=1e-6)
+
+
+def _fuser_inputs(g):
+    sd = {k[3:]: T(v) for k, v in g.items() if k.startswith("sd/")}
+    sd = {"fuser." + k: v for k, v in sd.items()}
+    views = [[T(g[f"view/{n}/{l}"]) for l in range(5)] for n in VIEWS]
+    proj = [(T(g[f"t{v}"]), T(g[f"p{v}"])) for v in range(3)]
+    shp = [T(g[f"shape{v}"]) for v in range(3)]
+    return sd, views, proj, shp
+
+
+def test_fuser_forward(golden):
+    g = golden("fuser_small.npz")
+    sd, views, proj, shp = _fuser_inputs(g)
+    c0 = T(g["center0"])
+    B = c0.shape[0]
+    query = sd["fuser.query"].unsqueeze(0).repeat(B, 1, 1)
+    qpos = sd["fuser.query_embedding.weight"].unsqueeze(0).repeat(B, 1, 1)
+    refs = [O.reference_points(c0, t, p, s) for (t, p), s in zip(proj, shp)]
+    ml = O.mlfusion(query, views[0], refs[0], qpos, sd,
+                    "fuser.mpfusion.fusion0.ml_fusion_layers.ms_deform_attn0", 8, 4, "Mish")
+    close(ml, g["ml00_out"])
+    mp = O.mpfusion(query, views, refs, qpos, sd, "fuser.mpfusion.fusion0", [8] * 3, [4] * 3, "Mish")
+    close(mp, g["mp0_out"])
+    out = O.impfusion(views, shp, proj, c0, sd, "fuser", FUSER_CFG)
+    assert list(out.keys()) == ["center", "size", "angle", "class"]
+    for k in out:
+        close(out[k], g[f"out/{k}"])
+    # bit-exact index outputs
+    assert torch.equal(out["class"].argmax(-1), T(g["out/class"]).argmax(-1))
+
+
+def test_fuser_grads(golden):
+    g = golden("fuser_small.npz")
+    gg = golden("fuser_grads.npz")
+    sd, views, proj, shp = _fuser_inputs(g)
+    sd = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    views = [[l.clone().requires_grad_(True) for l in lv] for lv in views]
+    out = O.impfusion(views, shp, proj, T(g["center0"]), sd, "fuser", FUSER_CFG)
+    loss = sum((out[k] * T(gg[f"cot/{k}"])).sum() for k in out)
+    close(loss.detach(), gg["loss"], rtol=1e-4)
+    loss.backward()
+    for k, v in gg.items():
+        if k.startswith("grad/"):
+            close(sd["fuser." + k[5:]].grad, v, rtol=2e-3, atol_scale=2e-4)
+    for vi, n in enumerate(VIEWS):
+        for l in range(5):
+            close(views[vi][l].grad, gg[f"gview/{n}/{l}"], rtol=2e-3, atol_scale=2e-4)
+
+
+def test_head(golden):
+    g = golden("head.npz")
+    sd = {"h." + k[3:]: T(v) for k, v in g.items() if k.startswith("sd/")}
+    out = O.detection_head(T(g["x"]), T(g["ref"]), sd, "h")
+    for k in out:
+        close(out[k], g[f"out/{k}"], rtol=1e-5)
+
+
+def test_loss_pieces(golden):
+    g = golden("loss.npz")
+    close(O.focal_loss(T(g["focal_in"]), T(g["focal_tgt"])), g["focal_out"], rtol=1e-6)
+    pred = {k: T(g[f"pred/{k}"])[0] for k in ("class", "center", "size", "angle")}
+    tgt = {k: T(g[f"tgt/{k}"])[0] for k in ("gt_class", "gt_center", "gt_size", "gt_angle")}
+    losses = O.set_criterion(pred, tgt, T(g["i"])[0], T(g["j"])[0])
+    for k, v in losses.items():
+        close(v, g[f"loss/{k}"], rtol=1e-5)
+    corners = O.box_corners(tgt["gt_center"], tgt["gt_size"], T(g["yaw"])[0])
+    close(corners, T(g["corners"])[0], rtol=1e-5)
+
+
+def test_msda_core_vs_scalar_restatement():
+    """grid_sample core == scalar restatement of the upstream kernel body, fp64."""
+    gen = torch.Generator().manual_seed(0)
+    shapes = [(5, 7), (3, 4), (1, 2)]
+    lsi = [0, 35, 47]
+    N, M, D, Lq, L, P = 2, 2, 2, 3, 3, 2
+    value = torch.randn(N, 49, M, D, generator=gen, dtype=torch.float64)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=gen, dtype=torch.float64) * 1.4 - 0.2
+    attn = torch.rand(N, Lq, M, L, P, generator=gen, dtype=torch.float64)
+    a = O.msda_core(value, shapes, loc, attn)
+    b = O.msda_core_scalar(value, shapes, lsi, loc, attn)
+    torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
+
+
+def test_msda_core_vs_transformers():
+    """Independent second opinion (this container only): transformers' pure-PyTorch MSDA."""
+    try:
+        from transformers.models.deformable_detr.modeling_deformable_detr import (
+            MultiScaleDeformableAttention as HFMSDA)
+    except Exception:
+        pytest.skip("transformers MSDA not importable")
+    gen = torch.Generator().manual_seed(1)
+    shapes = [(6, 9), (3, 5)]
+    N, M, D, Lq, L, P = 2, 4, 2, 5, 2, 3
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(N, S, M, D, generator=gen)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=gen)
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=gen), -1).view(N, Lq, M, L, P)
+    try:
+        ref = HFMSDA().forward(value, torch.tensor(shapes), shapes, torch.tensor([0, 54]), loc, attn, 64)
+    except Exception as e:  # API drift
+        pytest.skip(f"transformers MSDA signature differs: {e}")
+    torch.testing.assert_close(O.msda_core(value, shapes, loc, attn), ref, rtol=1e-5, atol=1e-6)
+
+
+def test_giou_yaw_basic():
+    c = torch.tensor([[0.0, 0, 0], [10, 0, 0], [0.5, 0, 0]])
+    s = torch.tensor([[2.0, 2, 2]] * 3)
+    a = torch.zeros(3)
+    g = O.giou3d_yaw(c, s, a, c, s, a)
+    assert abs(float(g[0, 0]) - 1.0) < 1e-9
+    assert float(g[0, 1]) == -1.0                       # disjoint => reference quirk: exactly -1
+    inter = 1.5 * 2 * 2; iou = inter / (16 - inter); evol = 2.5 * 2 * 2; uni = inter / iou
+    assert abs(float(g[0, 2]) - (iou - (evol - uni) / evol)) < 1e-9
+    # rotation by 90 degrees of a cube changes nothing
+    g2 = O.giou3d_yaw(c[:1], s[:1], torch.tensor([1.5707963267948966]), c[:1], s[:1], a[:1])
+    assert abs(float(g2[0, 0]) - 1.0) < 1e-6
+    # degenerate (zero size) prediction => -1 like the reference's validity mask
+    g3 = O.giou3d_yaw(c[:1], torch.tensor([[0.0, 2, 2]]), a[:1], c[:1], s[:1], a[:1])
+    assert float(g3[0, 0]) == -1.0
