@@ -1,0 +1,553 @@
+// BatchNorm / ReLU / residual / max-pool / FPN glue kernels on NHWC fp32 (HBM-bound, float4 lanes).
+// Replaces the ATen/cuDNN elementwise + reduction kernels behind torchvision's ResNet body and FPN
+// (reference call sites: src/dprt/models/backbones/resnet.py:54-55, src/dprt/models/necks/fpn.py:39-43)
+// and the in-place sinusoidal embedding add (src/dprt/models/embeddings/sinusoidal.py:107-108).
+#include "common.h"
+
+#include <algorithm>
+
+namespace dpft {
+
+// ---------------------------------------------------------------------------------------------
+// per-tile (mean, M2) of y[M][K]; tile = tile_rows consecutive rows. block = one tile x 256-col slab
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ y, float* __restrict__ stats,
+                                                        int64_t M, int K, int tile_rows) {
+    __shared__ float red[256];
+    __shared__ float smean[256];
+    const int tile = blockIdx.x;
+    const int kc = min(K, 256);
+    const int groups = 256 / kc;
+    const int c_local = threadIdx.x % kc, g = threadIdx.x / kc;
+    const int c = blockIdx.y * 256 + c_local;
+    const int64_t r0 = (int64_t)tile * tile_rows;
+    const int cnt = (int)min((int64_t)tile_rows, M - r0);
+    const bool act = g < groups && c < K;
+    float s = 0.f;
+    if (act)
+        for (int r = g; r < cnt; r += groups) s += y[(r0 + r) * K + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < kc) {
+        float t = 0.f;
+        for (int i = 0; i < groups; ++i) t += red[threadIdx.x + i * kc];
+        smean[threadIdx.x] = t / (float)cnt;
+    }
+    __syncthreads();
+    const float mean = smean[c_local];
+    s = 0.f;
+    if (act)
+        for (int r = g; r < cnt; r += groups) {
+            const float d = y[(r0 + r) * K + c] - mean;
+            s += d * d;
+        }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < kc && c < K) {
+        float t = 0.f;
+        for (int i = 0; i < groups; ++i) t += red[threadIdx.x + i * kc];
+        stats[((size_t)tile * 2 + 0) * K + c] = mean;
+        stats[((size_t)tile * 2 + 1) * K + c] = t;
+    }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t M,
+                                   int K, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                   float eps, float momentum, float* running_mean, float* running_var,
+                                   float* save_mean, float* save_invstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int t = 0; t < tiles; ++t) {
+        const float cnt = (float)min((int64_t)tile_rows, M - (int64_t)t * tile_rows);
+        const float mt = stats[((size_t)t * 2 + 0) * K + c];
+        const float m2t = stats[((size_t)t * 2 + 1) * K + c];
+        const float nn = n + cnt;
+        const float delta = mt - mean;
+        mean += delta * (cnt / nn);
+        m2 += m2t + delta * delta * (n * cnt / nn);
+        n = nn;
+    }
+    const float var = m2 / (float)M;
+    const float invstd = 1.0f / sqrtf(var + eps);
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - mean * sc;
+    if (save_mean) save_mean[c] = mean;
+    if (save_invstd) save_invstd[c] = invstd;
+    if (running_mean) {
+        const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * unbiased;
+    }
+}
+
+__global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ rm, const float* __restrict__ rv, float eps, int K,
+                               float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    const float sc = gamma[c] / sqrtf(rv[c] + eps);
+    scale[c] = sc;
+    shift[c] = beta[c] - rm[c] * sc;
+}
+
+// out = [relu](y*scale+shift [+ res*rs+rsh | + res]); K % 4 == 0
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, const float* __restrict__ res,
+                                                      const float* __restrict__ rs, const float* __restrict__ rsh,
+                                                      int relu, float* __restrict__ out, int64_t n4, int K4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % K4) * 4;
+        f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        if (res) {
+            f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
+            if (rs) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(rs + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(rsh + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) r[e] = fmaf(r[e], a[e], b[e]);
+            }
+            v += r;
+        }
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+// stem: maxpool3x3/s2/p1 of relu(bn(y)); one thread per (b,ph,pw,4 channels)
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                               const float* __restrict__ shift, float* __restrict__ out,
+                                                               int B, int H, int W, int K4, int PH, int PW) {
+    const int64_t total = (int64_t)B * PH * PW * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        int64_t p = i / K4;
+        const int pw = (int)(p % PW); p /= PW;
+        const int ph = (int)(p % PH);
+        const int b = (int)(p / PH);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        f32x4 m = {0.f, 0.f, 0.f, 0.f};  // relu >= 0 and every window holds a valid pixel
+#pragma unroll
+        for (int di = 0; di < 3; ++di) {
+            const int h = ph * 2 - 1 + di;
+            if ((unsigned)h >= (unsigned)H) continue;
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const int w = pw * 2 - 1 + dj;
+                if ((unsigned)w >= (unsigned)W) continue;
+                const f32x4 v = reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + h) * W + w) * K4 + c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fmaf(v[e], sc[e], sh[e]));
+            }
+        }
+        reinterpret_cast<f32x4*>(out)[i] = m;
+    }
+}
+
+// backward of the above, gather form: dz[b,h,w,c] = (a>0) * sum_{windows containing (h,w) whose first
+// arg-max is (h,w)} dout.  a = relu(bn(y)) recomputed on the fly.
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, const float* __restrict__ dout,
+                                                                   float* __restrict__ dz, int B, int H, int W, int K4, int PH, int PW) {
+    const int64_t total = (int64_t)B * H * W * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        int64_t p = i / K4;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int b = (int)(p / H);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
+        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 a0;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) a0[e] = fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        // candidate windows: ph in {(h+1)/2 - (0|1)} with 2*ph-1 <= h <= 2*ph+1
+        const int ph_hi = (h + 1) >> 1, pw_hi = (w + 1) >> 1;
+        for (int ph = ph_hi - 1; ph <= ph_hi; ++ph) {
+            if (ph < 0 || ph >= PH || h < 2 * ph - 1 || h > 2 * ph + 1) continue;
+            for (int pw = pw_hi - 1; pw <= pw_hi; ++pw) {
+                if (pw < 0 || pw >= PW || w < 2 * pw - 1 || w > 2 * pw + 1) continue;
+                // first arg-max of the window in scan order, per channel
+                f32x4 best = {-1.f, -1.f, -1.f, -1.f};
+                int bi[4] = {-1, -1, -1, -1};
+#pragma unroll
+                for (int di = 0; di < 3; ++di) {
+                    const int hh = ph * 2 - 1 + di;
+                    if ((unsigned)hh >= (unsigned)H) continue;
+#pragma unroll
+                    for (int dj = 0; dj < 3; ++dj) {
+                        const int ww = pw * 2 - 1 + dj;
+                        if ((unsigned)ww >= (unsigned)W) continue;
+                        const f32x4 v = reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + hh) * W + ww) * K4 + c4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float av = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+                            if (av > best[e]) { best[e] = av; bi[e] = di * 3 + dj; }
+                        }
+                    }
+                }
+                const int me = (h - (ph * 2 - 1)) * 3 + (w - (pw * 2 - 1));
+                const f32x4 d = reinterpret_cast<const f32x4*>(dout)[(((int64_t)b * PH + ph) * PW + pw) * K4 + c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += (bi[e] == me) ? d[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = a0[e] > 0.f ? g[e] : 0.f;
+        reinterpret_cast<f32x4*>(dz)[i] = g;
+    }
+}
+
+// BN backward pass 1: sums[0][k] += sum dz, sums[1][k] += sum dz*xhat
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                             const float* __restrict__ outp, const float* __restrict__ msc,
+                                                             const float* __restrict__ msh, const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, float* __restrict__ sums,
+                                                             int64_t M, int K, int rows_per_block) {
+    __shared__ float red0[256 * 4];
+    __shared__ float red1[256 * 4];
+    const int K4 = K / 4;
+    // slab of up to 256 float4-chunks of channels per blockIdx.y
+    const int kc = min(K4 - (int)blockIdx.y * 256, 256);
+    const int groups = 256 / kc;
+    const int cl = threadIdx.x % kc, g = threadIdx.x / kc;
+    const int c4 = blockIdx.y * 256 + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+    if (g < groups) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
+        f32x4 ksc = {0.f, 0.f, 0.f, 0.f}, ksh = ksc;
+        if (msc) {
+            ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4);
+            ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4);
+        }
+        for (int64_t r = r0 + g; r < r1; r += groups) {
+            const int64_t idx = r * K4 + c4;
+            f32x4 d = reinterpret_cast<const f32x4*>(dout)[idx];
+            const f32x4 yv = reinterpret_cast<const f32x4*>(y)[idx];
+            if (outp) {
+                const f32x4 o = reinterpret_cast<const f32x4*>(outp)[idx];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            } else if (msc) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = fmaf(yv[e], ksc[e], ksh[e]) > 0.f ? d[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s0[e] += d[e];
+                s1[e] += d[e] * ((yv[e] - mu[e]) * is[e]);
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red0[threadIdx.x * 4 + e] = s0[e];
+        red1[threadIdx.x * 4 + e] = s1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < kc) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t0 = 0.f, t1 = 0.f;
+            for (int i = 0; i < groups; ++i) {
+                t0 += red0[(threadIdx.x + i * kc) * 4 + e];
+                t1 += red1[(threadIdx.x + i * kc) * 4 + e];
+            }
+            atomicAdd(&sums[c4 * 4 + e], t0);
+            atomicAdd(&sums[K + c4 * 4 + e], t1);
+        }
+    }
+}
+
+// BN backward pass 2
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                            const float* __restrict__ outp, const float* __restrict__ msc,
+                                                            const float* __restrict__ msh, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ sums, float* __restrict__ dy,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int64_t n4, int K, float invM) {
+    const int K4 = K / 4;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < K; c += blockDim.x) {
+            if (dbeta) dbeta[c] = sums[c];
+            if (dgamma) dgamma[c] = sums[K + c];
+        }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % K4) * 4;
+        f32x4 d = reinterpret_cast<const f32x4*>(dout)[i];
+        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+        if (outp) {
+            const f32x4 o = reinterpret_cast<const f32x4*>(outp)[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        } else if (msc) {
+            const f32x4 ksc = *reinterpret_cast<const f32x4*>(msc + c);
+            const f32x4 ksh = *reinterpret_cast<const f32x4*>(msh + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = fmaf(yv[e], ksc[e], ksh[e]) > 0.f ? d[e] : 0.f;
+        }
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
+        f32x4 r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (yv[e] - mu[e]) * is[e];
+            r[e] = ga[e] * is[e] * (d[e] - s0[e] * invM - xh * s1[e] * invM);
+        }
+        reinterpret_cast<f32x4*>(dy)[i] = r;
+    }
+}
+
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outp,
+                                                        float* __restrict__ dz, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 d = reinterpret_cast<const f32x4*>(dout)[i];
+        const f32x4 o = reinterpret_cast<const f32x4*>(outp)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+        reinterpret_cast<f32x4*>(dz)[i] = d;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        dz[i] = outp[i] > 0.f ? dout[i] : 0.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
+    const int64_t n4 = n / 4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<f32x4*>(a)[i];
+        v += reinterpret_cast<const f32x4*>(b)[i];
+        reinterpret_cast<f32x4*>(a)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const int64_t i = n4 * 4 + threadIdx.x;
+        a[i] += b[i];
+    }
+}
+
+__device__ __forceinline__ int nearest_src(int dst, float scale, int n_in) {
+    return min((int)floorf((float)dst * scale), n_in - 1);
+}
+
+// lat += nearest_upsample(top)
+__global__ __launch_bounds__(256) void fpn_topdown_add_kernel(float* __restrict__ lat, const float* __restrict__ top,
+                                                               int B, int H, int W, int TH, int TW, int K4,
+                                                               float sh, float sw) {
+    const int64_t total = (int64_t)B * H * W * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        int64_t p = i / K4;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        const int b = (int)(p / H);
+        const int th = (TH == H) ? h : nearest_src(h, sh, TH);
+        const int tw = (TW == W) ? w : nearest_src(w, sw, TW);
+        f32x4 v = reinterpret_cast<f32x4*>(lat)[i];
+        v += reinterpret_cast<const f32x4*>(top)[(((int64_t)b * TH + th) * TW + tw) * K4 + c4];
+        reinterpret_cast<f32x4*>(lat)[i] = v;
+    }
+}
+
+// dtop += sum over destination pixels mapping to each source pixel (gather, deterministic)
+__global__ __launch_bounds__(256) void fpn_topdown_add_bwd_kernel(const float* __restrict__ dlat, float* __restrict__ dtop,
+                                                                   int B, int H, int W, int TH, int TW, int K4,
+                                                                   float sh, float sw) {
+    const int64_t total = (int64_t)B * TH * TW * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        int64_t p = i / K4;
+        const int tw = (int)(p % TW); p /= TW;
+        const int th = (int)(p % TH);
+        const int b = (int)(p / TH);
+        // candidate destination range (conservative), filtered by the exact forward map
+        const int h_lo = max(0, (int)floorf((float)th / sh) - 2), h_hi = min(H - 1, (int)ceilf((float)(th + 1) / sh) + 2);
+        const int w_lo = max(0, (int)floorf((float)tw / sw) - 2), w_hi = min(W - 1, (int)ceilf((float)(tw + 1) / sw) + 2);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int h = h_lo; h <= h_hi; ++h) {
+            const int s_h = (TH == H) ? h : nearest_src(h, sh, TH);
+            if (s_h != th) continue;
+            for (int w = w_lo; w <= w_hi; ++w) {
+                const int s_w = (TW == W) ? w : nearest_src(w, sw, TW);
+                if (s_w != tw) continue;
+                acc += reinterpret_cast<const f32x4*>(dlat)[(((int64_t)b * H + h) * W + w) * K4 + c4];
+            }
+        }
+        f32x4 v = reinterpret_cast<f32x4*>(dtop)[i];
+        v += acc;
+        reinterpret_cast<f32x4*>(dtop)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_pos_kernel(float* __restrict__ x, const float* __restrict__ pos_x,
+                                                       const float* __restrict__ pos_y, int B, int H, int W, int K4) {
+    const int64_t total = (int64_t)B * H * W * K4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % K4);
+        int64_t p = i / K4;
+        const int w = (int)(p % W); p /= W;
+        const int h = (int)(p % H);
+        f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+        v += reinterpret_cast<const f32x4*>(pos_x)[(int64_t)w * K4 + c4];
+        v += reinterpret_cast<const f32x4*>(pos_y)[(int64_t)h * K4 + c4];
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+
+static inline int ew_blocks(int64_t work_items) {
+    return (int)std::max<int64_t>(1, std::min<int64_t>((work_items + 255) / 256, (int64_t)kNumCU * 8));
+}
+
+}  // namespace dpft
+
+using namespace dpft;
+
+extern "C" int dpft_bn_stats_f32(const float* y, float* stats, int64_t M, int32_t K, int32_t tile_rows,
+                                 dpft_stream_t stream) {
+    DPFT_REQUIRE(y && stats && M > 0 && K > 0 && tile_rows > 0, "bn_stats: bad arguments");
+    dim3 grid(cdiv(M, tile_rows), cdiv(K, 256));
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(256), 0, (hipStream_t)stream, y, stats, M, K, tile_rows);
+    return check_launch("bn_stats");
+}
+
+extern "C" int dpft_bn_finalize_f32(const float* stats, int32_t tiles, int32_t tile_rows, int64_t M, int32_t K,
+                                    const float* gamma, const float* beta, float eps, float momentum,
+                                    float* running_mean, float* running_var, float* save_mean,
+                                    float* save_invstd, float* scale, float* shift, dpft_stream_t stream) {
+    DPFT_REQUIRE(stats && gamma && beta && scale && shift, "bn_finalize: null tensor");
+    DPFT_REQUIRE(tiles == cdiv(M, tile_rows), "bn_finalize: tiles (%d) != ceil(M/tile_rows)", tiles);
+    DPFT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 64)), dim3(64), 0, (hipStream_t)stream, stats, tiles,
+                       tile_rows, M, K, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
+                       save_invstd, scale, shift);
+    return check_launch("bn_finalize");
+}
+
+extern "C" int dpft_bn_eval_scale_shift_f32(const float* gamma, const float* beta, const float* running_mean,
+                                            const float* running_var, float eps, int32_t K, float* scale,
+                                            float* shift, dpft_stream_t stream) {
+    DPFT_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && K > 0, "bn_eval: bad arguments");
+    hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(K, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
+                       running_mean, running_var, eps, K, scale, shift);
+    return check_launch("bn_eval_scale_shift");
+}
+
+extern "C" int dpft_bn_act_f32(const float* y, const float* scale, const float* shift, const float* res,
+                               const float* res_scale, const float* res_shift, int32_t relu, float* out,
+                               int64_t M, int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && scale && shift && out && M > 0 && K > 0 && K % 4 == 0, "bn_act: bad arguments (K=%d)", K);
+    DPFT_REQUIRE((res_scale == nullptr) == (res_shift == nullptr), "bn_act: res_scale/res_shift must come in pairs");
+    const int64_t n4 = M * K / 4;
+    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
+                       res_scale, res_shift, relu, out, n4, K / 4);
+    return check_launch("bn_act");
+}
+
+extern "C" int dpft_bn_relu_maxpool_f32(const float* y, const float* scale, const float* shift, float* out,
+                                        int32_t B, int32_t H, int32_t W, int32_t K, int32_t PH, int32_t PW,
+                                        dpft_stream_t stream) {
+    DPFT_REQUIRE(y && scale && shift && out && K % 4 == 0, "bn_relu_maxpool: bad arguments");
+    DPFT_REQUIRE(PH == (H + 2 - 3) / 2 + 1 && PW == (W + 2 - 3) / 2 + 1, "bn_relu_maxpool: PH/PW inconsistent");
+    const int64_t total = (int64_t)B * PH * PW * (K / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, scale,
+                       shift, out, B, H, W, K / 4, PH, PW);
+    return check_launch("bn_relu_maxpool");
+}
+
+extern "C" int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* scale, const float* shift,
+                                            const float* dout, float* dact, int32_t B, int32_t H, int32_t W,
+                                            int32_t K, int32_t PH, int32_t PW, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && scale && shift && dout && dact && K % 4 == 0, "bn_relu_maxpool_bwd: bad arguments");
+    const int64_t total = (int64_t)B * H * W * (K / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y,
+                       scale, shift, dout, dact, B, H, W, K / 4, PH, PW);
+    return check_launch("bn_relu_maxpool_bwd");
+}
+
+extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const float* out,
+                                      const float* mask_scale, const float* mask_shift, const float* mean,
+                                      const float* invstd, float* sums, int64_t M, int32_t K,
+                                      dpft_stream_t stream) {
+    DPFT_REQUIRE(y && dout && mean && invstd && sums && M > 0 && K > 0 && K % 4 == 0, "bn_bwd_reduce: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * K, st);
+    const int K4 = K / 4;
+    const int slabs = cdiv(K4, 256);
+    const int kc = std::min(K4, 256);
+    const int groups = 256 / kc;
+    int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + kNumCU * 4 - 1) / (kNumCU * 4));
+    dim3 grid(cdiv(M, rows_per_block), slabs);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_scale, mask_shift, mean, invstd, sums, M, K,
+                       (int)rows_per_block);
+    return check_launch("bn_bwd_reduce");
+}
+
+extern "C" int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const float* out,
+                                     const float* mask_scale, const float* mask_shift, const float* mean,
+                                     const float* invstd, const float* gamma, const float* sums, float* dy,
+                                     float* dgamma, float* dbeta, int64_t M, int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && dout && mean && invstd && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
+    const int64_t n4 = M * K / 4;
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
+                       mask_scale, mask_shift, mean, invstd, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M);
+    return check_launch("bn_bwd_apply");
+}
+
+extern "C" int dpft_relu_bwd_f32(const float* dout, const float* out, float* dz, int64_t n, dpft_stream_t stream) {
+    DPFT_REQUIRE(dout && out && dz && n > 0, "relu_bwd: bad arguments");
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, dout, out, dz, n);
+    return check_launch("relu_bwd");
+}
+
+extern "C" int dpft_add_inplace_f32(float* a, const float* b, int64_t n, dpft_stream_t stream) {
+    DPFT_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
+    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, n);
+    return check_launch("add_inplace");
+}
+
+extern "C" int dpft_fpn_topdown_add_f32(float* lat, const float* top, int32_t B, int32_t H, int32_t W,
+                                        int32_t TH, int32_t TW, int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(lat && top && K % 4 == 0 && TH <= H && TW <= W, "fpn_topdown_add: bad arguments");
+    const int64_t total = (int64_t)B * H * W * (K / 4);
+    hipLaunchKernelGGL(fpn_topdown_add_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, lat, top, B,
+                       H, W, TH, TW, K / 4, (float)TH / (float)H, (float)TW / (float)W);
+    return check_launch("fpn_topdown_add");
+}
+
+extern "C" int dpft_fpn_topdown_add_bwd_f32(const float* dlat, float* dtop, int32_t B, int32_t H, int32_t W,
+                                            int32_t TH, int32_t TW, int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(dlat && dtop && K % 4 == 0 && TH <= H && TW <= W, "fpn_topdown_add_bwd: bad arguments");
+    const int64_t total = (int64_t)B * TH * TW * (K / 4);
+    hipLaunchKernelGGL(fpn_topdown_add_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, dlat,
+                       dtop, B, H, W, TH, TW, K / 4, (float)TH / (float)H, (float)TW / (float)W);
+    return check_launch("fpn_topdown_add_bwd");
+}
+
+extern "C" int dpft_add_pos_f32(float* x, const float* pos_x, const float* pos_y, int32_t B, int32_t H,
+                                int32_t W, int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(x && pos_x && pos_y && K % 4 == 0, "add_pos: bad arguments");
+    const int64_t total = (int64_t)B * H * W * (K / 4);
+    hipLaunchKernelGGL(add_pos_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, x, pos_x, pos_y, B,
+                       H, W, K / 4);
+    return check_launch("add_pos");
+}

@@ -1,0 +1,48 @@
+// Shared helpers for libdpft_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/dpft_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace dpft {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: launch failed: %s", what, hipGetErrorString(e));
+        return DPFT_ERR_LAUNCH;
+    }
+    return DPFT_OK;
+}
+
+inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+constexpr int kNumCU = 256;   // MI355X
+constexpr int kNumXCD = 8;
+
+// XCD-aware bijective remap of a linear workgroup id: consecutive logical ids land on the same
+// XCD (hardware places block b on XCD b % 8), so neighbouring tiles share that XCD's L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg / kNumXCD, r = nwg % kNumXCD;
+    const int xcd = bid % kNumXCD, idx = bid / kNumXCD;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace dpft
+
+#define DPFT_REQUIRE(cond, ...)                 \
+    do {                                        \
+        if (!(cond)) {                          \
+            dpft::set_error(__VA_ARGS__);       \
+            return DPFT_ERR_ARG;                \
+        }                                       \
+    } while (0)

@@ -1,0 +1,998 @@
+// NHWC fp32 convolution family for gfx950 as MFMA implicit GEMM (v_mfma_f32_32x32x2_f32).
+//
+//   forward :  Y[M = B*OH*OW][N = K]  = A[M][kh*kw*C] * W^T        A gathered from x on the fly
+//   dgrad   :  dX[M = B*H*W][N = C]   = A'[M][kh*kw*K] * Wt^T      A' gathered from dy (stride via
+//                                                                   divisibility test), Wt = [C][taps][K]
+//   wgrad   :  dW[K][tap][C]          = sum_pixels dY[p][k] * A[p][tap][c]
+//
+// Replaces the cuDNN kernels behind torchvision's ResNet/FPN in the reference
+// (src/dprt/models/backbones/resnet.py:47-55,80-107; src/dprt/models/necks/fpn.py:39-43).
+//
+// Tiling (64-lane waves, 4 waves / workgroup): workgroup tile BM x BN, wave tile (RB*32) x (CB*32)
+// of 32x32 MFMA blocks, BK = 32 per K-step staged through LDS with a register prefetch of the next
+// step.  The A/B fragments are read from LDS with ds_read_b128: lanes 0-31 take k0..k0+3 and lanes
+// 32-63 take k0+4..k0+7 of their row, and MFMA j consumes register j of both operands, i.e. a
+// fixed permutation of the K order that both operands share (fp32 sums are order-independent up to
+// rounding).  Rows are padded to 36 floats so the 16-lane groups of ds_read_b128 hit 16 distinct
+// 16-byte slots.  Workgroup ids are remapped so that consecutive tiles (same A rows) share an XCD L2.
+//
+// Fused prologue (PRO): the producer's BatchNorm-apply + ReLU is applied to the A operand while it
+// is staged (padding stays exactly zero).  Fused epilogue: per-tile per-channel (mean, M2) of the
+// raw conv output for train-mode BatchNorm (combined later with Chan's formula: deterministic, no
+// atomics, no E[x^2]-E[x]^2 cancellation).
+#include "common.h"
+
+#include <math.h>
+
+#include <algorithm>
+
+namespace dpft {
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;   // vector path: padded LDS row (144 B, 16-B aligned)
+constexpr int LDG = BK + 1;   // generic path: odd pad, ds_read_b32 fragments
+
+struct IgemmArgs {
+    const float* x;
+    const float* w;
+    float* y;
+    const float* bias;
+    const float* pro_scale;
+    const float* pro_shift;
+    float* stats;     // [mtiles][2][N] or null
+    float* partial;   // split-K: [splits][M][N] or null
+    int B, H, W, C;   // A-source tensor
+    int OH, OW, N;    // output tensor
+    int kh, kw, stride, pad;
+    int M, Ktot;
+    int mtiles, ntiles, splits, ksteps, ksteps_per_split;
+    int pro_relu;
+    int accumulate;   // y += result (dgrad into an existing gradient)
+};
+
+// ---------------------------------------------------------------------------------------------
+// shared epilogue: store accumulators (+bias), optional split-K partial, optional BN tile stats
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, int RB, int CB>
+__device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[RB][CB], int m0,
+                                               int n0, int mt, int split, float* smem) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int rbase = m0 + wm * RB * 32 + 4 * (lane >> 5);
+    const int cbase = n0 + wn * CB * 32 + (lane & 31);
+    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.M * a.N : a.y;
+    const bool add_bias = (a.bias != nullptr) && (a.partial == nullptr);
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const int col = cbase + cb * 32;
+        if (col >= a.N) continue;
+        const float bv = add_bias ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < a.M) {
+                    float v = acc[rb][cb][r] + bv;
+                    if (a.accumulate && a.partial == nullptr) v += out[(size_t)row * a.N + col];
+                    out[(size_t)row * a.N + col] = v;
+                }
+            }
+        }
+    }
+    if (a.stats == nullptr) return;
+    // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
+    float* red = smem;               // [WGM][BN]
+    float* smean = smem + WGM * BN;  // [BN]
+    const int cnt = min(BM, a.M - m0);
+    __syncthreads();  // LDS tiles are dead now
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        float s = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
+                s += (row < a.M) ? acc[rb][cb][r] : 0.f;
+            }
+        s += __shfl_xor(s, 32);
+        if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;
+    }
+    __syncthreads();
+    if (tid < BN) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
+        const float mean = s / (float)cnt;
+        smean[tid] = mean;
+        if (n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb) {
+        const float mean = smean[wn * CB * 32 + cb * 32 + (lane & 31)];
+        float s = 0.f;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
+                const float d = acc[rb][cb][r] - mean;
+                s += (row < a.M) ? d * d : 0.f;
+            }
+        s += __shfl_xor(s, 32);
+        if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;  // red is free: barrier above
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < a.N) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
+        a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+    }
+}
+
+__device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt, int& split) {
+    const int nwg = a.mtiles * a.ntiles * a.splits;
+    int bid = xcd_remap(blockIdx.x, nwg);
+    const int per = a.mtiles * a.ntiles;
+    split = bid / per;
+    bid -= split * per;
+    mt = bid / a.ntiles;
+    nt = bid - mt * a.ntiles;
+}
+
+// ---------------------------------------------------------------------------------------------
+// vector path: C % 32 == 0 (every bottleneck conv); float4 global loads, b128 LDS fragments
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO>
+__global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
+    constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
+    constexpr int AP = BM / 32, BP = BN / 32;
+    static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1, "bad tile");
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    float* As = smem;
+    float* Bs = smem + BM * LDK;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+    int mt, nt, split;
+    decode_tile(a, mt, nt, split);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    const int chunk = tid & 7, rowl = tid >> 3;
+    int a_bh[AP], a_bw[AP];
+    const float* a_base[AP];
+    const int ohw = a.OH * a.OW;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + rowl + 32 * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw;
+        const int rem = mm - b * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        if (!DGRAD) {
+            a_bh[i] = ok ? oh * a.stride - a.pad : -(1 << 28);
+            a_bw[i] = ow * a.stride - a.pad;
+        } else {
+            a_bh[i] = ok ? oh + a.pad : -(1 << 28);
+            a_bw[i] = ow + a.pad;
+        }
+        a_base[i] = a.x + (size_t)b * a.H * a.W * a.C + chunk * 4;
+    }
+    const float* b_base[BP];
+    bool b_ok[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + rowl + 32 * i;
+        b_ok[i] = n < a.N;
+        b_base[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Ktot + chunk * 4;
+    }
+    const int cpt = a.C / BK;  // K-steps per filter tap
+
+    f32x4 ra[AP], rbv[BP];
+    auto load_tile = [&](int kt) {
+        const int tap = kt / cpt;
+        const int c0 = (kt - tap * cpt) * BK;
+        const int r = tap / a.kw, s = tap - r * a.kw;
+        f32x4 sc, sh;
+        if (PRO) {
+            sc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + chunk * 4);
+            sh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + chunk * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            int hi, wi;
+            bool v;
+            if (!DGRAD) {
+                hi = a_bh[i] + r;
+                wi = a_bw[i] + s;
+                v = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            } else {
+                const int th = a_bh[i] - r, tw = a_bw[i] - s;
+                v = th >= 0 && tw >= 0;
+                if (a.stride == 1) {
+                    hi = th;
+                    wi = tw;
+                } else {
+                    hi = th / a.stride;
+                    wi = tw / a.stride;
+                    v = v && (hi * a.stride == th) && (wi * a.stride == tw);
+                }
+                v = v && hi < a.H && wi < a.W;
+            }
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (v) {
+                val = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0);
+                if (PRO) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = fmaf(val[e], sc[e], sh[e]);
+                        val[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
+                    }
+                }
+            }
+            ra[i] = val;
+        }
+#pragma unroll
+        for (int i = 0; i < BP; ++i) {
+            f32x4 val = {0.f, 0.f, 0.f, 0.f};
+            if (b_ok[i]) val = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BK);
+            rbv[i] = val;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+            *reinterpret_cast<f32x4*>(&As[(rowl + 32 * i) * LDK + chunk * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[(rowl + 32 * i) * LDK + chunk * 4]) = rbv[i];
+    };
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int kt_begin = split * a.ksteps_per_split;
+    const int kt_end = min(a.ksteps, kt_begin + a.ksteps_per_split);
+    const float* a_frag = As + (wm * RB * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    const float* b_frag = Bs + (wn * CB * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
+#pragma unroll
+        for (int kg = 0; kg < BK / 8; ++kg) {
+            f32x4 af[RB], bf[CB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDK + kg * 8);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    igemm_epilogue<BM, BN, WGM, WGN, RB, CB>(a, acc, m0, n0, mt, split, smem);
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic path: any C (stem C=3, FPN C=3/6/16); K flattened as (tap, c); scalar gathers
+// workgroup tile 128 x BN (BN = 32 or 64), waves 4 x 1
+// ---------------------------------------------------------------------------------------------
+template <int BN, bool DGRAD>
+__global__ __launch_bounds__(256) void igemm_gen_kernel(IgemmArgs a) {
+    constexpr int BM = 128, WGM = 4, WGN = 1, RB = 1, CB = BN / 32;
+    constexpr int KPB = BN / 8;  // k elements per thread for the B tile
+    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDG];
+    float* As = smem;
+    float* Bs = smem + BM * LDG;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave;
+    int mt, nt, split;
+    decode_tile(a, mt, nt, split);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // A: one row per thread, 16 consecutive k
+    const int arow = tid & 127, akh = tid >> 7;
+    int bh, bw;
+    const float* abase;
+    {
+        const int m = m0 + arow;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int ohw = a.OH * a.OW;
+        const int b = mm / ohw;
+        const int rem = mm - b * ohw;
+        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        if (!DGRAD) {
+            bh = ok ? oh * a.stride - a.pad : -(1 << 28);
+            bw = ow * a.stride - a.pad;
+        } else {
+            bh = ok ? oh + a.pad : -(1 << 28);
+            bw = ow + a.pad;
+        }
+        abase = a.x + (size_t)b * a.H * a.W * a.C;
+    }
+    const int brow = tid % BN, bkq = tid / BN;
+    const bool bok = (n0 + brow) < a.N;
+    const float* bbase = a.w + (size_t)(bok ? n0 + brow : 0) * a.Ktot;
+
+    float ra[16], rbv[KPB];
+    auto load_tile = [&](int kt) {
+        int k = kt * BK + akh * 16;
+        int tap = k / a.C;
+        int c = k - tap * a.C;
+        int r = tap / a.kw, s = tap - r * a.kw;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            int hi, wi;
+            bool v = (k + e) < a.Ktot;
+            if (!DGRAD) {
+                hi = bh + r;
+                wi = bw + s;
+                v = v && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            } else {
+                const int th = bh - r, tw = bw - s;
+                v = v && th >= 0 && tw >= 0;
+                hi = th / a.stride;
+                wi = tw / a.stride;
+                v = v && (hi * a.stride == th) && (wi * a.stride == tw) && hi < a.H && wi < a.W;
+            }
+            ra[e] = v ? abase[((size_t)hi * a.W + wi) * a.C + c] : 0.f;
+            if (++c == a.C) {
+                c = 0;
+                if (++s == a.kw) {
+                    s = 0;
+                    ++r;
+                }
+            }
+        }
+        const int kb = kt * BK + bkq * KPB;
+#pragma unroll
+        for (int e = 0; e < KPB; ++e) rbv[e] = (bok && (kb + e) < a.Ktot) ? bbase[kb + e] : 0.f;
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) As[arow * LDG + akh * 16 + e] = ra[e];
+#pragma unroll
+        for (int e = 0; e < KPB; ++e) Bs[brow * LDG + bkq * KPB + e] = rbv[e];
+    };
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int j = 0; j < CB; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
+
+    const int kt_begin = split * a.ksteps_per_split;
+    const int kt_end = min(a.ksteps, kt_begin + a.ksteps_per_split);
+    const float* a_frag = As + (wm * 32 + (lane & 31)) * LDG + (lane >> 5);
+    const float* b_frag = Bs + (lane & 31) * LDG + (lane >> 5);
+    if (kt_begin < kt_end) {
+        load_tile(kt_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = kt + 1 < kt_end;
+        if (more) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            const float av = a_frag[kk * 2];
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+                acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_frag[j * 32 * LDG + kk * 2],
+                                                                 acc[0][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    igemm_epilogue<BM, BN, WGM, WGN, RB, CB>(a, acc, m0, n0, mt, split, smem);
+}
+
+// split-K reduce: y = sum_s partial[s] (+bias)
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ bias,
+                                     float* __restrict__ y, int64_t MN, int N, int splits, int accumulate) {
+    int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i >= MN) return;
+    if (i + 3 < MN && (N % 4) == 0) {
+        f32x4 s = *reinterpret_cast<const f32x4*>(partial + i);
+        for (int k = 1; k < splits; ++k) {
+            f32x4 t = *reinterpret_cast<const f32x4*>(partial + (size_t)k * MN + i);
+            s += t;
+        }
+        if (bias) {
+            const int c = (int)(i % N);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s[e] += bias[c + e];
+        }
+        if (accumulate) s += *reinterpret_cast<const f32x4*>(y + i);
+        *reinterpret_cast<f32x4*>(y + i) = s;
+    } else {
+        for (int e = 0; e < 4 && i + e < MN; ++e) {
+            float s = 0.f;
+            for (int k = 0; k < splits; ++k) s += partial[(size_t)k * MN + i + e];
+            if (bias) s += bias[(i + e) % N];
+            if (accumulate) s += y[i + e];
+            y[i + e] = s;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// wgrad: dW[n][tap][c] = sum_p dY[p][n] * act(x)[p@tap][c]
+// LDS holds [32 pixels][BMn] of dY and [32 pixels][BNc] of x; both fragments are ds_read_b32
+// (consecutive lanes -> consecutive channels, conflict free).
+// ---------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* dw;        // [K][taps][C]
+    float* partial;   // [splits][K*taps*C] or null
+    const float* pro_scale;
+    const float* pro_shift;
+    int B, H, W, C;   // input
+    int OH, OW, K;    // dy
+    int kh, kw, stride, pad;
+    int M;            // B*OH*OW pixels (reduction)
+    int ktiles, ctiles, taps, splits, psteps, psteps_per_split;
+    int pro_relu;
+    int J;            // generic path: taps*C
+};
+
+template <int BMn, int BNc, int WGM, int WGN, bool PRO>
+__global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
+    constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
+    constexpr int YCH = BMn / 4, XCH = BNc / 4;        // float4 chunks per pixel row
+    constexpr int YRP = 256 / YCH, XRP = 256 / XCH;    // pixel rows per pass
+    constexpr int YP = BK / YRP, XP = BK / XRP;
+    static_assert(WGM * WGN == 4 && YP >= 1 && XP >= 1, "bad wgrad tile");
+    __shared__ __attribute__((aligned(16))) float smem[BK * (BMn + BNc)];
+    float* Ys = smem;
+    float* Xs = smem + BK * BMn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int nwg = a.ktiles * a.ctiles * a.taps * a.splits;
+    int bid = xcd_remap(blockIdx.x, nwg);
+    const int split = bid / (a.ktiles * a.ctiles * a.taps);
+    bid -= split * (a.ktiles * a.ctiles * a.taps);
+    const int tap = bid / (a.ktiles * a.ctiles);
+    bid -= tap * (a.ktiles * a.ctiles);
+    const int kt_ = bid / a.ctiles, ct_ = bid - kt_ * a.ctiles;
+    const int n0 = kt_ * BMn, c0 = ct_ * BNc;
+    const int r = tap / a.kw, s = tap - r * a.kw;
+
+    const int ych = tid % YCH, yrow = tid / YCH;
+    const int xch = tid % XCH, xrow = tid / XCH;
+    const bool y_ok = (n0 + ych * 4) < a.K;
+    const bool x_ok = (c0 + xch * 4) < a.C;
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (PRO && x_ok) {
+        sc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + xch * 4);
+        sh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + xch * 4);
+    }
+    const int ohw = a.OH * a.OW;
+
+    f32x4 ry[YP], rx[XP];
+    auto load_tile = [&](int ps) {
+        const int p0 = ps * BK;
+#pragma unroll
+        for (int i = 0; i < YP; ++i) {
+            const int p = p0 + yrow + i * YRP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (y_ok && p < a.M) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.K + n0 + ych * 4);
+            ry[i] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int p = p0 + xrow + i * XRP;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (x_ok && p < a.M) {
+                const int b = p / ohw;
+                const int rem = p - b * ohw;
+                const int oh = rem / a.OW, ow = rem - oh * a.OW;
+                const int hi = oh * a.stride - a.pad + r, wi = ow * a.stride - a.pad + s;
+                if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
+                    v = *reinterpret_cast<const f32x4*>(
+                        a.x + (((size_t)b * a.H + hi) * a.W + wi) * a.C + c0 + xch * 4);
+                    if (PRO) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            float t = fmaf(v[e], sc[e], sh[e]);
+                            v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
+                        }
+                    }
+                }
+            }
+            rx[i] = v;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < YP; ++i)
+            *reinterpret_cast<f32x4*>(&Ys[(yrow + i * YRP) * BMn + ych * 4]) = ry[i];
+#pragma unroll
+        for (int i = 0; i < XP; ++i)
+            *reinterpret_cast<f32x4*>(&Xs[(xrow + i * XRP) * BNc + xch * 4]) = rx[i];
+    };
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    const int ps_begin = split * a.psteps_per_split;
+    const int ps_end = min(a.psteps, ps_begin + a.psteps_per_split);
+    const float* y_frag = Ys + (lane >> 5) * BMn + wm * RB * 32 + (lane & 31);
+    const float* x_frag = Xs + (lane >> 5) * BNc + wn * CB * 32 + (lane & 31);
+    if (ps_begin < ps_end) {
+        load_tile(ps_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int ps = ps_begin; ps < ps_end; ++ps) {
+        const bool more = ps + 1 < ps_end;
+        if (more) load_tile(ps + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float av[RB], bv[CB];
+#pragma unroll
+            for (int i = 0; i < RB; ++i) av[i] = y_frag[kk * 2 * BMn + i * 32];
+#pragma unroll
+            for (int j = 0; j < CB; ++j) bv[j] = x_frag[kk * 2 * BNc + j * 32];
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.K * a.taps * a.C : a.dw;
+    const int rbase = n0 + wm * RB * 32 + 4 * (lane >> 5);
+    const int cbase = c0 + wn * CB * 32 + (lane & 31);
+#pragma unroll
+    for (int j = 0; j < CB; ++j) {
+        const int c = cbase + j * 32;
+        if (c >= a.C) continue;
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int n = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
+                if (n < a.K) out[((size_t)n * a.taps + tap) * a.C + c] = acc[i][j][q];
+            }
+    }
+}
+
+// generic wgrad: flattened j = tap*C + c (any C); tile 64 (n) x 64 (j); waves 2 x 2
+__global__ __launch_bounds__(256) void wgrad_gen_kernel(WgradArgs a) {
+    constexpr int BMn = 64, BNj = 64;
+    __shared__ __attribute__((aligned(16))) float smem[BK * (BMn + BNj)];
+    float* Ys = smem;
+    float* Xs = smem + BK * BMn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int jtiles = a.ctiles;
+    const int nwg = a.ktiles * jtiles * a.splits;
+    int bid = xcd_remap(blockIdx.x, nwg);
+    const int split = bid / (a.ktiles * jtiles);
+    bid -= split * (a.ktiles * jtiles);
+    const int kt_ = bid / jtiles, jt_ = bid - kt_ * jtiles;
+    const int n0 = kt_ * BMn, j0 = jt_ * BNj;
+
+    // thread -> column (n or j) and a group of 8 consecutive pixels
+    const int col = tid & 63, pg = tid >> 6;
+    const bool y_ok = (n0 + col) < a.K;
+    const int j = j0 + col;
+    const bool x_ok = j < a.J;
+    const int tap = x_ok ? j / a.C : 0;
+    const int c = x_ok ? j - tap * a.C : 0;
+    const int r = tap / a.kw, s = tap - r * a.kw;
+    const int ohw = a.OH * a.OW;
+
+    float ry[8], rx[8];
+    auto load_tile = [&](int ps) {
+        const int p0 = ps * BK + pg * 8;
+        int b = p0 / ohw;
+        int rem = p0 - b * ohw;
+        int oh = rem / a.OW, ow = rem - oh * a.OW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int p = p0 + e;
+            const bool pv = p < a.M;
+            ry[e] = (y_ok && pv) ? a.dy[(size_t)p * a.K + n0 + col] : 0.f;
+            const int hi = oh * a.stride - a.pad + r, wi = ow * a.stride - a.pad + s;
+            const bool v = x_ok && pv && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            rx[e] = v ? a.x[(((size_t)b * a.H + hi) * a.W + wi) * a.C + c] : 0.f;
+            if (++ow == a.OW) {
+                ow = 0;
+                if (++oh == a.OH) {
+                    oh = 0;
+                    ++b;
+                }
+            }
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            Ys[(pg * 8 + e) * BMn + col] = ry[e];
+            Xs[(pg * 8 + e) * BNj + col] = rx[e];
+        }
+    };
+    f32x16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const int ps_begin = split * a.psteps_per_split;
+    const int ps_end = min(a.psteps, ps_begin + a.psteps_per_split);
+    const float* y_frag = Ys + (lane >> 5) * BMn + wm * 32 + (lane & 31);
+    const float* x_frag = Xs + (lane >> 5) * BNj + wn * 32 + (lane & 31);
+    if (ps_begin < ps_end) {
+        load_tile(ps_begin);
+        store_tile();
+    }
+    __syncthreads();
+    for (int ps = ps_begin; ps < ps_end; ++ps) {
+        const bool more = ps + 1 < ps_end;
+        if (more) load_tile(ps + 1);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(y_frag[kk * 2 * BMn], x_frag[kk * 2 * BNj], acc, 0, 0, 0);
+        __syncthreads();
+        if (more) store_tile();
+        __syncthreads();
+    }
+    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.K * a.J : a.dw;
+    const int jj = j0 + wn * 32 + (lane & 31);
+    if (jj < a.J) {
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int n = n0 + wm * 32 + 4 * (lane >> 5) + (q & 3) + 8 * (q >> 2);
+            if (n < a.K) out[(size_t)n * a.J + jj] = acc[q];
+        }
+    }
+}
+
+// [K][taps][C] -> [C][taps][K]
+__global__ void weight_transpose_kernel(const float* __restrict__ w, float* __restrict__ wt, int K,
+                                        int taps, int C) {
+    __shared__ float tile[32][33];
+    const int tap = blockIdx.z;
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int i = ty; i < 32; i += 8) {
+        const int k = k0 + i, c = c0 + tx;
+        tile[i][tx] = (k < K && c < C) ? w[((size_t)k * taps + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        if (c < C && k < K) wt[((size_t)c * taps + tap) * K + k] = tile[tx][i];
+    }
+}
+
+// db[k] += sum_m dy[m][k]; db zeroed by the launcher; K <= 256
+__global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int64_t M, int K) {
+    __shared__ float red[256];
+    const int rpi = 256 / K;            // rows per iteration
+    const int c = threadIdx.x % K, r0 = threadIdx.x / K;
+    float s = 0.f;
+    if (r0 < rpi)
+        for (int64_t m = (int64_t)blockIdx.x * rpi + r0; m < M; m += (int64_t)gridDim.x * rpi)
+            s += dy[m * K + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float t = 0.f;
+        for (int i = 0; i < rpi; ++i) t += red[threadIdx.x + i * K];
+        atomicAdd(&db[threadIdx.x], t);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-side tile selection
+// ---------------------------------------------------------------------------------------------
+struct TileChoice {
+    int bm, bn, splits;
+    bool vec;
+};
+
+static TileChoice choose_tile(int M, int N, int C, int ksteps) {
+    TileChoice t;
+    t.vec = (C % BK) == 0;
+    if (!t.vec) {
+        t.bm = 128;
+        t.bn = (N <= 32) ? 32 : 64;
+        t.splits = 1;
+        return t;
+    }
+    // candidate tiles ordered by per-flop efficiency; pick the one that fills the chip best
+    const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    const double eff[3] = {1.0, 0.92, 0.80};
+    double best = -1;
+    t.bm = 64; t.bn = 64;
+    for (int i = 0; i < 3; ++i) {
+        const int bm = cand[i][0], bn = cand[i][1];
+        if (bn > 64 && N <= 64) continue;
+        const int64_t nwg = (int64_t)cdiv(M, bm) * cdiv(N, bn);
+        const int slots = kNumCU * 2;  // two resident workgroups per CU
+        const double waves = (double)nwg / slots;
+        const double fill = waves / ceil(waves);
+        // padding waste in N and M
+        const double pad = ((double)M * N) / ((double)cdiv(M, bm) * bm * (double)cdiv(N, bn) * bn);
+        const double score = eff[i] * fill * pad;
+        if (score > best) {
+            best = score;
+            t.bm = bm;
+            t.bn = bn;
+        }
+    }
+    // split-K when even the smallest tile leaves most CUs idle (radar branches, layer4)
+    const int64_t nwg = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
+    t.splits = 1;
+    if (nwg < kNumCU && ksteps >= 8) {
+        int s = (int)((kNumCU * 2 + nwg - 1) / nwg);
+        s = s > 16 ? 16 : s;
+        while (s > 1 && ksteps / s < 4) --s;
+        t.splits = s;
+    }
+    return t;
+}
+
+static void fill_igemm(IgemmArgs& a, const dpft_conv_desc* d, bool dgrad) {
+    memset(&a, 0, sizeof(a));
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+    if (!dgrad) {
+        a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C;
+        a.OH = d->OH; a.OW = d->OW; a.N = d->K;
+    } else {
+        a.B = d->B; a.H = d->OH; a.W = d->OW; a.C = d->K;
+        a.OH = d->H; a.OW = d->W; a.N = d->C;
+    }
+    a.M = a.B * a.OH * a.OW;
+    a.Ktot = a.kh * a.kw * a.C;
+    a.ksteps = cdiv(a.Ktot, BK);
+}
+
+template <bool DGRAD>
+static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t st) {
+    a.mtiles = cdiv(a.M, t.bm);
+    a.ntiles = cdiv(a.N, t.bn);
+    a.splits = t.splits;
+    a.ksteps_per_split = cdiv(a.ksteps, a.splits);
+    const int nwg = a.mtiles * a.ntiles * a.splits;
+    dim3 grid(nwg), block(256);
+#define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
+    do {                                                                                      \
+        if (pro) hipLaunchKernelGGL((igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>), grid, block, 0, st, a); \
+        else hipLaunchKernelGGL((igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false>), grid, block, 0, st, a);      \
+    } while (0)
+    if (t.vec) {
+        if (t.bm == 128 && t.bn == 128) LAUNCH_VEC(128, 128, 2, 2);
+        else if (t.bm == 128 && t.bn == 64) LAUNCH_VEC(128, 64, 2, 2);
+        else LAUNCH_VEC(64, 64, 2, 2);
+    } else {
+        if (t.bn == 32) hipLaunchKernelGGL((igemm_gen_kernel<32, DGRAD>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((igemm_gen_kernel<64, DGRAD>), grid, block, 0, st, a);
+    }
+#undef LAUNCH_VEC
+    return check_launch("conv igemm");
+}
+
+static int check_desc(const dpft_conv_desc* d) {
+    DPFT_REQUIRE(d != nullptr, "conv: null descriptor");
+    DPFT_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0, "conv: non-positive dims");
+    DPFT_REQUIRE(d->kh > 0 && d->kw > 0 && d->stride > 0 && d->pad >= 0, "conv: bad filter geometry");
+    const int oh = (d->H + 2 * d->pad - d->kh) / d->stride + 1;
+    const int ow = (d->W + 2 * d->pad - d->kw) / d->stride + 1;
+    DPFT_REQUIRE(oh == d->OH && ow == d->OW, "conv: OH/OW (%d,%d) inconsistent with geometry (%d,%d)",
+                 d->OH, d->OW, oh, ow);
+    DPFT_REQUIRE((int64_t)d->B * d->H * d->W * d->C < (1ll << 31) &&
+                 (int64_t)d->B * d->OH * d->OW * d->K < (1ll << 31), "conv: tensor too large for 32-bit row indices");
+    return DPFT_OK;
+}
+
+}  // namespace dpft
+
+using namespace dpft;
+
+extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
+    if (check_desc(d) != DPFT_OK) return -1;
+    // worst case over fwd / dgrad / wgrad split-K partials
+    int64_t best = 0;
+    {
+        IgemmArgs a; fill_igemm(a, d, false);
+        TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+        if (t.splits > 1) best = std::max<int64_t>(best, (int64_t)t.splits * a.M * a.N * 4);
+    }
+    {
+        IgemmArgs a; fill_igemm(a, d, true);
+        TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+        if (t.splits > 1) best = std::max<int64_t>(best, (int64_t)t.splits * a.M * a.N * 4);
+    }
+    // wgrad: up to 64 splits of the weight tensor
+    best = std::max<int64_t>(best, (int64_t)64 * d->K * d->kh * d->kw * d->C * 4);
+    return best;
+}
+
+extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows) {
+    if (check_desc(d) != DPFT_OK) return -1;
+    IgemmArgs a; fill_igemm(a, d, false);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (tile_rows) *tile_rows = t.bm;
+    return cdiv(a.M, t.bm);
+}
+
+extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x, const float* w,
+                                        const float* bias, const float* pro_scale,
+                                        const float* pro_shift, int32_t pro_relu, float* y,
+                                        float* stats, void* workspace, dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    IgemmArgs a; fill_igemm(a, d, false);
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
+    a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu;
+    const bool pro = pro_scale != nullptr;
+    DPFT_REQUIRE(!pro || pro_shift, "conv fwd: pro_scale without pro_shift");
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 32 == 0 (C=%d)", d->C);
+    if (t.splits > 1) {
+        DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
+        a.partial = (float*)workspace;
+        a.stats = nullptr;
+    }
+    rc = launch_igemm<false>(a, t, pro, st);
+    if (rc) return rc;
+    if (t.splits > 1) {
+        const int64_t MN = (int64_t)a.M * a.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 1024)), dim3(256), 0, st, a.partial, bias, y, MN, a.N, t.splits, 0);
+        rc = check_launch("conv fwd split-K reduce");
+        if (rc) return rc;
+        if (stats) {  // stats from the reduced output (tile_rows = t.bm rows per tile)
+            rc = dpft_bn_stats_f32(y, stats, a.M, a.N, t.bm, stream);
+        }
+    }
+    return rc;
+}
+
+extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,
+                                          float* dx, int32_t accumulate, void* workspace,
+                                          dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(dy && w_t && dx, "conv dgrad: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    IgemmArgs a; fill_igemm(a, d, true);
+    a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (t.splits > 1) {
+        DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
+        a.partial = (float*)workspace;
+    }
+    rc = launch_igemm<true>(a, t, false, st);
+    if (rc) return rc;
+    if (t.splits > 1) {
+        const int64_t MN = (int64_t)a.M * a.N;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 1024)), dim3(256), 0, st, a.partial, (const float*)nullptr, dx, MN, a.N, t.splits, accumulate);
+        rc = check_launch("conv dgrad split-K reduce");
+    }
+    return rc;
+}
+
+extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,
+                                          const float* pro_scale, const float* pro_shift,
+                                          int32_t pro_relu, float* dw, void* workspace,
+                                          dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(x && dy && dw, "conv wgrad: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    WgradArgs a; memset(&a, 0, sizeof(a));
+    a.x = x; a.dy = dy; a.dw = dw; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.OH = d->OH; a.OW = d->OW; a.K = d->K;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
+    a.M = d->B * d->OH * d->OW;
+    a.taps = d->kh * d->kw;
+    a.J = a.taps * a.C;
+    a.psteps = cdiv(a.M, BK);
+    const bool pro = pro_scale != nullptr;
+    const bool vec = (d->C % 32 == 0) && (d->K % 4 == 0);
+    DPFT_REQUIRE(!(pro && !vec), "conv wgrad: fused prologue needs C %% 32 == 0");
+    int bmn, bnc;
+    int64_t tiles;
+    if (vec) {
+        if (d->K <= 32) { bmn = 32; bnc = 128; }
+        else if (d->K >= 128 && d->C >= 128) { bmn = 128; bnc = 128; }
+        else { bmn = 64; bnc = 64; }
+        a.ktiles = cdiv(d->K, bmn);
+        a.ctiles = cdiv(d->C, bnc);
+        tiles = (int64_t)a.ktiles * a.ctiles * a.taps;
+    } else {
+        bmn = 64; bnc = 64;
+        a.ktiles = cdiv(d->K, 64);
+        a.ctiles = cdiv(a.J, 64);
+        tiles = (int64_t)a.ktiles * a.ctiles;
+    }
+    int splits = (int)((kNumCU * 2 + tiles - 1) / tiles);
+    if (splits > 64) splits = 64;
+    while (splits > 1 && a.psteps / splits < 4) --splits;
+    if (splits < 1) splits = 1;
+    if (splits > 1 && !workspace) splits = 1;
+    a.splits = splits;
+    a.psteps_per_split = cdiv(a.psteps, splits);
+    a.partial = splits > 1 ? (float*)workspace : nullptr;
+    const int nwg = (int)(tiles * splits);
+    dim3 grid(nwg), block(256);
+    if (vec) {
+#define LAUNCH_WG(BM_, BN_, WGM_, WGN_)                                                           \
+    do {                                                                                          \
+        if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \
+        else hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, st, a);     \
+    } while (0)
+        if (bmn == 128) LAUNCH_WG(128, 128, 2, 2);
+        else if (bmn == 64) LAUNCH_WG(64, 64, 2, 2);
+        else LAUNCH_WG(32, 128, 1, 4);
+#undef LAUNCH_WG
+    } else {
+        hipLaunchKernelGGL(wgrad_gen_kernel, grid, block, 0, st, a);
+    }
+    rc = check_launch("conv wgrad");
+    if (rc) return rc;
+    if (splits > 1) {
+        const int64_t n = (int64_t)d->K * a.J;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, st, a.partial, (const float*)nullptr, dw, n, 4, splits, 0);
+        rc = check_launch("conv wgrad split-K reduce");
+    }
+    return rc;
+}
+
+extern "C" int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, int32_t taps,
+                                         int32_t C, dpft_stream_t stream) {
+    DPFT_REQUIRE(w && w_t && K > 0 && taps > 0 && C > 0, "weight_transpose: bad arguments");
+    dim3 grid(cdiv(C, 32), cdiv(K, 32), taps);
+    hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, w_t, K, taps, C);
+    return check_launch("weight_transpose");
+}
+
+extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K,
+                                  dpft_stream_t stream) {
+    DPFT_REQUIRE(dy && db && M > 0 && K > 0 && K <= 256, "bias_grad: bad arguments (K=%d)", K);
+    (void)hipMemsetAsync(db, 0, sizeof(float) * K, (hipStream_t)stream);
+    const int rpi = 256 / K;
+    int blocks = (int)std::min<int64_t>(1024, (M + rpi - 1) / rpi);
+    hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, M, K);
+    return check_launch("bias_grad");
+}

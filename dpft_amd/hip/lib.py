@@ -1,0 +1,128 @@
+"""ctypes binding of libdpft_hip.so -- one thin Python function per C-ABI entry point
+(include/dpft_hip.h).  No torch types cross the boundary: tensors are passed as raw device
+pointers, the stream as the raw hipStream_t of torch's current stream.
+
+There is deliberately NO fallback: a missing library or a failing call raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+import torch
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "libdpft_hip.so")
+MAX_LEVELS = 8
+
+
+class HipLibraryError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "K", "kh", "kw", "stride", "pad", "OH", "OW")]
+
+
+class Pyramid(C.Structure):
+    _fields_ = [("level", C.c_void_p * MAX_LEVELS), ("grad", C.c_void_p * MAX_LEVELS),
+                ("H", C.c_int32 * MAX_LEVELS), ("W", C.c_int32 * MAX_LEVELS), ("L", C.c_int32)]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+_DESC = C.POINTER(ConvDesc)
+_PYR = C.POINTER(Pyramid)
+
+# name -> (restype, argtypes); must list every symbol include/dpft_hip.h declares
+SIGNATURES = {
+    "dpft_version": (_I, []),
+    "dpft_last_error": (C.c_char_p, []),
+    "dpft_conv2d_workspace_bytes": (_L, [_DESC]),
+    "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
+    "dpft_conv2d_nhwc_fwd_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "dpft_conv2d_nhwc_dgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P]),
+    "dpft_conv2d_nhwc_wgrad_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "dpft_weight_transpose_f32": (_I, [_P, _P, _I, _I, _I, _P]),
+    "dpft_bias_grad_f32": (_I, [_P, _P, _L, _I, _P]),
+    "dpft_bn_stats_f32": (_I, [_P, _P, _L, _I, _I, _P]),
+    "dpft_bn_finalize_f32": (_I, [_P, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
+    "dpft_bn_eval_scale_shift_f32": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
+    "dpft_bn_act_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),
+    "dpft_bn_relu_maxpool_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_bn_relu_maxpool_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_bn_bwd_reduce_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dpft_bn_bwd_apply_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dpft_relu_bwd_f32": (_I, [_P, _P, _P, _L, _P]),
+    "dpft_add_inplace_f32": (_I, [_P, _P, _L, _P]),
+    "dpft_fpn_topdown_add_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_fpn_topdown_add_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_add_pos_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dpft_msda_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_msda_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_xattn_fwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dpft_xattn_bwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "dpft_giou3d_yaw_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+}
+
+
+class _Lib:
+    """Lazy loader so that importing the package (host logic, state-dict plumbing) works on a
+    machine where the library has not been built; any *use* without it raises."""
+
+    def __init__(self):
+        self._dll = None
+
+    def load(self):
+        if self._dll is None:
+            if not os.path.exists(LIB_PATH):
+                raise HipLibraryError(
+                    f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C dpft_amd/csrc`. dpft_amd has no CPU/PyTorch fallback.")
+            dll = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(dll, name)
+                fn.restype, fn.argtypes = res, args
+            self._dll = dll
+        return self._dll
+
+    def __getattr__(self, name):
+        return getattr(self.load(), name)
+
+    def call(self, name: str, *args):
+        rc = getattr(self.load(), name)(*args)
+        if rc != 0:
+            msg = self._dll.dpft_last_error().decode("utf-8", "replace")
+            raise HipLibraryError(f"{name} failed (code {rc}): {msg}")
+
+
+lib = _Lib()
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Raw device pointer of a contiguous fp32/int64 CUDA tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise HipLibraryError("dpft_amd ops need CUDA (ROCm) tensors; there is no CPU path")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def make_desc(B, H, W, Cin, K, kh, kw, stride, pad) -> ConvDesc:
+    OH = (H + 2 * pad - kh) // stride + 1
+    OW = (W + 2 * pad - kw) // stride + 1
+    return ConvDesc(B, H, W, Cin, K, kh, kw, stride, pad, OH, OW)
+
+
+def make_pyramid(levels: Sequence[torch.Tensor], grads: Optional[Sequence[torch.Tensor]] = None) -> Pyramid:
+    p = Pyramid()
+    p.L = len(levels)
+    for i, l in enumerate(levels):
+        assert l.is_contiguous() and l.dtype == torch.float32
+        p.level[i] = l.data_ptr()
+        p.H[i], p.W[i] = l.shape[1], l.shape[2]
+        p.grad[i] = grads[i].data_ptr() if grads is not None else None
+    return p

@@ -1,0 +1,262 @@
+"""Tensor-level wrappers over the C-ABI: allocate outputs with torch, pass raw pointers.
+
+These are *not* autograd functions; the hand-scheduled forward/backward pipelines in
+``dpft_amd.models`` compose them and expose autograd at module granularity.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from dpft_amd.hip.lib import ConvDesc, lib, make_desc, make_pyramid, ptr, stream
+
+_ws_cache = {}
+
+
+def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
+    """One grow-only scratch buffer per device (split-K partials).  Stream-ordered reuse is safe
+    because every consumer of the scratch is enqueued on the same stream before the next producer."""
+    if nbytes <= 0:
+        return None
+    key = (device.type, device.index)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+class Conv:
+    """Geometry + cached descriptor/workspace size of one convolution problem."""
+    __slots__ = ("desc", "ws_bytes", "tiles", "tile_rows", "B", "H", "W", "C", "K", "kh", "kw", "stride", "pad",
+                 "OH", "OW")
+
+    def __init__(self, B, H, W, Cin, K, kh, kw, stride, pad):
+        self.desc = make_desc(B, H, W, Cin, K, kh, kw, stride, pad)
+        self.B, self.H, self.W, self.C, self.K = B, H, W, Cin, K
+        self.kh, self.kw, self.stride, self.pad = kh, kw, stride, pad
+        self.OH, self.OW = self.desc.OH, self.desc.OW
+        self.ws_bytes = int(lib.dpft_conv2d_workspace_bytes(C.byref(self.desc)))
+        if self.ws_bytes < 0:
+            raise RuntimeError("bad conv descriptor: " + lib.dpft_last_error().decode())
+        tr = C.c_int32(0)
+        self.tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(self.desc), C.byref(tr)))
+        self.tile_rows = tr.value
+
+    @property
+    def M(self):
+        return self.B * self.OH * self.OW
+
+
+_conv_cache = {}
+
+
+def conv_problem(B, H, W, Cin, K, kh, kw, stride, pad) -> Conv:
+    key = (B, H, W, Cin, K, kh, kw, stride, pad)
+    c = _conv_cache.get(key)
+    if c is None:
+        c = _conv_cache[key] = Conv(*key)
+    return c
+
+
+def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False):
+    """x (B,H,W,C) contiguous; w physical [K][kh][kw][C]. pro = (scale, shift, relu) or None.
+    Returns y (B,OH,OW,K) and the per-tile stats tensor (or None)."""
+    y = torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
+    stats = torch.empty((cv.tiles, 2, cv.K), dtype=torch.float32, device=x.device) if want_stats else None
+    ws = workspace(cv.ws_bytes, x.device)
+    ps, psh, prelu = (pro[0], pro[1], int(pro[2])) if pro is not None else (None, None, 0)
+    lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(ps), ptr(psh), prelu,
+             ptr(y), ptr(stats), ptr(ws), stream())
+    return y, stats
+
+
+def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
+    """dx (B,H,W,C); w_t physical [C][kh][kw][K]."""
+    if out is None:
+        out = torch.empty((cv.B, cv.H, cv.W, cv.C), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    ws = workspace(cv.ws_bytes, dy.device)
+    lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate), ptr(ws),
+             stream())
+    return out
+
+
+def conv_wgrad(cv: Conv, x, dy, pro=None):
+    """dw physical [K][kh][kw][C] (returned as a (K,kh,kw,C) tensor)."""
+    dw = torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
+    ws = workspace(cv.ws_bytes, x.device)
+    ps, psh, prelu = (pro[0], pro[1], int(pro[2])) if pro is not None else (None, None, 0)
+    lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(ps), ptr(psh), prelu, ptr(dw),
+             ptr(ws), stream())
+    return dw
+
+
+def weight_transpose(w_khwc: torch.Tensor) -> torch.Tensor:
+    """[K][kh][kw][C] -> [C][kh][kw][K]"""
+    K, kh, kw, Cin = w_khwc.shape
+    wt = torch.empty((Cin, kh, kw, K), dtype=torch.float32, device=w_khwc.device)
+    lib.call("dpft_weight_transpose_f32", ptr(w_khwc), ptr(wt), K, kh * kw, Cin, stream())
+    return wt
+
+
+def bias_grad(dy: torch.Tensor) -> torch.Tensor:
+    K = dy.shape[-1]
+    db = torch.empty((K,), dtype=torch.float32, device=dy.device)
+    lib.call("dpft_bias_grad_f32", ptr(dy), ptr(db), dy.numel() // K, K, stream())
+    return db
+
+
+def bn_stats(y: torch.Tensor, tile_rows: int = 128) -> torch.Tensor:
+    K = y.shape[-1]
+    M = y.numel() // K
+    tiles = (M + tile_rows - 1) // tile_rows
+    stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=y.device)
+    lib.call("dpft_bn_stats_f32", ptr(y), ptr(stats), M, K, tile_rows, stream())
+    return stats
+
+
+def bn_finalize(stats, tile_rows, M, gamma, beta, eps, momentum, running_mean=None, running_var=None):
+    """-> scale, shift, mean, invstd (each (K,)); updates the running buffers in place."""
+    K = gamma.numel()
+    buf = torch.empty((4, K), dtype=torch.float32, device=gamma.device)
+    lib.call("dpft_bn_finalize_f32", ptr(stats), stats.shape[0], tile_rows, M, K, ptr(gamma), ptr(beta),
+             float(eps), float(momentum), ptr(running_mean), ptr(running_var), ptr(buf[2]), ptr(buf[3]),
+             ptr(buf[0]), ptr(buf[1]), stream())
+    return buf[0], buf[1], buf[2], buf[3]
+
+
+def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
+    K = gamma.numel()
+    buf = torch.empty((2, K), dtype=torch.float32, device=gamma.device)
+    lib.call("dpft_bn_eval_scale_shift_f32", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
+             K, ptr(buf[0]), ptr(buf[1]), stream())
+    return buf[0], buf[1]
+
+
+def bn_act(y, scale, shift, res=None, res_scale=None, res_shift=None, relu=True):
+    out = torch.empty_like(y)
+    K = y.shape[-1]
+    lib.call("dpft_bn_act_f32", ptr(y), ptr(scale), ptr(shift), ptr(res), ptr(res_scale), ptr(res_shift), int(relu),
+             ptr(out), y.numel() // K, K, stream())
+    return out
+
+
+def bn_relu_maxpool(y, scale, shift):
+    B, H, W, K = y.shape
+    PH, PW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
+    out = torch.empty((B, PH, PW, K), dtype=torch.float32, device=y.device)
+    lib.call("dpft_bn_relu_maxpool_f32", ptr(y), ptr(scale), ptr(shift), ptr(out), B, H, W, K, PH, PW, stream())
+    return out
+
+
+def bn_relu_maxpool_bwd(y, scale, shift, dout):
+    B, H, W, K = y.shape
+    PH, PW = dout.shape[1], dout.shape[2]
+    dz = torch.empty_like(y)
+    lib.call("dpft_bn_relu_maxpool_bwd_f32", ptr(y), ptr(scale), ptr(shift), ptr(dout), ptr(dz), B, H, W, K, PH, PW,
+             stream())
+    return dz
+
+
+def bn_bwd(y, dout, mean, invstd, gamma, out=None, mask=None):
+    """Full BatchNorm backward (two passes).  mask = (scale, shift) recomputes a fused ReLU.
+    Returns dy, dgamma, dbeta."""
+    K = y.shape[-1]
+    M = y.numel() // K
+    sums = torch.empty((2, K), dtype=torch.float32, device=y.device)
+    ms, msh = (mask[0], mask[1]) if mask is not None else (None, None)
+    lib.call("dpft_bn_bwd_reduce_f32", ptr(y), ptr(dout), ptr(out), ptr(ms), ptr(msh), ptr(mean), ptr(invstd),
+             ptr(sums), M, K, stream())
+    dy = torch.empty_like(y)
+    dg = torch.empty((K,), dtype=torch.float32, device=y.device)
+    db = torch.empty((K,), dtype=torch.float32, device=y.device)
+    lib.call("dpft_bn_bwd_apply_f32", ptr(y), ptr(dout), ptr(out), ptr(ms), ptr(msh), ptr(mean), ptr(invstd),
+             ptr(gamma), ptr(sums), ptr(dy), ptr(dg), ptr(db), M, K, stream())
+    return dy, dg, db
+
+
+def relu_bwd(dout, out):
+    dz = torch.empty_like(dout)
+    lib.call("dpft_relu_bwd_f32", ptr(dout), ptr(out), ptr(dz), dout.numel(), stream())
+    return dz
+
+
+def add_(a, b):
+    lib.call("dpft_add_inplace_f32", ptr(a), ptr(b), a.numel(), stream())
+    return a
+
+
+def fpn_topdown_add_(lat, top):
+    B, H, W, K = lat.shape
+    lib.call("dpft_fpn_topdown_add_f32", ptr(lat), ptr(top), B, H, W, top.shape[1], top.shape[2], K, stream())
+    return lat
+
+
+def fpn_topdown_add_bwd_(dlat, dtop):
+    B, H, W, K = dlat.shape
+    lib.call("dpft_fpn_topdown_add_bwd_f32", ptr(dlat), ptr(dtop), B, H, W, dtop.shape[1], dtop.shape[2], K,
+             stream())
+    return dtop
+
+
+def add_pos_(x, pos_x, pos_y):
+    B, H, W, K = x.shape
+    lib.call("dpft_add_pos_f32", ptr(x), ptr(pos_x), ptr(pos_y), B, H, W, K, stream())
+    return x
+
+
+def msda_fwd(value, shapes, lsi, loc, attn):
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    out = torch.empty((N, Lq, M * D), dtype=torch.float32, device=value.device)
+    lib.call("dpft_msda_fwd_f32", ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(attn), ptr(out), N, S, M, D, Lq,
+             L, P, stream())
+    return out
+
+
+def msda_bwd(value, shapes, lsi, loc, attn, grad_out):
+    N, S, M, D = value.shape
+    _, Lq, _, L, P, _ = loc.shape
+    gv = torch.zeros_like(value)
+    gl = torch.empty_like(loc)
+    ga = torch.empty_like(attn)
+    lib.call("dpft_msda_bwd_f32", ptr(value), ptr(shapes), ptr(lsi), ptr(loc), ptr(attn), ptr(grad_out), ptr(gv),
+             ptr(gl), ptr(ga), N, S, M, D, Lq, L, P, stream())
+    return gv, gl, ga
+
+
+def xattn_fwd(levels: Sequence[torch.Tensor], ref, off, attn, Wv, bv, n_heads: int, n_points: int):
+    B, Q, _ = ref.shape
+    Cm = levels[0].shape[-1]
+    D = Cm // n_heads
+    pyr = make_pyramid(levels)
+    out = torch.empty((B, Q, Cm), dtype=torch.float32, device=ref.device)
+    samp = torch.empty((B, Q, n_heads, Cm), dtype=torch.float32, device=ref.device)
+    mass = torch.empty((B, Q, n_heads), dtype=torch.float32, device=ref.device)
+    lib.call("dpft_xattn_fwd_f32", C.byref(pyr), ptr(ref), ptr(off), ptr(attn), ptr(Wv), ptr(bv), ptr(out),
+             ptr(samp), ptr(mass), B, Q, n_heads, D, n_points, stream())
+    return out, samp, mass
+
+
+def xattn_bwd(levels, level_grads, ref, off, attn, Wv, bv, grad_out, n_heads: int, n_points: int):
+    B, Q, _ = ref.shape
+    D = levels[0].shape[-1] // n_heads
+    pyr = make_pyramid(levels, level_grads)
+    goff = torch.empty_like(off)
+    gattn = torch.empty_like(attn)
+    gref = torch.empty_like(ref)
+    lib.call("dpft_xattn_bwd_f32", C.byref(pyr), ptr(ref), ptr(off), ptr(attn), ptr(Wv), ptr(bv), ptr(grad_out),
+             ptr(goff), ptr(gattn), ptr(gref), B, Q, n_heads, D, n_points, stream())
+    return goff, gattn, gref
+
+
+def giou3d_yaw(pred7: torch.Tensor, gt7: torch.Tensor) -> torch.Tensor:
+    """pred (B,N,7), gt (B,M,7) rows (x,y,z,l,w,h,yaw) -> (B,N,M)."""
+    B, N, _ = pred7.shape
+    Mg = gt7.shape[1]
+    out = torch.empty((B, N, Mg), dtype=torch.float32, device=pred7.device)
+    lib.call("dpft_giou3d_yaw_f32", ptr(pred7), ptr(gt7), ptr(out), B, N, Mg, stream())
+    return out

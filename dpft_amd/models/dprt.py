@@ -1,0 +1,97 @@
+"""Dual Perspective Radar Transformer -- top-level module.
+
+Mirror of ``src/dprt/models/dprt.py`` (DPRT :67-244): same constructor, ``from_config``, batch-dict
+contract (``X``, ``X_shape``, ``label_to_X_t``, ``label_to_X_p`` per input) and output dict
+(``center, size, angle, class``), same ``state_dict`` names.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Callable, Dict, List, Tuple
+
+import torch
+from torch import nn
+
+from dpft_amd.models.backbones import build_backbone
+from dpft_amd.models.embeddings import build_embedding
+from dpft_amd.models.fusers import build_fuser
+from dpft_amd.models.heads import build_head
+from dpft_amd.models.necks import build_neck
+from dpft_amd.models.queries import build_querent
+
+
+def _build_module(build_fn: Callable, module_name: str, config: Dict[str, Any], computing: Dict[str, Any],
+                  *args, **kwargs) -> nn.Module:
+    module = config.get(module_name)
+    if module is not None:
+        return build_fn(module["name"], dict(computing | module), *args, **kwargs)
+    return None
+
+
+def _build_modules(build_fn: Callable, module_name: str, config: Dict[str, Any], computing: Dict[str, Any],
+                   *args, **kwargs) -> Dict[str, nn.Module]:
+    modules = config.get(module_name)
+    if modules is not None:
+        return {k: _build_module(build_fn, k, modules, computing, *args, **kwargs) for k in modules.keys()}
+    return None
+
+
+class DPRT(nn.Module):
+    def __init__(self, inputs: List[str], skiplinks: Dict[str, bool] = None,
+                 backbones: Dict[str, nn.Module] = None, necks: Dict[str, nn.Module] = None,
+                 embeddings: Dict[str, nn.Module] = None, querent: nn.Module = None, fuser: nn.Module = None,
+                 head: nn.Module = None, **kwargs):
+        super().__init__()
+        self.inputs = inputs
+        self.skiplinks = skiplinks if skiplinks is not None else {}
+        self.skiplinks = {i: self.skiplinks.get(i, False) for i in inputs}
+        self.backbones = self._init_unspecified(backbones if backbones is not None else {})
+        self.necks = self._init_unspecified(necks if necks is not None else {})
+        self.embeddings = self._init_unspecified(embeddings if embeddings is not None else {})
+        self.querent = self._module_or_identity(querent)
+        self.fuser = self._module_or_identity(fuser)
+        self.head = self._module_or_identity(head)
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]) -> "DPRT":
+        computing, model = config["computing"], config["model"]
+        head = _build_module(build_head, "head", model, computing)
+        fuser = _build_module(build_fuser, "fuser", model, computing, head=head)
+        return cls(inputs=model.get("inputs"), skiplinks=model.get("skiplinks"),
+                   backbones=_build_modules(build_backbone, "backbones", model, computing),
+                   necks=_build_modules(build_neck, "necks", model, computing),
+                   embeddings=_build_modules(build_embedding, "embeddings", model, computing),
+                   querent=_build_module(build_querent, "querent", model, computing),
+                   fuser=fuser, head=head)
+
+    def _init_unspecified(self, submodule: Dict[str, nn.Module]) -> nn.ModuleDict:
+        return nn.ModuleDict({i: self._module_or_identity(submodule.get(i)) for i in self.inputs})
+
+    @staticmethod
+    def _module_or_identity(module: nn.Module = None) -> nn.Module:
+        return module if module is not None else nn.Identity()
+
+    @staticmethod
+    def _add_raw_data(features: "OrderedDict[str, torch.Tensor]", raw_data: torch.Tensor):
+        features["0"] = raw_data
+        features.move_to_end("0", last=False)
+        return features
+
+    @staticmethod
+    def _get_projetions(inputs: List[str], batch: Dict[str, torch.Tensor]) -> List[Tuple[torch.Tensor, torch.Tensor]]:
+        return [(batch[f"label_to_{i}_t"], batch[f"label_to_{i}_p"]) for i in inputs]
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
+        shapes = {i: batch[f"{i}_shape"] for i in self.inputs}
+        features = {i: self.backbones[i](batch[i]) for i in self.inputs}
+        features = {i: self._add_raw_data(features[i], batch[i]) for i in self.inputs if self.skiplinks[i]}
+        features = {i: self.necks[i](features[i]) for i in self.inputs}
+        features = {i: self.embeddings[i](features[i]) for i in self.inputs}
+        out = self.querent(batch)
+        return self.fuser(batch=[features[i] for i in self.inputs],
+                          shape=[shapes[i][:, :2] for i in self.inputs],
+                          projection=self._get_projetions(self.inputs, batch), out=out)
+
+
+def build_dprt(*args, **kwargs):
+    return DPRT.from_config(*args, **kwargs)

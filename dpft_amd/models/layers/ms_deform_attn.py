@@ -1,0 +1,192 @@
+"""Multi-scale deformable attention module, MI355X-native.
+
+Mirror of ``src/dprt/models/layers/ms_deform_attn.py`` (MSDeformAttnFunction :27-68, MSDeformAttn
+:71-217): same parameters / init (``sampling_offsets``, ``attention_weights``, ``value_proj``,
+``output_proj``), same ``forward`` signature, plus the fused hot path ``forward_levels`` that reads
+the NHWC FPN levels in place ("sample-then-project", include/dpft_hip.h dpft_xattn_*), which is
+what ``MLFusion.forward_cross_attn`` uses.
+"""
+from __future__ import annotations
+
+import math
+import warnings
+from typing import List, Sequence
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.init import constant_, xavier_uniform_
+
+from dpft_amd.hip import ops
+
+
+class MSDeformAttnFunction(Function):
+    """Operator-level drop-in for the MSDA extension (ms_deform_attn.py:27-68) on the C-ABI."""
+
+    @staticmethod
+    def forward(ctx, value, value_spatial_shapes, value_level_start_index, sampling_locations,
+                attention_weights, im2col_step):
+        ctx.im2col_step = im2col_step
+        value, sampling_locations = value.contiguous(), sampling_locations.contiguous()
+        attention_weights = attention_weights.contiguous()
+        shapes = value_spatial_shapes.to(torch.int64).contiguous()
+        lsi = value_level_start_index.to(torch.int64).contiguous()
+        out = ops.msda_fwd(value, shapes, lsi, sampling_locations, attention_weights)
+        ctx.save_for_backward(value, shapes, lsi, sampling_locations, attention_weights)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        value, shapes, lsi, loc, attn = ctx.saved_tensors
+        gv, gl, ga = ops.msda_bwd(value, shapes, lsi, loc, attn, grad_output.contiguous())
+        return gv, None, None, gl, ga, None
+
+
+class PyramidState:
+    """One view's FPN pyramid for one forward pass: detached level tensors shared by every
+    cross-attention call of the pass + lazily zero-initialised gradient buffers that all of those
+    calls accumulate into (fp32 atomics), handed to autograd exactly once by ``_PyramidHub``."""
+
+    def __init__(self, levels: Sequence[torch.Tensor]):
+        self.levels = [l.detach().contiguous() for l in levels]
+        self.grads = None
+
+    def grad_buffers(self) -> List[torch.Tensor]:
+        if self.grads is None:
+            self.grads = [torch.zeros_like(l) for l in self.levels]
+        return self.grads
+
+
+class _PyramidHub(Function):
+    @staticmethod
+    def forward(ctx, state: PyramidState, *levels):
+        ctx.state = state
+        ctx.n = len(levels)
+        return levels[0].new_zeros(())
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        g = ctx.state.grads
+        ctx.state.grads = None
+        return (None, *(g if g is not None else [None] * ctx.n))
+
+
+def make_pyramid_state(levels: Sequence[torch.Tensor]):
+    """-> (state, token).  ``token`` threads the autograd dependency from every cross-attention
+    call back to the level tensors."""
+    state = PyramidState(levels)
+    token = _PyramidHub.apply(state, *levels)
+    return state, token
+
+
+class _XAttnFn(Function):
+    @staticmethod
+    def forward(ctx, state: PyramidState, token, ref, off, attn, Wv, bv, n_heads: int, n_points: int):
+        ref, off, attn = ref.contiguous(), off.contiguous(), attn.contiguous()
+        Wv, bv = Wv.contiguous(), bv.contiguous()
+        out, samp, mass = ops.xattn_fwd(state.levels, ref, off, attn, Wv, bv, n_heads, n_points)
+        ctx.state, ctx.n_heads, ctx.n_points = state, n_heads, n_points
+        ctx.save_for_backward(ref, off, attn, Wv, bv, samp, mass)
+        return out
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, gout):
+        ref, off, attn, Wv, bv, samp, mass = ctx.saved_tensors
+        state = ctx.state
+        gout = gout.contiguous()
+        goff, gattn, gref = ops.xattn_bwd(state.levels, state.grad_buffers(), ref, off, attn, Wv, bv, gout,
+                                          ctx.n_heads, ctx.n_points)
+        B, Q, C = gout.shape
+        M = ctx.n_heads
+        g4 = gout.view(B, Q, M, C // M)
+        gWv = torch.einsum("bqmd,bqmc->mdc", g4, samp).reshape(C, C)
+        gbv = torch.einsum("bqmd,bqm->md", g4, mass).reshape(C)
+        gtoken = torch.zeros((), dtype=gout.dtype, device=gout.device)
+        return None, gtoken, gref, goff, gattn, gWv, gbv, None, None
+
+
+def _is_power_of_2(n):
+    if (not isinstance(n, int)) or (n < 0):
+        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
+    return (n & (n - 1) == 0) and n != 0
+
+
+class MSDeformAttn(nn.Module):
+    def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        if d_model % n_heads != 0:
+            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
+        if not _is_power_of_2(d_model // n_heads):
+            warnings.warn("d_model // n_heads should be a power of 2")
+        self.im2col_step = 64
+        self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
+        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = nn.Linear(d_model, d_model)
+        self.output_proj = nn.Linear(d_model, d_model)
+        self._reset_parameters()
+
+    def _reset_parameters(self):
+        # ms_deform_attn.py:117-136
+        constant_(self.sampling_offsets.weight.data, 0.)
+        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
+        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2) \
+            .repeat(1, self.n_levels, self.n_points, 1)
+        for i in range(self.n_points):
+            grid_init[:, :, i, :] *= i + 1
+        with torch.no_grad():
+            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
+        constant_(self.attention_weights.weight.data, 0.)
+        constant_(self.attention_weights.bias.data, 0.)
+        xavier_uniform_(self.value_proj.weight.data)
+        constant_(self.value_proj.bias.data, 0.)
+        xavier_uniform_(self.output_proj.weight.data)
+        constant_(self.output_proj.bias.data, 0.)
+
+    def _offsets_and_weights(self, query):
+        N, Len_q, _ = query.shape
+        off = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        aw = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
+        aw = F.softmax(aw, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
+        return off, aw
+
+    def forward_levels(self, query, reference_points, state: PyramidState, token):
+        """Fused hot path.  query (N,Lq,C) [with pos]; reference_points (N,Lq,2) (the same 2-D point is
+        used for every level, mpfusion.py:190); state/token from ``make_pyramid_state``."""
+        assert len(state.levels) == self.n_levels
+        off, aw = self._offsets_and_weights(query)
+        out = _XAttnFn.apply(state, token, reference_points, off, aw, self.value_proj.weight,
+                             self.value_proj.bias, self.n_heads, self.n_points)
+        return self.output_proj(out)
+
+    def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
+                input_padding_mask=None):
+        """Reference signature (ms_deform_attn.py:138-217) on the operator-level C-ABI."""
+        N, Len_q, _ = query.shape
+        N, Len_in, _ = input_flatten.shape
+        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
+        assert reference_points.shape[2] == input_spatial_shapes.shape[0] == \
+            input_level_start_index.shape[0] == self.n_levels
+        value = self.value_proj(input_flatten)
+        if input_padding_mask is not None:
+            value = value.masked_fill(input_padding_mask[..., None], float(0))
+        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
+        sampling_offsets, attention_weights = self._offsets_and_weights(query)
+        if reference_points.shape[-1] == 2:
+            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
+            sampling_locations = reference_points[:, :, None, :, None, :] \
+                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
+        elif reference_points.shape[-1] == 4:
+            sampling_locations = reference_points[:, :, None, :, None, :2] \
+                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+        else:
+            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
+                             .format(reference_points.shape[-1]))
+        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
+                                            sampling_locations, attention_weights, self.im2col_step)
+        return self.output_proj(output)

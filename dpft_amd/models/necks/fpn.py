@@ -1,0 +1,113 @@
+"""Feature Pyramid Network neck, MI355X-native.
+
+Mirror of ``src/dprt/models/necks/fpn.py`` (FPN :11-83) around torchvision's
+``FeaturePyramidNetwork(in_channels_list, out_channels, norm_layer=None)``: state-dict names
+``fpn.inner_blocks.{i}.0.{weight,bias}`` (1x1) and ``fpn.layer_blocks.{i}.0.{weight,bias}`` (3x3,
+pad 1); kaiming_uniform_(a=1) weights, zero bias; NHWC in / NHWC out.  One autograd node with a
+hand-scheduled backward over the HIP conv / top-down kernels.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Any, Dict, List, Optional
+
+import torch
+from torch import nn
+
+from dpft_amd.hip import ops
+from dpft_amd.models.backbones.resnet import khwc
+
+
+def _fpn_conv(cin, cout, k, pad) -> nn.Sequential:
+    conv = nn.Conv2d(cin, cout, k, padding=pad, bias=True)
+    nn.init.kaiming_uniform_(conv.weight, a=1)
+    nn.init.constant_(conv.bias, 0)
+    conv.weight.data = conv.weight.data.contiguous(memory_format=torch.channels_last)
+    return nn.Sequential(conv)          # Conv2dNormActivation without norm/activation => key ".0."
+
+
+class FeaturePyramidNetwork(nn.Module):
+    def __init__(self, in_channels_list: List[int], out_channels: int):
+        super().__init__()
+        self.inner_blocks = nn.ModuleList([_fpn_conv(c, out_channels, 1, 0) for c in in_channels_list])
+        self.layer_blocks = nn.ModuleList([_fpn_conv(out_channels, out_channels, 3, 1) for _ in in_channels_list])
+        self.out_channels = out_channels
+
+
+class _FPNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fpn: FeaturePyramidNetwork, n: int, *tensors: torch.Tensor):
+        xs = [t.contiguous() for t in tensors[:n]]
+        K = fpn.out_channels
+        lasts, outs, ci, cl = [None] * n, [None] * n, [None] * n, [None] * n
+        for i in range(n - 1, -1, -1):
+            B, H, W, C = xs[i].shape
+            ci[i] = ops.conv_problem(B, H, W, C, K, 1, 1, 1, 0)
+            conv = fpn.inner_blocks[i][0]
+            lat, _ = ops.conv_fwd(ci[i], xs[i], khwc(conv.weight), bias=conv.bias)
+            if i < n - 1:
+                ops.fpn_topdown_add_(lat, lasts[i + 1])
+            lasts[i] = lat
+            cl[i] = ops.conv_problem(B, H, W, K, K, 3, 3, 1, 1)
+            conv = fpn.layer_blocks[i][0]
+            outs[i], _ = ops.conv_fwd(cl[i], lat, khwc(conv.weight), bias=conv.bias)
+        ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl = fpn, n, xs, lasts, ci, cl
+        ctx.params = tensors[n:]
+        ctx.x_needs = [t.requires_grad for t in tensors[:n]]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        fpn, n, xs, lasts, ci, cl = ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl
+        grads: Dict[nn.Parameter, torch.Tensor] = {}
+        dxs: List[Optional[torch.Tensor]] = [None] * n
+        g_prev = None
+        for i in range(n):
+            conv = fpn.layer_blocks[i][0]
+            if douts[i] is None:
+                g = torch.zeros_like(lasts[i])
+            else:
+                do = douts[i].contiguous()
+                grads[conv.weight] = ops.conv_wgrad(cl[i], lasts[i], do).permute(0, 3, 1, 2)
+                grads[conv.bias] = ops.bias_grad(do)
+                g = ops.conv_dgrad(cl[i], do, ops.weight_transpose(khwc(conv.weight)))
+            if g_prev is not None:
+                ops.fpn_topdown_add_bwd_(g_prev, g)       # grad(last_i) += upsample_bwd(grad(last_{i-1}))
+            conv = fpn.inner_blocks[i][0]
+            grads[conv.weight] = ops.conv_wgrad(ci[i], xs[i], g).permute(0, 3, 1, 2)
+            grads[conv.bias] = ops.bias_grad(g)
+            if ctx.x_needs[i]:
+                dxs[i] = ops.conv_dgrad(ci[i], g, ops.weight_transpose(khwc(conv.weight)))
+            g_prev = g
+        return (None, None, *dxs, *[grads.get(p) for p in ctx.params])
+
+
+class FPN(nn.Module):
+    def __init__(self, in_channels_list: List[int], out_channels: int, norm_layer=None,
+                 channel_last: bool = True, **kwargs):
+        super().__init__()
+        if norm_layer is not None:
+            raise ValueError("dpft_amd FPN: norm_layer is not supported (no reference config uses it)")
+        self.in_channels_list = in_channels_list
+        self.out_channels = out_channels
+        self.channel_last = channel_last
+        self.fpn = FeaturePyramidNetwork(in_channels_list, out_channels)
+
+    @classmethod
+    def from_config(cls, config: Dict[str, Any]):
+        return cls(config["in_channels_list"], config["out_channels"], config.get("norm_layer"))
+
+    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        keys = list(batch.keys())
+        xs = list(batch.values())
+        if not self.channel_last:
+            xs = [x.movedim(1, -1) for x in xs]
+        outs = _FPNFn.apply(self.fpn, len(xs), *xs, *self.fpn.parameters())
+        if not self.channel_last:
+            outs = [o.movedim(-1, 1) for o in outs]
+        return OrderedDict(zip(keys, outs))
+
+
+def build_fpn(name: str, *args, **kwargs):
+    if "fpn" in name.lower():
+        return FPN.from_config(*args, **kwargs)

@@ -1,0 +1,204 @@
+/* dpft_hip.h -- C-ABI of libdpft_hip.so (gfx950 / MI355X).
+ *
+ * This is the drop-in boundary for the DPFT hot path.  Every entry point is a
+ * plain C function over raw device pointers + sizes + a hipStream_t; no torch types.  Rules:
+ *   - the caller owns every buffer (inputs, outputs, workspaces); nothing is allocated inside;
+ *   - no hidden synchronisation: every call only enqueues work on `stream` (graph-capturable);
+ *   - re-entrant and stream-ordered;
+ *   - return 0 on success, a negative code otherwise; dpft_last_error() returns the message of
+ *     the last failure on the calling thread (the Python side raises RuntimeError from it).
+ *
+ * Reference interfaces replaced (paths relative to the TUMFTM/DPFT checkout):
+ *   dpft_msda_fwd_f32 / dpft_msda_bwd_f32
+ *       MSDA.ms_deform_attn_forward / ms_deform_attn_backward, the only native seam the
+ *       reference has: src/dprt/models/layers/ms_deform_attn.py:24,32-39,58-66.
+ *   dpft_xattn_fwd_f32 / dpft_xattn_bwd_f32
+ *       the flatten+cat -> value_proj -> MSDA core chain of MLFusion.forward_cross_attn /
+ *       MSDeformAttn.forward: src/dprt/models/fusers/mpfusion.py:150-208 and
+ *       src/dprt/models/layers/ms_deform_attn.py:172-213 ("sample-then-project", reads the
+ *       NHWC FPN levels in place).
+ *   dpft_conv2d_nhwc_{fwd,dgrad,wgrad}_f32, dpft_bn_*, dpft_maxpool_*, dpft_bn_add_relu_*
+ *       the cuDNN kernels torch dispatches for the torchvision ResNet body and FPN:
+ *       src/dprt/models/backbones/resnet.py:47-55,80-107, src/dprt/models/necks/fpn.py:39-43,70-83.
+ *   dpft_fpn_topdown_*, dpft_add_pos_*
+ *       F.interpolate(nearest)+add inside torchvision FPN, and the in-place sinusoidal
+ *       embedding src/dprt/models/embeddings/sinusoidal.py:63-110.
+ *   dpft_giou3d_yaw_f32
+ *       pytorch3d.ops.box3d_overlap as used by src/dprt/utils/iou.py:121-210.
+ */
+#ifndef DPFT_HIP_H
+#define DPFT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPFT_OK 0
+#define DPFT_ERR_ARG (-1)
+#define DPFT_ERR_LAUNCH (-2)
+#define DPFT_ERR_UNSUPPORTED (-3)
+
+typedef void* dpft_stream_t; /* hipStream_t */
+
+int dpft_version(void);
+const char* dpft_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Convolution family: NHWC activations, weights physically [Cout][kh][kw][Cin]
+ * (= torch OIHW tensor in channels_last memory format), fp32, MFMA implicit GEMM.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dpft_conv_desc {
+    int32_t B, H, W, C;      /* input  (B,H,W,C)                      */
+    int32_t K;               /* output channels                       */
+    int32_t kh, kw, stride, pad;
+    int32_t OH, OW;          /* output spatial size                   */
+} dpft_conv_desc;
+
+/* bytes of workspace dpft_conv2d_* may need for this problem (split-K partials); may be 0 */
+int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d);
+/* number of M-tiles the forward kernel uses for its fused BN-statistics epilogue
+ * (rows of the `stats` buffer: stats is [mtiles][2][K] floats = per-tile mean and M2);
+ * *tile_rows receives the tile height so the caller can recover per-tile counts. */
+int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows);
+
+/* y[B,OH,OW,K] = conv(act(x), w) (+bias).  Optional fused prologue on the input operand:
+ * act(x) = max(x*pro_scale[c] + pro_shift[c], 0) (BatchNorm-apply + ReLU of the producer),
+ * enabled when pro_scale != NULL (pro_relu selects the max).  Optional fused epilogue: per-M-tile
+ * per-channel (mean, M2) of y into `stats` for train-mode BatchNorm (NULL to skip). */
+int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x, const float* w,
+                             const float* bias, const float* pro_scale, const float* pro_shift,
+                             int32_t pro_relu, float* y, float* stats, void* workspace,
+                             dpft_stream_t stream);
+/* dx[B,H,W,C] (+)= conv_transpose(dy, w).  w_t is the transposed weight [C][kh][kw][K]
+ * (see dpft_weight_transpose_f32); accumulate != 0 adds into dx instead of overwriting it. */
+int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,
+                               float* dx, int32_t accumulate, void* workspace,
+                               dpft_stream_t stream);
+/* dw[K][kh][kw][C] = sum_pixels dy (x) act(x); same optional prologue on x as forward.
+ * dw is overwritten. */
+int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,
+                               const float* pro_scale, const float* pro_shift, int32_t pro_relu,
+                               float* dw, void* workspace, dpft_stream_t stream);
+/* [K][taps][C] -> [C][taps][K] */
+int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, int32_t taps, int32_t C,
+                              dpft_stream_t stream);
+/* db[K] = sum over rows of dy[M][K] */
+int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * BatchNorm (train + eval), ReLU, residual, max-pool on NHWC fp32
+ * ---------------------------------------------------------------------------------------- */
+/* standalone per-tile statistics of y[M][K] in the same [tiles][2][K] format (tile_rows rows each) */
+int dpft_bn_stats_f32(const float* y, float* stats, int64_t M, int32_t K, int32_t tile_rows,
+                      dpft_stream_t stream);
+/* combine tiles (Chan), produce scale = gamma*invstd, shift = beta - mean*scale, save mean/invstd,
+ * update running stats (momentum; unbiased variance) when running_mean != NULL. */
+int dpft_bn_finalize_f32(const float* stats, int32_t tiles, int32_t tile_rows, int64_t M, int32_t K,
+                         const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, float* save_mean,
+                         float* save_invstd, float* scale, float* shift, dpft_stream_t stream);
+/* eval mode: scale/shift from running statistics */
+int dpft_bn_eval_scale_shift_f32(const float* gamma, const float* beta, const float* running_mean,
+                                 const float* running_var, float eps, int32_t K, float* scale,
+                                 float* shift, dpft_stream_t stream);
+/* out = [relu]( y*scale + shift  [+ (res*res_scale + res_shift | res)] ) elementwise over [M][K] */
+int dpft_bn_act_f32(const float* y, const float* scale, const float* shift, const float* res,
+                    const float* res_scale, const float* res_shift, int32_t relu, float* out,
+                    int64_t M, int32_t K, dpft_stream_t stream);
+/* stem: out[B,PH,PW,K] = maxpool3x3s2p1( relu(y*scale+shift) ), y is [B,H,W,K] */
+int dpft_bn_relu_maxpool_f32(const float* y, const float* scale, const float* shift, float* out,
+                             int32_t B, int32_t H, int32_t W, int32_t K, int32_t PH, int32_t PW,
+                             dpft_stream_t stream);
+/* backward of the stem pool + ReLU: dz[B,H,W,K] = grad wrt bn(y) = (relu(bn(y))>0) * sum of dout over
+ * the pool windows whose first arg-max (scan order, strict >) is this pixel */
+int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* scale, const float* shift,
+                                 const float* dout, float* dz, int32_t B, int32_t H, int32_t W,
+                                 int32_t K, int32_t PH, int32_t PW, dpft_stream_t stream);
+/* BatchNorm backward, two passes.  dz = dout * mask with
+ *   mask = (out > 0)                          if out != NULL        (out = post-activation tensor)
+ *   mask = (y*mask_scale + mask_shift > 0)    elif mask_scale != NULL (recompute the fused ReLU)
+ *   mask = 1                                  otherwise.
+ * pass 1: sums[0][k] = sum dz, sums[1][k] = sum dz * xhat   (xhat = (y-mean)*invstd) */
+int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const float* out,
+                           const float* mask_scale, const float* mask_shift, const float* mean,
+                           const float* invstd, float* sums, int64_t M, int32_t K,
+                           dpft_stream_t stream);
+/* pass 2: dy = gamma*invstd*(dz - sums0/M - xhat*sums1/M); dgamma = sums1, dbeta = sums0 */
+int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const float* out,
+                          const float* mask_scale, const float* mask_shift, const float* mean,
+                          const float* invstd, const float* gamma, const float* sums, float* dy,
+                          float* dgamma, float* dbeta, int64_t M, int32_t K, dpft_stream_t stream);
+/* dz = dout * (out > 0)  (residual branch gradient) */
+int dpft_relu_bwd_f32(const float* dout, const float* out, float* dz, int64_t n,
+                      dpft_stream_t stream);
+/* a += b */
+int dpft_add_inplace_f32(float* a, const float* b, int64_t n, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * FPN glue + positional embedding
+ * ---------------------------------------------------------------------------------------- */
+/* lat[B,H,W,K] += nearest_upsample(top[B,TH,TW,K]) with src = min(floor(dst*in/out), in-1) */
+int dpft_fpn_topdown_add_f32(float* lat, const float* top, int32_t B, int32_t H, int32_t W,
+                             int32_t TH, int32_t TW, int32_t K, dpft_stream_t stream);
+/* dtop[B,TH,TW,K] += sum of dlat over the pixels that map to each source pixel */
+int dpft_fpn_topdown_add_bwd_f32(const float* dlat, float* dtop, int32_t B, int32_t H, int32_t W,
+                                 int32_t TH, int32_t TW, int32_t K, dpft_stream_t stream);
+/* x[B,H,W,K] += pos_x[W][K]; x += pos_y[H][K]  (two fp32 adds in the reference's order) */
+int dpft_add_pos_f32(float* x, const float* pos_x, const float* pos_y, int32_t B, int32_t H,
+                     int32_t W, int32_t K, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Multi-scale deformable attention
+ * ---------------------------------------------------------------------------------------- */
+/* Operator-level drop-in for the MSDA extension (same tensor semantics):
+ * value (N,S,M,D) f32; shapes (L,2) int64 [H,W]; lsi (L) int64; loc (N,Lq,M,L,P,2) f32 (x,y in
+ * [0,1]); attn (N,Lq,M,L,P) f32; out (N,Lq,M*D). */
+int dpft_msda_fwd_f32(const float* value, const int64_t* shapes, const int64_t* lsi,
+                      const float* loc, const float* attn, float* out, int32_t N, int32_t S,
+                      int32_t M, int32_t D, int32_t Lq, int32_t L, int32_t P, dpft_stream_t stream);
+/* grad_value must be zero-filled by the caller (atomics accumulate into it). */
+int dpft_msda_bwd_f32(const float* value, const int64_t* shapes, const int64_t* lsi,
+                      const float* loc, const float* attn, const float* grad_out,
+                      float* grad_value, float* grad_loc, float* grad_attn, int32_t N, int32_t S,
+                      int32_t M, int32_t D, int32_t Lq, int32_t L, int32_t P, dpft_stream_t stream);
+
+#define DPFT_MAX_LEVELS 8
+typedef struct dpft_pyramid {
+    const float* level[DPFT_MAX_LEVELS]; /* (B,H_l,W_l,C) NHWC, C = d_model */
+    float* grad[DPFT_MAX_LEVELS];        /* same shapes, accumulated into (backward only) */
+    int32_t H[DPFT_MAX_LEVELS], W[DPFT_MAX_LEVELS];
+    int32_t L;
+} dpft_pyramid;
+
+/* Fused sample-then-project cross attention (C = M*D <= 64, L*P <= 32):
+ *   samp[b,q,m,:C]  = sum_{l,p} attn * bilinear(level_l, ref + off/(W_l,H_l))     (raw features)
+ *   mass[b,q,m]     = sum_{l,p} attn * (in-bounds bilinear weight mass)
+ *   out[b,q,m*D+d]  = Wv[m*D+d,:] . samp[b,q,m,:] + bv[m*D+d] * mass[b,q,m]
+ * which equals value_proj -> MSDA core of the reference (SURVEY App. C fusion identity).
+ * ref (B,Q,2) (u,v); off (B,Q,M,L,P,2) raw sampling_offsets output; attn (B,Q,M,L,P) softmaxed.
+ * samp (B,Q,M,C) and mass (B,Q,M) are saved for backward. */
+int dpft_xattn_fwd_f32(const dpft_pyramid* pyr, const float* ref, const float* off,
+                       const float* attn, const float* Wv, const float* bv, float* out,
+                       float* samp, float* mass, int32_t B, int32_t Q, int32_t M, int32_t D,
+                       int32_t P, dpft_stream_t stream);
+/* grad_off/grad_attn/grad_ref are overwritten (grad_ref may be NULL); pyr->grad[] are accumulated
+ * into with fp32 atomics (caller zero-fills).  Gradients of Wv/bv are tiny reductions of
+ * grad_out (x) samp / mass and are left to the host framework. */
+int dpft_xattn_bwd_f32(const dpft_pyramid* pyr, const float* ref, const float* off,
+                       const float* attn, const float* Wv, const float* bv, const float* grad_out,
+                       float* grad_off, float* grad_attn, float* grad_ref, int32_t B, int32_t Q,
+                       int32_t M, int32_t D, int32_t P, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Matcher cost helper: GIoU3D of yaw-only boxes, (B,N) predictions x (B,Mg) targets.
+ * boxes are (x,y,z,l,w,h,yaw) rows of 7 floats; out (B,N,Mg).
+ * ---------------------------------------------------------------------------------------- */
+int dpft_giou3d_yaw_f32(const float* pred, const float* gt, float* out, int32_t B, int32_t N,
+                        int32_t Mg, dpft_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPFT_HIP_H */

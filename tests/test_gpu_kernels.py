@@ -1,0 +1,292 @@
+"""Parity of every HIP kernel (through the C-ABI) against torch-CPU restatements of the same op.
+fp32 kernels vs fp64 CPU references; tolerance rtol 1e-4, atol 1e-5*max|ref|."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def close(a, b, rtol=1e-4, atol_scale=1e-5, what=""):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    atol = atol_scale * max(float(b.abs().max()), 1e-6)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+def _ops():
+    from dpft_amd.hip import ops
+    return ops
+
+
+CONV_CASES = [
+    # B, H, W, C, K, k, stride, pad
+    (2, 9, 13, 64, 128, 1, 1, 0),
+    (2, 12, 10, 64, 64, 3, 1, 1),
+    (2, 13, 11, 128, 128, 3, 2, 1),
+    (2, 13, 11, 256, 512, 1, 2, 0),
+    (2, 37, 43, 3, 64, 7, 2, 3),        # stem (generic gather path)
+    (2, 19, 23, 16, 16, 3, 1, 1),       # FPN layer block
+    (2, 19, 23, 6, 16, 1, 1, 0),        # FPN lateral on the raw radar input
+    (2, 5, 7, 2048, 16, 1, 1, 0),       # FPN lateral on layer4
+    (2, 21, 17, 6, 3, 1, 1, 0),         # radar adjustment layer
+    (4, 32, 57, 256, 256, 3, 1, 1),     # camera layer3 conv2 at the bench shape
+    (4, 8, 4, 512, 512, 3, 1, 1),       # radar layer4: split-K
+    (4, 16, 7, 1024, 256, 1, 1, 0),     # small M, long K
+    (1, 128, 228, 64, 256, 1, 1, 0),    # big M
+]
+
+
+def _conv_ref(x, w, bias, stride, pad, pro):
+    xd = x.double()
+    if pro is not None:
+        xd = xd * pro[0].double() + pro[1].double()
+        if pro[2]:
+            xd = xd.clamp_min(0)
+    xa = xd.permute(0, 3, 1, 2).requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    y = F.conv2d(xa, wd, None if bias is None else bias.double(), stride=stride, padding=pad)
+    return xa, wd, y
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("fused", [False, True])
+def test_conv_fwd_dgrad_wgrad(case, fused):
+    ops = _ops()
+    B, H, W, C, K, k, stride, pad = case
+    g = torch.Generator().manual_seed(hash(case) % 1000)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = (torch.randn(K, C, k, k, generator=g) / (C * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    use_pro = fused and C % 32 == 0
+    use_bias = (K == 16) and not fused
+    bias = torch.randn(K, generator=g) if use_bias else None
+    pro = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, True) if use_pro else None
+    xa, wd, yref = _conv_ref(x, w, bias, stride, pad, pro)
+    cv = ops.conv_problem(B, H, W, C, K, k, k, stride, pad)
+    w_dev = w.to(DEV).permute(0, 2, 3, 1)
+    assert w_dev.is_contiguous()
+    prod = None if pro is None else (pro[0].to(DEV), pro[1].to(DEV), True)
+    y, stats = ops.conv_fwd(cv, x.to(DEV), w_dev, bias=None if bias is None else bias.to(DEV), pro=prod,
+                            want_stats=fused and not use_bias)
+    close(y.permute(0, 3, 1, 2), yref, what="conv fwd")
+    if stats is not None:
+        # fused BN statistics: finalize and compare against the batch statistics of the reference
+        gamma, beta = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
+        rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+        sc, sh, mean, invstd = ops.bn_finalize(stats, cv.tile_rows, cv.M, gamma, beta, 1e-5, 0.1, rm, rv)
+        yr = yref.detach().permute(0, 2, 3, 1).reshape(-1, K)
+        close(mean, yr.mean(0), what="bn mean")
+        close(invstd, 1 / torch.sqrt(yr.var(0, unbiased=False) + 1e-5), what="bn invstd")
+        close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), what="running var")
+        close(rm, 0.1 * yr.mean(0), what="running mean")
+    dy = torch.randn(yref.shape, generator=g, dtype=torch.float64)
+    (yref * dy).sum().backward()
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().float().to(DEV)
+    dw = ops.conv_wgrad(cv, x.to(DEV), dy_nhwc, pro=prod)
+    close(dw.permute(0, 3, 1, 2), wd.grad, what="conv wgrad")
+    dx = ops.conv_dgrad(cv, dy_nhwc, ops.weight_transpose(w_dev))
+    close(dx.permute(0, 3, 1, 2), xa.grad, what="conv dgrad")   # grad wrt the (activated) operand
+    # accumulate mode
+    base = torch.randn(B, H, W, C, generator=g).to(DEV)
+    acc = base.clone()
+    ops.conv_dgrad(cv, dy_nhwc, ops.weight_transpose(w_dev), out=acc, accumulate=True)
+    close((acc - base).permute(0, 3, 1, 2), xa.grad, rtol=1e-3, atol_scale=1e-4, what="conv dgrad accumulate")
+
+
+def test_bias_grad_and_transpose():
+    ops = _ops()
+    g = torch.Generator().manual_seed(3)
+    dy = torch.randn(3, 17, 19, 16, generator=g)
+    close(ops.bias_grad(dy.to(DEV)), dy.double().sum((0, 1, 2)), what="bias grad")
+    w = torch.randn(48, 3, 3, 20, generator=g)
+    close(ops.weight_transpose(w.to(DEV)), w.permute(3, 1, 2, 0), rtol=0, atol_scale=0, what="transpose")
+
+
+@pytest.mark.parametrize("shape", [(2, 9, 11, 64), (3, 5, 7, 256), (1, 33, 20, 2048), (4, 16, 29, 512)])
+def test_bn_train_forward_backward(shape):
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    K = shape[-1]
+    y = torch.randn(shape, generator=g) * 3 + torch.randn(K, generator=g) * 5
+    gamma, beta = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    dout = torch.randn(shape, generator=g)
+    res = torch.randn(shape, generator=g)
+    # reference (fp64): out = relu(bn(y) + res)
+    yd = y.double().requires_grad_(True)
+    gd, bd = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    rd = res.double().requires_grad_(True)
+    ref = F.relu(F.batch_norm(yd.permute(0, 3, 1, 2), None, None, gd, bd, training=True, eps=1e-5)
+                 .permute(0, 2, 3, 1) + rd)
+    (ref * dout.double()).sum().backward()
+    M = y.numel() // K
+    yg = y.to(DEV)
+    stats = ops.bn_stats(yg, 128)
+    rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
+    sc, sh, mean, invstd = ops.bn_finalize(stats, 128, M, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm, rv)
+    out = ops.bn_act(yg, sc, sh, res=res.to(DEV), relu=True)
+    close(out, ref, what="bn_act")
+    dy, dg, db = ops.bn_bwd(yg, dout.to(DEV), mean, invstd, gamma.to(DEV), out=out)
+    close(dy, yd.grad, rtol=1e-3, atol_scale=1e-4, what="bn dy")
+    close(dg, gd.grad, rtol=1e-3, atol_scale=1e-4, what="bn dgamma")
+    close(db, bd.grad, rtol=1e-3, atol_scale=1e-4, what="bn dbeta")
+    close(ops.relu_bwd(dout.to(DEV), out), rd.grad, what="relu bwd")
+    # fused-ReLU mask recomputed from (scale, shift): a = relu(bn(y))
+    yd2 = y.double().requires_grad_(True)
+    ref2 = F.relu(F.batch_norm(yd2.permute(0, 3, 1, 2), None, None, gamma.double(), beta.double(),
+                               training=True, eps=1e-5).permute(0, 2, 3, 1))
+    (ref2 * dout.double()).sum().backward()
+    dy2, _, _ = ops.bn_bwd(yg, dout.to(DEV), mean, invstd, gamma.to(DEV), mask=(sc, sh))
+    close(dy2, yd2.grad, rtol=1e-3, atol_scale=1e-4, what="bn dy (mask)")
+    # eval-mode scale/shift
+    sce, she = ops.bn_eval_scale_shift(gamma.to(DEV), beta.to(DEV), rm, rv, 1e-5)
+    ref_e = F.batch_norm(y.double().permute(0, 3, 1, 2), rm.double().cpu(), rv.double().cpu(), gamma.double(),
+                         beta.double(), training=False, eps=1e-5).permute(0, 2, 3, 1)
+    close(ops.bn_act(yg, sce, she, relu=False), ref_e, what="bn eval")
+
+
+@pytest.mark.parametrize("shape", [(2, 19, 27, 64), (1, 8, 8, 64), (2, 37, 54, 64)])
+def test_bn_relu_maxpool(shape):
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    K = shape[-1]
+    y = torch.randn(shape, generator=g)
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    yd = y.double().requires_grad_(True)
+    a = F.relu(yd * sc.double() + sh.double())
+    ref = F.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    out = ops.bn_relu_maxpool(y.to(DEV), sc.to(DEV), sh.to(DEV))
+    close(out, ref, what="maxpool fwd")
+    dout = torch.randn(ref.shape, generator=g)
+    # reference gradient wrt z = y*sc+sh
+    z = (y.double() * sc.double() + sh.double()).requires_grad_(True)
+    r2 = F.max_pool2d(F.relu(z).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
+    (r2 * dout.double()).sum().backward()
+    dz = ops.bn_relu_maxpool_bwd(y.to(DEV), sc.to(DEV), sh.to(DEV), dout.to(DEV))
+    close(dz, z.grad, what="maxpool bwd")
+
+
+@pytest.mark.parametrize("hw", [((57, 114), (29, 57)), ((16, 28), (4, 7)), ((37, 107), (10, 27)), ((5, 14), (3, 7)),
+                                ((8, 8), (8, 8)), ((512, 910), (128, 228))])
+def test_fpn_topdown(hw):
+    ops = _ops()
+    (H, W), (TH, TW) = hw
+    g = torch.Generator().manual_seed(9)
+    B = 1 if H > 100 else 2
+    lat = torch.randn(B, H, W, 16, generator=g)
+    top = torch.randn(B, TH, TW, 16, generator=g)
+    td = top.double().permute(0, 3, 1, 2).requires_grad_(True)
+    up = F.interpolate(td, size=(H, W), mode="nearest")
+    ref = lat.double() + up.permute(0, 2, 3, 1)
+    out = ops.fpn_topdown_add_(lat.to(DEV).clone(), top.to(DEV))
+    close(out, ref, rtol=0, atol_scale=1e-7, what="topdown add")          # index-exact
+    dlat = torch.randn(B, H, W, 16, generator=g)
+    (up * dlat.double().permute(0, 3, 1, 2)).sum().backward()
+    base = torch.randn(B, TH, TW, 16, generator=g)
+    dtop = ops.fpn_topdown_add_bwd_(dlat.to(DEV), base.to(DEV).clone())
+    close(dtop - base.to(DEV), td.grad.permute(0, 2, 3, 1), rtol=1e-4, atol_scale=1e-5, what="topdown bwd")
+
+
+def test_add_pos_matches_oracle():
+    from dpft_amd.models.embeddings.sinusoidal import SinusoidalEmbedding
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 13, 29, 16, generator=g)
+    emb = SinusoidalEmbedding(num_feats=16, normalize=True)
+    out = emb(x.to(DEV).clone())
+    close(out, O.sinusoidal_embedding(x, num_feats=16, normalize=True), rtol=1e-6, atol_scale=1e-6, what="pos emb")
+
+
+def _msda_inputs(g, N=2, M=8, D=2, Lq=37, P=4, shapes=((13, 9), (7, 5), (4, 3), (2, 2), (1, 1)), dtype=torch.float32):
+    L = len(shapes)
+    S = sum(h * w for h, w in shapes)
+    value = torch.randn(N, S, M, D, generator=g, dtype=dtype)
+    loc = torch.rand(N, Lq, M, L, P, 2, generator=g, dtype=dtype) * 1.3 - 0.15     # incl. out-of-range samples
+    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=g, dtype=dtype), -1).view(N, Lq, M, L, P)
+    lsi = [0]
+    for h, w in shapes[:-1]:
+        lsi.append(lsi[-1] + h * w)
+    return value, loc, attn, list(shapes), lsi
+
+
+def test_msda_operator_fwd_bwd():
+    """Operator-level drop-in (dpft_msda_*) == grid_sample core + its autograd."""
+    ops = _ops()
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(13)
+    value, loc, attn, shapes, lsi = _msda_inputs(g)
+    v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, attn))
+    ref = O.msda_core(v64, shapes, l64, a64)
+    sh_t = torch.tensor(shapes, dtype=torch.int64, device=DEV)
+    lsi_t = torch.tensor(lsi, dtype=torch.int64, device=DEV)
+    out = ops.msda_fwd(value.to(DEV), sh_t, lsi_t, loc.to(DEV), attn.to(DEV))
+    close(out, ref, what="msda fwd")
+    go = torch.randn(ref.shape, generator=g)
+    (ref * go.double()).sum().backward()
+    gv, gl, ga = ops.msda_bwd(value.to(DEV), sh_t, lsi_t, loc.to(DEV), attn.to(DEV), go.to(DEV))
+    close(gv, v64.grad, rtol=1e-3, atol_scale=1e-4, what="msda grad value")
+    close(gl, l64.grad, rtol=1e-3, atol_scale=1e-4, what="msda grad loc")
+    close(ga, a64.grad, rtol=1e-3, atol_scale=1e-4, what="msda grad attn")
+
+
+@pytest.mark.parametrize("B,Q", [(2, 50), (4, 400)])
+def test_xattn_fused_fwd_bwd(B, Q):
+    """Fused sample-then-project (dpft_xattn_*) == value_proj -> MSDA core of the reference."""
+    ops = _ops()
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(17)
+    shapes = [(13, 29), (7, 15), (4, 8), (2, 4), (1, 2)]
+    M, D, P, C = 8, 2, 4, 16
+    L = len(shapes)
+    levels = [torch.randn(B, h, w, C, generator=g) for h, w in shapes]
+    ref_pts = torch.rand(B, Q, 2, generator=g)
+    ref_pts[0, 0] = torch.tensor([0.0, 0.0]); ref_pts[0, 1] = torch.tensor([1.0, 1.0])     # borders
+    off = torch.randn(B, Q, M, L, P, 2, generator=g) * 2.5
+    attn = torch.softmax(torch.randn(B, Q, M, L * P, generator=g), -1).view(B, Q, M, L, P)
+    Wv, bv = torch.randn(C, C, generator=g) * 0.3, torch.randn(C, generator=g)
+    # fp64 reference with autograd
+    lv64 = [l.double().requires_grad_(True) for l in levels]
+    r64, o64, a64 = (t.double().requires_grad_(True) for t in (ref_pts, off, attn))
+    W64, b64 = Wv.double().requires_grad_(True), bv.double().requires_grad_(True)
+    value = F.linear(torch.cat([l.flatten(1, 2) for l in lv64], 1), W64, b64).view(B, -1, M, D)
+    norm = torch.tensor([[w, h] for h, w in shapes], dtype=torch.float64)
+    loc = r64[:, :, None, None, None, :] + o64 / norm[None, None, None, :, None, :]
+    ref = O.msda_core(value, shapes, loc, a64)
+    lv_dev = [l.to(DEV) for l in levels]
+    out, samp, mass = ops.xattn_fwd(lv_dev, ref_pts.to(DEV), off.to(DEV), attn.to(DEV), Wv.to(DEV), bv.to(DEV), M, P)
+    close(out, ref, what="xattn fwd")
+    go = torch.randn(ref.shape, generator=g)
+    (ref * go.double()).sum().backward()
+    grads = [torch.zeros_like(l) for l in lv_dev]
+    goff, gattn, gref = ops.xattn_bwd(lv_dev, grads, ref_pts.to(DEV), off.to(DEV), attn.to(DEV), Wv.to(DEV),
+                                      bv.to(DEV), go.to(DEV), M, P)
+    close(goff, o64.grad, rtol=2e-3, atol_scale=2e-4, what="xattn grad off")
+    close(gattn, a64.grad, rtol=2e-3, atol_scale=2e-4, what="xattn grad attn")
+    close(gref, r64.grad, rtol=2e-3, atol_scale=2e-4, what="xattn grad ref")
+    for l in range(L):
+        close(grads[l], lv64[l].grad, rtol=2e-3, atol_scale=2e-4, what=f"xattn grad level {l}")
+    g4 = go.to(DEV).view(B, Q, M, D)
+    close(torch.einsum("bqmd,bqmc->mdc", g4, samp).reshape(C, C), W64.grad, rtol=2e-3, atol_scale=2e-4, what="grad Wv")
+    close(torch.einsum("bqmd,bqm->md", g4, mass).reshape(C), b64.grad, rtol=2e-3, atol_scale=2e-4, what="grad bv")
+
+
+def test_giou3d_yaw_vs_oracle():
+    ops = _ops()
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(19)
+    N, Mg = 60, 5
+    pc = torch.randn(N, 3, generator=g) * 3
+    ps = torch.rand(N, 3, generator=g) * 4
+    ps[:5] = 0.0                                    # degenerate predictions (ReLU'd sizes)
+    pa = (torch.rand(N, generator=g) * 2 - 1) * 3.1
+    gc = torch.randn(Mg, 3, generator=g) * 3
+    gs = torch.rand(Mg, 3, generator=g) * 3 + 1
+    ga = (torch.rand(Mg, generator=g) * 2 - 1) * 3.1
+    pc[10] = gc[0]; ps[10] = gs[0]; pa[10] = ga[0]   # identical boxes -> 1
+    ref = O.giou3d_yaw(pc, ps, pa, gc, gs, ga)
+    pred7 = torch.cat((pc, ps, pa[:, None]), -1)[None].to(DEV)
+    gt7 = torch.cat((gc, gs, ga[:, None]), -1)[None].to(DEV)
+    out = ops.giou3d_yaw(pred7, gt7)[0]
+    close(out, ref, rtol=1e-5, atol_scale=1e-5, what="giou")
+    assert abs(float(out[10, 0]) - 1.0) < 1e-5 and float(out[0, 0]) == -1.0

@@ -1,0 +1,185 @@
+"""Module- and model-level parity on the GPU: dpft_amd (HIP path through the C-ABI) vs the oracle's
+functional restatement fed with the *same* state_dict and the same seeded synthetic batch."""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def close(a, b, rtol=1e-4, atol_scale=1e-5, what=""):
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    atol = atol_scale * max(float(b.abs().max()), 1e-6)
+    torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
+
+
+def small_config(dropout=0.0, camera="ResNet50"):
+    from dpft_amd.configs import load_config
+    cfg = load_config("kradar")
+    cfg = copy.deepcopy(cfg)
+    cfg["model"]["backbones"]["camera_mono"]["name"] = camera
+    cfg["model"]["fuser"]["dropout"] = dropout
+    return cfg
+
+
+SHAPES = {"camera_mono": (96, 160, 3), "radar_bev": (64, 43, 6), "radar_front": (37, 43, 6)}
+
+
+def randomise_bn(model, g):
+    """Non-trivial BN affine + running statistics so eval-mode parity actually exercises them."""
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+
+
+def randomise_decoder(model, g):
+    with torch.no_grad():
+        for n, p in model.fuser.named_parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.05)
+
+
+def state_dict_f64(model):
+    return {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu())
+            for k, v in model.state_dict().items()}
+
+
+@pytest.mark.parametrize("name,cin", [("ResNet50", 6), ("ResNet101", 3)])
+def test_backbone_train_fwd_bwd(name, cin):
+    from dpft_amd.models.backbones import build_backbone
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(1)
+    torch.manual_seed(1)
+    bb = build_backbone(name, dict(name=name, weights="", in_channels=cin, multi_scale=4, norm_layer="BatchNorm2d"))
+    randomise_bn(bb, g)
+    sd = {"bb." + k: v for k, v in state_dict_f64(bb).items()}
+    x = torch.rand(2, 128, 96, cin, generator=g) * 255
+    bb = bb.to(DEV).train()
+    outs = bb(x.to(DEV))
+    sd_ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+              for k, v in sd.items()}
+    ref = O.backbone(x.double(), sd_ref, "bb", name, train=True, multi_scale=4)
+    assert list(outs.keys()) == ["1", "2", "3", "4"]
+    for k in outs:
+        assert outs[k].shape == ref[k].shape
+        close(outs[k], ref[k], rtol=1e-3, atol_scale=1e-4, what=f"{name} layer{k}")
+    cots = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in ref}
+    sum((ref[k] * cots[k]).sum() for k in ref).backward()
+    sum((outs[k] * cots[k].float().to(DEV)).sum() for k in outs).backward()
+    worst = 0.0
+    for n, p in bb.named_parameters():
+        gref = sd_ref["bb." + n].grad
+        assert p.grad is not None, n
+        assert p.grad.shape == p.shape
+        err = float((p.grad.double().cpu() - gref).abs().max() / (gref.abs().max() + 1e-12))
+        worst = max(worst, err)
+        assert err < 5e-3, (n, err)
+    # running statistics were updated exactly once
+    assert int(bb.body.bn1.num_batches_tracked) == 1
+
+
+def test_fpn_and_embedding_fwd_bwd():
+    from dpft_amd.models.embeddings import build_embedding
+    from dpft_amd.models.necks import build_neck
+    from oracle import dprt_oracle as O
+    from collections import OrderedDict
+    g = torch.Generator().manual_seed(2)
+    torch.manual_seed(2)
+    chans = [6, 256, 512, 1024, 2048]
+    sizes = [(37, 43), (10, 11), (5, 6), (3, 3), (2, 2)]
+    neck = build_neck("FPN", dict(name="FPN", in_channels_list=chans, out_channels=16))
+    emb = build_embedding("sinusoidal_embedding", dict(name="sinusoidal_embedding", num_feats=16, n_levels=5,
+                                                       normalize=True))
+    with torch.no_grad():
+        for p in neck.parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.02)
+    sd = {"necks.v." + k: v.clone().requires_grad_(True) for k, v in state_dict_f64(neck).items()}
+    feats = OrderedDict((str(i), torch.randn(2, h, w, c, generator=g)) for i, ((h, w), c) in enumerate(zip(sizes, chans)))
+    f64 = OrderedDict((k, v.double().requires_grad_(True)) for k, v in feats.items())
+    ref = O.fpn(f64, sd, "necks.v")
+    ref = OrderedDict((k, O.sinusoidal_embedding(v, num_feats=16, normalize=True)) for k, v in ref.items())
+    neck = neck.to(DEV)
+    fdev = OrderedDict((k, v.to(DEV).requires_grad_(k != "0")) for k, v in feats.items())
+    out = emb(neck(fdev))
+    for k in out:
+        close(out[k], ref[k], what=f"fpn level {k}")
+    cots = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in ref}
+    sum((ref[k] * cots[k]).sum() for k in ref).backward()
+    sum((out[k] * cots[k].float().to(DEV)).sum() for k in out).backward()
+    for n, p in neck.named_parameters():
+        close(p.grad, sd["necks.v." + n].grad, rtol=2e-3, atol_scale=2e-4, what=f"fpn grad {n}")
+    for k in "1234":
+        close(fdev[k].grad, f64[k].grad, rtol=2e-3, atol_scale=2e-4, what=f"fpn grad input {k}")
+
+
+def _build(cfg, g):
+    from dpft_amd.models import build
+    torch.manual_seed(0)
+    model = build("dprt", cfg)
+    randomise_bn(model, g)
+    randomise_decoder(model, g)
+    return model
+
+
+def test_dprt_eval_forward_matches_oracle():
+    from dpft_amd.synthetic import make_batch
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(3)
+    cfg = small_config(dropout=0.1)
+    model = _build(cfg, g)
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in state_dict_f64(model).items()}
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=42, shapes=SHAPES)
+    ref = O.dprt_forward(sd, cfg, batch, train=False)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+    assert list(out.keys()) == ["center", "size", "angle", "class"]
+    for k in out:
+        assert out[k].dtype == torch.float32 and out[k].shape == ref[k].shape
+        close(out[k], ref[k], rtol=1e-4, atol_scale=1e-4, what=f"eval out {k}")
+    # index-valued outputs must be bit-exact
+    assert torch.equal(out["class"].argmax(-1).cpu(), ref["class"].argmax(-1))
+
+
+def test_dprt_train_forward_backward_matches_oracle():
+    from dpft_amd.synthetic import make_batch
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(4)
+    cfg = small_config(dropout=0.0)
+    model = _build(cfg, g)
+    sd64 = state_dict_f64(model)
+    sd_ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
+              for k, v in sd64.items()}
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=SHAPES)
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    ref = O.dprt_forward(sd_ref, cfg, b64, train=True)
+    model = model.to(DEV).train()
+    out = model({k: v.to(DEV) for k, v in batch.items()})
+    for k in out:
+        close(out[k], ref[k], rtol=1e-3, atol_scale=1e-3, what=f"train out {k}")
+    cots = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in ref}
+    sum((ref[k] * cots[k]).sum() for k in ref).backward()
+    sum((out[k] * cots[k].float().to(DEV)).sum() for k in out).backward()
+    checked = 0
+    bad = []
+    for n, p in model.named_parameters():
+        gref = sd_ref[n].grad
+        if gref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n      # template head (App. A)
+            continue
+        assert p.grad is not None, n
+        err = float((p.grad.double().cpu() - gref).abs().max() / (gref.abs().max() + 1e-12))
+        if err > 2e-2:
+            bad.append((n, err))
+        checked += 1
+    assert checked > 300
+    assert not bad, bad[:10]
