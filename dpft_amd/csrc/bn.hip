@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
 __global__ void bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t M,
                                    int K, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean, float* running_var,
-                                   float* save_mean, float* save_invstd, float* scale, float* shift) {
+                                   float* bnp) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= K) return;
     float n = 0.f, mean = 0.f, m2 = 0.f;
@@ -70,11 +70,10 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int tiles, i
     }
     const float var = m2 / (float)M;
     const float invstd = 1.0f / sqrtf(var + eps);
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - mean * sc;
-    if (save_mean) save_mean[c] = mean;
-    if (save_invstd) save_invstd[c] = invstd;
+    bnp[c] = mean;
+    bnp[K + c] = gamma[c] * invstd;
+    bnp[2 * K + c] = beta[c];
+    bnp[3 * K + c] = invstd;
     if (running_mean) {
         const float unbiased = M > 1 ? m2 / (float)(M - 1) : var;
         running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -84,34 +83,37 @@ __global__ void bn_finalize_kernel(const float* __restrict__ stats, int tiles, i
 
 __global__ void bn_eval_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ rm, const float* __restrict__ rv, float eps, int K,
-                               float* scale, float* shift) {
+                               float* bnp) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= K) return;
-    const float sc = gamma[c] / sqrtf(rv[c] + eps);
-    scale[c] = sc;
-    shift[c] = beta[c] - rm[c] * sc;
+    const float invstd = 1.0f / sqrtf(rv[c] + eps);
+    bnp[c] = rm[c];
+    bnp[K + c] = gamma[c] * invstd;
+    bnp[2 * K + c] = beta[c];
+    bnp[3 * K + c] = invstd;
 }
 
-// out = [relu](y*scale+shift [+ res*rs+rsh | + res]); K % 4 == 0
-__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                      const float* __restrict__ shift, const float* __restrict__ res,
-                                                      const float* __restrict__ rs, const float* __restrict__ rsh,
+// BN block convention: bnp[4][K] = (mean, scale = gamma*invstd, beta, invstd); bn(y) = (y-mean)*scale+beta
+__device__ __forceinline__ f32x4 bn_apply4(f32x4 v, const float* __restrict__ bnp, int K, int c) {
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + K + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(bnp + 2 * K + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e] - mu[e], sc[e], be[e]);
+    return v;
+}
+
+// out = [relu](bn(y) [+ bn_r(res) | + res]); K % 4 == 0
+__global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                      const float* __restrict__ res, const float* __restrict__ rbnp,
                                                       int relu, float* __restrict__ out, int64_t n4, int K4) {
+    const int K = K4 * 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % K4) * 4;
-        f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e], sc[e], sh[e]);
+        f32x4 v = bn_apply4(reinterpret_cast<const f32x4*>(y)[i], bnp, K, c);
         if (res) {
             f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
-            if (rs) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(rs + c);
-                const f32x4 b = *reinterpret_cast<const f32x4*>(rsh + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) r[e] = fmaf(r[e], a[e], b[e]);
-            }
+            if (rbnp) r = bn_apply4(r, rbnp, K, c);
             v += r;
         }
         if (relu) {
@@ -123,9 +125,10 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
 }
 
 // stem: maxpool3x3/s2/p1 of relu(bn(y)); one thread per (b,ph,pw,4 channels)
-__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                               const float* __restrict__ shift, float* __restrict__ out,
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                               float* __restrict__ out,
                                                                int B, int H, int W, int K4, int PH, int PW) {
+    const int K = K4 * 4;
     const int64_t total = (int64_t)B * PH * PW * K4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % K4);
@@ -133,8 +136,6 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
         const int pw = (int)(p % PW); p /= PW;
         const int ph = (int)(p % PH);
         const int b = (int)(p / PH);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
         f32x4 m = {0.f, 0.f, 0.f, 0.f};  // relu >= 0 and every window holds a valid pixel
 #pragma unroll
         for (int di = 0; di < 3; ++di) {
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
             for (int dj = 0; dj < 3; ++dj) {
                 const int w = pw * 2 - 1 + dj;
                 if ((unsigned)w >= (unsigned)W) continue;
-                const f32x4 v = reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + h) * W + w) * K4 + c4];
+                const f32x4 v = bn_apply4(reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + h) * W + w) * K4 + c4], bnp, K, c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], fmaf(v[e], sc[e], sh[e]));
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
             }
         }
         reinterpret_cast<f32x4*>(out)[i] = m;
@@ -155,9 +156,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
 
 // backward of the above, gather form: dz[b,h,w,c] = (a>0) * sum_{windows containing (h,w) whose first
 // arg-max is (h,w)} dout.  a = relu(bn(y)) recomputed on the fly.
-__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ scale,
-                                                                   const float* __restrict__ shift, const float* __restrict__ dout,
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                                   const float* __restrict__ dout,
                                                                    float* __restrict__ dz, int B, int H, int W, int K4, int PH, int PW) {
+    const int K = K4 * 4;
     const int64_t total = (int64_t)B * H * W * K4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int c4 = (int)(i % K4);
@@ -165,12 +167,9 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
         const int w = (int)(p % W); p /= W;
         const int h = (int)(p % H);
         const int b = (int)(p / H);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + c4 * 4);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(shift + c4 * 4);
-        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
-        f32x4 a0;
+        f32x4 a0 = bn_apply4(reinterpret_cast<const f32x4*>(y)[i], bnp, K, c4 * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a0[e] = fmaxf(fmaf(yv[e], sc[e], sh[e]), 0.f);
+        for (int e = 0; e < 4; ++e) a0[e] = fmaxf(a0[e], 0.f);
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         // candidate windows: ph in {(h+1)/2 - (0|1)} with 2*ph-1 <= h <= 2*ph+1
         const int ph_hi = (h + 1) >> 1, pw_hi = (w + 1) >> 1;
@@ -189,10 +188,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
                     for (int dj = 0; dj < 3; ++dj) {
                         const int ww = pw * 2 - 1 + dj;
                         if ((unsigned)ww >= (unsigned)W) continue;
-                        const f32x4 v = reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + hh) * W + ww) * K4 + c4];
+                        const f32x4 v = bn_apply4(reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + hh) * W + ww) * K4 + c4], bnp, K, c4 * 4);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            const float av = fmaxf(fmaf(v[e], sc[e], sh[e]), 0.f);
+                            const float av = fmaxf(v[e], 0.f);
                             if (av > best[e]) { best[e] = av; bi[e] = di * 3 + dj; }
                         }
                     }
@@ -211,9 +210,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
 
 // BN backward pass 1: sums[0][k] += sum dz, sums[1][k] += sum dz*xhat
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
-                                                             const float* __restrict__ outp, const float* __restrict__ msc,
-                                                             const float* __restrict__ msh, const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, float* __restrict__ sums,
+                                                             const float* __restrict__ outp, const float* __restrict__ mbnp,
+                                                             const float* __restrict__ bnp, float* __restrict__ sums,
                                                              int64_t M, int K, int rows_per_block) {
     __shared__ float red0[256 * 4];
     __shared__ float red1[256 * 4];
@@ -227,13 +225,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     const int64_t r1 = min(M, r0 + rows_per_block);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
     if (g < groups) {
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c4 * 4);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c4 * 4);
-        f32x4 ksc = {0.f, 0.f, 0.f, 0.f}, ksh = ksc;
-        if (msc) {
-            ksc = *reinterpret_cast<const f32x4*>(msc + c4 * 4);
-            ksh = *reinterpret_cast<const f32x4*>(msh + c4 * 4);
-        }
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c4 * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c4 * 4);
         for (int64_t r = r0 + g; r < r1; r += groups) {
             const int64_t idx = r * K4 + c4;
             f32x4 d = reinterpret_cast<const f32x4*>(dout)[idx];
@@ -242,9 +235,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 const f32x4 o = reinterpret_cast<const f32x4*>(outp)[idx];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-            } else if (msc) {
+            } else if (mbnp) {
+                const f32x4 a = bn_apply4(yv, mbnp, K, c4 * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = fmaf(yv[e], ksc[e], ksh[e]) > 0.f ? d[e] : 0.f;
+                for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : 0.f;
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -275,9 +269,8 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 
 // BN backward pass 2
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
-                                                            const float* __restrict__ outp, const float* __restrict__ msc,
-                                                            const float* __restrict__ msh, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                            const float* __restrict__ outp, const float* __restrict__ mbnp,
+                                                            const float* __restrict__ bnp, const float* __restrict__ gamma,
                                                             const float* __restrict__ sums, float* __restrict__ dy,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int64_t n4, int K, float invM) {
@@ -296,14 +289,13 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const f32x4 o = reinterpret_cast<const f32x4*>(outp)[i];
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-        } else if (msc) {
-            const f32x4 ksc = *reinterpret_cast<const f32x4*>(msc + c);
-            const f32x4 ksh = *reinterpret_cast<const f32x4*>(msh + c);
+        } else if (mbnp) {
+            const f32x4 a = bn_apply4(yv, mbnp, K, c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = fmaf(yv[e], ksc[e], ksh[e]) > 0.f ? d[e] : 0.f;
+            for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : 0.f;
         }
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + c);
-        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c);
         const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
         const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
@@ -432,63 +424,60 @@ extern "C" int dpft_bn_stats_f32(const float* y, float* stats, int64_t M, int32_
 
 extern "C" int dpft_bn_finalize_f32(const float* stats, int32_t tiles, int32_t tile_rows, int64_t M, int32_t K,
                                     const float* gamma, const float* beta, float eps, float momentum,
-                                    float* running_mean, float* running_var, float* save_mean,
-                                    float* save_invstd, float* scale, float* shift, dpft_stream_t stream) {
-    DPFT_REQUIRE(stats && gamma && beta && scale && shift, "bn_finalize: null tensor");
+                                    float* running_mean, float* running_var, float* bnp,
+                                    dpft_stream_t stream) {
+    DPFT_REQUIRE(stats && gamma && beta && bnp, "bn_finalize: null tensor");
     DPFT_REQUIRE(tiles == cdiv(M, tile_rows), "bn_finalize: tiles (%d) != ceil(M/tile_rows)", tiles);
     DPFT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
     hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 64)), dim3(64), 0, (hipStream_t)stream, stats, tiles,
-                       tile_rows, M, K, gamma, beta, eps, momentum, running_mean, running_var, save_mean,
-                       save_invstd, scale, shift);
+                       tile_rows, M, K, gamma, beta, eps, momentum, running_mean, running_var, bnp);
     return check_launch("bn_finalize");
 }
 
-extern "C" int dpft_bn_eval_scale_shift_f32(const float* gamma, const float* beta, const float* running_mean,
-                                            const float* running_var, float eps, int32_t K, float* scale,
-                                            float* shift, dpft_stream_t stream) {
-    DPFT_REQUIRE(gamma && beta && running_mean && running_var && scale && shift && K > 0, "bn_eval: bad arguments");
+extern "C" int dpft_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_mean,
+                                       const float* running_var, float eps, int32_t K, float* bnp,
+                                       dpft_stream_t stream) {
+    DPFT_REQUIRE(gamma && beta && running_mean && running_var && bnp && K > 0, "bn_eval: bad arguments");
     hipLaunchKernelGGL(bn_eval_kernel, dim3(cdiv(K, 64)), dim3(64), 0, (hipStream_t)stream, gamma, beta,
-                       running_mean, running_var, eps, K, scale, shift);
-    return check_launch("bn_eval_scale_shift");
+                       running_mean, running_var, eps, K, bnp);
+    return check_launch("bn_eval_params");
 }
 
-extern "C" int dpft_bn_act_f32(const float* y, const float* scale, const float* shift, const float* res,
-                               const float* res_scale, const float* res_shift, int32_t relu, float* out,
-                               int64_t M, int32_t K, dpft_stream_t stream) {
-    DPFT_REQUIRE(y && scale && shift && out && M > 0 && K > 0 && K % 4 == 0, "bn_act: bad arguments (K=%d)", K);
-    DPFT_REQUIRE((res_scale == nullptr) == (res_shift == nullptr), "bn_act: res_scale/res_shift must come in pairs");
+extern "C" int dpft_bn_act_f32(const float* y, const float* bnp, const float* res, const float* res_bnp,
+                               int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && bnp && out && M > 0 && K > 0 && K % 4 == 0, "bn_act: bad arguments (K=%d)", K);
+    DPFT_REQUIRE(res || !res_bnp, "bn_act: res_bnp without res");
     const int64_t n4 = M * K / 4;
-    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, scale, shift, res,
-                       res_scale, res_shift, relu, out, n4, K / 4);
+    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
+                       res_bnp, relu, out, n4, K / 4);
     return check_launch("bn_act");
 }
 
-extern "C" int dpft_bn_relu_maxpool_f32(const float* y, const float* scale, const float* shift, float* out,
+extern "C" int dpft_bn_relu_maxpool_f32(const float* y, const float* bnp, float* out,
                                         int32_t B, int32_t H, int32_t W, int32_t K, int32_t PH, int32_t PW,
                                         dpft_stream_t stream) {
-    DPFT_REQUIRE(y && scale && shift && out && K % 4 == 0, "bn_relu_maxpool: bad arguments");
+    DPFT_REQUIRE(y && bnp && out && K % 4 == 0, "bn_relu_maxpool: bad arguments");
     DPFT_REQUIRE(PH == (H + 2 - 3) / 2 + 1 && PW == (W + 2 - 3) / 2 + 1, "bn_relu_maxpool: PH/PW inconsistent");
     const int64_t total = (int64_t)B * PH * PW * (K / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, scale,
-                       shift, out, B, H, W, K / 4, PH, PW);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, bnp,
+                       out, B, H, W, K / 4, PH, PW);
     return check_launch("bn_relu_maxpool");
 }
 
-extern "C" int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* scale, const float* shift,
+extern "C" int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* bnp,
                                             const float* dout, float* dact, int32_t B, int32_t H, int32_t W,
                                             int32_t K, int32_t PH, int32_t PW, dpft_stream_t stream) {
-    DPFT_REQUIRE(y && scale && shift && dout && dact && K % 4 == 0, "bn_relu_maxpool_bwd: bad arguments");
+    DPFT_REQUIRE(y && bnp && dout && dact && K % 4 == 0, "bn_relu_maxpool_bwd: bad arguments");
     const int64_t total = (int64_t)B * H * W * (K / 4);
     hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y,
-                       scale, shift, dout, dact, B, H, W, K / 4, PH, PW);
+                       bnp, dout, dact, B, H, W, K / 4, PH, PW);
     return check_launch("bn_relu_maxpool_bwd");
 }
 
 extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const float* out,
-                                      const float* mask_scale, const float* mask_shift, const float* mean,
-                                      const float* invstd, float* sums, int64_t M, int32_t K,
-                                      dpft_stream_t stream) {
-    DPFT_REQUIRE(y && dout && mean && invstd && sums && M > 0 && K > 0 && K % 4 == 0, "bn_bwd_reduce: bad arguments");
+                                      const float* mask_bnp, const float* bnp, float* sums, int64_t M,
+                                      int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && dout && bnp && sums && M > 0 && K > 0 && K % 4 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * K, st);
     const int K4 = K / 4;
@@ -497,19 +486,19 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
     const int groups = 256 / kc;
     int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + kNumCU * 4 - 1) / (kNumCU * 4));
     dim3 grid(cdiv(M, rows_per_block), slabs);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_scale, mask_shift, mean, invstd, sums, M, K,
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
                        (int)rows_per_block);
     return check_launch("bn_bwd_reduce");
 }
 
 extern "C" int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const float* out,
-                                     const float* mask_scale, const float* mask_shift, const float* mean,
-                                     const float* invstd, const float* gamma, const float* sums, float* dy,
-                                     float* dgamma, float* dbeta, int64_t M, int32_t K, dpft_stream_t stream) {
-    DPFT_REQUIRE(y && dout && mean && invstd && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
+                                     const float* mask_bnp, const float* bnp, const float* gamma,
+                                     const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
+                                     int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && dout && bnp && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = M * K / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                       mask_scale, mask_shift, mean, invstd, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M);
+                       mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M);
     return check_launch("bn_bwd_apply");
 }
 

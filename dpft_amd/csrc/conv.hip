@@ -37,8 +37,7 @@ struct IgemmArgs {
     const float* w;
     float* y;
     const float* bias;
-    const float* pro_scale;
-    const float* pro_shift;
+    const float* pro;      // producer BN block [4][C] = mean, scale, beta, invstd (or null)
     float* stats;     // [mtiles][2][N] or null
     float* partial;   // split-K: [splits][M][N] or null
     int B, H, W, C;   // A-source tensor
@@ -197,10 +196,11 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BK;
         const int r = tap / a.kw, s = tap - r * a.kw;
-        f32x4 sc, sh;
+        f32x4 mu, sc, sh;
         if (PRO) {
-            sc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + chunk * 4);
-            sh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + chunk * 4);
+            mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
+            sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
+            sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
         }
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                 if (PRO) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        float t = fmaf(val[e], sc[e], sh[e]);
+                        float t = fmaf(val[e] - mu[e], sc[e], sh[e]);
                         val[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
                     }
                 }
@@ -453,8 +453,7 @@ struct WgradArgs {
     const float* dy;
     float* dw;        // [K][taps][C]
     float* partial;   // [splits][K*taps*C] or null
-    const float* pro_scale;
-    const float* pro_shift;
+    const float* pro; // BN block [4][C] of the x operand or null
     int B, H, W, C;   // input
     int OH, OW, K;    // dy
     int kh, kw, stride, pad;
@@ -491,10 +490,11 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     const int xch = tid % XCH, xrow = tid / XCH;
     const bool y_ok = (n0 + ych * 4) < a.K;
     const bool x_ok = (c0 + xch * 4) < a.C;
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     if (PRO && x_ok) {
-        sc = *reinterpret_cast<const f32x4*>(a.pro_scale + c0 + xch * 4);
-        sh = *reinterpret_cast<const f32x4*>(a.pro_shift + c0 + xch * 4);
+        mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + xch * 4);
+        sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + xch * 4);
+        sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + xch * 4);
     }
     const int ohw = a.OH * a.OW;
 
@@ -523,7 +523,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
                     if (PRO) {
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            float t = fmaf(v[e], sc[e], sh[e]);
+                            float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
                             v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
                         }
                     }
@@ -855,18 +855,16 @@ extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* til
 }
 
 extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x, const float* w,
-                                        const float* bias, const float* pro_scale,
-                                        const float* pro_shift, int32_t pro_relu, float* y,
-                                        float* stats, void* workspace, dpft_stream_t stream) {
+                                        const float* bias, const float* pro_bn, int32_t pro_relu,
+                                        float* y, float* stats, void* workspace, dpft_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
     hipStream_t st = (hipStream_t)stream;
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
-    a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu;
-    const bool pro = pro_scale != nullptr;
-    DPFT_REQUIRE(!pro || pro_shift, "conv fwd: pro_scale without pro_shift");
+    a.pro = pro_bn; a.pro_relu = pro_relu;
+    const bool pro = pro_bn != nullptr;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 32 == 0 (C=%d)", d->C);
     if (t.splits > 1) {
@@ -913,22 +911,21 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
 }
 
 extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,
-                                          const float* pro_scale, const float* pro_shift,
-                                          int32_t pro_relu, float* dw, void* workspace,
-                                          dpft_stream_t stream) {
+                                          const float* pro_bn, int32_t pro_relu, float* dw,
+                                          void* workspace, dpft_stream_t stream) {
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(x && dy && dw, "conv wgrad: null tensor");
     hipStream_t st = (hipStream_t)stream;
     WgradArgs a; memset(&a, 0, sizeof(a));
-    a.x = x; a.dy = dy; a.dw = dw; a.pro_scale = pro_scale; a.pro_shift = pro_shift; a.pro_relu = pro_relu;
+    a.x = x; a.dy = dy; a.dw = dw; a.pro = pro_bn; a.pro_relu = pro_relu;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.OH = d->OH; a.OW = d->OW; a.K = d->K;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.M = d->B * d->OH * d->OW;
     a.taps = d->kh * d->kw;
     a.J = a.taps * a.C;
     a.psteps = cdiv(a.M, BK);
-    const bool pro = pro_scale != nullptr;
+    const bool pro = pro_bn != nullptr;
     const bool vec = (d->C % 32 == 0) && (d->K % 4 == 0);
     DPFT_REQUIRE(!(pro && !vec), "conv wgrad: fused prologue needs C %% 32 == 0");
     int bmn, bnc;

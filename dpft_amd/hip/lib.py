@@ -39,19 +39,19 @@ SIGNATURES = {
     "dpft_last_error": (C.c_char_p, []),
     "dpft_conv2d_workspace_bytes": (_L, [_DESC]),
     "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
-    "dpft_conv2d_nhwc_fwd_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "dpft_conv2d_nhwc_fwd_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_dgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P]),
-    "dpft_conv2d_nhwc_wgrad_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _P, _P, _P]),
+    "dpft_conv2d_nhwc_wgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P, _P]),
     "dpft_weight_transpose_f32": (_I, [_P, _P, _I, _I, _I, _P]),
     "dpft_bias_grad_f32": (_I, [_P, _P, _L, _I, _P]),
     "dpft_bn_stats_f32": (_I, [_P, _P, _L, _I, _I, _P]),
-    "dpft_bn_finalize_f32": (_I, [_P, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P, _P, _P, _P]),
-    "dpft_bn_eval_scale_shift_f32": (_I, [_P, _P, _P, _P, _F, _I, _P, _P, _P]),
-    "dpft_bn_act_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _P]),
-    "dpft_bn_relu_maxpool_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dpft_bn_relu_maxpool_bwd_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
-    "dpft_bn_bwd_reduce_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
-    "dpft_bn_bwd_apply_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dpft_bn_finalize_f32": (_I, [_P, _I, _I, _L, _I, _P, _P, _F, _F, _P, _P, _P, _P]),
+    "dpft_bn_eval_params_f32": (_I, [_P, _P, _P, _P, _F, _I, _P, _P]),
+    "dpft_bn_act_f32": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _P]),
+    "dpft_bn_relu_maxpool_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_bn_relu_maxpool_bwd_f32": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_bn_bwd_reduce_f32": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _P]),
+    "dpft_bn_bwd_apply_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _P]),
     "dpft_relu_bwd_f32": (_I, [_P, _P, _P, _L, _P]),
     "dpft_add_inplace_f32": (_I, [_P, _P, _L, _P]),
     "dpft_fpn_topdown_add_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),

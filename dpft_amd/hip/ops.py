@@ -62,13 +62,13 @@ def conv_problem(B, H, W, Cin, K, kh, kw, stride, pad) -> Conv:
 
 
 def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False):
-    """x (B,H,W,C) contiguous; w physical [K][kh][kw][C]. pro = (scale, shift, relu) or None.
+    """x (B,H,W,C) contiguous; w physical [K][kh][kw][C]. pro = (bn_block[4][C], relu) or None.
     Returns y (B,OH,OW,K) and the per-tile stats tensor (or None)."""
     y = torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
     stats = torch.empty((cv.tiles, 2, cv.K), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(cv.ws_bytes, x.device)
-    ps, psh, prelu = (pro[0], pro[1], int(pro[2])) if pro is not None else (None, None, 0)
-    lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(ps), ptr(psh), prelu,
+    pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
+    lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(pb), prelu,
              ptr(y), ptr(stats), ptr(ws), stream())
     return y, stats
 
@@ -88,8 +88,8 @@ def conv_wgrad(cv: Conv, x, dy, pro=None):
     """dw physical [K][kh][kw][C] (returned as a (K,kh,kw,C) tensor)."""
     dw = torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
     ws = workspace(cv.ws_bytes, x.device)
-    ps, psh, prelu = (pro[0], pro[1], int(pro[2])) if pro is not None else (None, None, 0)
-    lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(ps), ptr(psh), prelu, ptr(dw),
+    pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
+    lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(pb), prelu, ptr(dw),
              ptr(ws), stream())
     return dw
 
@@ -119,63 +119,59 @@ def bn_stats(y: torch.Tensor, tile_rows: int = 128) -> torch.Tensor:
 
 
 def bn_finalize(stats, tile_rows, M, gamma, beta, eps, momentum, running_mean=None, running_var=None):
-    """-> scale, shift, mean, invstd (each (K,)); updates the running buffers in place."""
+    """-> BN block (4,K) = (mean, gamma*invstd, beta, invstd); updates the running buffers in place."""
     K = gamma.numel()
-    buf = torch.empty((4, K), dtype=torch.float32, device=gamma.device)
+    bnp = torch.empty((4, K), dtype=torch.float32, device=gamma.device)
     lib.call("dpft_bn_finalize_f32", ptr(stats), stats.shape[0], tile_rows, M, K, ptr(gamma), ptr(beta),
-             float(eps), float(momentum), ptr(running_mean), ptr(running_var), ptr(buf[2]), ptr(buf[3]),
-             ptr(buf[0]), ptr(buf[1]), stream())
-    return buf[0], buf[1], buf[2], buf[3]
+             float(eps), float(momentum), ptr(running_mean), ptr(running_var), ptr(bnp), stream())
+    return bnp
 
 
-def bn_eval_scale_shift(gamma, beta, running_mean, running_var, eps):
+def bn_eval_params(gamma, beta, running_mean, running_var, eps):
     K = gamma.numel()
-    buf = torch.empty((2, K), dtype=torch.float32, device=gamma.device)
-    lib.call("dpft_bn_eval_scale_shift_f32", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
-             K, ptr(buf[0]), ptr(buf[1]), stream())
-    return buf[0], buf[1]
+    bnp = torch.empty((4, K), dtype=torch.float32, device=gamma.device)
+    lib.call("dpft_bn_eval_params_f32", ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), float(eps),
+             K, ptr(bnp), stream())
+    return bnp
 
 
-def bn_act(y, scale, shift, res=None, res_scale=None, res_shift=None, relu=True):
+def bn_act(y, bnp, res=None, res_bnp=None, relu=True):
     out = torch.empty_like(y)
     K = y.shape[-1]
-    lib.call("dpft_bn_act_f32", ptr(y), ptr(scale), ptr(shift), ptr(res), ptr(res_scale), ptr(res_shift), int(relu),
-             ptr(out), y.numel() // K, K, stream())
+    lib.call("dpft_bn_act_f32", ptr(y), ptr(bnp), ptr(res), ptr(res_bnp), int(relu), ptr(out), y.numel() // K, K,
+             stream())
     return out
 
 
-def bn_relu_maxpool(y, scale, shift):
+def bn_relu_maxpool(y, bnp):
     B, H, W, K = y.shape
     PH, PW = (H + 2 - 3) // 2 + 1, (W + 2 - 3) // 2 + 1
     out = torch.empty((B, PH, PW, K), dtype=torch.float32, device=y.device)
-    lib.call("dpft_bn_relu_maxpool_f32", ptr(y), ptr(scale), ptr(shift), ptr(out), B, H, W, K, PH, PW, stream())
+    lib.call("dpft_bn_relu_maxpool_f32", ptr(y), ptr(bnp), ptr(out), B, H, W, K, PH, PW, stream())
     return out
 
 
-def bn_relu_maxpool_bwd(y, scale, shift, dout):
+def bn_relu_maxpool_bwd(y, bnp, dout):
     B, H, W, K = y.shape
     PH, PW = dout.shape[1], dout.shape[2]
     dz = torch.empty_like(y)
-    lib.call("dpft_bn_relu_maxpool_bwd_f32", ptr(y), ptr(scale), ptr(shift), ptr(dout), ptr(dz), B, H, W, K, PH, PW,
-             stream())
+    lib.call("dpft_bn_relu_maxpool_bwd_f32", ptr(y), ptr(bnp), ptr(dout), ptr(dz), B, H, W, K, PH, PW, stream())
     return dz
 
 
-def bn_bwd(y, dout, mean, invstd, gamma, out=None, mask=None):
-    """Full BatchNorm backward (two passes).  mask = (scale, shift) recomputes a fused ReLU.
+def bn_bwd(y, dout, bnp, gamma, out=None, mask_bnp=None):
+    """Full BatchNorm backward (two passes).  mask_bnp recomputes a fused ReLU mask from a BN block.
     Returns dy, dgamma, dbeta."""
     K = y.shape[-1]
     M = y.numel() // K
     sums = torch.empty((2, K), dtype=torch.float32, device=y.device)
-    ms, msh = (mask[0], mask[1]) if mask is not None else (None, None)
-    lib.call("dpft_bn_bwd_reduce_f32", ptr(y), ptr(dout), ptr(out), ptr(ms), ptr(msh), ptr(mean), ptr(invstd),
-             ptr(sums), M, K, stream())
+    lib.call("dpft_bn_bwd_reduce_f32", ptr(y), ptr(dout), ptr(out), ptr(mask_bnp), ptr(bnp), ptr(sums), M, K,
+             stream())
     dy = torch.empty_like(y)
-    dg = torch.empty((K,), dtype=torch.float32, device=y.device)
-    db = torch.empty((K,), dtype=torch.float32, device=y.device)
-    lib.call("dpft_bn_bwd_apply_f32", ptr(y), ptr(dout), ptr(out), ptr(ms), ptr(msh), ptr(mean), ptr(invstd),
-             ptr(gamma), ptr(sums), ptr(dy), ptr(dg), ptr(db), M, K, stream())
-    return dy, dg, db
+    dgb = torch.empty((2, K), dtype=torch.float32, device=y.device)
+    lib.call("dpft_bn_bwd_apply_f32", ptr(y), ptr(dout), ptr(out), ptr(mask_bnp), ptr(bnp), ptr(gamma), ptr(sums),
+             ptr(dy), ptr(dgb[0]), ptr(dgb[1]), M, K, stream())
+    return dy, dgb[0], dgb[1]
 
 
 def relu_bwd(dout, out):

@@ -81,19 +81,12 @@ class ResNetBody(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # hand-scheduled forward / backward
 # ------------------------------------------------------------------------------------------------
-class _BNState:
-    __slots__ = ("scale", "shift", "mean", "invstd")
-
-
-def _bn_forward(bn: nn.BatchNorm2d, stats, cv: ops.Conv, train: bool) -> _BNState:
-    st = _BNState()
+def _bn_forward(bn: nn.BatchNorm2d, stats, cv: ops.Conv, train: bool) -> torch.Tensor:
+    """-> BN block (4,K): mean, gamma*invstd, beta, invstd (batch statistics in train mode)."""
     if train:
-        st.scale, st.shift, st.mean, st.invstd = ops.bn_finalize(
-            stats, cv.tile_rows, cv.M, bn.weight, bn.bias, bn.eps, bn.momentum, bn.running_mean, bn.running_var)
-    else:
-        st.scale, st.shift = ops.bn_eval_scale_shift(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
-        st.mean = st.invstd = None
-    return st
+        return ops.bn_finalize(stats, cv.tile_rows, cv.M, bn.weight, bn.bias, bn.eps, bn.momentum,
+                               bn.running_mean, bn.running_var)
+    return ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
 def _block_forward(blk: Bottleneck, x: torch.Tensor, train: bool, rec: Optional[dict]):
@@ -103,19 +96,19 @@ def _block_forward(blk: Bottleneck, x: torch.Tensor, train: bool, rec: Optional[
     y1, s1 = ops.conv_fwd(c1, x, khwc(blk.conv1.weight), want_stats=train)
     b1 = _bn_forward(blk.bn1, s1, c1, train)
     c2 = ops.conv_problem(B, H, W, planes, planes, 3, 3, blk.stride, 1)
-    y2, s2 = ops.conv_fwd(c2, y1, khwc(blk.conv2.weight), pro=(b1.scale, b1.shift, True), want_stats=train)
+    y2, s2 = ops.conv_fwd(c2, y1, khwc(blk.conv2.weight), pro=(b1, True), want_stats=train)
     b2 = _bn_forward(blk.bn2, s2, c2, train)
     c3 = ops.conv_problem(B, c2.OH, c2.OW, planes, planes * 4, 1, 1, 1, 0)
-    y3, s3 = ops.conv_fwd(c3, y2, khwc(blk.conv3.weight), pro=(b2.scale, b2.shift, True), want_stats=train)
+    y3, s3 = ops.conv_fwd(c3, y2, khwc(blk.conv3.weight), pro=(b2, True), want_stats=train)
     b3 = _bn_forward(blk.bn3, s3, c3, train)
     if blk.downsample is not None:
         cd = ops.conv_problem(B, H, W, Cin, planes * 4, 1, 1, blk.stride, 0)
         yd, sd = ops.conv_fwd(cd, x, khwc(blk.downsample[0].weight), want_stats=train)
         bd = _bn_forward(blk.downsample[1], sd, cd, train)
-        out = ops.bn_act(y3, b3.scale, b3.shift, res=yd, res_scale=bd.scale, res_shift=bd.shift, relu=True)
+        out = ops.bn_act(y3, b3, res=yd, res_bnp=bd, relu=True)
     else:
         cd = yd = bd = None
-        out = ops.bn_act(y3, b3.scale, b3.shift, res=x, relu=True)
+        out = ops.bn_act(y3, b3, res=x, relu=True)
     if rec is not None:
         rec.update(x=x, y1=y1, y2=y2, y3=y3, yd=yd, out=out, b1=b1, b2=b2, b3=b3, bd=bd, c1=c1, c2=c2, c3=c3, cd=cd)
     return out
@@ -127,24 +120,24 @@ def _block_backward(blk: Bottleneck, rec: dict, dout: torch.Tensor, grads: Dict[
     b1, b2, b3, bd = rec["b1"], rec["b2"], rec["b3"], rec["bd"]
     c1, c2, c3, cd = rec["c1"], rec["c2"], rec["c3"], rec["cd"]
     # bn3 (+ residual ReLU mask from `out`)
-    dy3, dg, db = ops.bn_bwd(y3, dout, b3.mean, b3.invstd, blk.bn3.weight, out=out)
+    dy3, dg, db = ops.bn_bwd(y3, dout, b3, blk.bn3.weight, out=out)
     grads[blk.bn3.weight], grads[blk.bn3.bias] = dg, db
     # conv3: input operand = relu(bn2(y2)) recomputed in the prologue
-    grads[blk.conv3.weight] = ops.conv_wgrad(c3, y2, dy3, pro=(b2.scale, b2.shift, True)).permute(0, 3, 1, 2)
+    grads[blk.conv3.weight] = ops.conv_wgrad(c3, y2, dy3, pro=(b2, True)).permute(0, 3, 1, 2)
     da2 = ops.conv_dgrad(c3, dy3, ops.weight_transpose(khwc(blk.conv3.weight)))
     del dy3
-    dy2, dg, db = ops.bn_bwd(y2, da2, b2.mean, b2.invstd, blk.bn2.weight, mask=(b2.scale, b2.shift))
+    dy2, dg, db = ops.bn_bwd(y2, da2, b2, blk.bn2.weight, mask_bnp=b2)
     grads[blk.bn2.weight], grads[blk.bn2.bias] = dg, db
     del da2
-    grads[blk.conv2.weight] = ops.conv_wgrad(c2, y1, dy2, pro=(b1.scale, b1.shift, True)).permute(0, 3, 1, 2)
+    grads[blk.conv2.weight] = ops.conv_wgrad(c2, y1, dy2, pro=(b1, True)).permute(0, 3, 1, 2)
     da1 = ops.conv_dgrad(c2, dy2, ops.weight_transpose(khwc(blk.conv2.weight)))
     del dy2
-    dy1, dg, db = ops.bn_bwd(y1, da1, b1.mean, b1.invstd, blk.bn1.weight, mask=(b1.scale, b1.shift))
+    dy1, dg, db = ops.bn_bwd(y1, da1, b1, blk.bn1.weight, mask_bnp=b1)
     grads[blk.bn1.weight], grads[blk.bn1.bias] = dg, db
     del da1
     grads[blk.conv1.weight] = ops.conv_wgrad(c1, x, dy1).permute(0, 3, 1, 2)
     if blk.downsample is not None:
-        dyd, dg, db = ops.bn_bwd(yd, dout, bd.mean, bd.invstd, blk.downsample[1].weight, out=out)
+        dyd, dg, db = ops.bn_bwd(yd, dout, bd, blk.downsample[1].weight, out=out)
         grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dg, db
         grads[blk.downsample[0].weight] = ops.conv_wgrad(cd, x, dyd).permute(0, 3, 1, 2)
         dx = ops.conv_dgrad(cd, dyd, ops.weight_transpose(khwc(blk.downsample[0].weight)))
@@ -158,10 +151,9 @@ class _BodyFn(torch.autograd.Function):
     """x (B,H,W,3) NHWC -> (c1, c2, c3, c4) NHWC.  params are passed so autograd routes their grads."""
 
     @staticmethod
-    def forward(ctx, owner: "BackboneBase", x: torch.Tensor, *params: torch.Tensor):
+    def forward(ctx, owner: "BackboneBase", need_grad: bool, x: torch.Tensor, *params: torch.Tensor):
         body: ResNetBody = owner.body
         train = owner.training
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if need_grad and not train:
             raise NotImplementedError("dpft_amd: backward through eval-mode BatchNorm is not implemented")
         recs: List[dict] = [] if need_grad else None
@@ -177,7 +169,7 @@ class _BodyFn(torch.autograd.Function):
         c0 = ops.conv_problem(B, H, W, 3, 64, 7, 7, 2, 3)
         y0, s0 = ops.conv_fwd(c0, xa, khwc(body.conv1.weight), want_stats=train)
         b0 = _bn_forward(body.bn1, s0, c0, train)
-        cur = ops.bn_relu_maxpool(y0, b0.scale, b0.shift)
+        cur = ops.bn_relu_maxpool(y0, b0)
         stem.update(c0=c0, xa=xa, y0=y0, b0=b0)
         outs = []
         for li in range(body.n_layers):
@@ -218,15 +210,15 @@ class _BodyFn(torch.autograd.Function):
             rec.clear()
         # stem: maxpool + relu + bn1 + conv1 (+ adjustment conv)
         b0, y0, c0, xa = stem["b0"], stem["y0"], stem["c0"], stem["xa"]
-        dz0 = ops.bn_relu_maxpool_bwd(y0, b0.scale, b0.shift, g)
-        dy0, dg, db = ops.bn_bwd(y0, dz0, b0.mean, b0.invstd, body.bn1.weight)
+        dz0 = ops.bn_relu_maxpool_bwd(y0, b0, g)
+        dy0, dg, db = ops.bn_bwd(y0, dz0, b0, body.bn1.weight)
         grads[body.bn1.weight], grads[body.bn1.bias] = dg, db
         grads[body.conv1.weight] = ops.conv_wgrad(c0, xa, dy0).permute(0, 3, 1, 2)
         dx = None
         if owner.adjustment_layer is not None:
             dxa = ops.conv_dgrad(c0, dy0, ops.weight_transpose(khwc(body.conv1.weight)))
             grads[owner.adjustment_layer.weight] = ops.conv_wgrad(stem["ca"], stem["x_raw"], dxa).permute(0, 3, 1, 2)
-        out = [None, dx]
+        out = [None, None, dx]
         for p in params:
             out.append(grads.get(p))
         return tuple(out)
@@ -255,7 +247,9 @@ class BackboneBase(nn.Module):
         if not self.channel_last:
             batch = batch.movedim(1, -1)
         params = [p for p in self.parameters()]
-        outs = _BodyFn.apply(self, batch, *params)
+        # grad mode is off inside Function.forward, so the decision is taken here
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        outs = _BodyFn.apply(self, need_grad, batch, *params)
         out = OrderedDict((str(i + 1), o) for i, o in enumerate(outs))
         if not self.channel_last:
             out = OrderedDict((k, v.movedim(-1, 1)) for k, v in out.items())

@@ -63,14 +63,17 @@ int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d);
  * *tile_rows receives the tile height so the caller can recover per-tile counts. */
 int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows);
 
+/* BN parameter block convention used across the library: bnp[4][K] floats =
+ *   row 0 mean, row 1 scale = gamma*invstd, row 2 beta, row 3 invstd;   bn(v) = (v - mean)*scale + beta
+ * (mean is subtracted first: no beta - mean*scale cancellation when |mean| >> std). */
+
 /* y[B,OH,OW,K] = conv(act(x), w) (+bias).  Optional fused prologue on the input operand:
- * act(x) = max(x*pro_scale[c] + pro_shift[c], 0) (BatchNorm-apply + ReLU of the producer),
- * enabled when pro_scale != NULL (pro_relu selects the max).  Optional fused epilogue: per-M-tile
- * per-channel (mean, M2) of y into `stats` for train-mode BatchNorm (NULL to skip). */
+ * act(x) = [max(., 0)] bn(x) with the PRODUCER's BN block pro_bn[4][C] (NULL = identity; pro_relu
+ * selects the max).  Padding stays exactly zero.  Optional fused epilogue: per-M-tile per-channel
+ * (mean, M2) of y into `stats` for train-mode BatchNorm (NULL to skip). */
 int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x, const float* w,
-                             const float* bias, const float* pro_scale, const float* pro_shift,
-                             int32_t pro_relu, float* y, float* stats, void* workspace,
-                             dpft_stream_t stream);
+                             const float* bias, const float* pro_bn, int32_t pro_relu, float* y,
+                             float* stats, void* workspace, dpft_stream_t stream);
 /* dx[B,H,W,C] (+)= conv_transpose(dy, w).  w_t is the transposed weight [C][kh][kw][K]
  * (see dpft_weight_transpose_f32); accumulate != 0 adds into dx instead of overwriting it. */
 int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,
@@ -79,8 +82,8 @@ int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const f
 /* dw[K][kh][kw][C] = sum_pixels dy (x) act(x); same optional prologue on x as forward.
  * dw is overwritten. */
 int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,
-                               const float* pro_scale, const float* pro_shift, int32_t pro_relu,
-                               float* dw, void* workspace, dpft_stream_t stream);
+                               const float* pro_bn, int32_t pro_relu, float* dw, void* workspace,
+                               dpft_stream_t stream);
 /* [K][taps][C] -> [C][taps][K] */
 int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, int32_t taps, int32_t C,
                               dpft_stream_t stream);
@@ -93,43 +96,39 @@ int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K, dpft_st
 /* standalone per-tile statistics of y[M][K] in the same [tiles][2][K] format (tile_rows rows each) */
 int dpft_bn_stats_f32(const float* y, float* stats, int64_t M, int32_t K, int32_t tile_rows,
                       dpft_stream_t stream);
-/* combine tiles (Chan), produce scale = gamma*invstd, shift = beta - mean*scale, save mean/invstd,
- * update running stats (momentum; unbiased variance) when running_mean != NULL. */
+/* combine tiles (Chan's parallel variance), write the BN block bnp[4][K], update the running
+ * statistics (momentum; unbiased variance) when running_mean != NULL. */
 int dpft_bn_finalize_f32(const float* stats, int32_t tiles, int32_t tile_rows, int64_t M, int32_t K,
                          const float* gamma, const float* beta, float eps, float momentum,
-                         float* running_mean, float* running_var, float* save_mean,
-                         float* save_invstd, float* scale, float* shift, dpft_stream_t stream);
-/* eval mode: scale/shift from running statistics */
-int dpft_bn_eval_scale_shift_f32(const float* gamma, const float* beta, const float* running_mean,
-                                 const float* running_var, float eps, int32_t K, float* scale,
-                                 float* shift, dpft_stream_t stream);
-/* out = [relu]( y*scale + shift  [+ (res*res_scale + res_shift | res)] ) elementwise over [M][K] */
-int dpft_bn_act_f32(const float* y, const float* scale, const float* shift, const float* res,
-                    const float* res_scale, const float* res_shift, int32_t relu, float* out,
-                    int64_t M, int32_t K, dpft_stream_t stream);
-/* stem: out[B,PH,PW,K] = maxpool3x3s2p1( relu(y*scale+shift) ), y is [B,H,W,K] */
-int dpft_bn_relu_maxpool_f32(const float* y, const float* scale, const float* shift, float* out,
-                             int32_t B, int32_t H, int32_t W, int32_t K, int32_t PH, int32_t PW,
-                             dpft_stream_t stream);
+                         float* running_mean, float* running_var, float* bnp, dpft_stream_t stream);
+/* eval mode: BN block from the running statistics */
+int dpft_bn_eval_params_f32(const float* gamma, const float* beta, const float* running_mean,
+                            const float* running_var, float eps, int32_t K, float* bnp,
+                            dpft_stream_t stream);
+/* out = [relu]( bn(y)  [+ (bn_res(res) | res)] ) elementwise over [M][K] */
+int dpft_bn_act_f32(const float* y, const float* bnp, const float* res, const float* res_bnp,
+                    int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream);
+/* stem: out[B,PH,PW,K] = maxpool3x3s2p1( relu(bn(y)) ), y is [B,H,W,K] */
+int dpft_bn_relu_maxpool_f32(const float* y, const float* bnp, float* out, int32_t B, int32_t H,
+                             int32_t W, int32_t K, int32_t PH, int32_t PW, dpft_stream_t stream);
 /* backward of the stem pool + ReLU: dz[B,H,W,K] = grad wrt bn(y) = (relu(bn(y))>0) * sum of dout over
  * the pool windows whose first arg-max (scan order, strict >) is this pixel */
-int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* scale, const float* shift,
-                                 const float* dout, float* dz, int32_t B, int32_t H, int32_t W,
-                                 int32_t K, int32_t PH, int32_t PW, dpft_stream_t stream);
+int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* bnp, const float* dout, float* dz,
+                                 int32_t B, int32_t H, int32_t W, int32_t K, int32_t PH, int32_t PW,
+                                 dpft_stream_t stream);
 /* BatchNorm backward, two passes.  dz = dout * mask with
- *   mask = (out > 0)                          if out != NULL        (out = post-activation tensor)
- *   mask = (y*mask_scale + mask_shift > 0)    elif mask_scale != NULL (recompute the fused ReLU)
- *   mask = 1                                  otherwise.
- * pass 1: sums[0][k] = sum dz, sums[1][k] = sum dz * xhat   (xhat = (y-mean)*invstd) */
+ *   mask = (out > 0)              if out != NULL       (out = post-activation tensor)
+ *   mask = (bn_mask(y) > 0)       elif mask_bnp != NULL (recompute the fused ReLU from its BN block)
+ *   mask = 1                      otherwise.
+ * pass 1: sums[0][k] = sum dz, sums[1][k] = sum dz * xhat   (xhat = (y-mean)*invstd from bnp) */
 int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const float* out,
-                           const float* mask_scale, const float* mask_shift, const float* mean,
-                           const float* invstd, float* sums, int64_t M, int32_t K,
-                           dpft_stream_t stream);
+                           const float* mask_bnp, const float* bnp, float* sums, int64_t M,
+                           int32_t K, dpft_stream_t stream);
 /* pass 2: dy = gamma*invstd*(dz - sums0/M - xhat*sums1/M); dgamma = sums1, dbeta = sums0 */
 int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const float* out,
-                          const float* mask_scale, const float* mask_shift, const float* mean,
-                          const float* invstd, const float* gamma, const float* sums, float* dy,
-                          float* dgamma, float* dbeta, int64_t M, int32_t K, dpft_stream_t stream);
+                          const float* mask_bnp, const float* bnp, const float* gamma,
+                          const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
+                          int32_t K, dpft_stream_t stream);
 /* dz = dout * (out > 0)  (residual branch gradient) */
 int dpft_relu_bwd_f32(const float* dout, const float* out, float* dz, int64_t n,
                       dpft_stream_t stream);

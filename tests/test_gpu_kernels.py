@@ -41,9 +41,9 @@ CONV_CASES = [
 
 def _conv_ref(x, w, bias, stride, pad, pro):
     xd = x.double()
-    if pro is not None:
-        xd = xd * pro[0].double() + pro[1].double()
-        if pro[2]:
+    if pro is not None:       # pro = (bn block (4,C): mean, scale, beta, invstd ; relu)
+        xd = (xd - pro[0][0].double()) * pro[0][1].double() + pro[0][2].double()
+        if pro[1]:
             xd = xd.clamp_min(0)
     xa = xd.permute(0, 3, 1, 2).requires_grad_(True)
     wd = w.double().requires_grad_(True)
@@ -62,12 +62,13 @@ def test_conv_fwd_dgrad_wgrad(case, fused):
     use_pro = fused and C % 32 == 0
     use_bias = (K == 16) and not fused
     bias = torch.randn(K, generator=g) if use_bias else None
-    pro = (torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, True) if use_pro else None
+    pro = (torch.stack((torch.randn(C, generator=g) * 0.5, torch.rand(C, generator=g) + 0.5,
+                        torch.randn(C, generator=g) * 0.3, torch.ones(C))), True) if use_pro else None
     xa, wd, yref = _conv_ref(x, w, bias, stride, pad, pro)
     cv = ops.conv_problem(B, H, W, C, K, k, k, stride, pad)
     w_dev = w.to(DEV).permute(0, 2, 3, 1)
     assert w_dev.is_contiguous()
-    prod = None if pro is None else (pro[0].to(DEV), pro[1].to(DEV), True)
+    prod = None if pro is None else (pro[0].to(DEV), True)
     y, stats = ops.conv_fwd(cv, x.to(DEV), w_dev, bias=None if bias is None else bias.to(DEV), pro=prod,
                             want_stats=fused and not use_bias)
     close(y.permute(0, 3, 1, 2), yref, what="conv fwd")
@@ -75,10 +76,11 @@ def test_conv_fwd_dgrad_wgrad(case, fused):
         # fused BN statistics: finalize and compare against the batch statistics of the reference
         gamma, beta = torch.ones(K, device=DEV), torch.zeros(K, device=DEV)
         rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
-        sc, sh, mean, invstd = ops.bn_finalize(stats, cv.tile_rows, cv.M, gamma, beta, 1e-5, 0.1, rm, rv)
+        bnp = ops.bn_finalize(stats, cv.tile_rows, cv.M, gamma, beta, 1e-5, 0.1, rm, rv)
         yr = yref.detach().permute(0, 2, 3, 1).reshape(-1, K)
-        close(mean, yr.mean(0), what="bn mean")
-        close(invstd, 1 / torch.sqrt(yr.var(0, unbiased=False) + 1e-5), what="bn invstd")
+        close(bnp[0], yr.mean(0), what="bn mean")
+        close(bnp[3], 1 / torch.sqrt(yr.var(0, unbiased=False) + 1e-5), what="bn invstd")
+        close(bnp[1], bnp[3], rtol=0, atol_scale=0, what="scale = gamma*invstd")
         close(rv, 0.9 + 0.1 * yr.var(0, unbiased=True), what="running var")
         close(rm, 0.1 * yr.mean(0), what="running mean")
     dy = torch.randn(yref.shape, generator=g, dtype=torch.float64)
@@ -124,10 +126,10 @@ def test_bn_train_forward_backward(shape):
     yg = y.to(DEV)
     stats = ops.bn_stats(yg, 128)
     rm, rv = torch.zeros(K, device=DEV), torch.ones(K, device=DEV)
-    sc, sh, mean, invstd = ops.bn_finalize(stats, 128, M, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm, rv)
-    out = ops.bn_act(yg, sc, sh, res=res.to(DEV), relu=True)
+    bnp = ops.bn_finalize(stats, 128, M, gamma.to(DEV), beta.to(DEV), 1e-5, 0.1, rm, rv)
+    out = ops.bn_act(yg, bnp, res=res.to(DEV), relu=True)
     close(out, ref, what="bn_act")
-    dy, dg, db = ops.bn_bwd(yg, dout.to(DEV), mean, invstd, gamma.to(DEV), out=out)
+    dy, dg, db = ops.bn_bwd(yg, dout.to(DEV), bnp, gamma.to(DEV), out=out)
     close(dy, yd.grad, rtol=1e-3, atol_scale=1e-4, what="bn dy")
     close(dg, gd.grad, rtol=1e-3, atol_scale=1e-4, what="bn dgamma")
     close(db, bd.grad, rtol=1e-3, atol_scale=1e-4, what="bn dbeta")
@@ -137,13 +139,13 @@ def test_bn_train_forward_backward(shape):
     ref2 = F.relu(F.batch_norm(yd2.permute(0, 3, 1, 2), None, None, gamma.double(), beta.double(),
                                training=True, eps=1e-5).permute(0, 2, 3, 1))
     (ref2 * dout.double()).sum().backward()
-    dy2, _, _ = ops.bn_bwd(yg, dout.to(DEV), mean, invstd, gamma.to(DEV), mask=(sc, sh))
+    dy2, _, _ = ops.bn_bwd(yg, dout.to(DEV), bnp, gamma.to(DEV), mask_bnp=bnp)
     close(dy2, yd2.grad, rtol=1e-3, atol_scale=1e-4, what="bn dy (mask)")
     # eval-mode scale/shift
-    sce, she = ops.bn_eval_scale_shift(gamma.to(DEV), beta.to(DEV), rm, rv, 1e-5)
+    bnp_e = ops.bn_eval_params(gamma.to(DEV), beta.to(DEV), rm, rv, 1e-5)
     ref_e = F.batch_norm(y.double().permute(0, 3, 1, 2), rm.double().cpu(), rv.double().cpu(), gamma.double(),
                          beta.double(), training=False, eps=1e-5).permute(0, 2, 3, 1)
-    close(ops.bn_act(yg, sce, she, relu=False), ref_e, what="bn eval")
+    close(ops.bn_act(yg, bnp_e, relu=False), ref_e, what="bn eval")
 
 
 @pytest.mark.parametrize("shape", [(2, 19, 27, 64), (1, 8, 8, 64), (2, 37, 54, 64)])
@@ -153,17 +155,18 @@ def test_bn_relu_maxpool(shape):
     K = shape[-1]
     y = torch.randn(shape, generator=g)
     sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.5
+    bnp = torch.stack((torch.zeros(K), sc, sh, torch.ones(K))).to(DEV)
     yd = y.double().requires_grad_(True)
     a = F.relu(yd * sc.double() + sh.double())
     ref = F.max_pool2d(a.permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
-    out = ops.bn_relu_maxpool(y.to(DEV), sc.to(DEV), sh.to(DEV))
+    out = ops.bn_relu_maxpool(y.to(DEV), bnp)
     close(out, ref, what="maxpool fwd")
     dout = torch.randn(ref.shape, generator=g)
     # reference gradient wrt z = y*sc+sh
     z = (y.double() * sc.double() + sh.double()).requires_grad_(True)
     r2 = F.max_pool2d(F.relu(z).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1)
     (r2 * dout.double()).sum().backward()
-    dz = ops.bn_relu_maxpool_bwd(y.to(DEV), sc.to(DEV), sh.to(DEV), dout.to(DEV))
+    dz = ops.bn_relu_maxpool_bwd(y.to(DEV), bnp, dout.to(DEV))
     close(dz, z.grad, what="maxpool bwd")
 
 
@@ -283,7 +286,8 @@ def test_giou3d_yaw_vs_oracle():
     gc = torch.randn(Mg, 3, generator=g) * 3
     gs = torch.rand(Mg, 3, generator=g) * 3 + 1
     ga = (torch.rand(Mg, generator=g) * 2 - 1) * 3.1
-    pc[10] = gc[0]; ps[10] = gs[0]; pa[10] = ga[0]   # identical boxes -> 1
+    ga[0] = 0.0
+    pc[10] = gc[0]; ps[10] = gs[0]; pa[10] = ga[0]   # identical axis-aligned boxes -> 1 (enclosing box is an AABB)
     ref = O.giou3d_yaw(pc, ps, pa, gc, gs, ga)
     pred7 = torch.cat((pc, ps, pa[:, None]), -1)[None].to(DEV)
     gt7 = torch.cat((gc, gs, ga[:, None]), -1)[None].to(DEV)

@@ -19,6 +19,12 @@ def close(a, b, rtol=1e-4, atol_scale=1e-5, what=""):
     torch.testing.assert_close(a, b, rtol=rtol, atol=atol, msg=lambda m: f"{what}: {m}")
 
 
+def rel_l2(a, ref):
+    a = a.detach().double().cpu()
+    ref = ref.detach().double().cpu()
+    return float((a - ref).norm() / (ref.norm() + 1e-30))
+
+
 def small_config(dropout=0.0, camera="ResNet50"):
     from dpft_amd.configs import load_config
     cfg = load_config("kradar")
@@ -28,7 +34,7 @@ def small_config(dropout=0.0, camera="ResNet50"):
     return cfg
 
 
-SHAPES = {"camera_mono": (96, 160, 3), "radar_bev": (64, 43, 6), "radar_front": (37, 43, 6)}
+SHAPES = {"camera_mono": (96, 160, 3), "radar_bev": (128, 43, 6), "radar_front": (37, 107, 6)}
 
 
 def randomise_bn(model, g):
@@ -69,20 +75,35 @@ def test_backbone_train_fwd_bwd(name, cin):
               for k, v in sd.items()}
     ref = O.backbone(x.double(), sd_ref, "bb", name, train=True, multi_scale=4)
     assert list(outs.keys()) == ["1", "2", "3", "4"]
+    # the CPU fp32 path's own rounding error (vs fp64) is the yardstick for a 50/101-layer chain
+    sd32 = {k: (v.float().requires_grad_(True) if v.is_floating_point() and "running" not in k else
+                (v.float() if v.is_floating_point() else v)) for k, v in sd.items()}
+    ref32 = O.backbone(x, sd32, "bb", name, train=True, multi_scale=4)
     for k in outs:
         assert outs[k].shape == ref[k].shape
-        close(outs[k], ref[k], rtol=1e-3, atol_scale=1e-4, what=f"{name} layer{k}")
+        e, e32 = rel_l2(outs[k], ref[k]), rel_l2(ref32[k], ref[k])
+        print(f"{name} layer{k}: rel-L2 gpu {e:.2e}  cpu-fp32 {e32:.2e}")
+        assert e < max(1e-5, 4 * e32), (k, e, e32)
     cots = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in ref}
     sum((ref[k] * cots[k]).sum() for k in ref).backward()
     sum((outs[k] * cots[k].float().to(DEV)).sum() for k in outs).backward()
-    worst = 0.0
+    sum((ref32[k] * cots[k].float()).sum() for k in ref32).backward()
+    # ReLU-mask flips at near-zero pre-activations make max-abs errors heavy-tailed (they also hit the CPU
+    # fp32 path), so the gradient metric is the relative Frobenius error, with the CPU fp32 path's own
+    # error (vs fp64) as the yardstick for a 50/101-layer train-mode-BN chain on a batch of 2.
+    report = []
     for n, p in bb.named_parameters():
         gref = sd_ref["bb." + n].grad
         assert p.grad is not None, n
         assert p.grad.shape == p.shape
-        err = float((p.grad.double().cpu() - gref).abs().max() / (gref.abs().max() + 1e-12))
-        worst = max(worst, err)
-        assert err < 5e-3, (n, err)
+        den = float(gref.norm()) + 1e-12
+        err = float((p.grad.double().cpu() - gref).norm()) / den
+        err32 = float((sd32["bb." + n].grad.double() - gref).norm()) / den
+        report.append((err / max(err32, 1e-6), err, err32, n))
+    report.sort(reverse=True)
+    print("worst grads (ratio, gpu rel-L2 err, cpu-fp32 rel-L2 err):", report[:5])
+    for ratio, err, err32, n in report:
+        assert err < max(2e-3, 4 * err32), (n, err, err32)
     # running statistics were updated exactly once
     assert int(bb.body.bn1.num_batches_tracked) == 1
 
@@ -157,29 +178,38 @@ def test_dprt_train_forward_backward_matches_oracle():
     cfg = small_config(dropout=0.0)
     model = _build(cfg, g)
     sd64 = state_dict_f64(model)
-    sd_ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v)
-              for k, v in sd64.items()}
+
+    def leafs(sd, dtype):
+        return {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                    else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
+    sd_ref, sd32 = leafs(sd64, torch.float64), leafs(sd64, torch.float32)
     batch = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=SHAPES)
     b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
     ref = O.dprt_forward(sd_ref, cfg, b64, train=True)
+    ref32 = O.dprt_forward(sd32, cfg, batch, train=True)          # yardstick: CPU fp32 vs fp64
     model = model.to(DEV).train()
     out = model({k: v.to(DEV) for k, v in batch.items()})
     for k in out:
-        close(out[k], ref[k], rtol=1e-3, atol_scale=1e-3, what=f"train out {k}")
+        e, e32 = rel_l2(out[k], ref[k]), rel_l2(ref32[k], ref[k])
+        print(f"train out {k}: rel-L2 gpu {e:.2e} cpu-fp32 {e32:.2e}")
+        assert e < max(1e-4, 4 * e32), (k, e, e32)
     cots = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in ref}
     sum((ref[k] * cots[k]).sum() for k in ref).backward()
+    sum((ref32[k] * cots[k].float()).sum() for k in ref32).backward()
     sum((out[k] * cots[k].float().to(DEV)).sum() for k in out).backward()
-    checked = 0
-    bad = []
+    checked, bad, report = 0, [], []
     for n, p in model.named_parameters():
         gref = sd_ref[n].grad
         if gref is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n      # template head (App. A)
             continue
         assert p.grad is not None, n
-        err = float((p.grad.double().cpu() - gref).abs().max() / (gref.abs().max() + 1e-12))
-        if err > 2e-2:
-            bad.append((n, err))
+        e, e32 = rel_l2(p.grad, gref), rel_l2(sd32[n].grad, gref)
+        report.append((e / max(e32, 1e-7), e, e32, n))
+        if e > max(5e-3, 6 * e32):       # layer4 BN sees only 8-32 samples per channel at these sizes
+            bad.append((n, e, e32))
         checked += 1
+    report.sort(reverse=True)
+    print("worst grads (ratio, gpu, cpu-fp32):", report[:5])
     assert checked > 300
     assert not bad, bad[:10]
