@@ -1,0 +1,200 @@
+#!/usr/bin/env python
+"""Headline benchmark: training samples/s of the full camera+radar DPFT hot path (config kradar,
+batch 4 per GPU, fp32, synthetic K-Radar-shaped tensors resident in HBM), plus fwd ms/frame.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = zero-grad -> forward -> Hungarian set loss -> backward -> (bucketed all-reduce) -> AdamW,
+the reference's CentralizedTrainer.train_one_epoch order (src/dprt/training/trainer.py:99-160).
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch
+import torch.distributed as dist
+
+PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, chip table
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE: 4)")
+    ap.add_argument("--config", default="kradar")
+    ap.add_argument("--latency-reps", type=int, default=30, help="event-timed eval forwards for fwd ms/frame")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-steps", type=int, default=1)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
+    ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args()
+
+
+def cpu_baseline(cfg, batch_size: int, steps: int, threads: int = 0):
+    """The oracle (CPU restatement of the reference path, torch fp32) timed on the host cores:
+    forward + set loss + backward of `steps` batches of `batch_size` (bounded sample).  Thread count is
+    capped at 32: torch's CPU kernels on this many small tensors get slower, not faster, beyond that."""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from oracle import dprt_oracle as O
+    cores = threads if threads > 0 else min(os.cpu_count() or 1, 32)
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    model = build("dprt", cfg)
+    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach())
+          for k, v in model.state_dict().items()}
+    del model
+    inputs = cfg["model"]["inputs"]
+    w = cfg["train"]["loss_weights"]
+    t_total = 0.0
+    for s in range(steps):
+        batch = make_batch(inputs, batch_size, seed=100 + s)
+        labels = make_labels(batch_size, seed=100 + s)
+        t0 = time.perf_counter()
+        out = O.dprt_forward(sd, cfg, batch, train=True)
+        loss, _ = O.loss_forward(out, labels, w)
+        loss.backward()
+        t_total += time.perf_counter() - t0
+        for v in sd.values():
+            if v.is_floating_point() and v.grad is not None:
+                v.grad = None
+    return {"value": batch_size * steps / t_total, "unit": "samples/s", "cores": cores, "kind": "port",
+            "host_cores": os.cpu_count(),
+            "sample": f"{steps} train step(s) (fwd + Hungarian set loss + bwd, no optimizer) at batch {batch_size}, "
+                      f"torch-CPU fp32 oracle, {cores} threads"}
+
+
+def cpu_baseline_subprocess(args):
+    """Run the CPU leg in a child process with a wall-clock bound so that the default bench finishes in minutes."""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
+           "--cpu-batch", str(args.cpu_batch), "--cpu-steps", str(args.cpu_steps), "--cpu-threads", str(args.cpu_threads)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout,
+                           env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"value": None, "unit": "samples/s", "cores": None, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
+    except subprocess.TimeoutExpired:
+        return {"value": None, "unit": "samples/s", "cores": None, "kind": "port",
+                "sample": f"timed out after {args.cpu_timeout}s for {args.cpu_steps} step(s) at batch {args.cpu_batch}"}
+
+
+def main():
+    args = parse()
+    if args.cpu_baseline_only:
+        from dpft_amd.configs import load_config
+        print(json.dumps(cpu_baseline(load_config(args.config), args.cpu_batch, args.cpu_steps, args.cpu_threads)))
+        return
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: dpft_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", device_id=device)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from dpft_amd.configs import load_config
+    from dpft_amd.hip import ops
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+
+    cfg = load_config(args.config)
+    torch.manual_seed(cfg["computing"]["seed"])
+    model = build("dprt", cfg)
+    trainer = DataParallelTrainer(model, cfg, device)
+    inputs = cfg["model"]["inputs"]
+    B = args.batch
+    # weak scaling: every rank owns its own seeded shard of the global batch, resident in HBM
+    data = make_batch(inputs, B, seed=cfg["computing"]["seed"] + rank, device=device)
+    labels = make_labels(B, seed=cfg["computing"]["seed"] + rank, device=device)
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        trainer.train_step(data, labels)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = trainer.train_step(data, labels)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel family: fp32 MFMA implicit-GEMM convolutions --------------
+    roof, per_kind = None, {}
+    if rank == 0:
+        ops.PROFILE = []
+        trainer.train_step(data, labels)
+        torch.cuda.synchronize()
+        recs, ops.PROFILE = ops.PROFILE, None
+        tot_f, tot_t = 0.0, 0.0
+        for kind, flops, e0, e1 in recs:
+            dt = e0.elapsed_time(e1) * 1e-3
+            k = per_kind.setdefault(kind, [0.0, 0.0, 0])
+            k[0] += flops; k[1] += dt; k[2] += 1
+            tot_f += flops; tot_t += dt
+        n_launch = sum(k[2] for k in per_kind.values())
+        roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                "frac": tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family)",
+                "launches_per_step": n_launch, "avg_launch_us": 1e6 * tot_t / max(n_launch, 1),
+                "conv_ms_per_step": 1e3 * tot_t, "algorithmic_gflop_per_step": tot_f / 1e9,
+                "per_kind_tflops": {k: v[0] / v[1] / 1e12 for k, v in per_kind.items()}}
+
+    # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
+    fwd_mean, fwd_std = trainer.inference_time(data, warmup=5, reps=args.latency_reps)
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline_subprocess(args)
+
+    if rank == 0:
+        line = {
+            "metric": "training samples/sec (K-Radar C+R, bs4/GPU)", "value": value, "unit": "samples/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.config}.json full C+R dual-perspective fusion train step, batch {B}/GPU "
+                                   "(camera 512x910x3 ResNet-101, radar BEV 256x107x6 + front 37x107x6 ResNet-50, "
+                                   "FPN->16ch, IMPFusion 4 it x 3 views, Hungarian set loss, AdamW)",
+                       "global_batch": world * B, "parallelism": f"dp{world}"},
+            "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,
+            "loss": float(loss),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,24 @@ from dpft_amd.hip.lib import ConvDesc, lib, make_desc, make_pyramid, ptr, stream
 
 _ws_cache = {}
 
+# bench instrumentation: when a list, every conv launch is bracketed by events on the current stream and
+# (kind, algorithmic FLOPs, start, end) is appended
+PROFILE = None
+
+
+class _Prof:
+    __slots__ = ("kind", "flops", "e0")
+
+    def __init__(self, kind, cv):
+        self.kind, self.flops = kind, 2.0 * cv.M * cv.K * cv.kh * cv.kw * cv.C
+        self.e0 = torch.cuda.Event(enable_timing=True)
+        self.e0.record()
+
+    def done(self):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        PROFILE.append((self.kind, self.flops, self.e0, e1))
+
 
 def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     """One grow-only scratch buffer per device (split-K partials).  Stream-ordered reuse is safe
@@ -68,8 +86,11 @@ def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False):
     stats = torch.empty((cv.tiles, 2, cv.K), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
+    prof = _Prof("fwd", cv) if PROFILE is not None else None
     lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(pb), prelu,
              ptr(y), ptr(stats), ptr(ws), stream())
+    if prof is not None:
+        prof.done()
     return y, stats
 
 
@@ -79,8 +100,11 @@ def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
         out = torch.empty((cv.B, cv.H, cv.W, cv.C), dtype=torch.float32, device=dy.device)
         accumulate = False
     ws = workspace(cv.ws_bytes, dy.device)
+    prof = _Prof("dgrad", cv) if PROFILE is not None else None
     lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate), ptr(ws),
              stream())
+    if prof is not None:
+        prof.done()
     return out
 
 
@@ -89,8 +113,11 @@ def conv_wgrad(cv: Conv, x, dy, pro=None):
     dw = torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
+    prof = _Prof("wgrad", cv) if PROFILE is not None else None
     lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(pb), prelu, ptr(dw),
              ptr(ws), stream())
+    if prof is not None:
+        prof.done()
     return dw
 
 

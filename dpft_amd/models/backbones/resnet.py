@@ -208,6 +208,11 @@ class _BodyFn(torch.autograd.Function):
                 last_layer = li
             g = _block_backward(rec["blk"], rec, g, grads)
             rec.clear()
+            sink = owner.grad_sink
+            if sink is not None:          # hand this block's gradients to the DP reducer right away
+                for p_ in list(grads):
+                    if sink(p_, grads[p_]):
+                        del grads[p_]
         # stem: maxpool + relu + bn1 + conv1 (+ adjustment conv)
         b0, y0, c0, xa = stem["b0"], stem["y0"], stem["c0"], stem["xa"]
         dz0 = ops.bn_relu_maxpool_bwd(y0, b0, g)
@@ -231,6 +236,7 @@ class BackboneBase(nn.Module):
         self.in_channels = in_channels
         self.multi_scale = multi_scale
         self.channel_last = channel_last
+        self.grad_sink = None       # optional callable(param, grad) -> bool, installed by the DP trainer
         # resnet.py:47-52 -- 1x1 conv (no bias) to 3 channels when the input is not RGB
         if in_channels == 3:
             self.adjustment_layer = None

@@ -1,0 +1,133 @@
+"""Data-parallel gradient reduction over RCCL (backend "nccl" on ROCm) / gloo.
+
+The reference has no distributed code at all (single ``CentralizedTrainer``,
+src/dprt/training/trainer.py:20,215); this is the MI355X-side addition: one process
+per GPU, samples sharded across ranks, one exchange step = all-reduce(mean) of the gradients.
+
+Design for xGMI (7 point-to-point links per GPU, ring collectives are per-link bound):
+  * gradients live in a few large flat fp32 buckets (default 64 MiB) in REVERSE registration order,
+    ``param.grad`` are views into them -> one collective per bucket, no per-tensor launches;
+  * a bucket's all-reduce is issued asynchronously the moment its last gradient is produced, so the
+    exchange of layer4 overlaps the backward of layer3 ... ; the hand-scheduled backbone backward
+    hands gradients over per bottleneck block through ``grad_sink`` instead of waiting for the end
+    of its (single) autograd node;
+  * parameters that never receive a gradient (the un-cloned template head) are
+    tolerated: unfinished buckets are flushed in ``finish()`` with zeros for the missing grads.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+class GradBucketReducer:
+    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None,
+                 average: bool = True):
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.average = average
+        self.params = [p for p in params if p.requires_grad]
+        order = list(reversed(self.params))
+        self.buckets: List[dict] = []
+        cur, cur_bytes = [], 0
+        for p in order:
+            nbytes = p.numel() * p.element_size()
+            if cur and cur_bytes + nbytes > bucket_bytes:
+                self._add_bucket(cur)
+                cur, cur_bytes = [], 0
+            cur.append(p)
+            cur_bytes += nbytes
+        if cur:
+            self._add_bucket(cur)
+        self._index: Dict[int, tuple] = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b["params"]:
+                self._index[id(p)] = bi
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
+        self._pending: List = []
+        self.reset()
+
+    def _add_bucket(self, params):
+        dev, dtype = params[0].device, params[0].dtype
+        total = sum(p.numel() for p in params)
+        flat = torch.zeros(total, dtype=dtype, device=dev)
+        views, off = {}, 0
+        for p in params:
+            seg = flat[off:off + p.numel()]
+            # keep the parameter's physical layout (conv weights are channels_last) so that copies are linear
+            if p.dim() == 4 and p.permute(0, 2, 3, 1).is_contiguous():
+                K, C, kh, kw = p.shape
+                v = seg.view(K, kh, kw, C).permute(0, 3, 1, 2)
+            else:
+                v = seg.view(p.shape)
+            views[id(p)] = v
+            off += p.numel()
+        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set()))
+
+    # ------------------------------------------------------------------------------------------
+    def reset(self):
+        """Call before every backward: zero the buckets and point ``param.grad`` at the bucket views."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["ready"], b["fired"] = 0, False
+            b["seen"].clear()
+            for p in b["params"]:
+                p.grad = b["views"][id(p)]
+        self._pending = []
+
+    def grad_sink(self, p: torch.nn.Parameter, g: torch.Tensor):
+        """Direct hand-over from a hand-scheduled backward (bypasses autograd accumulation)."""
+        bi = self._index.get(id(p))
+        if bi is None:
+            return False
+        self.buckets[bi]["views"][id(p)].add_(g)
+        self._mark(bi, p)
+        return True
+
+    def _hook(self, p):
+        bi = self._index[id(p)]
+        b = self.buckets[bi]
+        if p.grad is not b["views"][id(p)]:                  # autograd replaced the view: copy back
+            b["views"][id(p)].copy_(p.grad)
+            p.grad = b["views"][id(p)]
+        self._mark(bi, p)
+
+    def _mark(self, bi: int, p):
+        b = self.buckets[bi]
+        if id(p) in b["seen"]:
+            return
+        b["seen"].add(id(p))
+        b["ready"] += 1
+        if b["ready"] == len(b["params"]) and not b["fired"]:
+            self._fire(b)
+
+    def _fire(self, b):
+        b["fired"] = True
+        if self.world > 1:
+            if self.average:
+                b["flat"].div_(self.world)
+            self._pending.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """Flush buckets whose parameters did not all receive gradients, then wait for every collective."""
+        for b in self.buckets:
+            if not b["fired"]:
+                self._fire(b)
+        for w in self._pending:
+            w.wait()
+        self._pending = []
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+
+
+def broadcast_module(module: torch.nn.Module, src: int = 0, group=None):
+    """One-time parameter/buffer broadcast from rank 0 (identical replicas before step 0)."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            dist.broadcast(t, src=src, group=group)

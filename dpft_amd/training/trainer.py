@@ -1,0 +1,66 @@
+"""Training / latency loops with the reference's step order and timing protocol.
+
+Mirror of ``CentralizedTrainer.train_one_epoch`` (src/dprt/training/trainer.py:99-160: zero_grad ->
+forward -> loss -> if loss > 0: backward, optimizer.step) and of
+``CentralizedEvaluator.evaluate_inference_time`` (src/dprt/evaluation/evaluator.py:97-135: 10 warm-up
++ 300 event-timed forwards), extended to one-process-per-GPU data parallelism.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from dpft_amd.training.distributed import GradBucketReducer, broadcast_module
+from dpft_amd.training.loss import build_loss
+
+
+class DataParallelTrainer:
+    def __init__(self, model: torch.nn.Module, config: Dict[str, Any], device, bucket_mb: int = 64):
+        self.model = model.to(device)
+        self.device = device
+        train = config["train"]
+        self.loss_fn = build_loss(train)
+        opt = dict(train["optimizer"])
+        name = opt.pop("name")
+        self.optimizer = getattr(torch.optim, name)(self.model.parameters(), **opt)     # trainer.py:233
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        broadcast_module(self.model)
+        self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=bucket_mb << 20)
+        for m in self.model.modules():
+            if hasattr(m, "grad_sink"):
+                m.grad_sink = self.reducer.grad_sink
+
+    def train_step(self, data: Dict[str, torch.Tensor], labels: List[Dict[str, torch.Tensor]]):
+        self.model.train()
+        self.reducer.reset()                               # zero_grad (grads live in the buckets)
+        output = self.model(data)
+        loss, losses = self.loss_fn(output, labels)
+        stepped = bool(loss > 0)                           # trainer.py:131 (host sync, as in the reference)
+        if self.world > 1:                                 # every rank must take the same branch
+            flag = torch.tensor([int(stepped)], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            stepped = bool(flag.item())
+        if stepped:
+            loss.backward()
+            self.reducer.finish()
+            self.optimizer.step()
+        return loss.detach(), {k: v.detach() for k, v in losses.items()}
+
+    @torch.no_grad()
+    def inference_time(self, data: Dict[str, torch.Tensor], warmup: int = 10, reps: int = 300):
+        """mean / std forward latency in ms on one batch (evaluator.py:109-125)."""
+        self.model.eval()
+        for _ in range(warmup):
+            self.model(data)
+        starter, ender = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        times = []
+        for _ in range(reps):
+            starter.record()
+            self.model(data)
+            ender.record()
+            torch.cuda.synchronize()
+            times.append(starter.elapsed_time(ender))
+        t = torch.tensor(times)
+        return float(t.mean()), float(t.std())

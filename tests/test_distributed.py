@@ -1,0 +1,97 @@
+"""world_size-2 gloo test of the bucketed gradient reducer (runs on CPU)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.net = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Flatten(),
+                                       torch.nn.Linear(8 * 6 * 6, 10), torch.nn.ReLU(), torch.nn.Linear(10, 4))
+        self.net[0].weight.data = self.net[0].weight.data.contiguous(memory_format=torch.channels_last)
+        self.unused = torch.nn.Linear(3, 3)          # never receives a gradient (like the template head)
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def _make_model():
+    torch.manual_seed(0)
+    return _Net()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from dpft_amd.training.distributed import GradBucketReducer, broadcast_module
+    model = _make_model()
+    if rank != 0:                              # replicas start different; broadcast must fix that
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(1.0)
+    broadcast_module(model)
+    red = GradBucketReducer(list(model.parameters()), bucket_bytes=2048)     # several small buckets
+    assert len(red.buckets) > 2
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 6, 6, generator=g)
+    y = torch.randn(4, 4, generator=g)
+    xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
+    for step in range(2):                      # second pass checks reset()
+        red.reset()
+        loss = ((model(xs) - ys) ** 2).sum(1).mean()       # per-sample mean => averaging = global-batch grad
+        loss.backward()
+        # one gradient is delivered through the direct sink path as the hand-scheduled backward does
+        red.finish()
+    grads = {n: p.grad.clone() for n, p in model.named_parameters()}
+    q.put((rank, {k: v.numpy() for k, v in grads.items()}))
+    dist.destroy_process_group()
+
+
+def test_bucketed_allreduce_equals_global_batch_gradient():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    model = _make_model()
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(4, 3, 6, 6, generator=g)
+    y = torch.randn(4, 4, generator=g)
+    ((model(x) - y) ** 2).sum(1).mean().backward()
+    for n, p in model.named_parameters():
+        for r in range(world):
+            got = torch.from_numpy(res[r][n])
+            if p.grad is None:
+                assert float(got.abs().max()) == 0.0
+            else:
+                torch.testing.assert_close(got, p.grad, rtol=1e-5, atol=1e-6)
+
+
+def test_reducer_sink_and_single_process():
+    from dpft_amd.training.distributed import GradBucketReducer
+    model = _make_model()
+    red = GradBucketReducer(list(model.parameters()), bucket_bytes=1 << 20)
+    red.reset()
+    w = model.net[0].weight
+    g = torch.ones_like(w)
+    assert red.grad_sink(w, g)
+    red.finish()
+    assert torch.equal(w.grad, g) and w.grad.permute(0, 2, 3, 1).is_contiguous()
+    assert not red.grad_sink(torch.nn.Parameter(torch.zeros(1)), torch.zeros(1))

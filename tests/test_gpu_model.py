@@ -213,3 +213,41 @@ def test_dprt_train_forward_backward_matches_oracle():
     print("worst grads (ratio, gpu, cpu-fp32):", report[:5])
     assert checked > 300
     assert not bad, bad[:10]
+
+
+def test_loss_and_matcher_match_oracle():
+    """Hungarian indices bit-exact, loss values within fp32 tolerance."""
+    from dpft_amd.configs import load_config
+    from dpft_amd.synthetic import make_labels
+    from dpft_amd.training.loss import build_loss
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(5)
+    cfg = load_config("kradar")
+    B, N = 3, 400
+    out = {"center": torch.randn(B, N, 3, generator=g) * torch.tensor([20.0, 4.0, 1.0]) + torch.tensor([35.0, 0, 0]),
+           "size": torch.relu(torch.randn(B, N, 3, generator=g) + 2.0),
+           "angle": torch.tanh(torch.randn(B, N, 2, generator=g)),
+           "class": torch.randn(B, N, 2, generator=g)}
+    labels = make_labels(B, seed=3)
+    labels[1] = {k: v[:0] for k, v in labels[1].items()}            # a sample without objects
+    w = cfg["train"]["loss_weights"]
+    ref_out = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+    ref_total, ref_losses = O.loss_forward(ref_out, labels, w)
+    ref_total.backward()
+    loss_fn = build_loss(cfg["train"])
+    dev_out = {k: v.to(DEV).requires_grad_(True) for k, v in out.items()}
+    dev_labels = [{k: v.to(DEV) for k, v in l.items()} for l in labels]
+    matches = loss_fn.anassigner(dev_out, dev_labels)
+    for b, lab in enumerate(labels):
+        if lab["gt_class"].shape[0] == 0:
+            assert matches[b] is None
+            continue
+        i_ref, j_ref, _ = O.hungarian({k: v[b] for k, v in out.items()}, lab, w)
+        assert torch.equal(matches[b][0].cpu(), i_ref) and torch.equal(matches[b][1].cpu(), j_ref)
+    total, losses = loss_fn(dev_out, dev_labels)
+    close(total, ref_total, rtol=1e-5, what="total loss")
+    for k in ref_losses:
+        close(losses[k], ref_losses[k], rtol=1e-5, what=f"loss {k}")
+    total.backward()
+    for k in out:
+        close(dev_out[k].grad, ref_out[k].grad, rtol=1e-4, what=f"dloss/d{k}")
