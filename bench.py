@@ -158,11 +158,19 @@ def main():
         torch.cuda.synchronize()
         recs, ops.PROFILE = ops.PROFILE, None
         tot_f, tot_t = 0.0, 0.0
-        for kind, flops, e0, e1 in recs:
+        shapes = {}
+        for kind, flops, e0, e1, shape in recs:
             dt = e0.elapsed_time(e1) * 1e-3
+            sh = shapes.setdefault((kind,) + shape, [0.0, 0.0, 0])
+            sh[0] += flops; sh[1] += dt; sh[2] += 1
             k = per_kind.setdefault(kind, [0.0, 0.0, 0])
             k[0] += flops; k[1] += dt; k[2] += 1
             tot_f += flops; tot_t += dt
+        if os.environ.get("DPFT_CONV_TABLE"):
+            with open(os.environ["DPFT_CONV_TABLE"], "w") as f:
+                f.write("kind B H W C K k s calls total_us TFLOPs\n")
+                for key, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
+                    f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f}\n")
         n_launch = sum(k[2] for k in per_kind.values())
         roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                 "frac": tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,

@@ -51,21 +51,38 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t M,
+// one block = 32 channels x 8 tile-groups; Chan's merge is associative, so every thread folds its strided
+// share of the tiles and the 8 partial (n, mean, M2) triples of a channel are merged through LDS.
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t M,
                                    int K, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    float* bnp) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= K) return;
+    __shared__ float sn[8][32], smean[8][32], sm2[8][32];
+    const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int c = blockIdx.x * 32 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
-    for (int t = 0; t < tiles; ++t) {
-        const float cnt = (float)min((int64_t)tile_rows, M - (int64_t)t * tile_rows);
-        const float mt = stats[((size_t)t * 2 + 0) * K + c];
-        const float m2t = stats[((size_t)t * 2 + 1) * K + c];
+    if (c < K) {
+        for (int t = g; t < tiles; t += 8) {
+            const float cnt = (float)min((int64_t)tile_rows, M - (int64_t)t * tile_rows);
+            const float mt = stats[((size_t)t * 2 + 0) * K + c];
+            const float m2t = stats[((size_t)t * 2 + 1) * K + c];
+            const float nn = n + cnt;
+            const float delta = mt - mean;
+            mean += delta * (cnt / nn);
+            m2 += m2t + delta * delta * (n * cnt / nn);
+            n = nn;
+        }
+    }
+    sn[g][cl] = n; smean[g][cl] = mean; sm2[g][cl] = m2;
+    __syncthreads();
+    if (g != 0 || c >= K) return;
+    for (int i = 1; i < 8; ++i) {
+        const float cnt = sn[i][cl];
+        if (cnt == 0.f) continue;
         const float nn = n + cnt;
-        const float delta = mt - mean;
+        const float delta = smean[i][cl] - mean;
         mean += delta * (cnt / nn);
-        m2 += m2t + delta * delta * (n * cnt / nn);
+        m2 += sm2[i][cl] + delta * delta * (n * cnt / nn);
         n = nn;
     }
     const float var = m2 / (float)M;
@@ -429,7 +446,7 @@ extern "C" int dpft_bn_finalize_f32(const float* stats, int32_t tiles, int32_t t
     DPFT_REQUIRE(stats && gamma && beta && bnp, "bn_finalize: null tensor");
     DPFT_REQUIRE(tiles == cdiv(M, tile_rows), "bn_finalize: tiles (%d) != ceil(M/tile_rows)", tiles);
     DPFT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 64)), dim3(64), 0, (hipStream_t)stream, stats, tiles,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(256), 0, (hipStream_t)stream, stats, tiles,
                        tile_rows, M, K, gamma, beta, eps, momentum, running_mean, running_var, bnp);
     return check_launch("bn_finalize");
 }
@@ -484,7 +501,8 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
     const int slabs = cdiv(K4, 256);
     const int kc = std::min(K4, 256);
     const int groups = 256 / kc;
-    int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + kNumCU * 4 - 1) / (kNumCU * 4));
+    const int want_blocks = std::max(1, (kNumCU * 2) / slabs);
+    int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + want_blocks - 1) / want_blocks);
     dim3 grid(cdiv(M, rows_per_block), slabs);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
                        (int)rows_per_block);

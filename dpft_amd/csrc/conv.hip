@@ -841,8 +841,12 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
         TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
         if (t.splits > 1) best = std::max<int64_t>(best, (int64_t)t.splits * a.M * a.N * 4);
     }
-    // wgrad: up to 64 splits of the weight tensor
-    best = std::max<int64_t>(best, (int64_t)64 * d->K * d->kh * d->kw * d->C * 4);
+    // wgrad: pixel-split partial slabs, at most min(512 splits, 64 MiB)
+    {
+        const int64_t wbytes = (int64_t)d->K * d->kh * d->kw * d->C * 4;
+        const int64_t ms = std::max<int64_t>(1, std::min<int64_t>(512, (64ll << 20) / wbytes));
+        best = std::max<int64_t>(best, ms * wbytes);
+    }
     return best;
 }
 
@@ -943,8 +947,11 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         a.ctiles = cdiv(a.J, 64);
         tiles = (int64_t)a.ktiles * a.ctiles;
     }
+    // enough pixel-splits to fill the chip; partial slabs bounded by 64 MiB (and by the workspace contract)
     int splits = (int)((kNumCU * 2 + tiles - 1) / tiles);
-    if (splits > 64) splits = 64;
+    const int64_t wbytes = (int64_t)d->K * a.J * 4;
+    const int max_splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, (64ll << 20) / wbytes));
+    if (splits > max_splits) splits = max_splits;
     while (splits > 1 && a.psteps / splits < 4) --splits;
     if (splits < 1) splits = 1;
     if (splits > 1 && !workspace) splits = 1;

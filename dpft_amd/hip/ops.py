@@ -20,17 +20,18 @@ PROFILE = None
 
 
 class _Prof:
-    __slots__ = ("kind", "flops", "e0")
+    __slots__ = ("kind", "flops", "e0", "shape")
 
     def __init__(self, kind, cv):
         self.kind, self.flops = kind, 2.0 * cv.M * cv.K * cv.kh * cv.kw * cv.C
+        self.shape = (cv.B, cv.H, cv.W, cv.C, cv.K, cv.kh, cv.stride)
         self.e0 = torch.cuda.Event(enable_timing=True)
         self.e0.record()
 
     def done(self):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        PROFILE.append((self.kind, self.flops, self.e0, e1))
+        PROFILE.append((self.kind, self.flops, self.e0, e1, self.shape))
 
 
 def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
