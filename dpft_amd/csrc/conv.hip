@@ -23,14 +23,18 @@
 #include "common.h"
 
 #include <math.h>
+#include <stdlib.h>
 
 #include <algorithm>
 
 namespace dpft {
 
-constexpr int BK = 32;
-constexpr int LDK = BK + 4;   // vector path: padded LDS row (144 B, 16-B aligned)
+constexpr int BK = 32;        // generic path K-step
+constexpr int BKV = 64;       // vector path K-step: one barrier pair per 2048+ MFMA cycles, and the register
+                              // prefetch of the next step has that long to land (HBM/L2 latency under load)
+constexpr int LDK = BKV + 4;  // vector path: padded LDS row (272 B = 17 x 16 B: odd slot stride, conflict-free b128)
 constexpr int LDG = BK + 1;   // generic path: odd pad, ds_read_b32 fragments
+constexpr int BKP = 64;       // wgrad vector path: pixels per step
 
 struct IgemmArgs {
     const float* x;
@@ -58,77 +62,112 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int rbase = m0 + wm * RB * 32 + 4 * (lane >> 5);
-    const int cbase = n0 + wn * CB * 32 + (lane & 31);
+    __syncthreads();  // LDS operand tiles are dead now
+    if (a.stats != nullptr) {
+        // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
+        float* red = smem;               // [WGM][BN]
+        float* smean = smem + WGM * BN;  // [BN]
+        const int cnt = min(BM, a.M - m0);
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            float s = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
+                    s += (row < a.M) ? acc[rb][cb][r] : 0.f;
+                }
+            s += __shfl_xor(s, 32);
+            if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
+            const float mean = s / (float)cnt;
+            smean[tid] = mean;
+            if (n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb) {
+            const float mean = smean[wn * CB * 32 + cb * 32 + (lane & 31)];
+            float s = 0.f;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
+                    const float d = acc[rb][cb][r] - mean;
+                    s += (row < a.M) ? d * d : 0.f;
+                }
+            s += __shfl_xor(s, 32);
+            if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;  // red is free: barrier above
+        }
+        __syncthreads();
+        if (tid < BN && n0 + tid < a.N) {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
+            a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+        }
+        __syncthreads();
+    }
+    // ---- stage the tile through LDS so that global stores are full 16-byte lanes along rows --------
+    // (per-register scalar stores are store-issue bound and, with vmcnt counting stores, serialise)
+    constexpr int LDC = BN + 4;
+    float* Cs = smem;  // [BM][LDC]
+#pragma unroll
+    for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = wm * RB * 32 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                Cs[row * LDC + wn * CB * 32 + cb * 32 + (lane & 31)] = acc[rb][cb][r];
+            }
+    __syncthreads();
     float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.M * a.N : a.y;
     const bool add_bias = (a.bias != nullptr) && (a.partial == nullptr);
+    const bool accum = a.accumulate && (a.partial == nullptr);
+    if ((a.N & 3) == 0) {
+        constexpr int C4 = BN / 4;
+        constexpr int ITER = BM * C4 / 256;
+        f32x4 old[ITER];
+        if (accum) {
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        const int col = cbase + cb * 32;
-        if (col >= a.N) continue;
-        const float bv = add_bias ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
-                if (row < a.M) {
-                    float v = acc[rb][cb][r] + bv;
-                    if (a.accumulate && a.partial == nullptr) v += out[(size_t)row * a.N + col];
-                    out[(size_t)row * a.N + col] = v;
-                }
+            for (int it = 0; it < ITER; ++it) {
+                const int idx = tid + it * 256;
+                const int row = idx / C4, c4 = idx - row * C4;
+                old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (m0 + row < a.M && n0 + c4 * 4 < a.N)
+                    old[it] = *reinterpret_cast<const f32x4*>(out + (size_t)(m0 + row) * a.N + n0 + c4 * 4);
             }
         }
-    }
-    if (a.stats == nullptr) return;
-    // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
-    float* red = smem;               // [WGM][BN]
-    float* smean = smem + WGM * BN;  // [BN]
-    const int cnt = min(BM, a.M - m0);
-    __syncthreads();  // LDS tiles are dead now
 #pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        float s = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
-                s += (row < a.M) ? acc[rb][cb][r] : 0.f;
+        for (int it = 0; it < ITER; ++it) {
+            const int idx = tid + it * 256;
+            const int row = idx / C4, c4 = idx - row * C4;
+            if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
+                if (add_bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + c4 * 4);
+                if (accum) v += old[it];
+                *reinterpret_cast<f32x4*>(out + (size_t)(m0 + row) * a.N + n0 + c4 * 4) = v;
             }
-        s += __shfl_xor(s, 32);
-        if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;
-    }
-    __syncthreads();
-    if (tid < BN) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
-        const float mean = s / (float)cnt;
-        smean[tid] = mean;
-        if (n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int cb = 0; cb < CB; ++cb) {
-        const float mean = smean[wn * CB * 32 + cb * 32 + (lane & 31)];
-        float s = 0.f;
-#pragma unroll
-        for (int rb = 0; rb < RB; ++rb)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = rbase + rb * 32 + (r & 3) + 8 * (r >> 2);
-                const float d = acc[rb][cb][r] - mean;
-                s += (row < a.M) ? d * d : 0.f;
+        }
+    } else {
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int row = idx / BN, c = idx - row * BN;
+            if (m0 + row < a.M && n0 + c < a.N) {
+                float v = Cs[row * LDC + c];
+                if (add_bias) v += a.bias[n0 + c];
+                float* o = out + (size_t)(m0 + row) * a.N + n0 + c;
+                if (accum) v += *o;
+                *o = v;
             }
-        s += __shfl_xor(s, 32);
-        if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;  // red is free: barrier above
-    }
-    __syncthreads();
-    if (tid < BN && n0 + tid < a.N) {
-        float s = 0.f;
-#pragma unroll
-        for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
-        a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+        }
     }
 }
 
@@ -148,9 +187,9 @@ __device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt
 template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO>
 __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
-    constexpr int AP = BM / 32, BP = BN / 32;
+    constexpr int AP = BM / 16, BP = BN / 16;      // 16 rows x 16 chunks (of 16 B) per loader pass
     static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1, "bad tile");
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDK];
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // (BM + BN) * LDK floats
     float* As = smem;
     float* Bs = smem + BM * LDK;
 
@@ -160,13 +199,13 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     decode_tile(a, mt, nt, split);
     const int m0 = mt * BM, n0 = nt * BN;
 
-    const int chunk = tid & 7, rowl = tid >> 3;
+    const int chunk = tid & 15, rowl = tid >> 4;
     int a_bh[AP], a_bw[AP];
     const float* a_base[AP];
     const int ohw = a.OH * a.OW;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + rowl + 32 * i;
+        const int m = m0 + rowl + 16 * i;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
         const int b = mm / ohw;
@@ -185,23 +224,27 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     bool b_ok[BP];
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-        const int n = n0 + rowl + 32 * i;
+        const int n = n0 + rowl + 16 * i;
         b_ok[i] = n < a.N;
         b_base[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Ktot + chunk * 4;
     }
-    const int cpt = a.C / BK;  // K-steps per filter tap
+    const int cpt = a.C / BKV;  // K-steps per filter tap
 
-    f32x4 ra[AP], rbv[BP];
+    // Raw operand registers of the NEXT K-step.  The producer's BN+ReLU (PRO) is applied when the
+    // registers are written to LDS, i.e. after the MFMAs of the current step: consuming the loads any
+    // earlier would put their full latency in front of the compute.
+    f32x4 ra[AP], rbv[BP], p_mu, p_sc, p_sh;
+    unsigned a_valid = 0;
     auto load_tile = [&](int kt) {
         const int tap = kt / cpt;
-        const int c0 = (kt - tap * cpt) * BK;
+        const int c0 = (kt - tap * cpt) * BKV;
         const int r = tap / a.kw, s = tap - r * a.kw;
-        f32x4 mu, sc, sh;
         if (PRO) {
-            mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
-            sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
-            sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
+            p_mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
+            p_sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
+            p_sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
         }
+        a_valid = 0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             int hi, wi;
@@ -226,30 +269,35 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (v) {
                 val = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0);
-                if (PRO) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        float t = fmaf(val[e] - mu[e], sc[e], sh[e]);
-                        val[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
-                    }
-                }
+                a_valid |= 1u << i;
             }
             ra[i] = val;
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[i]) val = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BK);
+            if (b_ok[i]) val = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BKV);
             rbv[i] = val;
         }
     };
     auto store_tile = [&]() {
 #pragma unroll
-        for (int i = 0; i < AP; ++i)
-            *reinterpret_cast<f32x4*>(&As[(rowl + 32 * i) * LDK + chunk * 4]) = ra[i];
+        for (int i = 0; i < AP; ++i) {
+            f32x4 val = ra[i];
+            if (PRO) {
+                const bool v = (a_valid >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaf(val[e] - p_mu[e], p_sc[e], p_sh[e]);
+                    t = a.pro_relu ? fmaxf(t, 0.f) : t;
+                    val[e] = v ? t : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
+        }
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(rowl + 32 * i) * LDK + chunk * 4]) = rbv[i];
+            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[i];
     };
 
     f32x16 acc[RB][CB];
@@ -274,7 +322,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         const bool more = kt + 1 < kt_end;
         if (more) load_tile(kt + 1);
 #pragma unroll
-        for (int kg = 0; kg < BK / 8; ++kg) {
+        for (int kg = 0; kg < BKV / 8; ++kg) {
             f32x4 af[RB], bf[CB];
 #pragma unroll
             for (int i = 0; i < RB; ++i)
@@ -306,7 +354,8 @@ template <int BN, bool DGRAD>
 __global__ __launch_bounds__(256) void igemm_gen_kernel(IgemmArgs a) {
     constexpr int BM = 128, WGM = 4, WGN = 1, RB = 1, CB = BN / 32;
     constexpr int KPB = BN / 8;  // k elements per thread for the B tile
-    __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDG];
+    constexpr int SMEM = ((BM + BN) * LDG > BM * (BN + 4)) ? (BM + BN) * LDG : BM * (BN + 4);
+    __shared__ __attribute__((aligned(16))) float smem[SMEM];
     float* As = smem;
     float* Bs = smem + BM * LDG;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -468,11 +517,11 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
     constexpr int YCH = BMn / 4, XCH = BNc / 4;        // float4 chunks per pixel row
     constexpr int YRP = 256 / YCH, XRP = 256 / XCH;    // pixel rows per pass
-    constexpr int YP = BK / YRP, XP = BK / XRP;
+    constexpr int YP = BKP / YRP, XP = BKP / XRP;
     static_assert(WGM * WGN == 4 && YP >= 1 && XP >= 1, "bad wgrad tile");
-    __shared__ __attribute__((aligned(16))) float smem[BK * (BMn + BNc)];
+    __shared__ __attribute__((aligned(16))) float smem[BKP * (BMn + BNc)];
     float* Ys = smem;
-    float* Xs = smem + BK * BMn;
+    float* Xs = smem + BKP * BMn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
 
@@ -499,8 +548,9 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     const int ohw = a.OH * a.OW;
 
     f32x4 ry[YP], rx[XP];
+    unsigned x_valid = 0;
     auto load_tile = [&](int ps) {
-        const int p0 = ps * BK;
+        const int p0 = ps * BKP;
 #pragma unroll
         for (int i = 0; i < YP; ++i) {
             const int p = p0 + yrow + i * YRP;
@@ -508,6 +558,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
             if (y_ok && p < a.M) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.K + n0 + ych * 4);
             ry[i] = v;
         }
+        x_valid = 0;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int p = p0 + xrow + i * XRP;
@@ -520,13 +571,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
                 if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
                     v = *reinterpret_cast<const f32x4*>(
                         a.x + (((size_t)b * a.H + hi) * a.W + wi) * a.C + c0 + xch * 4);
-                    if (PRO) {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
-                            v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
-                        }
-                    }
+                    x_valid |= 1u << i;
                 }
             }
             rx[i] = v;
@@ -537,8 +582,19 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         for (int i = 0; i < YP; ++i)
             *reinterpret_cast<f32x4*>(&Ys[(yrow + i * YRP) * BMn + ych * 4]) = ry[i];
 #pragma unroll
-        for (int i = 0; i < XP; ++i)
-            *reinterpret_cast<f32x4*>(&Xs[(xrow + i * XRP) * BNc + xch * 4]) = rx[i];
+        for (int i = 0; i < XP; ++i) {
+            f32x4 v = rx[i];
+            if (PRO) {      // producer BN+ReLU applied after the MFMAs of the current step (see igemm_vec_kernel)
+                const bool ok = (x_valid >> i) & 1u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
+                    t = a.pro_relu ? fmaxf(t, 0.f) : t;
+                    v[e] = ok ? t : 0.f;
+                }
+            }
+            *reinterpret_cast<f32x4*>(&Xs[(xrow + i * XRP) * BNc + xch * 4]) = v;
+        }
     };
 
     f32x16 acc[RB][CB];
@@ -562,7 +618,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         const bool more = ps + 1 < ps_end;
         if (more) load_tile(ps + 1);
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
+        for (int kk = 0; kk < BKP / 2; ++kk) {
             float av[RB], bv[CB];
 #pragma unroll
             for (int i = 0; i < RB; ++i) av[i] = y_frag[kk * 2 * BMn + i * 32];
@@ -730,7 +786,14 @@ struct TileChoice {
 
 static TileChoice choose_tile(int M, int N, int C, int ksteps) {
     TileChoice t;
-    t.vec = (C % BK) == 0;
+    t.vec = (C % BKV) == 0;
+    if (const char* f = getenv("DPFT_FORCE_TILE")) {      // tuning aid: "bm,bn,splits"
+        int bm, bn, sp;
+        if (t.vec && sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3) {
+            t.bm = bm; t.bn = bn; t.splits = sp < 1 ? 1 : sp;
+            return t;
+        }
+    }
     if (!t.vec) {
         t.bm = 128;
         t.bn = (N <= 32) ? 32 : 64;
@@ -782,7 +845,18 @@ static void fill_igemm(IgemmArgs& a, const dpft_conv_desc* d, bool dgrad) {
     }
     a.M = a.B * a.OH * a.OW;
     a.Ktot = a.kh * a.kw * a.C;
-    a.ksteps = cdiv(a.Ktot, BK);
+    a.ksteps = (a.C % BKV) == 0 ? a.Ktot / BKV : cdiv(a.Ktot, BK);
+}
+
+// launch with dynamic LDS; raises the per-kernel dynamic-LDS cap once (tiles above 64 KiB)
+template <typename K, typename A>
+static void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& args) {
+    static bool configured = false;       // one static per kernel instantiation
+    if (!configured) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        configured = true;
+    }
+    hipLaunchKernelGGL(kernel, grid, block, lds, st, args);
 }
 
 template <bool DGRAD>
@@ -795,8 +869,9 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     dim3 grid(nwg), block(256);
 #define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
     do {                                                                                      \
-        if (pro) hipLaunchKernelGGL((igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>), grid, block, 0, st, a); \
-        else hipLaunchKernelGGL((igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false>), grid, block, 0, st, a);      \
+        constexpr size_t lds = (size_t)(BM_ + BN_) * LDK * sizeof(float);                     \
+        if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>, grid, block, lds, st, a); \
+        else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false>, grid, block, lds, st, a);      \
     } while (0)
     if (t.vec) {
         if (t.bm == 128 && t.bn == 128) LAUNCH_VEC(128, 128, 2, 2);
@@ -870,7 +945,7 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
     a.pro = pro_bn; a.pro_relu = pro_relu;
     const bool pro = pro_bn != nullptr;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
-    DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 32 == 0 (C=%d)", d->C);
+    DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 64 == 0 (C=%d)", d->C);
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
         a.partial = (float*)workspace;
@@ -928,9 +1003,9 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     a.M = d->B * d->OH * d->OW;
     a.taps = d->kh * d->kw;
     a.J = a.taps * a.C;
-    a.psteps = cdiv(a.M, BK);
     const bool pro = pro_bn != nullptr;
     const bool vec = (d->C % 32 == 0) && (d->K % 4 == 0);
+    a.psteps = cdiv(a.M, vec ? BKP : BK);
     DPFT_REQUIRE(!(pro && !vec), "conv wgrad: fused prologue needs C %% 32 == 0");
     int bmn, bnc;
     int64_t tiles;
