@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--config", default="kradar")
     ap.add_argument("--latency-reps", type=int, default=30, help="event-timed eval forwards for fwd ms/frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graphs", action="store_true", help="do not replay the decoder from hipGraphs")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
@@ -135,6 +136,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if not args.no_graphs:
+        trainer.enable_graphs(data)
     for _ in range(args.warmup):
         trainer.train_step(data, labels)
     sync()
@@ -153,14 +156,13 @@ def main():
     # ---- roofline of the dominant kernel family: fp32 MFMA implicit-GEMM convolutions --------------
     roof, per_kind = None, {}
     if rank == 0:
-        ops.PROFILE = []
-        trainer.train_step(data, labels)
         torch.cuda.synchronize()
-        recs, ops.PROFILE = ops.PROFILE, None
+        ops.profile_start()
+        trainer.train_step(data, labels)
+        recs = ops.profile_collect()
         tot_f, tot_t = 0.0, 0.0
         shapes = {}
-        for kind, flops, e0, e1, shape in recs:
-            dt = e0.elapsed_time(e1) * 1e-3
+        for kind, flops, dt, shape in recs:
             sh = shapes.setdefault((kind,) + shape, [0.0, 0.0, 0])
             sh[0] += flops; sh[1] += dt; sh[2] += 1
             k = per_kind.setdefault(kind, [0.0, 0.0, 0])

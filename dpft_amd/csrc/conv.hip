@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <vector>
 
 namespace dpft {
 
@@ -777,6 +778,39 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// optional per-launch instrumentation (bench.py roofline): HIP events on the launch stream
+// ---------------------------------------------------------------------------------------------
+struct ProfRec {
+    int kind;            // 0 fwd, 1 dgrad, 2 wgrad
+    double flops;
+    hipEvent_t e0, e1;
+    int shape[7];        // B,H,W,C,K,k,stride
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof;
+
+struct ProfScope {
+    bool on;
+    hipStream_t st;
+    ProfRec r;
+    ProfScope(int kind, const dpft_conv_desc* d, hipStream_t s) : on(g_prof_on), st(s) {
+        if (!on) return;
+        r.kind = kind;
+        r.flops = 2.0 * d->B * d->OH * d->OW * (double)d->K * d->kh * d->kw * d->C;
+        const int sh[7] = {d->B, d->H, d->W, d->C, d->K, d->kh, d->stride};
+        memcpy(r.shape, sh, sizeof(sh));
+        (void)hipEventCreate(&r.e0);
+        (void)hipEventCreate(&r.e1);
+        (void)hipEventRecord(r.e0, st);
+    }
+    ~ProfScope() {
+        if (!on) return;
+        (void)hipEventRecord(r.e1, st);
+        g_prof.push_back(r);
+    }
+};
+
+// ---------------------------------------------------------------------------------------------
 // host-side tile selection
 // ---------------------------------------------------------------------------------------------
 struct TileChoice {
@@ -940,6 +974,7 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
     if (rc) return rc;
     DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(0, d, st);
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
     a.pro = pro_bn; a.pro_relu = pro_relu;
@@ -972,6 +1007,7 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     if (rc) return rc;
     DPFT_REQUIRE(dy && w_t && dx, "conv dgrad: null tensor");
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(1, d, st);
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
@@ -996,6 +1032,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     if (rc) return rc;
     DPFT_REQUIRE(x && dy && dw, "conv wgrad: null tensor");
     hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(2, d, st);
     WgradArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy; a.dw = dw; a.pro = pro_bn; a.pro_relu = pro_relu;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.OH = d->OH; a.OW = d->OW; a.K = d->K;
@@ -1074,4 +1111,29 @@ extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t
     int blocks = (int)std::min<int64_t>(1024, (M + rpi - 1) / rpi);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, M, K);
     return check_launch("bias_grad");
+}
+
+extern "C" int dpft_profile_start(void) {
+    for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    g_prof.clear();
+    g_prof_on = true;
+    return DPFT_OK;
+}
+
+extern "C" int32_t dpft_profile_stop(void) {
+    g_prof_on = false;
+    return (int32_t)g_prof.size();
+}
+
+extern "C" int dpft_profile_get(int32_t i, int32_t* kind, double* flops, float* ms, int32_t* shape7) {
+    DPFT_REQUIRE(i >= 0 && i < (int32_t)g_prof.size() && kind && flops && ms && shape7, "profile_get: bad index");
+    const ProfRec& r = g_prof[i];
+    *kind = r.kind;
+    *flops = r.flops;
+    if (hipEventElapsedTime(ms, r.e0, r.e1) != hipSuccess) {
+        set_error("profile_get: events not complete (synchronise the stream first)");
+        return DPFT_ERR_LAUNCH;
+    }
+    memcpy(shape7, r.shape, sizeof(r.shape));
+    return DPFT_OK;
 }

@@ -1,0 +1,371 @@
+// Native launch plan for the ResNet-50/101/152 body (forward + hand-scheduled backward).
+//
+// The Python mirror of src/dprt/models/backbones/resnet.py used to issue ~50 (fwd) + ~100 (bwd) C-ABI
+// calls per bottleneck from the interpreter; at ~25 us of host time per call the 3 backbones made the
+// training step host-bound.  A plan is built once per (architecture, input shape): it fixes every conv
+// descriptor, every activation's offset in a caller-owned arena and the order of kernel launches, so a
+// whole forward or a whole stage of the backward is ONE call that only enqueues work on the stream
+// (no allocation, no synchronisation: hipGraph-capturable).  Parameters and gradient buffers are passed
+// as pointer tables in registration order, so gradients land directly in the data-parallel buckets.
+#include <algorithm>
+#include <vector>
+
+#include "common.h"
+
+namespace dpft {
+
+struct ConvRef {
+    dpft_conv_desc d;
+    int w;  // index into the conv table
+};
+
+struct BlockPlan {
+    ConvRef c1, c2, c3, cd;
+    bool has_ds;
+    int bn1, bn2, bn3, bnd;
+    int layer;
+    // arena offsets (floats)
+    size_t x, y1, y2, y3, yd, out;
+    size_t p1, p2, p3, pd;      // BN blocks [4][K]
+    size_t s1, s2, s3, sd;      // stats [tiles][2][K]
+    int t1, t2, t3, td, r1, r2, r3, rd;   // stats tiles / tile rows
+};
+
+struct ResnetPlan {
+    dpft_resnet_desc desc;
+    std::vector<BlockPlan> blocks;
+    // stem
+    ConvRef adj, c0;
+    int bn0;
+    size_t xa, y0, p0, s0, pool;
+    int t0, r0;
+    int PH, PW;
+    int n_conv, n_bn;
+    size_t out_off[4];
+    int out_shape[4][4];
+    size_t fwd_floats;      // activations kept for backward
+    size_t bwd_floats;      // backward temporaries (placed after fwd_floats)
+    size_t ws_bytes;        // split-K workspace (placed last)
+    size_t arena_bytes;
+    // backward state
+    size_t g_off[2];
+    size_t gmax;            // floats of the largest activation gradient
+    size_t o_dy, o_da, o_dd, o_wt, o_sums;   // backward scratch offsets (floats)
+    int g_cur;
+    bool g_valid;
+};
+
+static size_t align64(size_t f) { return (f + 63) & ~(size_t)63; }
+
+static dpft_conv_desc mk(int B, int H, int W, int C, int K, int k, int s, int p) {
+    dpft_conv_desc d;
+    d.B = B; d.H = H; d.W = W; d.C = C; d.K = K; d.kh = k; d.kw = k; d.stride = s; d.pad = p;
+    d.OH = (H + 2 * p - k) / s + 1;
+    d.OW = (W + 2 * p - k) / s + 1;
+    return d;
+}
+
+static size_t nelem_out(const dpft_conv_desc& d) { return (size_t)d.B * d.OH * d.OW * d.K; }
+static size_t nelem_in(const dpft_conv_desc& d) { return (size_t)d.B * d.H * d.W * d.C; }
+static size_t nelem_w(const dpft_conv_desc& d) { return (size_t)d.K * d.kh * d.kw * d.C; }
+
+}  // namespace dpft
+
+using namespace dpft;
+
+extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
+    if (!desc || desc->B <= 0 || desc->H <= 0 || desc->W <= 0 || desc->n_layers < 1 || desc->n_layers > 4) {
+        set_error("resnet_plan_create: bad descriptor");
+        return 0;
+    }
+    ResnetPlan* p = new ResnetPlan();
+    p->desc = *desc;
+    size_t off = 0;
+    auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
+    int nconv = 0, nbn = 0;
+    const int B = desc->B;
+    size_t wsb = 0;
+    auto track_ws = [&](const dpft_conv_desc& d) {
+        int64_t w = dpft_conv2d_workspace_bytes(&d);
+        if (w > 0 && (size_t)w > wsb) wsb = (size_t)w;
+    };
+    size_t gmax = 0;
+    auto track_g = [&](size_t n) { if (n > gmax) gmax = n; };
+    auto stats_of = [&](const dpft_conv_desc& d, int& tiles, int& rows) {
+        int32_t r = 0;
+        tiles = dpft_conv2d_stats_tiles(&d, &r);
+        rows = r;
+        return (size_t)tiles * 2 * d.K;
+    };
+    // ---- stem ------------------------------------------------------------------------------------
+    int H = desc->H, W = desc->W;
+    if (desc->in_channels != 3) {
+        p->adj.d = mk(B, H, W, desc->in_channels, 3, 1, 1, 0);
+        p->adj.w = nconv++;
+        p->xa = take(nelem_out(p->adj.d));
+        track_ws(p->adj.d);
+    } else {
+        p->adj.w = -1;
+        p->xa = (size_t)-1;
+    }
+    p->c0.d = mk(B, H, W, 3, 64, 7, 2, 3);
+    p->c0.w = nconv++;
+    p->bn0 = nbn++;
+    track_ws(p->c0.d);
+    p->y0 = take(nelem_out(p->c0.d));
+    p->p0 = take(4 * 64);
+    p->s0 = take(stats_of(p->c0.d, p->t0, p->r0));
+    track_g(nelem_out(p->c0.d));
+    p->PH = (p->c0.d.OH + 2 - 3) / 2 + 1;
+    p->PW = (p->c0.d.OW + 2 - 3) / 2 + 1;
+    p->pool = take((size_t)B * p->PH * p->PW * 64);
+    track_g((size_t)B * p->PH * p->PW * 64);
+    // ---- stages ----------------------------------------------------------------------------------
+    int curH = p->PH, curW = p->PW, inC = 64;
+    size_t cur = p->pool;
+    const int planes_of[4] = {64, 128, 256, 512};
+    for (int li = 0; li < desc->n_layers; ++li) {
+        const int planes = planes_of[li];
+        for (int b = 0; b < desc->depths[li]; ++b) {
+            BlockPlan bp;
+            const int stride = (li > 0 && b == 0) ? 2 : 1;
+            bp.layer = li;
+            bp.has_ds = (b == 0);
+            bp.x = cur;
+            bp.c1.d = mk(B, curH, curW, inC, planes, 1, 1, 0);   bp.c1.w = nconv++;  bp.bn1 = nbn++;
+            bp.c2.d = mk(B, curH, curW, planes, planes, 3, stride, 1);  bp.c2.w = nconv++;  bp.bn2 = nbn++;
+            const int oh = bp.c2.d.OH, ow = bp.c2.d.OW;
+            bp.c3.d = mk(B, oh, ow, planes, planes * 4, 1, 1, 0);  bp.c3.w = nconv++;  bp.bn3 = nbn++;
+            if (bp.has_ds) {
+                bp.cd.d = mk(B, curH, curW, inC, planes * 4, 1, stride, 0);  bp.cd.w = nconv++;  bp.bnd = nbn++;
+            } else {
+                bp.cd.w = -1; bp.bnd = -1;
+            }
+            bp.y1 = take(nelem_out(bp.c1.d));  bp.p1 = take(4 * planes);  bp.s1 = take(stats_of(bp.c1.d, bp.t1, bp.r1));
+            bp.y2 = take(nelem_out(bp.c2.d));  bp.p2 = take(4 * planes);  bp.s2 = take(stats_of(bp.c2.d, bp.t2, bp.r2));
+            bp.y3 = take(nelem_out(bp.c3.d));  bp.p3 = take(4 * planes * 4);  bp.s3 = take(stats_of(bp.c3.d, bp.t3, bp.r3));
+            if (bp.has_ds) {
+                bp.yd = take(nelem_out(bp.cd.d));  bp.pd = take(4 * planes * 4);  bp.sd = take(stats_of(bp.cd.d, bp.td, bp.rd));
+                track_ws(bp.cd.d);
+            } else {
+                bp.yd = bp.pd = bp.sd = (size_t)-1; bp.td = bp.rd = 0;
+            }
+            bp.out = take(nelem_out(bp.c3.d));
+            track_ws(bp.c1.d); track_ws(bp.c2.d); track_ws(bp.c3.d);
+            track_g(nelem_in(bp.c1.d)); track_g(nelem_out(bp.c1.d)); track_g(nelem_out(bp.c2.d)); track_g(nelem_out(bp.c3.d));
+            p->blocks.push_back(bp);
+            cur = bp.out;
+            curH = oh; curW = ow; inC = planes * 4;
+        }
+        p->out_off[li] = cur;
+        p->out_shape[li][0] = B; p->out_shape[li][1] = curH; p->out_shape[li][2] = curW; p->out_shape[li][3] = inC;
+    }
+    p->n_conv = nconv;
+    p->n_bn = nbn;
+    p->fwd_floats = off;
+    // ---- backward temporaries: two running-gradient buffers + per-block scratch -----------------------
+    p->gmax = gmax;
+    p->g_off[0] = take(gmax);
+    p->g_off[1] = take(gmax);
+    // scratch: dy (gmax) + da (gmax) + dyd (gmax) + weight transpose (max weight) + bn sums
+    size_t wmax = 0;
+    for (auto& b : p->blocks) {
+        wmax = std::max(wmax, nelem_w(b.c1.d)); wmax = std::max(wmax, nelem_w(b.c2.d)); wmax = std::max(wmax, nelem_w(b.c3.d));
+        if (b.has_ds) wmax = std::max(wmax, nelem_w(b.cd.d));
+    }
+    wmax = std::max(wmax, nelem_w(p->c0.d));
+    p->bwd_floats = off;   // start of scratch
+    p->o_dy = take(gmax);
+    p->o_da = take(gmax);
+    p->o_dd = take(gmax);
+    p->o_wt = take(wmax);
+    p->o_sums = take(2 * 2048);
+    p->ws_bytes = wsb;
+    p->arena_bytes = off * sizeof(float) + wsb + 256;
+    p->g_valid = false;
+    p->g_cur = 0;
+    return (int64_t)(intptr_t)p;
+}
+
+extern "C" void dpft_resnet_plan_destroy(int64_t h) { delete (ResnetPlan*)(intptr_t)h; }
+
+extern "C" int64_t dpft_resnet_plan_query(int64_t h, int32_t what, int32_t idx) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    if (!p) return -1;
+    switch (what) {
+        case 0: return (int64_t)p->arena_bytes;
+        case 1: return p->n_conv;
+        case 2: return p->n_bn;
+        case 3: return (int64_t)p->out_off[idx];          // float offset of stage output idx
+        case 4: return p->out_shape[idx / 4][idx % 4];    // shape entries
+        case 5: return (int64_t)p->fwd_floats;
+        default: return -1;
+    }
+}
+
+namespace dpft {
+
+struct Tables {
+    const dpft_resnet_tables* t;
+    const float* w(int i) const { return (const float*)t->conv_w[i]; }
+    float* dw(int i) const { return (float*)t->conv_dw[i]; }
+    const float* gamma(int i) const { return (const float*)t->bn_gamma[i]; }
+    const float* beta(int i) const { return (const float*)t->bn_beta[i]; }
+    float* rm(int i) const { return (float*)t->bn_rm[i]; }
+    float* rv(int i) const { return (float*)t->bn_rv[i]; }
+    float* dgamma(int i) const { return (float*)t->bn_dgamma[i]; }
+    float* dbeta(int i) const { return (float*)t->bn_dbeta[i]; }
+};
+
+#define RC(call)              \
+    do {                      \
+        int rc_ = (call);     \
+        if (rc_) return rc_;  \
+    } while (0)
+
+static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* stats, int tiles, int rows, int64_t M,
+                     int K, float* bnp, bool train, dpft_stream_t st) {
+    if (train)
+        return dpft_bn_finalize_f32(stats, tiles, rows, M, K, T.gamma(bn), T.beta(bn), p->desc.eps, p->desc.momentum,
+                                    T.rm(bn), T.rv(bn), bnp, st);
+    return dpft_bn_eval_params_f32(T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), p->desc.eps, K, bnp, st);
+}
+
+}  // namespace dpft
+
+extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_tables* tables, void* arena,
+                                   int32_t train, dpft_stream_t st) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    DPFT_REQUIRE(p && x && tables && arena, "resnet_forward: null argument");
+    Tables T{tables};
+    float* A = (float*)arena;
+    void* ws = (char*)arena + (p->arena_bytes - p->ws_bytes - 128);
+    const bool tr = train != 0;
+    const float* xa = x;
+    if (p->adj.w >= 0) {
+        RC(dpft_conv2d_nhwc_fwd_f32(&p->adj.d, x, T.w(p->adj.w), nullptr, nullptr, 0, A + p->xa, nullptr, ws, st));
+        xa = A + p->xa;
+    }
+    RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr ? A + p->s0 : nullptr, ws, st));
+    RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr, st));
+    RC(dpft_bn_relu_maxpool_f32(A + p->y0, A + p->p0, A + p->pool, p->c0.d.B, p->c0.d.OH, p->c0.d.OW, 64, p->PH, p->PW, st));
+    for (const BlockPlan& b : p->blocks) {
+        const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
+        RC(dpft_conv2d_nhwc_fwd_f32(&b.c1.d, A + b.x, T.w(b.c1.w), nullptr, nullptr, 0, A + b.y1, tr ? A + b.s1 : nullptr, ws, st));
+        RC(bn_params(p, T, b.bn1, A + b.s1, b.t1, b.r1, M1, b.c1.d.K, A + b.p1, tr, st));
+        RC(dpft_conv2d_nhwc_fwd_f32(&b.c2.d, A + b.y1, T.w(b.c2.w), nullptr, A + b.p1, 1, A + b.y2, tr ? A + b.s2 : nullptr, ws, st));
+        RC(bn_params(p, T, b.bn2, A + b.s2, b.t2, b.r2, M2, b.c2.d.K, A + b.p2, tr, st));
+        RC(dpft_conv2d_nhwc_fwd_f32(&b.c3.d, A + b.y2, T.w(b.c3.w), nullptr, A + b.p2, 1, A + b.y3, tr ? A + b.s3 : nullptr, ws, st));
+        RC(bn_params(p, T, b.bn3, A + b.s3, b.t3, b.r3, M2, b.c3.d.K, A + b.p3, tr, st));
+        if (b.has_ds) {
+            RC(dpft_conv2d_nhwc_fwd_f32(&b.cd.d, A + b.x, T.w(b.cd.w), nullptr, nullptr, 0, A + b.yd, tr ? A + b.sd : nullptr, ws, st));
+            RC(bn_params(p, T, b.bnd, A + b.sd, b.td, b.rd, M2, b.cd.d.K, A + b.pd, tr, st));
+            RC(dpft_bn_act_f32(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, M2, b.c3.d.K, st));
+        } else {
+            RC(dpft_bn_act_f32(A + b.y3, A + b.p3, A + b.x, nullptr, 1, A + b.out, M2, b.c3.d.K, st));
+        }
+    }
+    p->g_valid = false;
+    return DPFT_OK;
+}
+
+namespace dpft {
+
+static int bn_backward(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
+                       const float* gamma, float* sums, float* dy, float* dgamma, float* dbeta, int64_t M, int K,
+                       dpft_stream_t st) {
+    RC(dpft_bn_bwd_reduce_f32(y, dout, out, mask_bnp, bnp, sums, M, K, st));
+    return dpft_bn_bwd_apply_f32(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, st);
+}
+
+static int block_backward(const ResnetPlan* p, const BlockPlan& b, const Tables& T, float* A, void* ws, const float* gp,
+                          float* dx, dpft_stream_t st) {
+    float* dyb = A + p->o_dy;
+    float* dab = A + p->o_da;
+    float* dyd = A + p->o_dd;
+    float* wt = A + p->o_wt;
+    float* sums = A + p->o_sums;
+    const int planes = b.c1.d.K, K3 = b.c3.d.K, inC = b.c1.d.C;
+    const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
+    // bn3 (+ the residual ReLU mask taken from the block output)
+    RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyb, T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st));
+    RC(dpft_conv2d_nhwc_wgrad_f32(&b.c3.d, A + b.y2, dyb, A + b.p2, 1, T.dw(b.c3.w), ws, st));
+    RC(dpft_weight_transpose_f32(T.w(b.c3.w), wt, K3, 1, planes, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyb, wt, dab, 0, ws, st));
+    // bn2 (fused-ReLU mask recomputed from its BN block)
+    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyb, T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st));
+    RC(dpft_conv2d_nhwc_wgrad_f32(&b.c2.d, A + b.y1, dyb, A + b.p1, 1, T.dw(b.c2.w), ws, st));
+    RC(dpft_weight_transpose_f32(T.w(b.c2.w), wt, planes, 9, planes, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyb, wt, dab, 0, ws, st));
+    // bn1
+    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyb, T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st));
+    RC(dpft_conv2d_nhwc_wgrad_f32(&b.c1.d, A + b.x, dyb, nullptr, 0, T.dw(b.c1.w), ws, st));
+    if (b.has_ds) {
+        RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st));
+        RC(dpft_conv2d_nhwc_wgrad_f32(&b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w), ws, st));
+        RC(dpft_weight_transpose_f32(T.w(b.cd.w), wt, K3, 1, inC, st));
+        RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt, dx, 0, ws, st));
+    } else {
+        RC(dpft_relu_bwd_f32(gp, A + b.out, dx, M2 * K3, st));      // identity branch: dz = dout * (out > 0)
+    }
+    RC(dpft_weight_transpose_f32(T.w(b.c1.w), wt, planes, 1, inC, st));
+    return dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyb, wt, dx, 1, ws, st);
+}
+
+}  // namespace dpft
+
+// Backward of one stage (stage = n_layers-1 ... 0; stage 0 also runs the stem).  `dout` is the external
+// gradient of that stage's output (may be NULL).  Parameter gradients are written to tables->conv_dw /
+// bn_dgamma / bn_dbeta (overwritten).  Stages must be called in descending order after a train forward.
+extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float* x, const dpft_resnet_tables* tables,
+                                          void* arena, const float* dout, dpft_stream_t st) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    DPFT_REQUIRE(p && x && tables && arena, "resnet_backward: null argument");
+    DPFT_REQUIRE(stage >= 0 && stage < p->desc.n_layers, "resnet_backward: bad stage %d", stage);
+    Tables T{tables};
+    float* A = (float*)arena;
+    void* ws = (char*)arena + (p->arena_bytes - p->ws_bytes - 128);
+    const size_t out_n = (size_t)p->out_shape[stage][0] * p->out_shape[stage][1] * p->out_shape[stage][2] * p->out_shape[stage][3];
+    const float* gp;
+    if (!p->g_valid) {
+        DPFT_REQUIRE(stage == p->desc.n_layers - 1, "resnet_backward: stages must start at the last one");
+        if (dout) {
+            gp = dout;
+        } else {
+            RC((int)hipMemsetAsync(A + p->g_off[p->g_cur], 0, out_n * sizeof(float), (hipStream_t)st));
+            gp = A + p->g_off[p->g_cur];
+        }
+    } else {
+        if (dout) RC(dpft_add_inplace_f32(A + p->g_off[p->g_cur], dout, (int64_t)out_n, st));
+        gp = A + p->g_off[p->g_cur];
+    }
+    for (int i = (int)p->blocks.size() - 1; i >= 0; --i) {
+        const BlockPlan& b = p->blocks[i];
+        if (b.layer != stage) continue;
+        float* dx = A + p->g_off[p->g_cur ^ 1];
+        RC(block_backward(p, b, T, A, ws, gp, dx, st));
+        p->g_cur ^= 1;
+        gp = dx;
+    }
+    p->g_valid = true;
+    if (stage == 0) {
+        // stem: maxpool + ReLU + bn1 + conv1 (+ the 1x1 adjustment conv of the radar views)
+        float* dyb = A + p->o_dy;
+        float* dab = A + p->o_da;
+        float* wt = A + p->o_wt;
+        float* sums = A + p->o_sums;
+        const dpft_conv_desc& d0 = p->c0.d;
+        const int64_t M0 = (int64_t)d0.B * d0.OH * d0.OW;
+        RC(dpft_bn_relu_maxpool_bwd_f32(A + p->y0, A + p->p0, gp, dab, d0.B, d0.OH, d0.OW, 64, p->PH, p->PW, st));
+        RC(bn_backward(A + p->y0, dab, nullptr, nullptr, A + p->p0, T.gamma(p->bn0), sums, dyb, T.dgamma(p->bn0), T.dbeta(p->bn0), M0, 64, st));
+        const float* xa = p->adj.w >= 0 ? A + p->xa : x;
+        RC(dpft_conv2d_nhwc_wgrad_f32(&d0, xa, dyb, nullptr, 0, T.dw(p->c0.w), ws, st));
+        if (p->adj.w >= 0) {
+            RC(dpft_weight_transpose_f32(T.w(p->c0.w), wt, 64, 49, 3, st));
+            RC(dpft_conv2d_nhwc_dgrad_f32(&d0, dyb, wt, dab, 0, ws, st));
+            RC(dpft_conv2d_nhwc_wgrad_f32(&p->adj.d, x, dab, nullptr, 0, T.dw(p->adj.w), ws, st));
+        }
+        p->g_valid = false;
+    }
+    return DPFT_OK;
+}

@@ -29,6 +29,16 @@ class Pyramid(C.Structure):
                 ("H", C.c_int32 * MAX_LEVELS), ("W", C.c_int32 * MAX_LEVELS), ("L", C.c_int32)]
 
 
+class ResnetDesc(C.Structure):
+    _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("in_channels", C.c_int32),
+                ("depths", C.c_int32 * 4), ("n_layers", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float)]
+
+
+class ResnetTables(C.Structure):
+    _fields_ = [(n, C.POINTER(C.c_void_p)) for n in
+                ("conv_w", "conv_dw", "bn_gamma", "bn_beta", "bn_rm", "bn_rv", "bn_dgamma", "bn_dbeta")]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(ConvDesc)
 _PYR = C.POINTER(Pyramid)
@@ -62,6 +72,15 @@ SIGNATURES = {
     "dpft_xattn_fwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpft_xattn_bwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpft_giou3d_yaw_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "dpft_profile_start": (_I, []),
+    "dpft_profile_stop": (_I, []),
+    "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
+    "dpft_adamw_f32": (_I, [_P, _I, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "dpft_resnet_plan_create": (_L, [C.POINTER(ResnetDesc)]),
+    "dpft_resnet_plan_destroy": (None, [_L]),
+    "dpft_resnet_plan_query": (_L, [_L, _I, _I]),
+    "dpft_resnet_forward": (_I, [_L, _P, C.POINTER(ResnetTables), _P, _I, _P]),
+    "dpft_resnet_backward_stage": (_I, [_L, _I, _P, C.POINTER(ResnetTables), _P, _P, _P]),
 }
 
 

@@ -14,24 +14,21 @@ from dpft_amd.hip.lib import ConvDesc, lib, make_desc, make_pyramid, ptr, stream
 
 _ws_cache = {}
 
-# bench instrumentation: when a list, every conv launch is bracketed by events on the current stream and
-# (kind, algorithmic FLOPs, start, end) is appended
-PROFILE = None
+def profile_start():
+    lib.call("dpft_profile_start")
 
 
-class _Prof:
-    __slots__ = ("kind", "flops", "e0", "shape")
-
-    def __init__(self, kind, cv):
-        self.kind, self.flops = kind, 2.0 * cv.M * cv.K * cv.kh * cv.kw * cv.C
-        self.shape = (cv.B, cv.H, cv.W, cv.C, cv.K, cv.kh, cv.stride)
-        self.e0 = torch.cuda.Event(enable_timing=True)
-        self.e0.record()
-
-    def done(self):
-        e1 = torch.cuda.Event(enable_timing=True)
-        e1.record()
-        PROFILE.append((self.kind, self.flops, self.e0, e1, self.shape))
+def profile_collect():
+    """-> list of (kind, flops, seconds, shape7) for every conv launch since profile_start() (syncs)."""
+    n = int(lib.dpft_profile_stop())
+    torch.cuda.synchronize()
+    out = []
+    kind, flops, ms, shape = C.c_int32(), C.c_double(), C.c_float(), (C.c_int32 * 7)()
+    names = ("fwd", "dgrad", "wgrad")
+    for i in range(n):
+        lib.call("dpft_profile_get", i, C.byref(kind), C.byref(flops), C.byref(ms), C.byref(shape))
+        out.append((names[kind.value], flops.value, ms.value * 1e-3, tuple(shape)))
+    return out
 
 
 def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
@@ -87,11 +84,8 @@ def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False):
     stats = torch.empty((cv.tiles, 2, cv.K), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
-    prof = _Prof("fwd", cv) if PROFILE is not None else None
     lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(pb), prelu,
              ptr(y), ptr(stats), ptr(ws), stream())
-    if prof is not None:
-        prof.done()
     return y, stats
 
 
@@ -101,11 +95,8 @@ def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
         out = torch.empty((cv.B, cv.H, cv.W, cv.C), dtype=torch.float32, device=dy.device)
         accumulate = False
     ws = workspace(cv.ws_bytes, dy.device)
-    prof = _Prof("dgrad", cv) if PROFILE is not None else None
     lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate), ptr(ws),
              stream())
-    if prof is not None:
-        prof.done()
     return out
 
 
@@ -114,11 +105,8 @@ def conv_wgrad(cv: Conv, x, dy, pro=None):
     dw = torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
-    prof = _Prof("wgrad", cv) if PROFILE is not None else None
     lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(pb), prelu, ptr(dw),
              ptr(ws), stream())
-    if prof is not None:
-        prof.done()
     return dw
 
 

@@ -22,7 +22,10 @@ from typing import Any, Dict, List, Optional
 import torch
 from torch import nn
 
+import ctypes as C
+
 from dpft_amd.hip import ops
+from dpft_amd.hip.lib import HipLibraryError, ResnetDesc, ResnetTables, lib, ptr, stream
 
 DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
 
@@ -79,154 +82,151 @@ class ResNetBody(nn.Module):
 
 
 # ------------------------------------------------------------------------------------------------
-# hand-scheduled forward / backward
+# native launch plan (dpft_amd/csrc/resnet_plan.hip): one C-ABI call per forward / per backward stage
 # ------------------------------------------------------------------------------------------------
-def _bn_forward(bn: nn.BatchNorm2d, stats, cv: ops.Conv, train: bool) -> torch.Tensor:
-    """-> BN block (4,K): mean, gamma*invstd, beta, invstd (batch statistics in train mode)."""
-    if train:
-        return ops.bn_finalize(stats, cv.tile_rows, cv.M, bn.weight, bn.bias, bn.eps, bn.momentum,
-                               bn.running_mean, bn.running_var)
-    return ops.bn_eval_params(bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
+class _Plan:
+    """Cached per (input shape): the C plan handle + arena geometry."""
+
+    def __init__(self, owner: "BackboneBase", B: int, H: int, W: int):
+        body = owner.body
+        d = ResnetDesc()
+        d.B, d.H, d.W, d.in_channels = B, H, W, owner.in_channels
+        for i, n in enumerate(owner.depths):
+            d.depths[i] = n
+        d.n_layers = body.n_layers
+        d.eps, d.momentum = body.bn1.eps, body.bn1.momentum
+        self.handle = lib.dpft_resnet_plan_create(C.byref(d))
+        if not self.handle:
+            raise RuntimeError("resnet plan: " + lib.dpft_last_error().decode())
+        q = lambda what, idx=0: int(lib.dpft_resnet_plan_query(self.handle, what, idx))
+        self.arena_bytes, self.n_conv, self.n_bn = q(0), q(1), q(2)
+        self.outs = [(q(3, li), tuple(q(4, li * 4 + k) for k in range(4))) for li in range(body.n_layers)]
+
+    def __del__(self):
+        try:
+            lib.dpft_resnet_plan_destroy(self.handle)
+        except Exception:
+            pass
 
 
-def _block_forward(blk: Bottleneck, x: torch.Tensor, train: bool, rec: Optional[dict]):
-    B, H, W, Cin = x.shape
-    planes = blk.conv1.out_channels
-    c1 = ops.conv_problem(B, H, W, Cin, planes, 1, 1, 1, 0)
-    y1, s1 = ops.conv_fwd(c1, x, khwc(blk.conv1.weight), want_stats=train)
-    b1 = _bn_forward(blk.bn1, s1, c1, train)
-    c2 = ops.conv_problem(B, H, W, planes, planes, 3, 3, blk.stride, 1)
-    y2, s2 = ops.conv_fwd(c2, y1, khwc(blk.conv2.weight), pro=(b1, True), want_stats=train)
-    b2 = _bn_forward(blk.bn2, s2, c2, train)
-    c3 = ops.conv_problem(B, c2.OH, c2.OW, planes, planes * 4, 1, 1, 1, 0)
-    y3, s3 = ops.conv_fwd(c3, y2, khwc(blk.conv3.weight), pro=(b2, True), want_stats=train)
-    b3 = _bn_forward(blk.bn3, s3, c3, train)
-    if blk.downsample is not None:
-        cd = ops.conv_problem(B, H, W, Cin, planes * 4, 1, 1, blk.stride, 0)
-        yd, sd = ops.conv_fwd(cd, x, khwc(blk.downsample[0].weight), want_stats=train)
-        bd = _bn_forward(blk.downsample[1], sd, cd, train)
-        out = ops.bn_act(y3, b3, res=yd, res_bnp=bd, relu=True)
-    else:
-        cd = yd = bd = None
-        out = ops.bn_act(y3, b3, res=x, relu=True)
-    if rec is not None:
-        rec.update(x=x, y1=y1, y2=y2, y3=y3, yd=yd, out=out, b1=b1, b2=b2, b3=b3, bd=bd, c1=c1, c2=c2, c3=c3, cd=cd)
-    return out
+def _ordered_modules(owner: "BackboneBase"):
+    """conv / bn modules in the plan's table order (include/dpft_hip.h dpft_resnet_tables)."""
+    body = owner.body
+    convs, bns = [], []
+    if owner.adjustment_layer is not None:
+        convs.append(owner.adjustment_layer)
+    convs.append(body.conv1)
+    bns.append(body.bn1)
+    for li in range(body.n_layers):
+        for blk in getattr(body, f"layer{li + 1}"):
+            convs += [blk.conv1, blk.conv2, blk.conv3]
+            bns += [blk.bn1, blk.bn2, blk.bn3]
+            if blk.downsample is not None:
+                convs.append(blk.downsample[0])
+                bns.append(blk.downsample[1])
+    return convs, bns
 
 
-def _block_backward(blk: Bottleneck, rec: dict, dout: torch.Tensor, grads: Dict[nn.Parameter, torch.Tensor]):
-    """dout: gradient wrt the block output (post-ReLU).  Returns the gradient wrt the block input."""
-    x, y1, y2, y3, yd, out = rec["x"], rec["y1"], rec["y2"], rec["y3"], rec["yd"], rec["out"]
-    b1, b2, b3, bd = rec["b1"], rec["b2"], rec["b3"], rec["bd"]
-    c1, c2, c3, cd = rec["c1"], rec["c2"], rec["c3"], rec["cd"]
-    # bn3 (+ residual ReLU mask from `out`)
-    dy3, dg, db = ops.bn_bwd(y3, dout, b3, blk.bn3.weight, out=out)
-    grads[blk.bn3.weight], grads[blk.bn3.bias] = dg, db
-    # conv3: input operand = relu(bn2(y2)) recomputed in the prologue
-    grads[blk.conv3.weight] = ops.conv_wgrad(c3, y2, dy3, pro=(b2, True)).permute(0, 3, 1, 2)
-    da2 = ops.conv_dgrad(c3, dy3, ops.weight_transpose(khwc(blk.conv3.weight)))
-    del dy3
-    dy2, dg, db = ops.bn_bwd(y2, da2, b2, blk.bn2.weight, mask_bnp=b2)
-    grads[blk.bn2.weight], grads[blk.bn2.bias] = dg, db
-    del da2
-    grads[blk.conv2.weight] = ops.conv_wgrad(c2, y1, dy2, pro=(b1, True)).permute(0, 3, 1, 2)
-    da1 = ops.conv_dgrad(c2, dy2, ops.weight_transpose(khwc(blk.conv2.weight)))
-    del dy2
-    dy1, dg, db = ops.bn_bwd(y1, da1, b1, blk.bn1.weight, mask_bnp=b1)
-    grads[blk.bn1.weight], grads[blk.bn1.bias] = dg, db
-    del da1
-    grads[blk.conv1.weight] = ops.conv_wgrad(c1, x, dy1).permute(0, 3, 1, 2)
-    if blk.downsample is not None:
-        dyd, dg, db = ops.bn_bwd(yd, dout, bd, blk.downsample[1].weight, out=out)
-        grads[blk.downsample[1].weight], grads[blk.downsample[1].bias] = dg, db
-        grads[blk.downsample[0].weight] = ops.conv_wgrad(cd, x, dyd).permute(0, 3, 1, 2)
-        dx = ops.conv_dgrad(cd, dyd, ops.weight_transpose(khwc(blk.downsample[0].weight)))
-    else:
-        dx = ops.relu_bwd(dout, out)                      # identity branch: dz = dout * (out > 0)
-    ops.conv_dgrad(c1, dy1, ops.weight_transpose(khwc(blk.conv1.weight)), out=dx, accumulate=True)
-    return dx
+def _ptr_array(tensors):
+    arr = (C.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr() if t is not None else None
+    return arr
 
 
 class _BodyFn(torch.autograd.Function):
-    """x (B,H,W,3) NHWC -> (c1, c2, c3, c4) NHWC.  params are passed so autograd routes their grads."""
+    """x (B,H,W,C) NHWC -> stage outputs NHWC (views of the plan arena).  params are passed so that
+    autograd routes their gradients; the computation is the native plan."""
 
     @staticmethod
     def forward(ctx, owner: "BackboneBase", need_grad: bool, x: torch.Tensor, *params: torch.Tensor):
-        body: ResNetBody = owner.body
         train = owner.training
         if need_grad and not train:
             raise NotImplementedError("dpft_amd: backward through eval-mode BatchNorm is not implemented")
-        recs: List[dict] = [] if need_grad else None
         x = x.contiguous()
+        if not x.is_cuda or x.dtype != torch.float32:
+            raise HipLibraryError("dpft_amd ops need CUDA (ROCm) fp32 tensors; there is no CPU path")
         B, H, W, Cin = x.shape
-        stem = {}
-        if owner.adjustment_layer is not None:
-            ca = ops.conv_problem(B, H, W, Cin, 3, 1, 1, 1, 0)
-            xa, _ = ops.conv_fwd(ca, x, khwc(owner.adjustment_layer.weight))
-            stem.update(ca=ca, x_raw=x)
-        else:
-            xa = x
-        c0 = ops.conv_problem(B, H, W, 3, 64, 7, 7, 2, 3)
-        y0, s0 = ops.conv_fwd(c0, xa, khwc(body.conv1.weight), want_stats=train)
-        b0 = _bn_forward(body.bn1, s0, c0, train)
-        cur = ops.bn_relu_maxpool(y0, b0)
-        stem.update(c0=c0, xa=xa, y0=y0, b0=b0)
-        outs = []
-        for li in range(body.n_layers):
-            for blk in getattr(body, f"layer{li + 1}"):
-                rec = {} if need_grad else None
-                cur = _block_forward(blk, cur, train, rec)
-                if need_grad:
-                    rec["blk"] = blk
-                    rec["layer"] = li
-                    recs.append(rec)
-            outs.append(cur.detach())       # alias: keeps ctx free of references to its own outputs
+        plan = owner._plan(B, H, W)
+        convs, bns = _ordered_modules(owner)
+        assert len(convs) == plan.n_conv and len(bns) == plan.n_bn
+        arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
+        weights = [khwc(c.weight) for c in convs]                       # physical [K][kh][kw][C]
+        # gradient buffers: straight into the DP buckets when a reducer is attached, else one flat buffer
+        direct = owner.grad_direct if need_grad else None
+        conv_g, bn_g, bn_b, flat = [None] * len(convs), [None] * len(bns), [None] * len(bns), None
+        if need_grad:
+            if direct is not None:
+                conv_g = [direct.grad_buffer(c.weight) for c in convs]
+                bn_g = [direct.grad_buffer(m.weight) for m in bns]
+                bn_b = [direct.grad_buffer(m.bias) for m in bns]
+            if direct is None or any(g is None for g in conv_g + bn_g + bn_b):
+                direct = None
+                total = sum(c.weight.numel() for c in convs) + 2 * sum(m.weight.numel() for m in bns)
+                flat = torch.empty(total, dtype=torch.float32, device=x.device)
+                off = 0
+                conv_g, bn_g, bn_b = [], [], []
+                for c in convs:
+                    K, Ci, kh, kw = c.weight.shape
+                    conv_g.append(flat[off:off + c.weight.numel()].view(K, kh, kw, Ci).permute(0, 3, 1, 2))
+                    off += c.weight.numel()
+                for m in bns:
+                    n = m.weight.numel()
+                    bn_g.append(flat[off:off + n]); bn_b.append(flat[off + n:off + 2 * n])
+                    off += 2 * n
+        t = ResnetTables()
+        keep = [_ptr_array(weights), _ptr_array(conv_g), _ptr_array([m.weight for m in bns]),
+                _ptr_array([m.bias for m in bns]), _ptr_array([m.running_mean for m in bns]),
+                _ptr_array([m.running_var for m in bns]), _ptr_array(bn_g), _ptr_array(bn_b)]
+        (t.conv_w, t.conv_dw, t.bn_gamma, t.bn_beta, t.bn_rm, t.bn_rv, t.bn_dgamma, t.bn_dbeta) = \
+            [C.cast(k, C.POINTER(C.c_void_p)) for k in keep]
+        lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), int(train), stream())
         if train:
-            nbt = [m.num_batches_tracked for m in body.modules() if isinstance(m, nn.BatchNorm2d)]
-            torch._foreach_add_(nbt, 1)
-        ctx.owner, ctx.recs, ctx.stem, ctx.params = owner, recs, stem, params
-        ctx.x_requires_grad = x.requires_grad
+            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        af = arena.view(torch.float32)
+        outs = []
+        for off, shape in plan.outs:
+            n = shape[0] * shape[1] * shape[2] * shape[3]
+            outs.append(af[off:off + n].view(shape))
+        if need_grad:
+            ctx.state = dict(owner=owner, plan=plan, x=x, arena=arena, tables=t, keep=keep, weights=weights,
+                             convs=convs, bns=bns, conv_g=conv_g, bn_g=bn_g, bn_b=bn_b, flat=flat, direct=direct,
+                             params=params)
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        owner, recs, stem, params = ctx.owner, ctx.recs, ctx.stem, ctx.params
-        body: ResNetBody = owner.body
-        grads: Dict[nn.Parameter, torch.Tensor] = {}
+        st = ctx.state
+        owner, plan, direct = st["owner"], st["plan"], st["direct"]
+        body = owner.body
         douts = list(douts) + [None] * (4 - len(douts))
-        g = None
-        last_layer = body.n_layers - 1
-        for rec in reversed(recs):
-            li = rec["layer"]
-            if li != last_layer or g is None:
-                # crossing a stage boundary: add the external gradient of that stage's output
-                ext = douts[li]
-                if g is None:
-                    g = ext.contiguous() if ext is not None else torch.zeros_like(rec["out"])
-                elif ext is not None:
-                    ops.add_(g, ext.contiguous())
-                last_layer = li
-            g = _block_backward(rec["blk"], rec, g, grads)
-            rec.clear()
-            sink = owner.grad_sink
-            if sink is not None:          # hand this block's gradients to the DP reducer right away
-                for p_ in list(grads):
-                    if sink(p_, grads[p_]):
-                        del grads[p_]
-        # stem: maxpool + relu + bn1 + conv1 (+ adjustment conv)
-        b0, y0, c0, xa = stem["b0"], stem["y0"], stem["c0"], stem["xa"]
-        dz0 = ops.bn_relu_maxpool_bwd(y0, b0, g)
-        dy0, dg, db = ops.bn_bwd(y0, dz0, b0, body.bn1.weight)
-        grads[body.bn1.weight], grads[body.bn1.bias] = dg, db
-        grads[body.conv1.weight] = ops.conv_wgrad(c0, xa, dy0).permute(0, 3, 1, 2)
-        dx = None
+        # stage -> parameters whose gradients are complete after that stage's call
+        stage_params = {li: [] for li in range(body.n_layers)}
+        for li in range(body.n_layers):
+            for blk in getattr(body, f"layer{li + 1}"):
+                stage_params[li] += list(blk.parameters())
+        stage_params[0] += [body.conv1.weight, body.bn1.weight, body.bn1.bias]
         if owner.adjustment_layer is not None:
-            dxa = ops.conv_dgrad(c0, dy0, ops.weight_transpose(khwc(body.conv1.weight)))
-            grads[owner.adjustment_layer.weight] = ops.conv_wgrad(stem["ca"], stem["x_raw"], dxa).permute(0, 3, 1, 2)
-        out = [None, None, dx]
-        for p in params:
-            out.append(grads.get(p))
-        return tuple(out)
+            stage_params[0].append(owner.adjustment_layer.weight)
+        keep_alive = []
+        for li in range(body.n_layers - 1, -1, -1):
+            d = douts[li]
+            if d is not None:
+                d = d.contiguous()
+                keep_alive.append(d)
+            lib.call("dpft_resnet_backward_stage", plan.handle, li, ptr(st["x"]), C.byref(st["tables"]),
+                     ptr(st["arena"]), ptr(d), stream())
+            if direct is not None:                       # this stage's gradients are in the DP buckets: release them
+                for p_ in stage_params[li]:
+                    direct.mark_ready(p_)
+        grads = {}
+        if direct is None:
+            for c, g in zip(st["convs"], st["conv_g"]):
+                grads[c.weight] = g
+            for m, g, b in zip(st["bns"], st["bn_g"], st["bn_b"]):
+                grads[m.weight], grads[m.bias] = g, b
+        ctx.state = None
+        return (None, None, None, *[grads.get(p_) for p_ in st["params"]])
 
 
 class BackboneBase(nn.Module):
@@ -236,7 +236,9 @@ class BackboneBase(nn.Module):
         self.in_channels = in_channels
         self.multi_scale = multi_scale
         self.channel_last = channel_last
-        self.grad_sink = None       # optional callable(param, grad) -> bool, installed by the DP trainer
+        self.grad_direct = None     # optional DP reducer (grad_buffer / mark_ready), installed by the trainer
+        self.depths = tuple(depths)
+        self._plans = {}
         # resnet.py:47-52 -- 1x1 conv (no bias) to 3 channels when the input is not RGB
         if in_channels == 3:
             self.adjustment_layer = None
@@ -247,6 +249,19 @@ class BackboneBase(nn.Module):
         self.body = ResNetBody(depths, n_layers=max(1, min(4, multi_scale)))
         if weights:
             self.load_state_dict(weights)
+
+    def _plan(self, B: int, H: int, W: int) -> "_Plan":
+        key = (B, H, W)
+        p = self._plans.get(key)
+        if p is None:
+            p = self._plans[key] = _Plan(self, B, H, W)
+        return p
+
+    def __getstate__(self):          # plans hold native handles: rebuild lazily after unpickling / deepcopy
+        st = self.__dict__.copy()
+        st["_plans"] = {}
+        st["grad_direct"] = None
+        return st
 
     def forward(self, batch: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         """(B,H,W,C) [channel_last] or (B,C,H,W) -> {'1': layer1, ...} in the input's channel format."""

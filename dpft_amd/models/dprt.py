@@ -88,9 +88,22 @@ class DPRT(nn.Module):
         features = {i: self.necks[i](features[i]) for i in self.inputs}
         features = {i: self.embeddings[i](features[i]) for i in self.inputs}
         out = self.querent(batch)
+        projection = self._get_projetions(self.inputs, batch)
+        graphed = self.__dict__.get("_graphed_fuser")
+        if graphed is not None and self.training and torch.is_grad_enabled():
+            return graphed(features, shapes, projection, out)
         return self.fuser(batch=[features[i] for i in self.inputs],
                           shape=[shapes[i][:, :2] for i in self.inputs],
-                          projection=self._get_projetions(self.inputs, batch), out=out)
+                          projection=projection, out=out)
+
+    def enable_fuser_graph(self, sample_batch: Dict[str, torch.Tensor]):
+        """Capture the launch-bound fusion decoder (forward and backward) into hipGraphs for training steps
+        with the static shapes of ``sample_batch`` (dpft_amd/models/fusers/graphed.py)."""
+        from dpft_amd.models.fusers.graphed import GraphedFuser
+        self.__dict__["_graphed_fuser"] = GraphedFuser(self, sample_batch)
+
+    def disable_fuser_graph(self):
+        self.__dict__.pop("_graphed_fuser", None)
 
 
 def build_dprt(*args, **kwargs):

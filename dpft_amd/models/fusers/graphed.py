@@ -1,0 +1,125 @@
+"""hipGraph capture of the fusion decoder for training.
+
+The decoder is ~700 tiny kernels per forward (B*400 x 16 tensors) and as many again backward: on MI355X
+it is bound by host launch time, not by the GPU (≈15 ms forward / ≈25 ms backward of host time for
+≈5 ms of kernels).  Its forward and its backward are recorded once each (static shapes, static
+addresses) and replayed with a single launch.  The fused cross-attention HIP kernels are launched on
+the capturing stream through the C-ABI, so they are part of the graphs.
+
+Capture is done by hand (not torch.cuda.make_graphed_callables) so that the two graphs live in
+SEPARATE memory pools: the backward graph's static gradient buffers must never share addresses with
+forward temporaries of the same pool.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Dict, List
+
+import torch
+from torch import nn
+
+
+class _FlatFuser(nn.Module):
+    """Tensor-only signature around IMPFusion.forward."""
+
+    def __init__(self, fuser: nn.Module, level_keys: List[List[str]], flags: List[bool]):
+        super().__init__()
+        self.fuser = fuser
+        self.level_keys = level_keys
+        self.flags = flags
+
+    def forward(self, center0, *tensors):
+        it = iter(tensors)
+        views = [OrderedDict((k, next(it)) for k in keys) for keys in self.level_keys]
+        n = len(self.level_keys)
+        shapes = [next(it) for _ in range(n)]
+        proj = [(next(it), next(it)) for _ in range(n)]
+        out = self.fuser(batch=views, shape=shapes, projection=proj, out=OrderedDict(center=center0),
+                         has_transformation=self.flags)
+        return out["center"], out["size"], out["angle"], out["class"]
+
+
+class _Replay(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, g: "GraphedFuser", *inputs):
+        for s, a in zip(g.static_inputs, inputs[:len(g.static_inputs)]):
+            if s.data_ptr() != a.data_ptr():
+                s.copy_(a)
+        g.fwd_graph.replay()
+        ctx.g = g
+        return tuple(o.detach().clone() for o in g.static_outputs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g = ctx.g
+        for s, a in zip(g.static_grad_outputs, grads):
+            s.copy_(a) if a is not None else s.zero_()
+        g.bwd_graph.replay()
+        # hand out copies: the static buffers are overwritten by the next replay
+        gi = [None if t is None else t.detach().clone() for t in g.static_grad_inputs]
+        n_other = len(g.static_inputs) - 1 - g.n_levels          # shapes + projection matrices
+        return (None, None, *gi[:g.n_levels], *([None] * n_other), *gi[g.n_levels:])
+
+
+class GraphedFuser:
+    def __init__(self, model: nn.Module, sample_batch: Dict[str, torch.Tensor], warmup: int = 3):
+        self.inputs = list(model.inputs)
+        was_training = model.training
+        # one eval-mode pass up to the fuser (no running-stat update, no autograd) for correctly shaped samples
+        model.eval()
+        with torch.no_grad():
+            feats = {i: model.backbones[i](sample_batch[i]) for i in self.inputs}
+            feats = {i: model._add_raw_data(feats[i], sample_batch[i]) for i in self.inputs}
+            feats = {i: model.embeddings[i](model.necks[i](feats[i])) for i in self.inputs}
+        proj = model._get_projetions(self.inputs, sample_batch)
+        self.flags = model.fuser.transformation_flags(proj)
+        self.level_keys = [list(feats[i].keys()) for i in self.inputs]
+        center0 = model.querent(sample_batch)["center"]
+        static = [center0.detach().clone()]
+        for i in self.inputs:
+            static += [v.detach().clone().requires_grad_(True) for v in feats[i].values()]
+        self.n_levels = len(static) - 1
+        static += [sample_batch[f"{i}_shape"][:, :2].clone() for i in self.inputs]
+        for t, p in proj:
+            static += [t.detach().clone(), p.detach().clone()]
+        model.train()
+        self.flat = _FlatFuser(model.fuser, self.level_keys, self.flags).train()
+        self.params = [p for p in self.flat.parameters() if p.requires_grad]
+        self.static_inputs = static
+        self.shapes = [tuple(s.shape) for s in static]
+        diff_inputs = static[1:1 + self.n_levels] + self.params
+
+        # warm-up on a side stream (lazy initialisations, allocator growth) -- nothing is accumulated into .grad
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                outs = self.flat(*static)
+                torch.autograd.grad(outs, diff_inputs, [torch.ones_like(o) for o in outs], allow_unused=True)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+
+        self.fwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd_graph):
+            self.static_outputs = self.flat(*static)
+        self.static_grad_outputs = [torch.zeros_like(o) for o in self.static_outputs]
+        self.bwd_graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.bwd_graph):                      # its own private pool (see module docstring)
+            grads = torch.autograd.grad(self.static_outputs, diff_inputs, self.static_grad_outputs,
+                                        allow_unused=True)
+        self.static_grad_inputs = list(grads)
+        torch.cuda.synchronize()
+        model.train(was_training)
+
+    def __call__(self, features, shapes, projection, out):
+        args = [out["center"]]
+        for i in self.inputs:
+            args += list(features[i].values())
+        args += [shapes[i][:, :2] for i in self.inputs]
+        for t, p in projection:
+            args += [t, p]
+        if [tuple(a.shape) for a in args] != self.shapes:
+            raise RuntimeError("graphed fuser called with shapes different from the captured ones")
+        # parameters are passed so that autograd routes their gradients (their values are read in place)
+        c, s, a, k = _Replay.apply(self, *args, *self.params)
+        return OrderedDict([("center", c), ("size", s), ("angle", a), ("class", k)])

@@ -174,13 +174,19 @@ class IMPFusion(nn.Module):
         v = (v - 0) / (shape[:, 0].unsqueeze(1) - 0) * (1 - 0) + 0
         return torch.clip(torch.stack((u, v), dim=-1), min=0.0, max=1.0)
 
+    @staticmethod
+    def transformation_flags(projection: List[Tuple[torch.Tensor, torch.Tensor]]) -> List[bool]:
+        """One host decision (one sync) for all views; the reference evaluates ``transformation.any()``
+        per view per iteration (mpfusion.py:647)."""
+        return [bool(f) for f in torch.stack([t.any() for t, _ in projection]).tolist()]
+
     def forward(self, batch: List[Dict[str, torch.Tensor]], shape: List[torch.Tensor],
-                projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor]):
+                projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor],
+                has_transformation: List[bool] = None):
         B = out["center"].shape[0]
         query = self.query.unsqueeze(0).repeat(B, 1, 1)
         query_pos = self.query_embedding.weight.unsqueeze(0).repeat(B, 1, 1)
-        # one host decision for all views (reference: transformation.any() per view per iteration)
-        flags = torch.stack([t.any() for t, _ in projection]).tolist()
+        flags = has_transformation if has_transformation is not None else self.transformation_flags(projection)
         pyramids = [make_pyramid_state(list(levels.values())) for levels in batch]
         for layer, head in zip(self.mpfusion.values(), self.heads):
             reference_points = [

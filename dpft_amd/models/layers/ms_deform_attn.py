@@ -150,7 +150,12 @@ class MSDeformAttn(nn.Module):
 
     def _offsets_and_weights(self, query):
         N, Len_q, _ = query.shape
-        off = self.sampling_offsets(query).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
+        # The bias is folded into the GEMM (ones column) instead of nn.Linear's addmm: the (B*Q x 320) column
+        # reduction that otherwise produces this bias' gradient returned garbage under hipGraph replay
+        # (ROCm 7.0 / torch 2.10; weight gradients and every other bias were unaffected).
+        w_aug = torch.cat((self.sampling_offsets.weight, self.sampling_offsets.bias[:, None]), dim=1)
+        q_aug = torch.cat((query, torch.ones_like(query[..., :1])), dim=-1)
+        off = F.linear(q_aug, w_aug).view(N, Len_q, self.n_heads, self.n_levels, self.n_points, 2)
         aw = self.attention_weights(query).view(N, Len_q, self.n_heads, self.n_levels * self.n_points)
         aw = F.softmax(aw, -1).view(N, Len_q, self.n_heads, self.n_levels, self.n_points)
         return off, aw

@@ -86,6 +86,17 @@ class GradBucketReducer:
         self._mark(bi, p)
         return True
 
+    def grad_buffer(self, p: torch.nn.Parameter):
+        """The bucket view a native backward writes this parameter's gradient into (None if unknown).
+        Conv weights get a view that is physically [K][kh][kw][C] contiguous."""
+        bi = self._index.get(id(p))
+        return None if bi is None else self.buckets[bi]["views"][id(p)]
+
+    def mark_ready(self, p: torch.nn.Parameter):
+        bi = self._index.get(id(p))
+        if bi is not None:
+            self._mark(bi, p)
+
     def _hook(self, p):
         bi = self._index[id(p)]
         b = self.buckets[bi]
@@ -109,6 +120,13 @@ class GradBucketReducer:
             if self.average:
                 b["flat"].div_(self.world)
             self._pending.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def seen_ids(self):
+        """ids of the parameters that received a gradient since the last reset()."""
+        out = set()
+        for b in self.buckets:
+            out |= b["seen"]
+        return out
 
     def finish(self):
         """Flush buckets whose parameters did not all receive gradients, then wait for every collective."""

@@ -14,6 +14,7 @@ import torch.distributed as dist
 
 from dpft_amd.training.distributed import GradBucketReducer, broadcast_module
 from dpft_amd.training.loss import build_loss
+from dpft_amd.training.optimizer import FusedAdamW, build_optimizer
 
 
 class DataParallelTrainer:
@@ -24,13 +25,19 @@ class DataParallelTrainer:
         self.loss_fn = build_loss(train)
         opt = dict(train["optimizer"])
         name = opt.pop("name")
-        self.optimizer = getattr(torch.optim, name)(self.model.parameters(), **opt)     # trainer.py:233
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         broadcast_module(self.model)
         self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=bucket_mb << 20)
+        self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         for m in self.model.modules():
-            if hasattr(m, "grad_sink"):
-                m.grad_sink = self.reducer.grad_sink
+            if hasattr(m, "grad_direct"):
+                m.grad_direct = self.reducer
+
+    def enable_graphs(self, sample_data: Dict[str, torch.Tensor]):
+        """Replay the launch-bound decoder from hipGraphs (static shapes of ``sample_data``)."""
+        self.reducer.reset()
+        self.model.enable_fuser_graph(sample_data)
+        self.optimizer.zero_grad(set_to_none=False)
 
     def train_step(self, data: Dict[str, torch.Tensor], labels: List[Dict[str, torch.Tensor]]):
         self.model.train()
@@ -45,6 +52,8 @@ class DataParallelTrainer:
         if stepped:
             loss.backward()
             self.reducer.finish()
+            if isinstance(self.optimizer, FusedAdamW):
+                self.optimizer.set_active(self.reducer.seen_ids())
             self.optimizer.step()
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
 

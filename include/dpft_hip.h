@@ -136,6 +136,48 @@ int dpft_relu_bwd_f32(const float* dout, const float* out, float* dz, int64_t n,
 int dpft_add_inplace_f32(float* a, const float* b, int64_t n, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Native launch plan of the ResNet body (conv1/bn1/relu/maxpool/layer1..n of torchvision's
+ * ResNet-50/101/152 behind IntermediateLayerGetter, src/dprt/models/backbones/resnet.py:54-55,
+ * incl. the optional 1x1 adjustment conv :47-52).  One call enqueues a whole forward, or the
+ * backward of one stage; everything lives in a caller-owned arena; nothing is allocated or
+ * synchronised inside (hipGraph-capturable).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dpft_resnet_desc {
+    int32_t B, H, W, in_channels;   /* NHWC input (B,H,W,in_channels); != 3 adds the adjustment conv */
+    int32_t depths[4];              /* bottlenecks per stage, e.g. {3,4,23,3}                       */
+    int32_t n_layers;               /* stages to run (multi_scale), 1..4                            */
+    float eps, momentum;            /* BatchNorm2d hyper-parameters (1e-5, 0.1)                     */
+} dpft_resnet_desc;
+
+/* Pointer tables in plan order.  conv: [adjustment], stem conv1, then per bottleneck conv1, conv2,
+ * conv3, [downsample.0].  bn: stem bn1, then per bottleneck bn1, bn2, bn3, [downsample.1].
+ * Weights are physical [K][kh][kw][C]; *_dw / bn_d* are written (overwritten) by the backward. */
+typedef struct dpft_resnet_tables {
+    void* const* conv_w;
+    void* const* conv_dw;
+    void* const* bn_gamma;
+    void* const* bn_beta;
+    void* const* bn_rm;
+    void* const* bn_rv;
+    void* const* bn_dgamma;
+    void* const* bn_dbeta;
+} dpft_resnet_tables;
+
+int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc);   /* 0 on error */
+void dpft_resnet_plan_destroy(int64_t plan);
+/* what: 0 arena bytes, 1 #convs, 2 #bns, 3 float offset of stage output idx in the arena,
+ *       4 shape entry (idx = stage*4 + dim of (B,H,W,C)), 5 floats kept for backward */
+int64_t dpft_resnet_plan_query(int64_t plan, int32_t what, int32_t idx);
+/* x (B,H,W,in_channels).  train != 0: batch statistics + running-stat update, activations kept. */
+int dpft_resnet_forward(int64_t plan, const float* x, const dpft_resnet_tables* tables, void* arena,
+                        int32_t train, dpft_stream_t stream);
+/* Backward of stage `stage` (call n_layers-1 ... 0 after a train forward; stage 0 also runs the
+ * stem).  dout = external gradient of that stage's output (NULL = none). */
+int dpft_resnet_backward_stage(int64_t plan, int32_t stage, const float* x,
+                               const dpft_resnet_tables* tables, void* arena, const float* dout,
+                               dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * FPN glue + positional embedding
  * ---------------------------------------------------------------------------------------- */
 /* lat[B,H,W,K] += nearest_upsample(top[B,TH,TW,K]) with src = min(floor(dst*in/out), in-1) */
@@ -196,6 +238,25 @@ int dpft_xattn_bwd_f32(const dpft_pyramid* pyr, const float* ref, const float* o
  * ---------------------------------------------------------------------------------------- */
 int dpft_giou3d_yaw_f32(const float* pred, const float* gt, float* out, int32_t B, int32_t N,
                         int32_t Mg, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Fused multi-tensor AdamW (torch.optim.AdamW semantics: decoupled decay, bias correction, no amsgrad),
+ * the optimizer the reference builds at src/dprt/training/trainer.py:233 / optimizer.py:6-7.
+ * chunks: device array of {float* p; const float* g; float* m; float* v; int32 n; int32 tensor}
+ * (4 pointers + 2 int32 = 40 bytes each); active: device int32 per tensor (0 = skip: gradient is None) or NULL.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, float lr, float beta1,
+                   float beta2, float eps, float weight_decay, int32_t step, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Measurement aid (bench.py `roofline`): while started, every dpft_conv2d_nhwc_* call is bracketed
+ * by HIP events on its launch stream.  Not thread-safe; do not use inside a graph capture.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_profile_start(void);
+int32_t dpft_profile_stop(void);                 /* -> number of recorded launches */
+/* kind 0 fwd / 1 dgrad / 2 wgrad; flops = algorithmic 2*M*K*kh*kw*C; ms = event-timed duration;
+ * shape7 = B,H,W,C,K,k,stride.  The stream must have been synchronised. */
+int dpft_profile_get(int32_t i, int32_t* kind, double* flops, float* ms, int32_t* shape7);
 
 #ifdef __cplusplus
 }

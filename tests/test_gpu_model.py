@@ -251,3 +251,71 @@ def test_loss_and_matcher_match_oracle():
     total.backward()
     for k in out:
         close(dev_out[k].grad, ref_out[k].grad, rtol=1e-4, what=f"dloss/d{k}")
+
+
+def test_fused_adamw_matches_torch():
+    from dpft_amd.training.optimizer import FusedAdamW
+    g = torch.Generator().manual_seed(6)
+    shapes = [(64, 3, 7, 7), (256,), (16, 48), (1000, 37), (5,)]
+    ref = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    ours = [r.detach().clone().requires_grad_(True) for r in ref]
+    frozen = ours[-1].detach().clone()
+    ours[0].data = ours[0].data.contiguous(memory_format=torch.channels_last)
+    o_ref = torch.optim.AdamW(ref, lr=1e-2)
+    for p in ours:
+        p.grad = torch.zeros_like(p)                      # persistent gradient buffers (as the DP buckets are)
+    o_ours = FusedAdamW(ours, lr=1e-2)
+    for step in range(5):
+        for r, p in zip(ref, ours):
+            gr = torch.randn(r.shape, generator=g).to(DEV)
+            r.grad = gr.clone()
+            p.grad.copy_(gr)
+        o_ref.step()
+        o_ours.set_active({id(p) for p in ours[:-1]})     # the last tensor has "no gradient": must stay untouched
+        o_ours.step()
+    for r, p in zip(ref[:-1], ours[:-1]):
+        close(p, r, rtol=1e-5, atol_scale=1e-6, what="adamw param")
+    assert torch.equal(ours[-1].detach(), frozen)
+    
+
+def test_graphed_decoder_step_equals_eager_step():
+    """Forward/loss/backward with the decoder replayed from hipGraphs == the same pass run eagerly.
+    (Gradients are compared, not post-AdamW weights: Adam turns noise-level gradients into +-lr steps.)"""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=9, shapes=SHAPES, device=DEV)
+    labels = make_labels(2, seed=9, device=DEV)
+    results = []
+    for graphs in (False, True):
+        torch.manual_seed(0)
+        tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+        if graphs:
+            tr.enable_graphs(batch)
+        tr.model.train()
+        for _ in range(2):                                 # second pass: replay, not capture
+            tr.reducer.reset()
+            out = tr.model(batch)
+            loss, _ = tr.loss_fn(out, labels)
+            loss.backward()
+            tr.reducer.finish()
+        grads = {n: p.grad.detach().clone() for n, p in tr.model.named_parameters()}
+        results.append((float(loss), {k: v.detach().clone() for k, v in out.items()}, grads))
+        loss2, _ = tr.train_step(batch, labels)            # and the full step runs
+        assert torch.isfinite(loss2)
+    (l0, o0, g0), (l1, o1, g1) = results
+    assert abs(l0 - l1) < 1e-4 * abs(l0), (l0, l1)
+    for k in o0:
+        close(o1[k], o0[k], rtol=1e-4, atol_scale=1e-4, what=f"graphed out {k}")
+    # relative to the gradient's own norm, floored at 1e-4 of a typical per-element magnitude (some offsets
+    # have exactly-zero true gradient: all their samples are clipped/out of range, what remains is rounding noise)
+    typical = torch.stack([g.abs().mean() for g in g0.values() if float(g.norm()) > 0]).median()
+    errs = []
+    for k in g0:
+        d = float((g1[k] - g0[k]).norm())
+        den = max(float(g0[k].norm()), 1e-4 * float(typical) * g0[k].numel() ** 0.5)
+        errs.append((d / den, k, float(g0[k].norm()), float(g1[k].norm())))
+    errs.sort(reverse=True)
+    print("graphed vs eager, worst gradients (err, name, |eager|, |graphed|):", errs[:4])
+    assert errs[0][0] < 5e-3, errs[:6]
