@@ -26,6 +26,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace dpft {
@@ -231,21 +232,24 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     }
     const int cpt = a.C / BKV;  // K-steps per filter tap
 
-    // Raw operand registers of the NEXT K-step.  The producer's BN+ReLU (PRO) is applied when the
-    // registers are written to LDS, i.e. after the MFMAs of the current step: consuming the loads any
-    // earlier would put their full latency in front of the compute.
-    f32x4 ra[AP], rbv[BP], p_mu, p_sc, p_sh;
-    unsigned a_valid = 0;
-    auto load_tile = [&](int kt) {
+    // Raw operand registers of the next DEPTH K-steps (register ring).  Loads are issued two steps ahead:
+    // under load HBM/L2 latency exceeds one step of MFMA work, and a wait right behind the MFMAs stalls every
+    // wave of the workgroup at once (probe: +30 % at 64x64).  The producer's BN+ReLU (PRO) is applied when a
+    // register set is written to LDS, never earlier: consuming a load puts its latency in front of the compute.
+    constexpr int DEPTH = (BM * BN >= 128 * 128) ? 1 : 2;       // 128x128 would exceed the VGPR budget at depth 2
+    f32x4 ra[DEPTH][AP], rbv[DEPTH][BP], p_mu[DEPTH], p_sc[DEPTH], p_sh[DEPTH];
+    unsigned a_valid[DEPTH];
+    auto load_tile = [&](auto S, int kt) {
+        constexpr int sidx = decltype(S)::value;
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BKV;
         const int r = tap / a.kw, s = tap - r * a.kw;
         if (PRO) {
-            p_mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
-            p_sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
-            p_sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
+            p_mu[sidx] = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
+            p_sc[sidx] = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
+            p_sh[sidx] = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
         }
-        a_valid = 0;
+        unsigned valid = 0;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             int hi, wi;
@@ -270,26 +274,28 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (v) {
                 val = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0);
-                a_valid |= 1u << i;
+                valid |= 1u << i;
             }
-            ra[i] = val;
+            ra[sidx][i] = val;
         }
+        a_valid[sidx] = valid;
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (b_ok[i]) val = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BKV);
-            rbv[i] = val;
+            rbv[sidx][i] = val;
         }
     };
-    auto store_tile = [&]() {
+    auto store_tile = [&](auto S) {
+        constexpr int sidx = decltype(S)::value;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
-            f32x4 val = ra[i];
+            f32x4 val = ra[sidx][i];
             if (PRO) {
-                const bool v = (a_valid >> i) & 1u;
+                const bool v = (a_valid[sidx] >> i) & 1u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(val[e] - p_mu[e], p_sc[e], p_sh[e]);
+                    float t = fmaf(val[e] - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
                     t = a.pro_relu ? fmaxf(t, 0.f) : t;
                     val[e] = v ? t : 0.f;
                 }
@@ -298,7 +304,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[i];
+            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
     };
 
     f32x16 acc[RB][CB];
@@ -313,15 +319,10 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     const int kt_end = min(a.ksteps, kt_begin + a.ksteps_per_split);
     const float* a_frag = As + (wm * RB * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
     const float* b_frag = Bs + (wn * CB * 32 + (lane & 31)) * LDK + (lane >> 5) * 4;
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, DEPTH - 1>;      // == S0 when DEPTH == 1
 
-    if (kt_begin < kt_end) {
-        load_tile(kt_begin);
-        store_tile();
-    }
-    __syncthreads();
-    for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = kt + 1 < kt_end;
-        if (more) load_tile(kt + 1);
+    auto compute = [&]() {
 #pragma unroll
         for (int kg = 0; kg < BKV / 8; ++kg) {
             f32x4 af[RB], bf[CB];
@@ -340,9 +341,36 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
                                                                          acc[i][j], 0, 0, 0);
         }
+    };
+
+    // tile t (relative to kt_begin) lives in register set t % DEPTH
+    if (kt_begin < kt_end) load_tile(S0{}, kt_begin);
+    if (DEPTH == 2 && kt_begin + 1 < kt_end) load_tile(S1{}, kt_begin + 1);
+    if (kt_begin < kt_end) {
+        store_tile(S0{});
+        if (kt_begin + DEPTH < kt_end) load_tile(S0{}, kt_begin + DEPTH);
+    }
+    __syncthreads();
+    for (int kt = kt_begin; kt < kt_end; kt += DEPTH) {
+        // ---- step kt: the next tile (kt+1) is in set 1 % DEPTH ----
+        compute();
         __syncthreads();
-        if (more) store_tile();
+        if (kt + 1 < kt_end) {
+            store_tile(S1{});
+            if (kt + 1 + DEPTH < kt_end) load_tile(S1{}, kt + 1 + DEPTH);
+        }
         __syncthreads();
+        if (DEPTH == 2) {
+            if (kt + 1 >= kt_end) break;
+            // ---- step kt+1: the next tile (kt+2) is in set 0 ----
+            compute();
+            __syncthreads();
+            if (kt + 2 < kt_end) {
+                store_tile(S0{});
+                if (kt + 2 + DEPTH < kt_end) load_tile(S0{}, kt + 2 + DEPTH);
+            }
+            __syncthreads();
+        }
     }
     igemm_epilogue<BM, BN, WGM, WGN, RB, CB>(a, acc, m0, n0, mt, split, smem);
 }

@@ -36,7 +36,8 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     because every consumer of the scratch is enqueued on the same stream before the next producer."""
     if nbytes <= 0:
         return None
-    key = (device.type, device.index)
+    # one scratch per (device, stream): the view encoders run concurrently on separate streams
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
         buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)

@@ -83,10 +83,7 @@ class DPRT(nn.Module):
 
     def forward(self, batch: Dict[str, torch.Tensor]) -> "OrderedDict[str, torch.Tensor]":
         shapes = {i: batch[f"{i}_shape"] for i in self.inputs}
-        features = {i: self.backbones[i](batch[i]) for i in self.inputs}
-        features = {i: self._add_raw_data(features[i], batch[i]) for i in self.inputs if self.skiplinks[i]}
-        features = {i: self.necks[i](features[i]) for i in self.inputs}
-        features = {i: self.embeddings[i](features[i]) for i in self.inputs}
+        features = self._encode_views(batch)
         out = self.querent(batch)
         projection = self._get_projetions(self.inputs, batch)
         graphed = self.__dict__.get("_graphed_fuser")
@@ -95,6 +92,36 @@ class DPRT(nn.Module):
         return self.fuser(batch=[features[i] for i in self.inputs],
                           shape=[shapes[i][:, :2] for i in self.inputs],
                           projection=projection, out=out)
+
+    def _encode_view(self, i: str, batch: Dict[str, torch.Tensor]):
+        f = self.backbones[i](batch[i])                                         # dprt.py:219
+        if self.skiplinks[i]:
+            f = self._add_raw_data(f, batch[i])                                 # :222-225
+        return self.embeddings[i](self.necks[i](f))                             # :228, :231
+
+    def _encode_views(self, batch: Dict[str, torch.Tensor]) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
+        """backbone -> (raw skip link) -> neck -> embedding per input.  On the GPU the views run on separate HIP
+        streams: the radar branches are tiny GEMMs that cannot fill 256 CUs and hide inside the camera
+        branch (autograd replays each view's backward on its forward stream, so the backward overlaps too)."""
+        first = batch[self.inputs[0]]
+        if len(self.inputs) == 1 or not first.is_cuda or not self.concurrent_views:
+            return {i: self._encode_view(i, batch) for i in self.inputs}
+        main = torch.cuda.current_stream(first.device)
+        if self.__dict__.get("_view_streams") is None or len(self._view_streams) != len(self.inputs) - 1:
+            self.__dict__["_view_streams"] = [torch.cuda.Stream(first.device) for _ in self.inputs[1:]]
+        features = {}
+        for i, s in zip(self.inputs[1:], self._view_streams):      # small views first, on side streams
+            s.wait_stream(main)
+            with torch.cuda.stream(s):
+                features[i] = self._encode_view(i, batch)
+        features[self.inputs[0]] = self._encode_view(self.inputs[0], batch)
+        for i, s in zip(self.inputs[1:], self._view_streams):
+            main.wait_stream(s)
+            for t in features[i].values():
+                t.record_stream(main)
+        return {i: features[i] for i in self.inputs}
+
+    concurrent_views = True
 
     def enable_fuser_graph(self, sample_batch: Dict[str, torch.Tensor]):
         """Capture the launch-bound fusion decoder (forward and backward) into hipGraphs for training steps

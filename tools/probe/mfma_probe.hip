@@ -27,6 +27,46 @@ __global__ __launch_bounds__(256) void probe(const float* __restrict__ g, float*
     f32x4 af[RB], bf[CB];
     for (int i = 0; i < RB; ++i) af[i] = f32x4{1.f, 0.5f, 0.25f, 0.125f};
     for (int j = 0; j < CB; ++j) bf[j] = f32x4{1.f, 0.5f, 0.25f, 0.125f};
+    if constexpr (VAR >= 4) {
+        // deeper register prefetch: DEPTH register sets in flight, consumed round-robin
+        constexpr int DEPTH = (VAR >= 4) ? VAR - 2 : 1;   // 4 -> 2 sets, 5 -> 3 sets
+        f32x4 pa[DEPTH][BM / 32], pb[DEPTH][BN / 32];
+        auto issue = [&](int slot, int kt) {
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) pa[slot][i] = *reinterpret_cast<const f32x4*>(gp + (size_t)(i * 32) * stride + kt * 32);
+#pragma unroll
+            for (int i = 0; i < BN / 32; ++i) pb[slot][i] = *reinterpret_cast<const f32x4*>(gp + (size_t)(i * 32 + 7) * stride + kt * 32);
+        };
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) issue(d, d);
+        for (int kt0 = 0; kt0 < ksteps; kt0 += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const int kt = kt0 + d;
+#pragma unroll
+                for (int kg = 0; kg < 4; ++kg) {
+#pragma unroll
+                    for (int i = 0; i < RB; ++i) af[i] = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDK + kg * 8);
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) bf[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDK + kg * 8);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int i = 0; i < RB; ++i)
+#pragma unroll
+                            for (int j = 0; j < CB; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e], acc[i][j], 0, 0, 0);
+                }
+                __syncthreads();
+#pragma unroll
+                for (int i = 0; i < BM / 32; ++i) *reinterpret_cast<f32x4*>(&smem[(rowl + 32 * i) * LDK + chunk * 4]) = pa[d][i];
+#pragma unroll
+                for (int i = 0; i < BN / 32; ++i) *reinterpret_cast<f32x4*>(&smem[BM * LDK + (rowl + 32 * i) * LDK + chunk * 4]) = pb[d][i];
+                if (kt + DEPTH < ksteps) issue(d, kt + DEPTH);
+                __syncthreads();
+            }
+        }
+    } else
     for (int kt = 0; kt < ksteps; ++kt) {
         if (VAR >= 3) {
             for (int i = 0; i < BM / 32; ++i) ra[i] = *reinterpret_cast<const f32x4*>(gp + (size_t)(i * 32) * stride + kt * 32);
@@ -88,10 +128,14 @@ int main() {
         run<1, 2, 2>("128x128 +lds reads", nwg, 72, g, out, stride);
         run<2, 2, 2>("128x128 +barriers+stores", nwg, 72, g, out, stride);
         run<3, 2, 2>("128x128 +global loads", nwg, 72, g, out, stride);
+        run<4, 2, 2>("128x128 prefetch x2", nwg, 72, g, out, stride);
+        run<5, 2, 2>("128x128 prefetch x3", nwg, 72, g, out, stride);
         run<0, 1, 1>("64x64 pure mfma", nwg, 72, g, out, stride);
         run<1, 1, 1>("64x64 +lds reads", nwg, 72, g, out, stride);
         run<2, 1, 1>("64x64 +barriers+stores", nwg, 72, g, out, stride);
         run<3, 1, 1>("64x64 +global loads", nwg, 72, g, out, stride);
+        run<4, 1, 1>("64x64 prefetch x2", nwg, 72, g, out, stride);
+        run<5, 1, 1>("64x64 prefetch x3", nwg, 72, g, out, stride);
     }
     return 0;
 }
