@@ -244,23 +244,37 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (g < groups) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c4 * 4);
         const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c4 * 4);
-        for (int64_t r = r0 + g; r < r1; r += groups) {
-            const int64_t idx = r * K4 + c4;
-            f32x4 d = reinterpret_cast<const f32x4*>(dout)[idx];
-            const f32x4 yv = reinterpret_cast<const f32x4*>(y)[idx];
-            if (outp) {
-                const f32x4 o = reinterpret_cast<const f32x4*>(outp)[idx];
+        // 4 rows per trip: 8-12 independent 16-byte loads in flight per lane (this kernel is pure HBM streaming)
+        for (int64_t rb = r0 + g; rb < r1; rb += 4 * groups) {
+            f32x4 dv[4], yv4[4], ov[4];
+            bool ok[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
-            } else if (mbnp) {
-                const f32x4 a = bn_apply4(yv, mbnp, K, c4 * 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : 0.f;
+            for (int u = 0; u < 4; ++u) {
+                const int64_t r = rb + (int64_t)u * groups;
+                ok[u] = r < r1;
+                const int64_t idx = (ok[u] ? r : r0) * K4 + c4;
+                dv[u] = reinterpret_cast<const f32x4*>(dout)[idx];
+                yv4[u] = reinterpret_cast<const f32x4*>(y)[idx];
+                if (outp) ov[u] = reinterpret_cast<const f32x4*>(outp)[idx];
             }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                s0[e] += d[e];
-                s1[e] += d[e] * ((yv[e] - mu[e]) * is[e]);
+            for (int u = 0; u < 4; ++u) {
+                if (!ok[u]) continue;
+                f32x4 d = dv[u];
+                const f32x4 yv = yv4[u];
+                if (outp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = ov[u][e] > 0.f ? d[e] : 0.f;
+                } else if (mbnp) {
+                    const f32x4 a = bn_apply4(yv, mbnp, K, c4 * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s0[e] += d[e];
+                    s1[e] += d[e] * ((yv[e] - mu[e]) * is[e]);
+                }
             }
         }
     }
@@ -501,7 +515,7 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
     const int slabs = cdiv(K4, 256);
     const int kc = std::min(K4, 256);
     const int groups = 256 / kc;
-    const int want_blocks = std::max(1, (kNumCU * 2) / slabs);
+    const int want_blocks = std::max(1, (kNumCU * 8) / slabs);
     int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + want_blocks - 1) / want_blocks);
     dim3 grid(cdiv(M, rows_per_block), slabs);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,

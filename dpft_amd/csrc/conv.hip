@@ -271,49 +271,57 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                 }
                 v = v && hi < a.H && wi < a.W;
             }
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (v) {
-                val = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0);
-                valid |= 1u << i;
-            }
-            ra[sidx][i] = val;
+            // unconditional load from a clamped (always valid) address; invalid rows are zeroed when the set is
+            // written to LDS.  No control flow around the loads => the compiler can keep counted vmcnt waits and
+            // the ring really stays two steps deep.
+            hi = min(max(hi, 0), a.H - 1);
+            wi = min(max(wi, 0), a.W - 1);
+            ra[sidx][i] = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0);
+            valid |= v ? (1u << i) : 0u;
         }
         a_valid[sidx] = valid;
 #pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (b_ok[i]) val = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BKV);
-            rbv[sidx][i] = val;
-        }
+        for (int i = 0; i < BP; ++i)
+            rbv[sidx][i] = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BKV);   // rows >= N: clamped row, zeroed at store
     };
     auto store_tile = [&](auto S) {
         constexpr int sidx = decltype(S)::value;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             f32x4 val = ra[sidx][i];
-            if (PRO) {
-                const bool v = (a_valid[sidx] >> i) & 1u;
+            const bool v = (a_valid[sidx] >> i) & 1u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(val[e] - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
+            for (int e = 0; e < 4; ++e) {
+                float t = val[e];
+                if (PRO) {
+                    t = fmaf(t - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
                     t = a.pro_relu ? fmaxf(t, 0.f) : t;
-                    val[e] = v ? t : 0.f;
                 }
+                val[e] = v ? t : 0.f;
             }
             *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
         }
 #pragma unroll
-        for (int i = 0; i < BP; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
+        for (int i = 0; i < BP; ++i) {
+            f32x4 val = rbv[sidx][i];
+            if (!b_ok[i]) val = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = val;
+        }
     };
 
-    f32x16 acc[RB][CB];
+    // NACC > 1 = K-interleaved partial accumulators per 32x32 block (summed in the epilogue) to break the
+    // single-accumulator MFMA chain of the small wave tiles (PMC at 64x64: MFMA busy 44 %, SQ_WAIT_INST_ANY
+    // 62 %).  Measured: no gain at 64x64 (70 vs 69 TF) and -15 % at 128x64 (occupancy), so it stays off.
+    constexpr int NACC = 1;
+    f32x16 accp[NACC][RB][CB];
 #pragma unroll
-    for (int i = 0; i < RB; ++i)
+    for (int q = 0; q < NACC; ++q)
 #pragma unroll
-        for (int j = 0; j < CB; ++j)
+        for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accp[q][i][j][r] = 0.f;
 
     const int kt_begin = split * a.ksteps_per_split;
     const int kt_end = min(a.ksteps, kt_begin + a.ksteps_per_split);
@@ -338,8 +346,8 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
-                                                                         acc[i][j], 0, 0, 0);
+                        accp[e % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                                                                                    accp[e % NACC][i][j], 0, 0, 0);
         }
     };
 
@@ -371,6 +379,13 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
             }
             __syncthreads();
         }
+    }
+    f32x16 (&acc)[RB][CB] = accp[0];
+    if (NACC == 2) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) acc[i][j] += accp[NACC - 1][i][j];
     }
     igemm_epilogue<BM, BN, WGM, WGN, RB, CB>(a, acc, m0, n0, mt, split, smem);
 }
@@ -663,20 +678,34 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         if (more) store_tile();
         __syncthreads();
     }
+    // epilogue: stage one wave-row of the tile at a time through LDS -> full 16-byte stores along c
     float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.K * a.taps * a.C : a.dw;
-    const int rbase = n0 + wm * RB * 32 + 4 * (lane >> 5);
-    const int cbase = c0 + wn * CB * 32 + (lane & 31);
+    constexpr int RP = RB * 32;          // rows (n) per pass
+    constexpr int LDC = BNc + 4;
+    static_assert(RP * LDC <= BKP * (BMn + BNc), "wgrad epilogue staging does not fit the operand LDS");
+    float* Cs = smem;
+    for (int h = 0; h < WGM; ++h) {
+        __syncthreads();
+        if (wm == h) {
 #pragma unroll
-    for (int j = 0; j < CB; ++j) {
-        const int c = cbase + j * 32;
-        if (c >= a.C) continue;
+            for (int j = 0; j < CB; ++j)
 #pragma unroll
-        for (int i = 0; i < RB; ++i)
+                for (int i = 0; i < RB; ++i)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int n = rbase + i * 32 + (q & 3) + 8 * (q >> 2);
-                if (n < a.K) out[((size_t)n * a.taps + tap) * a.C + c] = acc[i][j][q];
-            }
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                        Cs[row * LDC + wn * CB * 32 + j * 32 + (lane & 31)] = acc[i][j][q];
+                    }
+        }
+        __syncthreads();
+        constexpr int C4 = BNc / 4;
+        for (int idx = tid; idx < RP * C4; idx += 256) {
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int n = n0 + h * RP + row, c = c0 + c4 * 4;
+            if (n < a.K && c < a.C)
+                *reinterpret_cast<f32x4*>(out + ((size_t)n * a.taps + tap) * a.C + c) =
+                    *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
+        }
     }
 }
 

@@ -64,7 +64,7 @@ class GradBucketReducer:
                 v = seg.view(p.shape)
             views[id(p)] = v
             off += p.numel()
-        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set()))
+        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set(), events=[]))
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
@@ -73,6 +73,7 @@ class GradBucketReducer:
             b["flat"].zero_()
             b["ready"], b["fired"] = 0, False
             b["seen"].clear()
+            b["events"].clear()
             for p in b["params"]:
                 p.grad = b["views"][id(p)]
         self._pending = []
@@ -111,11 +112,21 @@ class GradBucketReducer:
             return
         b["seen"].add(id(p))
         b["ready"] += 1
+        if b["flat"].is_cuda:
+            # the view encoders (and therefore their backward) run on separate HIP streams: remember where this
+            # gradient was produced so that the bucket's collective can be ordered after every contribution
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream(b["flat"].device))
+            b["events"].append(ev)
         if b["ready"] == len(b["params"]) and not b["fired"]:
             self._fire(b)
 
     def _fire(self, b):
         b["fired"] = True
+        if b["flat"].is_cuda:
+            cur = torch.cuda.current_stream(b["flat"].device)
+            for ev in b["events"]:
+                cur.wait_event(ev)
         if self.world > 1:
             if self.average:
                 b["flat"].div_(self.world)
