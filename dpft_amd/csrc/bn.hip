@@ -515,7 +515,7 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
     const int slabs = cdiv(K4, 256);
     const int kc = std::min(K4, 256);
     const int groups = 256 / kc;
-    const int want_blocks = std::max(1, (kNumCU * 8) / slabs);
+    const int want_blocks = std::max(1, (kNumCU * 2) / slabs);
     int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + want_blocks - 1) / want_blocks);
     dim3 grid(cdiv(M, rows_per_block), slabs);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,

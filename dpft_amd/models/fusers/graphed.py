@@ -92,7 +92,7 @@ class GraphedFuser:
         # warm-up on a side stream (lazy initialisations, allocator growth) -- nothing is accumulated into .grad
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
+        with torch.enable_grad(), torch.cuda.stream(side):
             for _ in range(warmup):
                 outs = self.flat(*static)
                 torch.autograd.grad(outs, diff_inputs, [torch.ones_like(o) for o in outs], allow_unused=True)
@@ -100,15 +100,30 @@ class GraphedFuser:
         torch.cuda.synchronize()
 
         self.fwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.fwd_graph):
+        with torch.enable_grad(), torch.cuda.graph(self.fwd_graph):
             self.static_outputs = self.flat(*static)
         self.static_grad_outputs = [torch.zeros_like(o) for o in self.static_outputs]
         self.bwd_graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.bwd_graph):                      # its own private pool (see module docstring)
+        with torch.enable_grad(), torch.cuda.graph(self.bwd_graph):   # its own private pool (see module docstring)
             grads = torch.autograd.grad(self.static_outputs, diff_inputs, self.static_grad_outputs,
                                         allow_unused=True)
         self.static_grad_inputs = list(grads)
         torch.cuda.synchronize()
+        # inference replay: eval mode (dropout off, MHA fast path), no autograd
+        self.flat.eval()
+        self.eval_inputs = [t.detach().clone() for t in static]
+        with torch.no_grad():
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.flat(*self.eval_inputs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            self.eval_graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.eval_graph):
+                self.eval_outputs = self.flat(*self.eval_inputs)
+        torch.cuda.synchronize()
+        self.flat.train()
         model.train(was_training)
 
     def __call__(self, features, shapes, projection, out):
@@ -120,6 +135,12 @@ class GraphedFuser:
             args += [t, p]
         if [tuple(a.shape) for a in args] != self.shapes:
             raise RuntimeError("graphed fuser called with shapes different from the captured ones")
+        if not torch.is_grad_enabled():
+            for s_, a_ in zip(self.eval_inputs, args):
+                s_.copy_(a_)
+            self.eval_graph.replay()
+            c, s, a, k = (o.clone() for o in self.eval_outputs)
+            return OrderedDict([("center", c), ("size", s), ("angle", a), ("class", k)])
         # parameters are passed so that autograd routes their gradients (their values are read in place)
         c, s, a, k = _Replay.apply(self, *args, *self.params)
         return OrderedDict([("center", c), ("size", s), ("angle", a), ("class", k)])

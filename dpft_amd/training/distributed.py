@@ -24,21 +24,26 @@ import torch.distributed as dist
 
 class GradBucketReducer:
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None,
-                 average: bool = True):
+                 average: bool = True, group_of: Dict[int, str] = None):
+        """``group_of`` (id(param) -> group key) keeps buckets from spanning groups: the three view encoders run
+        (forward and backward) on their own HIP streams, and a bucket whose gradients all come from one stream
+        can be reduced from that stream without joining the others."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
         self.params = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))
         self.buckets: List[dict] = []
-        cur, cur_bytes = [], 0
+        cur, cur_bytes, cur_group = [], 0, None
         for p in order:
             nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > bucket_bytes:
+            grp = group_of.get(id(p)) if group_of else None
+            if cur and (cur_bytes + nbytes > bucket_bytes or grp != cur_group):
                 self._add_bucket(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
+            cur_group = grp
         if cur:
             self._add_bucket(cur)
         self._index: Dict[int, tuple] = {}
@@ -64,7 +69,7 @@ class GradBucketReducer:
                 v = seg.view(p.shape)
             views[id(p)] = v
             off += p.numel()
-        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set(), events=[]))
+        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set(), streams={}))
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
@@ -73,7 +78,7 @@ class GradBucketReducer:
             b["flat"].zero_()
             b["ready"], b["fired"] = 0, False
             b["seen"].clear()
-            b["events"].clear()
+            b["streams"].clear()
             for p in b["params"]:
                 p.grad = b["views"][id(p)]
         self._pending = []
@@ -113,20 +118,20 @@ class GradBucketReducer:
         b["seen"].add(id(p))
         b["ready"] += 1
         if b["flat"].is_cuda:
-            # the view encoders (and therefore their backward) run on separate HIP streams: remember where this
-            # gradient was produced so that the bucket's collective can be ordered after every contribution
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(b["flat"].device))
-            b["events"].append(ev)
+            # the view encoders (and therefore their backward) run on separate HIP streams: remember which
+            # streams produced gradients of this bucket so that its collective is ordered after all of them
+            st = torch.cuda.current_stream(b["flat"].device)
+            b["streams"][st.cuda_stream] = st
         if b["ready"] == len(b["params"]) and not b["fired"]:
             self._fire(b)
 
     def _fire(self, b):
         b["fired"] = True
-        if b["flat"].is_cuda:
+        if b["flat"].is_cuda and self.world > 1:      # single process: backward() itself joins the streams
             cur = torch.cuda.current_stream(b["flat"].device)
-            for ev in b["events"]:
-                cur.wait_event(ev)
+            for sid, st in b["streams"].items():
+                if sid != cur.cuda_stream:          # tail of that stream is after its last contribution
+                    cur.wait_stream(st)
         if self.world > 1:
             if self.average:
                 b["flat"].div_(self.world)

@@ -27,7 +27,13 @@ class DataParallelTrainer:
         name = opt.pop("name")
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         broadcast_module(self.model)
-        self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=bucket_mb << 20)
+        # one bucket group per view encoder (their backward runs on separate streams), one for the rest
+        group_of = {}
+        for n, p in self.model.named_parameters():
+            parts = n.split(".")
+            group_of[id(p)] = ".".join(parts[:2]) if parts[0] in ("backbones", "necks") else "decoder"
+        self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=bucket_mb << 20,
+                                         group_of=group_of)
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         for m in self.model.modules():
             if hasattr(m, "grad_direct"):

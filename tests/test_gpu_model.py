@@ -319,3 +319,23 @@ def test_graphed_decoder_step_equals_eager_step():
     errs.sort(reverse=True)
     print("graphed vs eager, worst gradients (err, name, |eager|, |graphed|):", errs[:4])
     assert errs[0][0] < 5e-3, errs[:6]
+
+
+def test_graphed_eval_forward_equals_eager():
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch
+    cfg = small_config(dropout=0.1)
+    g = torch.Generator().manual_seed(12)
+    model = _build(cfg, g).to(DEV)
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=11, shapes=SHAPES, device=DEV)
+    model.eval()
+    with torch.no_grad():
+        ref = model(batch)
+        model.enable_fuser_graph(batch)
+        model.eval()
+        out = model(batch)
+        out2 = model(batch)
+    for k in ref:
+        close(out[k], ref[k], rtol=1e-5, atol_scale=1e-5, what=f"graphed eval {k}")
+        close(out2[k], ref[k], rtol=1e-5, atol_scale=1e-5, what=f"graphed eval replay {k}")
+    assert torch.equal(out["class"].argmax(-1), ref["class"].argmax(-1))
