@@ -184,6 +184,40 @@ def main():
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
     fwd_mean, fwd_std = trainer.inference_time(data, warmup=5, reps=args.latency_reps)
 
+    # ---- HBM roofline of the deformable fusion decoder (SURVEY 8d "Roofline B") -------------------------
+    # unit of work = one IMPFusion.forward (eval); algorithmic bytes = every cross-attention call streams its
+    # view's 16-channel fp32 pyramid once + query-side I/O + parameters
+    dec = None
+    if rank == 0:
+        m = trainer.model
+        m.eval()
+        with torch.no_grad():
+            feats = m._encode_views(data)
+            proj = m._get_projetions(m.inputs, data)
+            shp = [data[f"{i}_shape"][:, :2] for i in m.inputs]
+            flags = m.fuser.transformation_flags(proj)
+            c0 = m.querent(data)
+            run = lambda: m.fuser(batch=[feats[i] for i in m.inputs], shape=shp, projection=proj, out=c0,
+                                  has_transformation=flags)
+            for _ in range(5):
+                run()
+            reps = max(args.latency_reps, 10)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                run()
+            e1.record()
+            torch.cuda.synchronize()
+        t_dec = e0.elapsed_time(e1) * 1e-3 / reps
+        tokens = sum(int(l.shape[1] * l.shape[2]) for i in m.inputs for l in feats[i].values())
+        fcfg = cfg["model"]["fuser"]
+        n_calls = fcfg["i_iter"] * len(m.inputs)
+        dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
+        dec = {"bound": "hbm", "achieved": dec_bytes / t_dec / 1e9, "peak": 8000.0, "unit": "GB/s",
+               "frac": dec_bytes / t_dec / 8.0e12, "traffic": None, "decoder_fwd_us": t_dec * 1e6,
+               "algorithmic_mb": dec_bytes / 1e6, "kernel": "decoder_selfattn + decoder_xattn_ffn + decoder_head "
+               f"({1 + fcfg['i_iter'] * (2 + len(m.inputs))} launches per forward)"}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(args)
@@ -199,7 +233,7 @@ def main():
                        "global_batch": world * B, "parallelism": f"dp{world}"},
             "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,
             "loss": float(loss),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:

@@ -39,6 +39,31 @@ class ResnetTables(C.Structure):
                 ("conv_w", "conv_dw", "bn_gamma", "bn_beta", "bn_rm", "bn_rv", "bn_dgamma", "bn_dbeta")]
 
 
+class DecoderView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in (
+        "in_proj_w", "in_proj_b", "out_proj_w", "out_proj_b", "norm1_w", "norm1_b",
+        "off_w", "off_b", "att_w", "att_b", "val_w", "val_b", "outp_w", "outp_b", "norm2_w", "norm2_b",
+        "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b", "norm3_w", "norm3_b")]
+
+
+class DecoderHead(C.Structure):
+    _fields_ = [("y3", C.c_void_p), ("red_w", C.c_void_p), ("head_w", (C.c_void_p * 3) * 4),
+                ("prev_center", C.c_void_p), ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
+                ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("query_out", C.c_void_p),
+                ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p),
+                ("refs", C.c_void_p), ("num_classes", C.c_int32)]
+
+
+class DecoderFwd(C.Structure):
+    _fields_ = [("B", C.c_int32), ("Q", C.c_int32), ("V", C.c_int32), ("iters", C.c_int32), ("num_classes", C.c_int32),
+                ("n_points", C.c_int32 * 4), ("views", C.c_void_p), ("pyr", C.c_void_p),
+                ("query0", C.c_void_p), ("pos", C.c_void_p), ("center0", C.c_void_p),
+                ("red_w", C.c_void_p * 8), ("head_w", ((C.c_void_p * 3) * 4) * 8),
+                ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
+                ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("work", C.c_void_p),
+                ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(ConvDesc)
 _PYR = C.POINTER(Pyramid)
@@ -72,6 +97,11 @@ SIGNATURES = {
     "dpft_xattn_fwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpft_xattn_bwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpft_giou3d_yaw_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "dpft_decoder_selfattn_fwd_f32": (_I, [_P, _P, C.POINTER(DecoderView), _I, _P, _I, _I, _P]),
+    "dpft_decoder_xattn_ffn_fwd_f32": (_I, [_PYR, C.POINTER(DecoderView), _P, _P, _P, _P, _I, _I, _I, _P]),
+    "dpft_decoder_head_fwd_f32": (_I, [C.POINTER(DecoderHead), _I, _I, _I, _P]),
+    "dpft_decoder_work_floats": (_L, [_I, _I, _I]),
+    "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),

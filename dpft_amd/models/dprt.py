@@ -87,8 +87,7 @@ class DPRT(nn.Module):
         out = self.querent(batch)
         projection = self._get_projetions(self.inputs, batch)
         graphed = self.__dict__.get("_graphed_fuser")
-        if graphed is not None and ((self.training and torch.is_grad_enabled()) or
-                                    (not self.training and not torch.is_grad_enabled())):
+        if graphed is not None and self.training and torch.is_grad_enabled():
             return graphed(features, shapes, projection, out)
         return self.fuser(batch=[features[i] for i in self.inputs],
                           shape=[shapes[i][:, :2] for i in self.inputs],

@@ -1,0 +1,104 @@
+"""Host side of the fused inference decoder (dpft_amd/csrc/decoder.hip): builds the C-ABI parameter
+structs from an ``IMPFusion`` module and runs 1 + 3*i_iter kernels instead of ~700 eager ops."""
+from __future__ import annotations
+
+import ctypes as C
+from collections import OrderedDict
+from typing import Dict, List, Tuple
+
+import torch
+from torch import nn
+
+from dpft_amd.hip.lib import DecoderFwd, DecoderHead, DecoderView, Pyramid, lib, make_pyramid, ptr, stream
+
+
+def supported(fuser: nn.Module) -> bool:
+    from dpft_amd.models.heads.detection import LinearDetectionHead
+    try:
+        ok = (fuser.d_model == 16 and fuser.d_ffn == 32 and fuser.norm and fuser.reduction == "linear"
+              and fuser.activation == "Mish" and 1 <= fuser.m_views <= 4
+              and all(h == 8 for h in fuser.n_heads)
+              and all(l * p <= 20 and l <= 8 for l, p in zip(fuser.n_levels, fuser.n_points)))
+        for h in fuser.heads:
+            ok = ok and isinstance(h, LinearDetectionHead) and h.num_reg_layers == 3 and h.num_cls_layers == 3 \
+                and not h.bias and h.num_classes <= 8
+        return bool(ok)
+    except AttributeError:
+        return False
+
+
+def _view_struct(ml: nn.Module) -> Tuple[DecoderView, list]:
+    a = ml.ms_deform_attn
+    tensors = [ml.self_attn.in_proj_weight, ml.self_attn.in_proj_bias, ml.self_attn.out_proj.weight,
+               ml.self_attn.out_proj.bias, ml.norm1.weight, ml.norm1.bias,
+               a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+               a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias,
+               ml.norm2.weight, ml.norm2.bias, ml.ffn1.weight, ml.ffn1.bias, ml.ffn2.weight, ml.ffn2.bias,
+               ml.norm3.weight, ml.norm3.bias]
+    for t in tensors:
+        assert t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda
+    return DecoderView(*[t.data_ptr() for t in tensors]), tensors
+
+
+class FusedDecoder:
+    def __init__(self, fuser: nn.Module):
+        self.fuser = fuser
+        self._key = None
+
+    def _build(self):
+        f = self.fuser
+        key = tuple(p.data_ptr() for p in f.parameters())
+        if key == self._key:
+            return
+        V, I = f.m_views, f.i_iter
+        self.views = (DecoderView * (I * V))()
+        d = DecoderFwd()
+        for it, layer in enumerate(f.mpfusion.values()):
+            for v, ml in enumerate(layer.ml_fusion_layers.values()):
+                self.views[it * V + v], _ = _view_struct(ml)
+            d.red_w[it] = layer.reduction_layer.weight.data_ptr()
+            head = f.heads[it]
+            for bi, name in enumerate(("center", "size", "angle", "class")):
+                seq = head.layers[name + "_head"]
+                for li, idx in enumerate((0, 3, 6)):
+                    d.head_w[it][bi][li] = seq[idx].weight.data_ptr()
+        d.V, d.iters, d.Q, d.num_classes = V, I, f.n_queries, f.heads[0].num_classes
+        for v in range(V):
+            d.n_points[v] = f.n_points[v]
+        d.views = C.cast(self.views, C.c_void_p)
+        d.query0, d.pos = f.query.data_ptr(), f.query_embedding.weight.data_ptr()
+        self.desc = d
+        self._key = key
+
+    @torch.no_grad()
+    def __call__(self, batch: List[Dict[str, torch.Tensor]], shape: List[torch.Tensor],
+                 projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor],
+                 flags: List[bool]):
+        """One C-ABI call: reference points + i_iter x (self-attention, V cross-attention/FFN, head)."""
+        f = self.fuser
+        self._build()
+        d = self.desc
+        V, Q = f.m_views, f.n_queries
+        center0 = out["center"][..., :3].contiguous().float()
+        B, dev = center0.shape[0], center0.device
+        keep = [[l if l.is_contiguous() else l.contiguous() for l in levels.values()] for levels in batch]
+        pyrs = (Pyramid * V)()
+        for v in range(V):
+            pyrs[v] = make_pyramid(keep[v])
+        shapes = [s.to(torch.int64).contiguous() for s in shape]
+        Ts = [t.contiguous().float() for t, _ in projection]
+        Ps = [p.contiguous().float() for _, p in projection]
+        d.B = B
+        d.pyr = C.cast(pyrs, C.c_void_p)
+        d.center0 = center0.data_ptr()
+        for v in range(V):
+            d.T[v], d.P[v], d.shape[v] = Ts[v].data_ptr(), Ps[v].data_ptr(), shapes[v].data_ptr()
+            d.p_rows[v], d.has_t[v] = Ps[v].shape[1], int(flags[v])
+        work = torch.empty(int(lib.dpft_decoder_work_floats(B, Q, V)), dtype=torch.float32, device=dev)
+        ncls = d.num_classes
+        res = (torch.empty((B, Q, 3), dtype=torch.float32, device=dev), torch.empty((B, Q, 3), dtype=torch.float32, device=dev),
+               torch.empty((B, Q, 2), dtype=torch.float32, device=dev), torch.empty((B, Q, ncls), dtype=torch.float32, device=dev))
+        d.work = work.data_ptr()
+        d.center, d.size, d.angle, d.cls = (t.data_ptr() for t in res)
+        lib.call("dpft_decoder_forward_f32", C.byref(d), stream())
+        return OrderedDict([("center", res[0]), ("size", res[1]), ("angle", res[2]), ("class", res[3])])

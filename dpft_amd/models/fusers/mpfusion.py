@@ -149,6 +149,8 @@ class IMPFusion(nn.Module):
     def from_config(cls, config: Dict[str, Any], **kwargs) -> "IMPFusion":
         return cls(**config, **kwargs)
 
+    use_fused_inference = True       # eval + no_grad forward runs the fused HIP decoder when the config allows
+
     def reset_parameters(self) -> None:
         self.q_init(self.query)
 
@@ -184,9 +186,17 @@ class IMPFusion(nn.Module):
                 projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor],
                 has_transformation: List[bool] = None):
         B = out["center"].shape[0]
+        flags = has_transformation if has_transformation is not None else self.transformation_flags(projection)
+        if not self.training and not torch.is_grad_enabled() and self.use_fused_inference \
+                and out["center"].is_cuda:
+            fused = self.__dict__.get("_fused_decoder")
+            if fused is None:
+                from dpft_amd.models.fusers import fused as _f
+                fused = self.__dict__["_fused_decoder"] = _f.FusedDecoder(self) if _f.supported(self) else False
+            if fused:
+                return fused(batch, shape, projection, out, flags)
         query = self.query.unsqueeze(0).repeat(B, 1, 1)
         query_pos = self.query_embedding.weight.unsqueeze(0).repeat(B, 1, 1)
-        flags = has_transformation if has_transformation is not None else self.transformation_flags(projection)
         pyramids = [make_pyramid_state(list(levels.values())) for levels in batch]
         for layer, head in zip(self.mpfusion.values(), self.heads):
             reference_points = [

@@ -321,21 +321,19 @@ def test_graphed_decoder_step_equals_eager_step():
     assert errs[0][0] < 5e-3, errs[:6]
 
 
-def test_graphed_eval_forward_equals_eager():
-    from dpft_amd.models import build
+def test_fused_inference_decoder_equals_eager_decoder():
+    """eval + no_grad forward through the fused HIP decoder kernels == the eager (torch-op) decoder."""
     from dpft_amd.synthetic import make_batch
     cfg = small_config(dropout=0.1)
     g = torch.Generator().manual_seed(12)
-    model = _build(cfg, g).to(DEV)
-    batch = make_batch(cfg["model"]["inputs"], 2, seed=11, shapes=SHAPES, device=DEV)
-    model.eval()
+    model = _build(cfg, g).to(DEV).eval()
+    batch = make_batch(cfg["model"]["inputs"], 3, seed=11, shapes=SHAPES, device=DEV)
     with torch.no_grad():
+        model.fuser.use_fused_inference = False
         ref = model(batch)
-        model.enable_fuser_graph(batch)
-        model.eval()
+        model.fuser.use_fused_inference = True
         out = model(batch)
-        out2 = model(batch)
+    assert model.fuser.__dict__.get("_fused_decoder"), "fused decoder was not used"
     for k in ref:
-        close(out[k], ref[k], rtol=1e-5, atol_scale=1e-5, what=f"graphed eval {k}")
-        close(out2[k], ref[k], rtol=1e-5, atol_scale=1e-5, what=f"graphed eval replay {k}")
+        close(out[k], ref[k], rtol=1e-4, atol_scale=1e-4, what=f"fused decoder {k}")
     assert torch.equal(out["class"].argmax(-1), ref["class"].argmax(-1))
