@@ -5,34 +5,111 @@
 //   (deformable cross attention), :210-229 (FFN), :416-470,:472-514 (view reduction), :617-696 (reference
 //   points), :698-745 (iteration), src/dprt/models/heads/detection.py:252-275 (head).
 // The eager decoder is ~700 launches of B*400x16-sized ops per forward (launch-bound: ~5 ms even when
-// replayed from a hipGraph); here one iteration is 3 kernels per view-set:
-//   K1 decoder_selfattn_kernel  : all views; K/V of the 400 keys in LDS, one thread per (query, head),
-//                                 out_proj + residual + LayerNorm1 in the epilogue
-//   K2 decoder_xattn_ffn_kernel : per view; one wave per (b, query): offsets/logits GEMV + softmax,
-//                                 sample-then-project gather on the NHWC pyramid, output_proj + LN2,
-//                                 FFN (Mish) + LN3
-//   K3 decoder_head_kernel      : 48->16 view reduction, 4 head MLPs, center += previous, reference points of
-//                                 every view for the next iteration
+// replayed from a hipGraph); here one iteration is 2 kernels:
+//   K1 decoder_selfattn_kernel   : all views; K/V of the 400 keys in LDS, lane = (head, key slice), 4 queries per
+//                                  wave in registers, online softmax; out_proj + residual + LayerNorm1 epilogue
+//   K2 decoder_xattn_head_kernel : block = the V waves of one (b, query).  Per wave: reference point from the
+//                                  previous center, offsets/logits GEMV + softmax, sample-then-project gather on
+//                                  the NHWC pyramid, output_proj + LN2, FFN (Mish) + LN3.  Then wave 0: 48->16
+//                                  view reduction and the 4 head MLPs (16 lanes per branch), center += previous.
+// All small matrices are read from PACKED blobs (dpft_decoder_pack_*): transposed so that the 64 lanes of a
+// wave read consecutive floats (a torch (out,in) row per lane is a 64-cache-line gather per instruction and
+// made the first version of K2 texture-addresser bound).
 #include "common.h"
+
+#define RC(call)              \
+    do {                      \
+        int rc_ = (call);     \
+        if (rc_) return rc_;  \
+    } while (0)
 
 namespace dpft {
 
 constexpr int DC = 16, DM = 8, DD = 2, DFF = 32;
+constexpr int NOA = 480;   // max offsets (8 heads * L*P * 2) + logits (8 * L*P), L*P <= 20
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-struct ViewW {   // device pointers, one MLFusion
-    const float *in_w, *in_b, *out_w, *out_b, *n1_w, *n1_b;
-    const float *off_w, *off_b, *att_w, *att_b, *val_w, *val_b, *outp_w, *outp_b, *n2_w, *n2_b;
-    const float *f1_w, *f1_b, *f2_w, *f2_b, *n3_w, *n3_b;
+// ---- packed view blob (floats) ----
+constexpr int PV_IN_W = 0;                       // in_proj_weight (48,16) as is (staged through LDS)
+constexpr int PV_IN_B = PV_IN_W + 768;           // 48
+constexpr int PV_OUT_WT = PV_IN_B + 48;          // out_proj.weight^T [k][c]
+constexpr int PV_OUT_B = PV_OUT_WT + 256;
+constexpr int PV_N1_W = PV_OUT_B + 16;
+constexpr int PV_N1_B = PV_N1_W + 16;
+constexpr int PV_OA_WT = PV_N1_B + 16;           // [16][NOA]: sampling_offsets rows then attention_weights rows, transposed
+constexpr int PV_OA_B = PV_OA_WT + 16 * NOA;     // [NOA]
+constexpr int PV_VAL_W = PV_OA_B + NOA;          // value_proj.weight (16,16) as is
+constexpr int PV_VAL_B = PV_VAL_W + 256;
+constexpr int PV_OUTP_WT = PV_VAL_B + 16;        // output_proj.weight^T [k][c]
+constexpr int PV_OUTP_B = PV_OUTP_WT + 256;
+constexpr int PV_N2_W = PV_OUTP_B + 16;
+constexpr int PV_N2_B = PV_N2_W + 16;
+constexpr int PV_F1_WT = PV_N2_B + 16;           // ffn1.weight^T [k 16][j 32]
+constexpr int PV_F1_B = PV_F1_WT + 512;
+constexpr int PV_F2_WT = PV_F1_B + 32;           // ffn2.weight^T [k 32][c 16]
+constexpr int PV_F2_B = PV_F2_WT + 512;
+constexpr int PV_N3_W = PV_F2_B + 16;
+constexpr int PV_N3_B = PV_N3_W + 16;
+constexpr int PV_FLOATS = PV_N3_B + 16;
+// ---- packed head blob ----
+constexpr int PH_RED_WT = 0;                     // [v 4][k 16][o 16]  = reduction_layer.weight[o][k*V + v]
+constexpr int PH_W = PH_RED_WT + 4 * 256;        // [layer 3][k 16][branch 4][o 16] (rows >= out_features are 0)
+constexpr int PH_FLOATS = PH_W + 3 * 1024;
+
+__global__ void pack_view_kernel(dpft_decoder_view s, int n_off, int n_att, float* __restrict__ d) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PV_FLOATS; i += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        int r;
+        if (i < PV_IN_B) v = s.in_proj_w[i];
+        else if (i < PV_OUT_WT) v = s.in_proj_b[i - PV_IN_B];
+        else if (i < PV_OUT_B) { r = i - PV_OUT_WT; v = s.out_proj_w[(r & 15) * 16 + (r >> 4)]; }
+        else if (i < PV_N1_W) v = s.out_proj_b[i - PV_OUT_B];
+        else if (i < PV_N1_B) v = s.norm1_w[i - PV_N1_W];
+        else if (i < PV_OA_WT) v = s.norm1_b[i - PV_N1_B];
+        else if (i < PV_OA_B) {
+            r = i - PV_OA_WT;
+            const int c = r / NOA, o = r - c * NOA;
+            v = o < n_off ? s.off_w[o * 16 + c] : (o < n_off + n_att ? s.att_w[(o - n_off) * 16 + c] : 0.f);
+        } else if (i < PV_VAL_W) {
+            const int o = i - PV_OA_B;
+            v = o < n_off ? s.off_b[o] : (o < n_off + n_att ? s.att_b[o - n_off] : 0.f);
+        } else if (i < PV_VAL_B) v = s.val_w[i - PV_VAL_W];
+        else if (i < PV_OUTP_WT) v = s.val_b[i - PV_VAL_B];
+        else if (i < PV_OUTP_B) { r = i - PV_OUTP_WT; v = s.outp_w[(r & 15) * 16 + (r >> 4)]; }
+        else if (i < PV_N2_W) v = s.outp_b[i - PV_OUTP_B];
+        else if (i < PV_N2_B) v = s.norm2_w[i - PV_N2_W];
+        else if (i < PV_F1_WT) v = s.norm2_b[i - PV_N2_B];
+        else if (i < PV_F1_B) { r = i - PV_F1_WT; v = s.ffn1_w[(r & 31) * 16 + (r >> 5)]; }
+        else if (i < PV_F2_WT) v = s.ffn1_b[i - PV_F1_B];
+        else if (i < PV_F2_B) { r = i - PV_F2_WT; v = s.ffn2_w[(r & 15) * 32 + (r >> 4)]; }
+        else if (i < PV_N3_W) v = s.ffn2_b[i - PV_F2_B];
+        else if (i < PV_N3_B) v = s.norm3_w[i - PV_N3_W];
+        else v = s.norm3_b[i - PV_N3_B];
+        d[i] = v;
+    }
+}
+
+struct HeadSrc {
+    const float* red_w;
+    const float* hw[4][3];
+    int nout[4];
+    int V;
 };
-struct SelfAttnArgs {
-    ViewW w[4];
-    const float* query;   // (B,Q,16), or (Q,16) broadcast over the batch when qstride == 0
-    const float* pos;     // (Q,16)
-    float* y1;            // (V,B,Q,16)
-    int B, Q, V;
-    long qstride;
-};
+__global__ void pack_head_kernel(HeadSrc s, float* __restrict__ d) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PH_FLOATS; i += gridDim.x * blockDim.x) {
+        float v = 0.f;
+        if (i < PH_W) {
+            const int vw = i >> 8, k = (i >> 4) & 15, o = i & 15;
+            if (vw < s.V) v = s.red_w[o * DC * s.V + k * s.V + vw];
+        } else {
+            const int r = i - PH_W;
+            const int layer = r >> 10, k = (r >> 6) & 15, g = (r >> 4) & 3, o = r & 15;
+            const int rows = layer == 2 ? s.nout[g] : DC;
+            if (o < rows) v = s.hw[g][layer][o * DC + k];
+        }
+        d[i] = v;
+    }
+}
 
 __device__ __forceinline__ float group16_sum(float v) {
     v += __shfl_xor(v, 1);
@@ -50,88 +127,135 @@ __device__ __forceinline__ float layernorm16(float v, float g, float b) {
     return d * (1.0f / sqrtf(var + 1e-5f)) * g + b;
 }
 
-constexpr int QT = 32;   // queries per block
+struct SelfAttnArgs {
+    const float* pv[4];   // packed view blobs
+    const float* query;   // (B,Q,16), or (Q,16) broadcast over the batch when qstride == 0
+    const float* pos;     // (Q,16)
+    float* y1;            // (V,B,Q,16)
+    int B, Q, V;
+    long qstride;
+};
 
+// block = QT = 4*QW queries of one (b, view): 4 waves x QW queries (register-blocked: every K/V read from LDS is
+// used for QW queries), lane = (head, key slice).  Every block recomputes K/V of all keys (~1/3 of its work), so
+// the host picks QW such that the grid is ONE round of <= 256 blocks (one per CU): with 300 blocks of 16 queries
+// 44 CUs ran two blocks back to back and the kernel took twice as long.
+template <int QW>
 __global__ __launch_bounds__(256) void decoder_selfattn_kernel(SelfAttnArgs a) {
+    constexpr int QT = 4 * QW;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int Q = a.Q;
-    float* Ks = sm;                 // [Q][16]
-    float* Vs = sm + Q * DC;        // [Q][16]
-    float* Ws = Vs + Q * DC;        // in_proj 48x16 + bias 48
-    float* At = Ws + 48 * 16 + 48;  // [QT][16] attention output tile
-    const int tid = threadIdx.x;
+    float* Ks = sm;                   // [Q][16]
+    float* Vs = sm + Q * DC;          // [Q][16]
+    float* Ws = Vs + Q * DC;          // in_proj rows [48][16] + bias [48]
+    float* Qs = Ws + 48 * 16 + 48;    // [QT][16] projected, scaled queries; reused as the attention output tile
+    float* Pt = Qs + QT * DC;         // [QT][8 heads][8 slices][4] partial (max, den, o0, o1)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int view = blockIdx.y, b = blockIdx.z, q0 = blockIdx.x * QT;
-    const ViewW& w = a.w[view];
-    for (int i = tid; i < 48 * 16; i += 256) Ws[i] = w.in_w[i];
-    if (tid < 48) Ws[48 * 16 + tid] = w.in_b[tid];
-    __syncthreads();
+    const float* pv = a.pv[view];
     const float* xb = a.query + (size_t)b * a.qstride;
-    // K = (x+pos) Wk^T + bk ; V = x Wv^T + bv for every key of this sample
-    for (int k = tid; k < Q; k += 256) {
-        float x[DC], xp[DC];
+    if (tid < (768 + 48) / 4) *reinterpret_cast<f32x4*>(Ws + tid * 4) = *reinterpret_cast<const f32x4*>(pv + PV_IN_W + tid * 4);
+    __syncthreads();
+    // rows of [Q | K | V] = in_proj(x + pos | x + pos | x): item = (key, K|V) plus (query of the tile, Q)
+    for (int i = tid; i < 2 * Q + QT; i += 256) {
+        const int isq = i >= 2 * Q;
+        const int k = isq ? min(q0 + i - 2 * Q, Q - 1) : (i >> 1);
+        const int isv = isq ? 0 : (i & 1);
+        const int row0 = isq ? 0 : 16 + 16 * isv;
+        float x[DC];
 #pragma unroll
         for (int c = 0; c < DC; c += 4) {
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (size_t)k * DC + c);
-            const f32x4 pv = *reinterpret_cast<const f32x4*>(a.pos + (size_t)k * DC + c);
+            f32x4 xv = *reinterpret_cast<const f32x4*>(xb + (size_t)k * DC + c);
+            if (!isv) xv += *reinterpret_cast<const f32x4*>(a.pos + (size_t)k * DC + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { x[c + e] = xv[e]; xp[c + e] = xv[e] + pv[e]; }
+            for (int e = 0; e < 4; ++e) x[c + e] = xv[e];
         }
-#pragma unroll
+        float* dst = isq ? Qs + (i - 2 * Q) * DC : (isv ? Vs : Ks) + k * DC;
+        const float scale = isq ? 0.70710678118654752f : 1.f;      // 1/sqrt(head_dim) folded into Q
+#pragma unroll 4
         for (int o = 0; o < DC; ++o) {
-            float sk = Ws[48 * 16 + 16 + o], sv = Ws[48 * 16 + 32 + o];
+            const float* wr = Ws + (row0 + o) * 16;
+            float sacc = Ws[48 * 16 + row0 + o];
 #pragma unroll
-            for (int c = 0; c < DC; ++c) {
-                sk = fmaf(Ws[(16 + o) * 16 + c], xp[c], sk);
-                sv = fmaf(Ws[(32 + o) * 16 + c], x[c], sv);
+            for (int c = 0; c < DC; c += 4) {
+                const f32x4 wv4 = *reinterpret_cast<const f32x4*>(wr + c);
+                sacc = fmaf(wv4[0], x[c], sacc); sacc = fmaf(wv4[1], x[c + 1], sacc);
+                sacc = fmaf(wv4[2], x[c + 2], sacc); sacc = fmaf(wv4[3], x[c + 3], sacc);
             }
-            Ks[k * DC + o] = sk;
-            Vs[k * DC + o] = sv;
+            dst[o] = sacc * scale;
         }
     }
     __syncthreads();
-    // one thread per (query, head): scaled dot-product attention over all keys
-    const int ql = tid >> 3, h = tid & 7;
-    const int q = q0 + ql;
-    if (q < Q) {
-        float qh[2];
+    {
+        const int slice = lane & 7, h = lane >> 3;
+        f32x2 qh[QW];
+        float mx[QW], den[QW], o0[QW], o1[QW];
 #pragma unroll
-        for (int d = 0; d < 2; ++d) {
-            float s = Ws[48 * 16 + h * 2 + d];
+        for (int i = 0; i < QW; ++i) {
+            qh[i] = *reinterpret_cast<const f32x2*>(Qs + (wv * QW + i) * DC + h * 2);
+            mx[i] = -INFINITY; den[i] = 0.f; o0[i] = 0.f; o1[i] = 0.f;
+        }
+        const float* kp = Ks + h * 2;
+        const float* vp = Vs + h * 2;
+#pragma unroll 1
+        for (int k = slice; k < Q; k += 16) {      // 2 keys of this slice per step, each used for QW queries
+            const int k2 = k + 8;
+            const bool has2 = k2 < Q;
+            const f32x2 ka = *reinterpret_cast<const f32x2*>(kp + k * DC), va = *reinterpret_cast<const f32x2*>(vp + k * DC);
+            const f32x2 kb = *reinterpret_cast<const f32x2*>(kp + (has2 ? k2 : k) * DC);
+            const f32x2 vb = *reinterpret_cast<const f32x2*>(vp + (has2 ? k2 : k) * DC);
 #pragma unroll
-            for (int c = 0; c < DC; ++c)
-                s = fmaf(Ws[(h * 2 + d) * 16 + c], xb[(size_t)q * DC + c] + a.pos[(size_t)q * DC + c], s);
-            qh[d] = s * 0.70710678118654752f;      // 1/sqrt(head_dim)
+            for (int i = 0; i < QW; ++i) {
+                const float sa = qh[i][0] * ka[0] + qh[i][1] * ka[1];
+                const float sb = has2 ? qh[i][0] * kb[0] + qh[i][1] * kb[1] : -INFINITY;
+                const float m_new = fmaxf(fmaxf(sa, sb), mx[i]);
+                const float corr = __expf(mx[i] - m_new);
+                const float pa = __expf(sa - m_new), pb = __expf(sb - m_new);
+                den[i] = den[i] * corr + pa + pb;
+                o0[i] = fmaf(pb, vb[0], fmaf(pa, va[0], o0[i] * corr));
+                o1[i] = fmaf(pb, vb[1], fmaf(pa, va[1], o1[i] * corr));
+                mx[i] = m_new;
+            }
         }
-        float mx = -INFINITY;
-        for (int k = 0; k < Q; ++k) {
-            const f32x2 kv = *reinterpret_cast<const f32x2*>(&Ks[k * DC + h * 2]);
-            mx = fmaxf(mx, qh[0] * kv[0] + qh[1] * kv[1]);
+#pragma unroll
+        for (int i = 0; i < QW; ++i) {
+            const f32x4 part = {mx[i], den[i], o0[i], o1[i]};
+            *reinterpret_cast<f32x4*>(Pt + (((wv * QW + i) * DM + h) * 8 + slice) * 4) = part;
         }
-        float den = 0.f, o0 = 0.f, o1 = 0.f;
-        for (int k = 0; k < Q; ++k) {
-            const f32x2 kv = *reinterpret_cast<const f32x2*>(&Ks[k * DC + h * 2]);
-            const f32x2 vv = *reinterpret_cast<const f32x2*>(&Vs[k * DC + h * 2]);
-            const float p = __expf(qh[0] * kv[0] + qh[1] * kv[1] - mx);
-            den += p;
-            o0 = fmaf(p, vv[0], o0);
-            o1 = fmaf(p, vv[1], o1);
-        }
-        At[ql * DC + h * 2 + 0] = o0 / den;
-        At[ql * DC + h * 2 + 1] = o1 / den;
     }
     __syncthreads();
-    // out_proj + residual + LayerNorm1: 16 lanes per query (2 passes of 16 queries)
-    for (int pass = 0; pass < 2; ++pass) {
-        const int ql2 = pass * 16 + (tid >> 4), c = tid & 15;
+    // merge the 8 key slices of each (query, head); a slice may be empty (max = -inf, den = 0)
+    if (tid < QT * DM) {
+        const float* pp = Pt + tid * 32;
+        float mm = -INFINITY;
+#pragma unroll 1
+        for (int s2 = 0; s2 < 8; ++s2) mm = fmaxf(mm, pp[s2 * 4]);
+        float dsum = 0.f, a0 = 0.f, a1 = 0.f;
+#pragma unroll 1
+        for (int s2 = 0; s2 < 8; ++s2) {
+            const f32x4 part = *reinterpret_cast<const f32x4*>(pp + s2 * 4);
+            const float cf = part[0] == -INFINITY ? 0.f : __expf(part[0] - mm);
+            dsum = fmaf(part[1], cf, dsum);
+            a0 = fmaf(part[2], cf, a0);
+            a1 = fmaf(part[3], cf, a1);
+        }
+        Qs[tid * 2 + 0] = a0 / dsum;      // tid = query * 8 + head  ->  channel head*2 + d
+        Qs[tid * 2 + 1] = a1 / dsum;
+    }
+    __syncthreads();
+    // out_proj + residual + LayerNorm1: 16 lanes per query
+    if (tid < QT * DC) {
+        const int ql2 = tid >> 4, c = tid & 15;
         const int q2 = q0 + ql2;
         float v = 0.f;
         if (q2 < Q) {
-            v = w.out_b[c];
-#pragma unroll
-            for (int j = 0; j < DC; ++j) v = fmaf(w.out_w[c * DC + j], At[ql2 * DC + j], v);
+            v = pv[PV_OUT_B + c];
+#pragma unroll 4
+            for (int j = 0; j < DC; ++j) v = fmaf(pv[PV_OUT_WT + j * DC + c], Qs[ql2 * DC + j], v);
             v += xb[(size_t)q2 * DC + c];
         }
-        v = layernorm16(v, w.n1_w[c], w.n1_b[c]);
+        v = layernorm16(v, pv[PV_N1_W + c], pv[PV_N1_B + c]);
         if (q2 < Q) a.y1[(((size_t)view * a.B + b) * Q + q2) * DC + c] = v;
     }
 }
@@ -141,14 +265,20 @@ struct Pyr5 {
     int H[DPFT_MAX_LEVELS], W[DPFT_MAX_LEVELS];
     int L;
 };
-struct XattnFfnArgs {
-    Pyr5 pyr;
-    ViewW w;
-    const float* y1;    // (B,Q,16)
-    const float* pos;   // (Q,16)
-    const float* ref;   // (B,Q,2)
-    float* y3;          // (B,Q,16)
-    int B, Q, P;
+struct XattnHeadArgs {
+    Pyr5 pyr[4];
+    const float* pv[4];         // packed view blobs
+    const float* ph;            // packed head blob
+    const float* y1;            // (V,B,Q,16)
+    const float* pos;           // (Q,16)
+    const float* prev_center;   // (B,Q,3): reference points are projected from it; center = head + prev_center
+    const float* T[4];          // (B,4,4)
+    const float* Pm[4];         // (B,prow,4)
+    const int64_t* shape[4];    // (B,2) = H, W
+    int prow[4], flag[4], P[4];
+    float* query_out;           // (B,Q,16)
+    float *center, *size, *angle, *cls;
+    int B, Q, V, ncls;
 };
 
 __device__ __forceinline__ float group8_sum_d(float v) {
@@ -164,33 +294,60 @@ __device__ __forceinline__ float mishf(float x) {
     return x * tanhf(sp);
 }
 
-// one wave per (b, q); 4 waves per block.  Per-wave LDS scratch: qp[16] | lin[480] | vec[32]
-__global__ __launch_bounds__(256) void decoder_xattn_ffn_kernel(XattnFfnArgs a) {
-    __shared__ float sm[4][16 + 480 + 32];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int bq = blockIdx.x * 4 + wv;
-    if (bq >= a.B * a.Q) return;
-    float* qp = sm[wv];
-    float* lin = qp + 16;     // [0,320): offsets (m,l,p,xy) ; [320,480): attention logits (m, l*P+p)
-    float* vec = lin + 480;
+// reference point of one view: cartesian center -> (optional T + spherical) -> projection P -> normalised, clamped
+// (mpfusion.py:617-696)
+__device__ __forceinline__ void reference_point(float cx, float cy, float cz, int flag, const float* T, const float* Pm,
+                                                float Hs, float Ws, float& u, float& vv) {
+    const float RAD2DEG = 57.29577951308232f;
+    float p0 = cx, p1 = cy, p2 = cz;
+    if (flag) {
+        const float tx = T[0] * cx + T[1] * cy + T[2] * cz + T[3];
+        const float ty = T[4] * cx + T[5] * cy + T[6] * cz + T[7];
+        const float tz = T[8] * cx + T[9] * cy + T[10] * cz + T[11];
+        const float r = sqrtf(tx * tx + ty * ty + tz * tz);
+        p0 = r;
+        p1 = atan2f(ty, tx) * RAD2DEG;
+        p2 = asinf(r != 0.f ? tz / r : 0.f) * RAD2DEG;
+    }
+    u = Pm[0] * p0 + Pm[1] * p1 + Pm[2] * p2 + Pm[3];
+    vv = Pm[4] * p0 + Pm[5] * p1 + Pm[6] * p2 + Pm[7];
+    const float wq = Pm[8] * p0 + Pm[9] * p1 + Pm[10] * p2 + Pm[11];
+    if (wq != 0.f) { u /= wq; vv /= wq; }
+    u = fminf(fmaxf(u / Ws, 0.f), 1.f);
+    vv = fminf(fmaxf(vv / Hs, 0.f), 1.f);
+}
+
+// block = the V waves of one (b, q); per-wave LDS scratch: qp[16] | lin[480] | vec[32]
+__global__ __launch_bounds__(256) void decoder_xattn_head_kernel(XattnHeadArgs a) {
+    __shared__ float sm[4][16 + NOA + 32];
+    __shared__ float y3s[4][DC];
+    __shared__ float hx[DC], hh1[4][DC], hh2[4][DC];
+    const int lane = threadIdx.x & 63;
+    const int view = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bq = blockIdx.x;
+    float* qp = sm[view];
+    float* lin = qp + 16;     // [0,n_off): offsets (m,l,p,xy) ; [n_off, n_off+n_att): attention logits (m, l*P+p)
+    float* vec = lin + NOA;
     const int b = bq / a.Q, q = bq - b * a.Q;
-    const ViewW& w = a.w;
-    const int L = a.pyr.L, P = a.P, LP = L * P;
-    const float y1c = lane < 16 ? a.y1[(size_t)bq * DC + lane] : 0.f;
+    const float* pv = a.pv[view];
+    const Pyr5& pyr = a.pyr[view];
+    const int L = pyr.L, P = a.P[view], LP = L * P;
+    const size_t vbq = (size_t)view * a.B * a.Q + bq;
+    const float y1c = lane < 16 ? a.y1[vbq * DC + lane] : 0.f;
     if (lane < 16) qp[lane] = y1c + a.pos[(size_t)q * DC + lane];
     __builtin_amdgcn_wave_barrier();
-    // GEMV: 320 offsets + 160 logits from the 16-vector qp
-    const int n_off = DM * LP * 2, n_att = DM * LP;
-    for (int o = lane; o < n_off + n_att; o += 64) {
-        const float* wr = o < n_off ? w.off_w + (size_t)o * DC : w.att_w + (size_t)(o - n_off) * DC;
-        float s = o < n_off ? w.off_b[o] : w.att_b[o - n_off];
+    // GEMV: n_off offsets + n_att logits from the 16-vector qp; lanes read consecutive columns of W^T
+    const int n_off = DM * LP * 2, n_all = DM * LP * 3;
+    {
+        float x[DC];
 #pragma unroll
-        for (int c = 0; c < DC; c += 4) {
-            const f32x4 wv4 = *reinterpret_cast<const f32x4*>(wr + c);
+        for (int c = 0; c < DC; ++c) x[c] = qp[c];
+        for (int o = lane; o < n_all; o += 64) {
+            float s = pv[PV_OA_B + o];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) s = fmaf(wv4[e], qp[c + e], s);
+            for (int c = 0; c < DC; ++c) s = fmaf(pv[PV_OA_WT + c * NOA + o], x[c], s);
+            lin[o] = s;
         }
-        lin[o] = s;
     }
     __builtin_amdgcn_wave_barrier();
     const int m = lane >> 3, j = lane & 7;
@@ -201,319 +358,244 @@ __global__ __launch_bounds__(256) void decoder_xattn_ffn_kernel(XattnFfnArgs a) 
     float den = 0.f;
     for (int i = 0; i < LP; ++i) den += __expf(lg[i] - mx);
     const float inv_den = 1.f / den;
-    const float rx = a.ref[bq * 2 + 0], ry = a.ref[bq * 2 + 1];
+    float rx, ry;
+    {
+        const float* pc = a.prev_center + (size_t)bq * 3;
+        reference_point(pc[0], pc[1], pc[2], a.flag[view], a.T[view] ? a.T[view] + (size_t)b * 16 : nullptr,
+                        a.Pm[view] + (size_t)b * a.prow[view] * 4, (float)a.shape[view][b * 2 + 0],
+                        (float)a.shape[view][b * 2 + 1], rx, ry);
+    }
     const float* offp = lin + m * LP * 2;
     f32x2 acc = {0.f, 0.f};
     float ms = 0.f;
     for (int l = 0; l < L; ++l) {
-        const int H = a.pyr.H[l], W = a.pyr.W[l];
-        const float* base = a.pyr.level[l] + (int64_t)b * H * W * DC + j * 2;
-        for (int p = 0; p < P; ++p) {
-            const float ox = offp[(l * P + p) * 2 + 0], oy = offp[(l * P + p) * 2 + 1];
-            const float aw = __expf(lg[l * P + p] - mx) * inv_den;
+        const int H = pyr.H[l], W = pyr.W[l];
+        const float* base = pyr.level[l] + (int64_t)b * H * W * DC + j * 2;
+        // all (<= 4) points of the level: addresses are clamped and the 16 gathers are issued back to back
+        // (independent loads in flight); invalid corners / out-of-range samples get weight 0
+        f32x2 v[4][4];
+        float wgt[4][4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bool act = p < P;
+            const int lp = act ? l * P + p : l * P;
+            const float ox = offp[lp * 2 + 0], oy = offp[lp * 2 + 1];
+            const float aw = act ? __expf(lg[lp] - mx) * inv_den : 0.f;
             const float lx = rx + ox / (float)W, ly = ry + oy / (float)H;
             const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
-            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
-                const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
-                const int h_hi = h_lo + 1, w_hi = w_lo + 1;
-                const float lh = h_im - h_lo, lw = w_im - w_lo, hh = 1 - lh, hw = 1 - lw;
-                const bool k1 = h_lo >= 0 && w_lo >= 0, k2 = h_lo >= 0 && w_hi <= W - 1;
-                const bool k3 = h_hi <= H - 1 && w_lo >= 0, k4 = h_hi <= H - 1 && w_hi <= W - 1;
-                f32x2 v1 = {0.f, 0.f}, v2 = v1, v3 = v1, v4 = v1;
-                if (k1) v1 = *reinterpret_cast<const f32x2*>(base + ((int64_t)h_lo * W + w_lo) * DC);
-                if (k2) v2 = *reinterpret_cast<const f32x2*>(base + ((int64_t)h_lo * W + w_hi) * DC);
-                if (k3) v3 = *reinterpret_cast<const f32x2*>(base + ((int64_t)h_hi * W + w_lo) * DC);
-                if (k4) v4 = *reinterpret_cast<const f32x2*>(base + ((int64_t)h_hi * W + w_hi) * DC);
-                const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                acc += aw * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
-                ms += aw * ((k1 ? w1 : 0.f) + (k2 ? w2 : 0.f) + (k3 ? w3 : 0.f) + (k4 ? w4 : 0.f));
-            }
+            const bool in = act && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+            const float hf = floorf(h_im), wf = floorf(w_im);
+            const int h_lo = (int)hf, w_lo = (int)wf, h_hi = h_lo + 1, w_hi = w_lo + 1;
+            const float lh = h_im - hf, lw = w_im - wf, hh = 1 - lh, hw = 1 - lw;
+            const bool k1 = in && h_lo >= 0 && w_lo >= 0, k2 = in && h_lo >= 0 && w_hi <= W - 1;
+            const bool k3 = in && h_hi <= H - 1 && w_lo >= 0, k4 = in && h_hi <= H - 1 && w_hi <= W - 1;
+            const int hl = min(max(h_lo, 0), H - 1), hh_ = min(max(h_hi, 0), H - 1);
+            const int wl = min(max(w_lo, 0), W - 1), wh_ = min(max(w_hi, 0), W - 1);
+            v[p][0] = *reinterpret_cast<const f32x2*>(base + ((int64_t)hl * W + wl) * DC);
+            v[p][1] = *reinterpret_cast<const f32x2*>(base + ((int64_t)hl * W + wh_) * DC);
+            v[p][2] = *reinterpret_cast<const f32x2*>(base + ((int64_t)hh_ * W + wl) * DC);
+            v[p][3] = *reinterpret_cast<const f32x2*>(base + ((int64_t)hh_ * W + wh_) * DC);
+            wgt[p][0] = k1 ? aw * hh * hw : 0.f;
+            wgt[p][1] = k2 ? aw * hh * lw : 0.f;
+            wgt[p][2] = k3 ? aw * lh * hw : 0.f;
+            wgt[p][3] = k4 ? aw * lh * lw : 0.f;
         }
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc += wgt[p][k] * v[p][k];
+                ms += wgt[p][k];
+            }
     }
     // value_proj on the sampled features (+ bias * in-bounds mass), head m -> channels 2m, 2m+1
-    const f32x2 wv0 = *reinterpret_cast<const f32x2*>(w.val_w + (m * DD + 0) * DC + j * 2);
-    const f32x2 wv1 = *reinterpret_cast<const f32x2*>(w.val_w + (m * DD + 1) * DC + j * 2);
+    const f32x2 wv0 = *reinterpret_cast<const f32x2*>(pv + PV_VAL_W + (m * DD + 0) * DC + j * 2);
+    const f32x2 wv1 = *reinterpret_cast<const f32x2*>(pv + PV_VAL_W + (m * DD + 1) * DC + j * 2);
     const float o0 = group8_sum_d(wv0[0] * acc[0] + wv0[1] * acc[1]);
     const float o1 = group8_sum_d(wv1[0] * acc[0] + wv1[1] * acc[1]);
     if (j == 0) {
-        vec[m * 2 + 0] = o0 + w.val_b[m * 2 + 0] * ms;
-        vec[m * 2 + 1] = o1 + w.val_b[m * 2 + 1] * ms;
+        vec[m * 2 + 0] = o0 + pv[PV_VAL_B + m * 2 + 0] * ms;
+        vec[m * 2 + 1] = o1 + pv[PV_VAL_B + m * 2 + 1] * ms;
     }
     __builtin_amdgcn_wave_barrier();
     // output_proj + residual + LayerNorm2 (lanes 0..15 = channels; other lanes mirror them)
     const int c = lane & 15;
-    float v = w.outp_b[c];
+    float vo = pv[PV_OUTP_B + c];
 #pragma unroll
-    for (int k = 0; k < DC; ++k) v = fmaf(w.outp_w[c * DC + k], vec[k], v);
-    v += __shfl(y1c, c);
-    const float y2 = layernorm16(v, w.n2_w[c], w.n2_b[c]);
+    for (int k = 0; k < DC; ++k) vo = fmaf(pv[PV_OUTP_WT + k * DC + c], vec[k], vo);
+    vo += __shfl(y1c, c);
+    const float y2 = layernorm16(vo, pv[PV_N2_W + c], pv[PV_N2_B + c]);
     __builtin_amdgcn_wave_barrier();
     if (lane < 16) qp[lane] = y2;            // reuse qp for y2
     __builtin_amdgcn_wave_barrier();
     // FFN: 16 -> 32 (Mish) -> 16, residual, LayerNorm3
-    if (lane < DFF) {
-        float hsum = w.f1_b[lane];
+    {
+        const int jf = lane & 31;
+        float hsum = pv[PV_F1_B + jf];
 #pragma unroll
-        for (int k = 0; k < DC; ++k) hsum = fmaf(w.f1_w[lane * DC + k], qp[k], hsum);
-        vec[lane] = mishf(hsum);
+        for (int k = 0; k < DC; ++k) hsum = fmaf(pv[PV_F1_WT + k * DFF + jf], qp[k], hsum);
+        if (lane < DFF) vec[lane] = mishf(hsum);
     }
     __builtin_amdgcn_wave_barrier();
-    float f = w.f2_b[c];
+    float f = pv[PV_F2_B + c];
 #pragma unroll
-    for (int k = 0; k < DFF; ++k) f = fmaf(w.f2_w[c * DFF + k], vec[k], f);
+    for (int k = 0; k < DFF; ++k) f = fmaf(pv[PV_F2_WT + k * DC + c], vec[k], f);
     f += y2;
-    const float y3 = layernorm16(f, w.n3_w[c], w.n3_b[c]);
-    if (lane < 16) a.y3[(size_t)bq * DC + lane] = y3;
-}
-
-struct HeadArgs {
-    const float* y3;            // (V,B,Q,16), may be null (reference points only)
-    const float* red_w;         // (16, 16*V)
-    const float* hw[4][3];      // center/size/angle/class x (Linear0, Linear3, Linear6)
-    const float* prev_center;   // (B,Q,3)
-    const float* T[4];          // (B,4,4)
-    const float* Pm[4];         // (B,prow,4)
-    const int64_t* shape[4];    // (B,2) = H, W
-    int prow[4], flag[4];
-    float* query_out;           // (B,Q,16)
-    float *center, *size, *angle, *cls;
-    float* refs;                // (V,B,Q,2)
-    int B, Q, V, ncls;
-};
-
-__device__ __forceinline__ void mlp3(const float* x, const float* w0, const float* w3, const float* w6, int nout,
-                                     float* out) {
-    float h1[DC], h2[DC];
+    const float y3 = layernorm16(f, pv[PV_N3_W + c], pv[PV_N3_B + c]);
+    if (lane < 16) y3s[view][lane] = y3;
+    __syncthreads();
+    if (view != 0) return;
+    // view reduction: queries.view(B,N,C*V) is channel-major / view-minor (mpfusion.py:436-438)
+    const float* ph = a.ph;
+    {
+        float x = 0.f;
+        for (int v2 = 0; v2 < a.V; ++v2)
 #pragma unroll
-    for (int o = 0; o < DC; ++o) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < DC; ++k) s = fmaf(w0[o * DC + k], x[k], s);
-        h1[o] = fmaxf(s, 0.f);
-    }
-#pragma unroll
-    for (int o = 0; o < DC; ++o) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < DC; ++k) s = fmaf(w3[o * DC + k], h1[k], s);
-        h2[o] = fmaxf(s, 0.f);
-    }
-    for (int o = 0; o < nout; ++o) {
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < DC; ++k) s = fmaf(w6[o * DC + k], h2[k], s);
-        out[o] = s;
-    }
-}
-
-__global__ __launch_bounds__(64) void decoder_head_kernel(HeadArgs a) {
-    const int bq = blockIdx.x * 64 + threadIdx.x;
-    if (bq >= a.B * a.Q) return;
-    const int b = bq / a.Q;
-    float cx, cy, cz;
-    if (a.y3 != nullptr) {
-        // view reduction: queries.view(B,N,C*V) is channel-major / view-minor (mpfusion.py:436-438)
-        float x[DC];
-#pragma unroll
-        for (int o = 0; o < DC; ++o) x[o] = 0.f;
-        for (int v = 0; v < a.V; ++v) {
-            float yv[DC];
-#pragma unroll
-            for (int c = 0; c < DC; c += 4) {
-                const f32x4 t = *reinterpret_cast<const f32x4*>(a.y3 + (((size_t)v * a.B * a.Q) + bq) * DC + c);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) yv[c + e] = t[e];
-            }
-#pragma unroll
-            for (int o = 0; o < DC; ++o)
-#pragma unroll
-                for (int c = 0; c < DC; ++c) x[o] = fmaf(a.red_w[o * DC * a.V + c * a.V + v], yv[c], x[o]);
+            for (int k = 0; k < DC; ++k) x = fmaf(ph[PH_RED_WT + (v2 * DC + k) * DC + c], y3s[v2][k], x);
+        if (lane < 16) {
+            hx[lane] = x;
+            a.query_out[(size_t)bq * DC + lane] = x;
         }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // heads (heads/detection.py:252-275): branch g = lane / 16 (center, size, angle, class), row o = lane % 16
+    const int g = lane >> 4, o = lane & 15;
+    float t = 0.f;
 #pragma unroll
-        for (int o = 0; o < DC; ++o) a.query_out[(size_t)bq * DC + o] = x[o];
-        float r[3];
-        mlp3(x, a.hw[0][0], a.hw[0][1], a.hw[0][2], 3, r);
-        cx = r[0] + a.prev_center[bq * 3 + 0];
-        cy = r[1] + a.prev_center[bq * 3 + 1];
-        cz = r[2] + a.prev_center[bq * 3 + 2];
-        a.center[bq * 3 + 0] = cx; a.center[bq * 3 + 1] = cy; a.center[bq * 3 + 2] = cz;
-        mlp3(x, a.hw[1][0], a.hw[1][1], a.hw[1][2], 3, r);
-        for (int i = 0; i < 3; ++i) a.size[bq * 3 + i] = fmaxf(r[i], 0.f);
-        mlp3(x, a.hw[2][0], a.hw[2][1], a.hw[2][2], 2, r);
-        for (int i = 0; i < 2; ++i) a.angle[bq * 2 + i] = tanhf(r[i]);
-        float rc[8];
-        mlp3(x, a.hw[3][0], a.hw[3][1], a.hw[3][2], a.ncls, rc);
-        for (int i = 0; i < a.ncls; ++i) a.cls[bq * a.ncls + i] = rc[i];
-    } else {
-        cx = a.prev_center[bq * 3 + 0]; cy = a.prev_center[bq * 3 + 1]; cz = a.prev_center[bq * 3 + 2];
+    for (int k = 0; k < DC; ++k) t = fmaf(ph[PH_W + (0 * DC + k) * 64 + lane], hx[k], t);
+    hh1[g][o] = fmaxf(t, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DC; ++k) t = fmaf(ph[PH_W + (1 * DC + k) * 64 + lane], hh1[g][k], t);
+    hh2[g][o] = fmaxf(t, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    t = 0.f;
+#pragma unroll
+    for (int k = 0; k < DC; ++k) t = fmaf(ph[PH_W + (2 * DC + k) * 64 + lane], hh2[g][k], t);
+    const int nout = g == 0 ? 3 : (g == 1 ? 3 : (g == 2 ? 2 : a.ncls));
+    if (o < nout) {
+        if (g == 0) a.center[bq * 3 + o] = t + a.prev_center[bq * 3 + o];
+        else if (g == 1) a.size[bq * 3 + o] = fmaxf(t, 0.f);
+        else if (g == 2) a.angle[bq * 2 + o] = tanhf(t);
+        else a.cls[bq * a.ncls + o] = t;
     }
-    if (a.refs == nullptr) return;
-    // reference points of every view for the next iteration (mpfusion.py:617-696)
-    const float RAD2DEG = 57.29577951308232f;
-    for (int v = 0; v < a.V; ++v) {
-        float p0 = cx, p1 = cy, p2 = cz;
-        if (a.flag[v]) {
-            const float* T = a.T[v] + (size_t)b * 16;
-            const float tx = T[0] * cx + T[1] * cy + T[2] * cz + T[3];
-            const float ty = T[4] * cx + T[5] * cy + T[6] * cz + T[7];
-            const float tz = T[8] * cx + T[9] * cy + T[10] * cz + T[11];
-            const float r = sqrtf(tx * tx + ty * ty + tz * tz);
-            p0 = r;
-            p1 = atan2f(ty, tx) * RAD2DEG;
-            p2 = asinf(r != 0.f ? tz / r : 0.f) * RAD2DEG;
-        }
-        const float* Pm = a.Pm[v] + (size_t)b * a.prow[v] * 4;
-        float u = Pm[0] * p0 + Pm[1] * p1 + Pm[2] * p2 + Pm[3];
-        float vv = Pm[4] * p0 + Pm[5] * p1 + Pm[6] * p2 + Pm[7];
-        const float wq = Pm[8] * p0 + Pm[9] * p1 + Pm[10] * p2 + Pm[11];
-        if (wq != 0.f) { u /= wq; vv /= wq; }
-        const float Hs = (float)a.shape[v][b * 2 + 0], Ws = (float)a.shape[v][b * 2 + 1];
-        u = fminf(fmaxf(u / Ws, 0.f), 1.f);
-        vv = fminf(fmaxf(vv / Hs, 0.f), 1.f);
-        float* rp = a.refs + (((size_t)v * a.B * a.Q) + bq) * 2;
-        rp[0] = u;
-        rp[1] = vv;
-    }
-}
-
-static void fill_view(ViewW& d, const dpft_decoder_view* s) {
-    d.in_w = s->in_proj_w; d.in_b = s->in_proj_b; d.out_w = s->out_proj_w; d.out_b = s->out_proj_b;
-    d.n1_w = s->norm1_w; d.n1_b = s->norm1_b;
-    d.off_w = s->off_w; d.off_b = s->off_b; d.att_w = s->att_w; d.att_b = s->att_b;
-    d.val_w = s->val_w; d.val_b = s->val_b; d.outp_w = s->outp_w; d.outp_b = s->outp_b;
-    d.n2_w = s->norm2_w; d.n2_b = s->norm2_b;
-    d.f1_w = s->ffn1_w; d.f1_b = s->ffn1_b; d.f2_w = s->ffn2_w; d.f2_b = s->ffn2_b;
-    d.n3_w = s->norm3_w; d.n3_b = s->norm3_b;
 }
 
 }  // namespace dpft
 
 using namespace dpft;
 
-#define RC(call)              \
-    do {                      \
-        int rc_ = (call);     \
-        if (rc_) return rc_;  \
-    } while (0)
+extern "C" int64_t dpft_decoder_packed_view_floats(void) { return PV_FLOATS; }
+extern "C" int64_t dpft_decoder_packed_head_floats(void) { return PH_FLOATS; }
 
-extern "C" int dpft_decoder_selfattn_fwd_f32(const float* query, const float* pos, const dpft_decoder_view* views,
-                                             int32_t V, float* y1, int32_t B, int32_t Q, dpft_stream_t stream) {
-    DPFT_REQUIRE(query && pos && views && y1 && V >= 1 && V <= 4 && B > 0 && Q > 0, "decoder_selfattn: bad arguments");
-    SelfAttnArgs a;
-    for (int v = 0; v < V; ++v) fill_view(a.w[v], views + v);
-    a.query = query; a.pos = pos; a.y1 = y1; a.B = B; a.Q = Q; a.V = V; a.qstride = (long)Q * DC;
-    const size_t lds = ((size_t)Q * 32 + 48 * 16 + 48 + QT * DC) * sizeof(float);
-    DPFT_REQUIRE(lds <= 160 * 1024, "decoder_selfattn: %d queries do not fit the LDS", Q);
-    static bool configured = false;
-    if (!configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_selfattn_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        configured = true;
-    }
-    hipLaunchKernelGGL(decoder_selfattn_kernel, dim3(cdiv(Q, QT), V, B), dim3(256), lds, (hipStream_t)stream, a);
-    return check_launch("decoder_selfattn");
+extern "C" int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
+                                          dpft_stream_t stream) {
+    DPFT_REQUIRE(view && packed, "decoder_pack_view: null argument");
+    DPFT_REQUIRE(L >= 1 && L <= DPFT_MAX_LEVELS && P >= 1 && P <= 4 && L * P * DM * 3 <= NOA,
+                 "decoder_pack_view: L=%d, P=%d exceed the fused kernel's budget (P <= 4, L*P <= 20)", L, P);
+    const float* const* f = reinterpret_cast<const float* const*>(view);
+    for (size_t i = 0; i < sizeof(dpft_decoder_view) / sizeof(float*); ++i)
+        DPFT_REQUIRE(f[i], "decoder_pack_view: parameter pointer %d is null", (int)i);
+    hipLaunchKernelGGL(pack_view_kernel, dim3(cdiv(PV_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, *view,
+                       DM * L * P * 2, DM * L * P, packed);
+    return check_launch("decoder_pack_view");
 }
 
-extern "C" int dpft_decoder_xattn_ffn_fwd_f32(const dpft_pyramid* pyr, const dpft_decoder_view* view, const float* y1,
-                                              const float* pos, const float* ref, float* y3, int32_t B, int32_t Q,
-                                              int32_t P, dpft_stream_t stream) {
-    DPFT_REQUIRE(pyr && view && y1 && pos && ref && y3 && B > 0 && Q > 0, "decoder_xattn_ffn: bad arguments");
-    DPFT_REQUIRE(pyr->L >= 1 && pyr->L <= DPFT_MAX_LEVELS && pyr->L * P * DM * 3 <= 480,
-                 "decoder_xattn_ffn: L*P = %d*%d exceeds the fused kernel's budget (L*P <= 20)", pyr->L, P);
-    XattnFfnArgs a;
-    a.pyr.L = pyr->L;
-    for (int l = 0; l < pyr->L; ++l) {
-        DPFT_REQUIRE(pyr->level[l], "decoder_xattn_ffn: level %d is null", l);
-        a.pyr.level[l] = pyr->level[l]; a.pyr.H[l] = pyr->H[l]; a.pyr.W[l] = pyr->W[l];
-    }
-    fill_view(a.w, view);
-    a.y1 = y1; a.pos = pos; a.ref = ref; a.y3 = y3; a.B = B; a.Q = Q; a.P = P;
-    hipLaunchKernelGGL(decoder_xattn_ffn_kernel, dim3(cdiv((int64_t)B * Q, 4)), dim3(256), 0, (hipStream_t)stream, a);
-    return check_launch("decoder_xattn_ffn");
+extern "C" int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, int32_t V, int32_t num_classes,
+                                          float* packed, dpft_stream_t stream) {
+    DPFT_REQUIRE(red_w && head_w && packed && V >= 1 && V <= 4, "decoder_pack_head: bad arguments");
+    DPFT_REQUIRE(num_classes >= 1 && num_classes <= 16, "decoder_pack_head: num_classes must be in [1,16]");
+    HeadSrc s;
+    s.red_w = red_w; s.V = V;
+    for (int g = 0; g < 4; ++g)
+        for (int k = 0; k < 3; ++k) {
+            DPFT_REQUIRE(head_w[g * 3 + k], "decoder_pack_head: head weight %d.%d is null", g, k);
+            s.hw[g][k] = head_w[g * 3 + k];
+        }
+    s.nout[0] = 3; s.nout[1] = 3; s.nout[2] = 2; s.nout[3] = num_classes;
+    hipLaunchKernelGGL(pack_head_kernel, dim3(cdiv(PH_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, s, packed);
+    return check_launch("decoder_pack_head");
 }
 
-extern "C" int dpft_decoder_head_fwd_f32(const dpft_decoder_head* h, int32_t B, int32_t Q, int32_t V, dpft_stream_t stream) {
-    DPFT_REQUIRE(h && B > 0 && Q > 0 && V >= 1 && V <= 4, "decoder_head: bad arguments");
-    DPFT_REQUIRE(h->prev_center, "decoder_head: prev_center is null");
-    DPFT_REQUIRE(h->y3 == nullptr || (h->red_w && h->query_out && h->center && h->size && h->angle && h->cls),
-                 "decoder_head: missing output / weight pointers");
-    DPFT_REQUIRE(h->num_classes >= 1 && h->num_classes <= 8, "decoder_head: num_classes must be in [1,8]");
-    HeadArgs a;
-    a.y3 = h->y3; a.red_w = h->red_w; a.prev_center = h->prev_center;
-    for (int i = 0; i < 4; ++i)
-        for (int k = 0; k < 3; ++k) a.hw[i][k] = h->head_w[i][k];
-    for (int v = 0; v < V; ++v) {
-        a.T[v] = h->T[v]; a.Pm[v] = h->P[v]; a.shape[v] = h->shape[v]; a.prow[v] = h->p_rows[v]; a.flag[v] = h->has_t[v];
-        DPFT_REQUIRE(h->refs == nullptr || (a.Pm[v] && a.shape[v] && (a.T[v] || !a.flag[v]) && a.prow[v] >= 3),
-                     "decoder_head: projection inputs of view %d missing", v);
-    }
-    a.query_out = h->query_out; a.center = h->center; a.size = h->size; a.angle = h->angle; a.cls = h->cls;
-    a.refs = h->refs; a.B = B; a.Q = Q; a.V = V; a.ncls = h->num_classes;
-    hipLaunchKernelGGL(decoder_head_kernel, dim3(cdiv((int64_t)B * Q, 64)), dim3(64), 0, (hipStream_t)stream, a);
-    return check_launch("decoder_head");
-}
-
-// Whole IMPFusion forward from ONE call: 1 + iters * (2 + V) launches, nothing else on the host
+// Whole IMPFusion forward from ONE call: 2 launches per iteration, nothing else on the host
 extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t stream) {
-    DPFT_REQUIRE(d && d->views && d->pyr && d->query0 && d->pos && d->center0 && d->work, "decoder_forward: null argument");
+    DPFT_REQUIRE(d && d->packed_views && d->packed_heads && d->pyr && d->query0 && d->pos && d->center0 && d->work,
+                 "decoder_forward: null argument");
+    DPFT_REQUIRE(d->center && d->size && d->angle && d->cls, "decoder_forward: null output");
     const int B = d->B, Q = d->Q, V = d->V;
     DPFT_REQUIRE(B > 0 && Q > 0 && V >= 1 && V <= 4 && d->iters >= 1 && d->iters <= 8, "decoder_forward: bad sizes");
+    DPFT_REQUIRE(d->num_classes >= 1 && d->num_classes <= 16, "decoder_forward: num_classes must be in [1,16]");
     const size_t nq = (size_t)B * Q;
     float* w = d->work;
     float* qbuf[2] = {w, w + nq * DC};
     float* y1 = w + 2 * nq * DC;
-    float* y3 = y1 + (size_t)V * nq * DC;
-    float* refs[2] = {y3 + (size_t)V * nq * DC, y3 + (size_t)V * nq * DC + (size_t)V * nq * 2};
-    float* cbuf[2] = {refs[1] + (size_t)V * nq * 2, refs[1] + (size_t)V * nq * 2 + nq * 3};
-    dpft_decoder_head h;
-    memset(&h, 0, sizeof(h));
+    float* cbuf[2] = {y1 + (size_t)V * nq * DC, y1 + (size_t)V * nq * DC + nq * 3};
+    XattnHeadArgs xa;
+    memset(&xa, 0, sizeof(xa));
     for (int v = 0; v < V; ++v) {
-        h.T[v] = d->T[v]; h.P[v] = d->P[v]; h.shape[v] = d->shape[v]; h.p_rows[v] = d->p_rows[v]; h.has_t[v] = d->has_t[v];
+        const dpft_pyramid* pyr = d->pyr + v;
+        const int P = d->n_points[v];
+        DPFT_REQUIRE(pyr->L >= 1 && pyr->L <= DPFT_MAX_LEVELS && P >= 1 && P <= 4 && pyr->L * P * DM * 3 <= NOA,
+                     "decoder_forward: L=%d, P=%d exceed the fused kernel's budget (P <= 4, L*P <= 20)", pyr->L, P);
+        xa.pyr[v].L = pyr->L;
+        for (int l = 0; l < pyr->L; ++l) {
+            DPFT_REQUIRE(pyr->level[l], "decoder_forward: view %d level %d is null", v, l);
+            xa.pyr[v].level[l] = pyr->level[l]; xa.pyr[v].H[l] = pyr->H[l]; xa.pyr[v].W[l] = pyr->W[l];
+        }
+        xa.P[v] = P;
+        xa.T[v] = d->T[v]; xa.Pm[v] = d->P[v]; xa.shape[v] = d->shape[v]; xa.prow[v] = d->p_rows[v]; xa.flag[v] = d->has_t[v];
+        DPFT_REQUIRE(xa.Pm[v] && xa.shape[v] && (xa.T[v] || !xa.flag[v]) && xa.prow[v] >= 3,
+                     "decoder_forward: projection inputs of view %d missing", v);
     }
-    h.num_classes = d->num_classes;
-    // reference points of the initial (querent) centers
-    h.y3 = nullptr; h.prev_center = d->center0; h.refs = refs[0];
-    RC(dpft_decoder_head_fwd_f32(&h, B, Q, V, stream));
+    xa.y1 = y1; xa.pos = d->pos; xa.B = B; xa.Q = Q; xa.V = V; xa.ncls = d->num_classes;
+    xa.size = d->size; xa.angle = d->angle; xa.cls = d->cls;
     const float* query = d->query0;
     const float* center = d->center0;
-    int cur = 0;
+    // queries per wave: one round of blocks over the 256 CUs
+    const int tiles = std::max(1, kNumCU / (V * B));
+    int qw = std::min(8, std::max(1, cdiv(cdiv(Q, tiles), 4)));
+    if (qw == 7) qw = 8;
+    const int qt = 4 * qw;
+    const size_t lds = ((size_t)Q * 32 + 48 * 16 + 48 + qt * DC + qt * DM * 8 * 4) * sizeof(float);
+    DPFT_REQUIRE(lds <= 160 * 1024, "decoder_forward: %d queries do not fit the LDS", Q);
+    void (*sa_kernel)(SelfAttnArgs) = nullptr;
+    switch (qw) {
+        case 1: sa_kernel = decoder_selfattn_kernel<1>; break;
+        case 2: sa_kernel = decoder_selfattn_kernel<2>; break;
+        case 3: sa_kernel = decoder_selfattn_kernel<3>; break;
+        case 4: sa_kernel = decoder_selfattn_kernel<4>; break;
+        case 5: sa_kernel = decoder_selfattn_kernel<5>; break;
+        case 6: sa_kernel = decoder_selfattn_kernel<6>; break;
+        default: sa_kernel = decoder_selfattn_kernel<8>; break;
+    }
+    static bool configured[9] = {false};
+    if (!configured[qw] && lds > 64 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sa_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  160 * 1024);
+        configured[qw] = true;
+    }
     for (int it = 0; it < d->iters; ++it) {
         SelfAttnArgs sa;
-        for (int v = 0; v < V; ++v) fill_view(sa.w[v], d->views + it * V + v);
+        for (int v = 0; v < 4; ++v) sa.pv[v] = xa.pv[v] = v < V ? d->packed_views + (size_t)(it * V + v) * PV_FLOATS : nullptr;
         sa.query = query; sa.pos = d->pos; sa.y1 = y1; sa.B = B; sa.Q = Q; sa.V = V;
         sa.qstride = (it == 0) ? 0 : (long)Q * DC;
-        const size_t lds = ((size_t)Q * 32 + 48 * 16 + 48 + QT * DC) * sizeof(float);
-        DPFT_REQUIRE(lds <= 160 * 1024, "decoder_forward: %d queries do not fit the LDS", Q);
-        static bool configured = false;
-        if (!configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decoder_selfattn_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            configured = true;
-        }
-        hipLaunchKernelGGL(decoder_selfattn_kernel, dim3(cdiv(Q, QT), V, B), dim3(256), lds, (hipStream_t)stream, sa);
+        hipLaunchKernelGGL(sa_kernel, dim3(cdiv(Q, qt), V, B), dim3(256), lds, (hipStream_t)stream, sa);
         RC(check_launch("decoder_selfattn"));
-        for (int v = 0; v < V; ++v)
-            RC(dpft_decoder_xattn_ffn_fwd_f32(d->pyr + v, d->views + it * V + v, y1 + (size_t)v * nq * DC, d->pos,
-                                              refs[cur] + (size_t)v * nq * 2, y3 + (size_t)v * nq * DC, B, Q,
-                                              d->n_points[v], stream));
         const bool last = it == d->iters - 1;
-        h.y3 = y3; h.red_w = d->red_w[it];
-        for (int i = 0; i < 4; ++i)
-            for (int k = 0; k < 3; ++k) h.head_w[i][k] = d->head_w[it][i][k];
-        h.prev_center = center;
-        h.query_out = qbuf[it & 1];
-        h.center = last ? d->center : cbuf[it & 1];
-        h.size = d->size; h.angle = d->angle; h.cls = d->cls;
-        h.refs = last ? nullptr : refs[cur ^ 1];
-        RC(dpft_decoder_head_fwd_f32(&h, B, Q, V, stream));
+        xa.ph = d->packed_heads + (size_t)it * PH_FLOATS;
+        xa.prev_center = center;
+        xa.query_out = qbuf[it & 1];
+        xa.center = last ? d->center : cbuf[it & 1];
+        hipLaunchKernelGGL(decoder_xattn_head_kernel, dim3((unsigned)nq), dim3(64 * V), 0, (hipStream_t)stream, xa);
+        RC(check_launch("decoder_xattn_head"));
         query = qbuf[it & 1];
-        center = h.center;
-        cur ^= 1;
+        center = xa.center;
     }
     return DPFT_OK;
 }
 
 extern "C" int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V) {
     const int64_t nq = (int64_t)B * Q;
-    return 2 * nq * DC + 2 * (int64_t)V * nq * DC + 2 * (int64_t)V * nq * 2 + 2 * nq * 3 + 64;
+    return 2 * nq * DC + (int64_t)V * nq * DC + 2 * nq * 3 + 64;
 }

@@ -46,19 +46,10 @@ class DecoderView(C.Structure):
         "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b", "norm3_w", "norm3_b")]
 
 
-class DecoderHead(C.Structure):
-    _fields_ = [("y3", C.c_void_p), ("red_w", C.c_void_p), ("head_w", (C.c_void_p * 3) * 4),
-                ("prev_center", C.c_void_p), ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
-                ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("query_out", C.c_void_p),
-                ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p),
-                ("refs", C.c_void_p), ("num_classes", C.c_int32)]
-
-
 class DecoderFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("Q", C.c_int32), ("V", C.c_int32), ("iters", C.c_int32), ("num_classes", C.c_int32),
-                ("n_points", C.c_int32 * 4), ("views", C.c_void_p), ("pyr", C.c_void_p),
-                ("query0", C.c_void_p), ("pos", C.c_void_p), ("center0", C.c_void_p),
-                ("red_w", C.c_void_p * 8), ("head_w", ((C.c_void_p * 3) * 4) * 8),
+                ("n_points", C.c_int32 * 4), ("packed_views", C.c_void_p), ("packed_heads", C.c_void_p),
+                ("pyr", C.c_void_p), ("query0", C.c_void_p), ("pos", C.c_void_p), ("center0", C.c_void_p),
                 ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
                 ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("work", C.c_void_p),
                 ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p)]
@@ -97,9 +88,10 @@ SIGNATURES = {
     "dpft_xattn_fwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpft_xattn_bwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "dpft_giou3d_yaw_f32": (_I, [_P, _P, _P, _I, _I, _I, _P]),
-    "dpft_decoder_selfattn_fwd_f32": (_I, [_P, _P, C.POINTER(DecoderView), _I, _P, _I, _I, _P]),
-    "dpft_decoder_xattn_ffn_fwd_f32": (_I, [_PYR, C.POINTER(DecoderView), _P, _P, _P, _P, _I, _I, _I, _P]),
-    "dpft_decoder_head_fwd_f32": (_I, [C.POINTER(DecoderHead), _I, _I, _I, _P]),
+    "dpft_decoder_packed_view_floats": (_L, []),
+    "dpft_decoder_packed_head_floats": (_L, []),
+    "dpft_decoder_pack_view_f32": (_I, [C.POINTER(DecoderView), _I, _I, _P, _P]),
+    "dpft_decoder_pack_head_f32": (_I, [_P, C.POINTER(C.c_void_p * 12), _I, _I, _P, _P]),
     "dpft_decoder_work_floats": (_L, [_I, _I, _I]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
     "dpft_profile_start": (_I, []),

@@ -1,5 +1,5 @@
 """Host side of the fused inference decoder (dpft_amd/csrc/decoder.hip): builds the C-ABI parameter
-structs from an ``IMPFusion`` module and runs 1 + 3*i_iter kernels instead of ~700 eager ops."""
+structs from an ``IMPFusion`` module and runs 2*i_iter kernels instead of ~700 eager ops."""
 from __future__ import annotations
 
 import ctypes as C
@@ -9,7 +9,7 @@ from typing import Dict, List, Tuple
 import torch
 from torch import nn
 
-from dpft_amd.hip.lib import DecoderFwd, DecoderHead, DecoderView, Pyramid, lib, make_pyramid, ptr, stream
+from dpft_amd.hip.lib import DecoderFwd, DecoderView, Pyramid, lib, make_pyramid, stream
 
 
 def supported(fuser: nn.Module) -> bool:
@@ -21,7 +21,7 @@ def supported(fuser: nn.Module) -> bool:
               and all(l * p <= 20 and l <= 8 for l, p in zip(fuser.n_levels, fuser.n_points)))
         for h in fuser.heads:
             ok = ok and isinstance(h, LinearDetectionHead) and h.num_reg_layers == 3 and h.num_cls_layers == 3 \
-                and not h.bias and h.num_classes <= 8
+                and not h.bias and h.num_classes <= 16
         return bool(ok)
     except AttributeError:
         return False
@@ -46,35 +46,47 @@ class FusedDecoder:
         self._key = None
 
     def _build(self):
+        """(Re)pack the parameters into the kernels' transposed blobs whenever a weight changed."""
         f = self.fuser
-        key = tuple(p.data_ptr() for p in f.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in f.parameters())
         if key == self._key:
             return
         V, I = f.m_views, f.i_iter
-        self.views = (DecoderView * (I * V))()
+        dev = f.query.device
+        nv, nh = int(lib.dpft_decoder_packed_view_floats()), int(lib.dpft_decoder_packed_head_floats())
+        self.packed_views = torch.empty(I * V * nv, dtype=torch.float32, device=dev)
+        self.packed_heads = torch.empty(I * nh, dtype=torch.float32, device=dev)
         d = DecoderFwd()
         for it, layer in enumerate(f.mpfusion.values()):
             for v, ml in enumerate(layer.ml_fusion_layers.values()):
-                self.views[it * V + v], _ = _view_struct(ml)
-            d.red_w[it] = layer.reduction_layer.weight.data_ptr()
+                view, _keep = _view_struct(ml)
+                lib.call("dpft_decoder_pack_view_f32", C.byref(view), f.n_levels[v], f.n_points[v],
+                         self.packed_views.data_ptr() + (it * V + v) * nv * 4, stream())
             head = f.heads[it]
+            hw = (C.c_void_p * 12)()
             for bi, name in enumerate(("center", "size", "angle", "class")):
                 seq = head.layers[name + "_head"]
                 for li, idx in enumerate((0, 3, 6)):
-                    d.head_w[it][bi][li] = seq[idx].weight.data_ptr()
+                    w = seq[idx].weight
+                    assert w.is_contiguous() and w.dtype == torch.float32
+                    hw[bi * 3 + li] = w.data_ptr()
+            red = layer.reduction_layer.weight
+            assert red.is_contiguous() and red.dtype == torch.float32
+            lib.call("dpft_decoder_pack_head_f32", red.data_ptr(), C.byref(hw), V, head.num_classes,
+                     self.packed_heads.data_ptr() + it * nh * 4, stream())
         d.V, d.iters, d.Q, d.num_classes = V, I, f.n_queries, f.heads[0].num_classes
         for v in range(V):
             d.n_points[v] = f.n_points[v]
-        d.views = C.cast(self.views, C.c_void_p)
+        d.packed_views, d.packed_heads = self.packed_views.data_ptr(), self.packed_heads.data_ptr()
         d.query0, d.pos = f.query.data_ptr(), f.query_embedding.weight.data_ptr()
         self.desc = d
         self._key = key
 
     @torch.no_grad()
-    def __call__(self, batch: List[Dict[str, torch.Tensor]], shape: List[torch.Tensor],
-                 projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor],
-                 flags: List[bool]):
-        """One C-ABI call: reference points + i_iter x (self-attention, V cross-attention/FFN, head)."""
+    def prepare(self, batch: List[Dict[str, torch.Tensor]], shape: List[torch.Tensor],
+                projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor],
+                flags: List[bool]):
+        """Fill the C-ABI descriptor for these inputs (allocates outputs + scratch); `launch()` then runs it."""
         f = self.fuser
         self._build()
         d = self.desc
@@ -100,5 +112,15 @@ class FusedDecoder:
                torch.empty((B, Q, 2), dtype=torch.float32, device=dev), torch.empty((B, Q, ncls), dtype=torch.float32, device=dev))
         d.work = work.data_ptr()
         d.center, d.size, d.angle, d.cls = (t.data_ptr() for t in res)
-        lib.call("dpft_decoder_forward_f32", C.byref(d), stream())
+        self._live = (keep, pyrs, shapes, Ts, Ps, center0, work)      # referenced by the descriptor
+        self._res = res
+
+    def launch(self):
+        """One C-ABI call: i_iter x (self attention | cross attention + FFN + view reduction + heads)."""
+        lib.call("dpft_decoder_forward_f32", C.byref(self.desc), stream())
+        res = self._res
         return OrderedDict([("center", res[0]), ("size", res[1]), ("angle", res[2]), ("class", res[3])])
+
+    def __call__(self, batch, shape, projection, out, flags):
+        self.prepare(batch, shape, projection, out, flags)
+        return self.launch()

@@ -235,9 +235,11 @@ int dpft_xattn_bwd_f32(const dpft_pyramid* pyr, const float* ref, const float* o
 /* ------------------------------------------------------------------------------------------
  * Fused inference decoder (eval mode, no autograd): d_model 16, 8 heads x head_dim 2, L*P <= 20, Mish
  * FFN (d_ffn 32), LayerNorm, 'linear' view reduction, 3-layer bias-free linear heads -- IMPFusion /
- * MPFusion / MLFusion / LinearDetectionHead at config/kradar*.json (src/dprt/models/fusers/mpfusion.py,
- * src/dprt/models/layers/ms_deform_attn.py, src/dprt/models/heads/detection.py).  One iteration =
- * selfattn_fwd [all views] + xattn_ffn_fwd [per view] + head_fwd.
+ * MPFusion / MLFusion / LinearDetectionHead at config/kradar*.json (src/dprt/models/fusers/mpfusion.py:122-229,
+ * :416-514,:617-745, src/dprt/models/layers/ms_deform_attn.py:138-217, src/dprt/models/heads/detection.py:252-275).
+ * Parameters are first PACKED (once per weight update) into lane-friendly transposed blobs; the forward is
+ * then one call = 2 launches per iteration (self attention of all views | cross attention + FFN of all views +
+ * view reduction + heads + next reference points).
  * ---------------------------------------------------------------------------------------- */
 typedef struct dpft_decoder_view {   /* parameters of one MLFusion, torch layouts (out_features, in_features) */
     const float *in_proj_w, *in_proj_b, *out_proj_w, *out_proj_b, *norm1_w, *norm1_b;       /* self attention */
@@ -245,47 +247,31 @@ typedef struct dpft_decoder_view {   /* parameters of one MLFusion, torch layout
     const float *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *norm3_w, *norm3_b;                       /* FFN */
 } dpft_decoder_view;
 
-typedef struct dpft_decoder_head {
-    const float* y3;             /* (V,B,Q,16) MLFusion outputs; NULL = only compute reference points   */
-    const float* red_w;          /* reduction_layer.weight (16, 16*V)                                   */
-    const float* head_w[4][3];   /* center/size/angle/class x (layers .0, .3, .6) weights               */
-    const float* prev_center;    /* (B,Q,3) centers of the previous iteration (querent output at first)  */
-    const float* T[4];           /* label_to_X_t (B,4,4)                                                */
-    const float* P[4];           /* label_to_X_p (B,p_rows,4)                                           */
-    const int64_t* shape[4];     /* X_shape[:, :2] contiguous (B,2) = (H, W)                            */
-    int32_t p_rows[4], has_t[4]; /* rows of P (3 or 4); transformation.any() per view                   */
-    float* query_out;            /* (B,Q,16)                                                            */
-    float *center, *size, *angle, *cls;   /* (B,Q,3) (B,Q,3) (B,Q,2) (B,Q,num_classes)                   */
-    float* refs;                 /* (V,B,Q,2) reference points for the next iteration; NULL to skip     */
-    int32_t num_classes;
-} dpft_decoder_head;
+int64_t dpft_decoder_packed_view_floats(void);   /* floats per packed MLFusion blob   */
+int64_t dpft_decoder_packed_head_floats(void);   /* floats per packed reduction+head blob */
+/* packed <- one MLFusion's parameters (L levels, P points of its MSDeformAttn) */
+int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
+                               dpft_stream_t stream);
+/* packed <- reduction_layer.weight (16, 16*V) and head_w[4][3] = center/size/angle/class x (layers .0,.3,.6)
+ * weights, passed as a flat array of 12 pointers */
+int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, int32_t V, int32_t num_classes,
+                               float* packed, dpft_stream_t stream);
 
-/* y1[v] = LayerNorm1(query + MHA(query+pos, query+pos, query)) for every view v; y1 is (V,B,Q,16) */
-int dpft_decoder_selfattn_fwd_f32(const float* query, const float* pos, const dpft_decoder_view* views,
-                                  int32_t V, float* y1, int32_t B, int32_t Q, dpft_stream_t stream);
-/* y3 = LN3(y2 + FFN(y2)), y2 = LN2(y1 + MSDeformAttn(y1+pos, ref, pyramid)) for one view; (B,Q,16) */
-int dpft_decoder_xattn_ffn_fwd_f32(const dpft_pyramid* pyr, const dpft_decoder_view* view,
-                                   const float* y1, const float* pos, const float* ref, float* y3,
-                                   int32_t B, int32_t Q, int32_t P, dpft_stream_t stream);
-int dpft_decoder_head_fwd_f32(const dpft_decoder_head* head, int32_t B, int32_t Q, int32_t V,
-                              dpft_stream_t stream);
-
-/* The whole IMPFusion forward from one call (1 + iters*(2+V) launches).  work: caller-owned scratch of
- * dpft_decoder_work_floats(B,Q,V) floats.  Final outputs go to center/size/angle/cls. */
+/* work: caller-owned scratch of dpft_decoder_work_floats(B,Q,V) floats.  Final outputs go to
+ * center/size/angle/cls: (B,Q,3) (B,Q,3) (B,Q,2) (B,Q,num_classes). */
 typedef struct dpft_decoder_fwd {
     int32_t B, Q, V, iters, num_classes;
     int32_t n_points[4];
-    const dpft_decoder_view* views;      /* [iters][V]                                   */
+    const float* packed_views;           /* [iters][V] blobs of dpft_decoder_packed_view_floats()  */
+    const float* packed_heads;           /* [iters] blobs of dpft_decoder_packed_head_floats()     */
     const dpft_pyramid* pyr;             /* [V]                                          */
     const float* query0;                 /* fuser.query (Q,16)                           */
     const float* pos;                    /* fuser.query_embedding.weight (Q,16)          */
     const float* center0;                /* querent output (B,Q,3)                       */
-    const float* red_w[8];               /* per iteration reduction_layer.weight         */
-    const float* head_w[8][4][3];        /* per iteration head weights                   */
-    const float* T[4];
-    const float* P[4];
-    const int64_t* shape[4];
-    int32_t p_rows[4], has_t[4];
+    const float* T[4];                   /* label_to_X_t (B,4,4)                         */
+    const float* P[4];                   /* label_to_X_p (B,p_rows,4)                    */
+    const int64_t* shape[4];             /* X_shape[:, :2] contiguous (B,2) = (H, W)     */
+    int32_t p_rows[4], has_t[4];         /* rows of P (3 or 4); transformation.any()     */
     float* work;
     float *center, *size, *angle, *cls;
 } dpft_decoder_fwd;
