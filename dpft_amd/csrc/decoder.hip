@@ -245,8 +245,8 @@ __global__ __launch_bounds__(256) void decoder_selfattn_kernel(SelfAttnArgs a) {
     }
     __syncthreads();
     // out_proj + residual + LayerNorm1: 16 lanes per query
-    if (tid < QT * DC) {
-        const int ql2 = tid >> 4, c = tid & 15;
+    for (int t = tid; t < QT * DC; t += 256) {      // QT * 16 is a multiple of 64: whole waves stay active
+        const int ql2 = t >> 4, c = t & 15;
         const int q2 = q0 + ql2;
         float v = 0.f;
         if (q2 < Q) {

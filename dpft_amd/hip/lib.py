@@ -46,6 +46,10 @@ class DecoderView(C.Structure):
         "ffn1_w", "ffn1_b", "ffn2_w", "ffn2_b", "norm3_w", "norm3_b")]
 
 
+class SaParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b")]
+
+
 class DecoderFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("Q", C.c_int32), ("V", C.c_int32), ("iters", C.c_int32), ("num_classes", C.c_int32),
                 ("n_points", C.c_int32 * 4), ("packed_views", C.c_void_p), ("packed_heads", C.c_void_p),
@@ -93,6 +97,9 @@ SIGNATURES = {
     "dpft_decoder_pack_view_f32": (_I, [C.POINTER(DecoderView), _I, _I, _P, _P]),
     "dpft_decoder_pack_head_f32": (_I, [_P, C.POINTER(C.c_void_p * 12), _I, _I, _P, _P]),
     "dpft_decoder_work_floats": (_L, [_I, _I, _I]),
+    "dpft_selfattn_train_fwd_f32": (_I, [_P, _I, _P, _L, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dpft_selfattn_train_bwd_f32": (_I, [_P, _I, _P, _L, _P, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dpft_selfattn_train_scratch_floats": (_L, [_I, _I, _I]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),

@@ -113,9 +113,20 @@ class MPFusion(nn.Module):
         B, N = query.shape[:2]
         return self.reduction_layer(queries.reshape(B, N, self.d_model * self.m_views))   # :436-438
 
-    def forward(self, query, batch, reference_points, query_positions):
+    use_fused_train = True      # CUDA: self-attention blocks of all views from the fused HIP kernels (train_fused.py)
+
+    def forward(self, query, batch, reference_points, query_positions, pos2d=None, seed=None, salt: int = 0):
+        layers = list(self.ml_fusion_layers.values())
+        if self.use_fused_train and query.is_cuda and pos2d is not None and seed is not None:
+            from dpft_amd.models.fusers import train_fused as _tf
+            if all(_tf.sa_supported(ml) for ml in layers):
+                y1 = _tf.self_attn_blocks(layers, query, pos2d, seed, salt, self.dropout if self.training else 0.0)
+                outs = [ml.forward_ffn(ml.forward_cross_attn(y1[v], pyr, ref, query_positions))
+                        for v, (ml, pyr, ref) in enumerate(zip(layers, batch, reference_points))]
+                queries = torch.stack(outs, dim=-1)
+                return self.reduce(query, queries, query_positions)
         outs = [layer(query, pyr, ref, query_positions)
-                for layer, pyr, ref in zip(self.ml_fusion_layers.values(), batch, reference_points)]
+                for layer, pyr, ref in zip(layers, batch, reference_points)]
         queries = torch.stack(outs, dim=-1)            # (B,N,C,V): channel-major / view-minor (:496-509)
         return self.reduce(query, queries, query_positions)
 
@@ -198,11 +209,16 @@ class IMPFusion(nn.Module):
         query = self.query.unsqueeze(0).repeat(B, 1, 1)
         query_pos = self.query_embedding.weight.unsqueeze(0).repeat(B, 1, 1)
         pyramids = [make_pyramid_state(list(levels.values())) for levels in batch]
-        for layer, head in zip(self.mpfusion.values(), self.heads):
+        seed = None
+        if query.is_cuda:
+            from dpft_amd.models.fusers.train_fused import advance_seed
+            seed = advance_seed(query.device)
+        for it, (layer, head) in enumerate(zip(self.mpfusion.values(), self.heads)):
             reference_points = [
                 self.get_reference_points(out["center"][..., :3], p[0], p[1], s, f)
                 for p, s, f in zip(projection, shape, flags)]
-            query = layer(query, pyramids, reference_points, query_pos)
+            query = layer(query, pyramids, reference_points, query_pos, pos2d=self.query_embedding.weight,
+                          seed=seed, salt=it)
             out = head(query, out)
         return out
 

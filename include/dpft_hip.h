@@ -279,6 +279,33 @@ int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V);
 int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training path of the decoder's self-attention block, all V views of one MPFusion layer per call:
+ *   y1[v] = LayerNorm1(x + dropout1(out_proj(MHA(x + pos, x + pos, x))))   with attention-probability dropout
+ * = MLFusion.forward_self_attn, src/dprt/models/fusers/mpfusion.py:122-148 (nn.MultiheadAttention, d_model 16,
+ * 8 heads).  Dropout masks are regenerated in the backward from (*seed, salt); p_drop = 0 disables them.
+ * Saved for backward (caller-owned): lse (V,B,Q,8), attn (V,B,Q,16), zhat (V,B,Q,16), rstd (V,B,Q).
+ * Backward: parameter gradients are ACCUMULATED into grads[v] (caller zero-fills); dx (V,B,Q,16) is the
+ * gradient w.r.t. x through view v, dxp (V,B,Q,16) the part that also flows to pos; scratch holds
+ * dpft_selfattn_train_scratch_floats(B,Q,V) floats.  x is (B,Q,16) with batch stride x_bstride (0 = broadcast).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dpft_sa_params {   /* torch layouts: in_proj (48,16), out_proj (16,16) */
+    const float *in_w, *in_b, *out_w, *out_b, *n1_w, *n1_b;
+} dpft_sa_params;
+typedef struct dpft_sa_grads {
+    float *in_w, *in_b, *out_w, *out_b, *n1_w, *n1_b;
+} dpft_sa_grads;
+int dpft_selfattn_train_fwd_f32(const dpft_sa_params* params, int32_t V, const float* x, int64_t x_bstride,
+                                const float* pos, float p_drop, const int64_t* seed, int32_t salt,
+                                float* y1, float* lse, float* attn, float* zhat, float* rstd,
+                                int32_t B, int32_t Q, dpft_stream_t stream);
+int dpft_selfattn_train_bwd_f32(const dpft_sa_params* params, int32_t V, const float* x, int64_t x_bstride,
+                                const float* pos, float p_drop, const int64_t* seed, int32_t salt,
+                                const float* dy1, const float* lse, const float* attn, const float* zhat,
+                                const float* rstd, const dpft_sa_grads* grads, float* dx, float* dxp,
+                                float* scratch, int32_t B, int32_t Q, dpft_stream_t stream);
+int64_t dpft_selfattn_train_scratch_floats(int32_t B, int32_t Q, int32_t V);
+
+/* ------------------------------------------------------------------------------------------
  * Matcher cost helper: GIoU3D of yaw-only boxes, (B,N) predictions x (B,Mg) targets.
  * boxes are (x,y,z,l,w,h,yaw) rows of 7 floats; out (B,N,Mg).
  * ---------------------------------------------------------------------------------------- */

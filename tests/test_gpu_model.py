@@ -321,13 +321,14 @@ def test_graphed_decoder_step_equals_eager_step():
     assert errs[0][0] < 5e-3, errs[:6]
 
 
-def test_fused_inference_decoder_equals_eager_decoder():
+@pytest.mark.parametrize("bsz", [1, 3, 4])      # different self-attention tilings (queries per block)
+def test_fused_inference_decoder_equals_eager_decoder(bsz):
     """eval + no_grad forward through the fused HIP decoder kernels == the eager (torch-op) decoder."""
     from dpft_amd.synthetic import make_batch
     cfg = small_config(dropout=0.1)
     g = torch.Generator().manual_seed(12)
     model = _build(cfg, g).to(DEV).eval()
-    batch = make_batch(cfg["model"]["inputs"], 3, seed=11, shapes=SHAPES, device=DEV)
+    batch = make_batch(cfg["model"]["inputs"], bsz, seed=11, shapes=SHAPES, device=DEV)
     with torch.no_grad():
         model.fuser.use_fused_inference = False
         ref = model(batch)

@@ -1,0 +1,25 @@
+"""N plain training steps (no latency / decoder / cpu legs) -- the target of per-step rocprof breakdowns."""
+import os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpft_amd.configs import load_config
+from dpft_amd.models import build
+from dpft_amd.synthetic import make_batch, make_labels
+from dpft_amd.training.trainer import DataParallelTrainer
+
+steps = int(os.environ.get("STEPS", "20"))
+cfg = load_config("kradar")
+torch.manual_seed(0)
+dev = torch.device("cuda", 0)
+tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
+data = make_batch(cfg["model"]["inputs"], 4, device=dev)
+labels = make_labels(4, device=dev)
+if os.environ.get("GRAPHS", "1") == "1":
+    tr.enable_graphs(data)
+for _ in range(3):
+    tr.train_step(data, labels)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(steps):
+    tr.train_step(data, labels)
+torch.cuda.synchronize()
+print(f"ms/step {(time.perf_counter() - t0) / steps * 1e3:.2f}  (steps {steps})")
