@@ -100,6 +100,9 @@ SIGNATURES = {
     "dpft_selfattn_train_fwd_f32": (_I, [_P, _I, _P, _L, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_selfattn_train_bwd_f32": (_I, [_P, _I, _P, _L, _P, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_selfattn_train_scratch_floats": (_L, [_I, _I, _I]),
+    "dpft_xattn_ffn_train_row_floats": (_L, []),
+    "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _I, _I, _P]),
+    "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),

@@ -120,10 +120,15 @@ class MPFusion(nn.Module):
         if self.use_fused_train and query.is_cuda and pos2d is not None and seed is not None:
             from dpft_amd.models.fusers import train_fused as _tf
             if all(_tf.sa_supported(ml) for ml in layers):
-                y1 = _tf.self_attn_blocks(layers, query, pos2d, seed, salt, self.dropout if self.training else 0.0)
-                outs = [ml.forward_ffn(ml.forward_cross_attn(y1[v], pyr, ref, query_positions))
-                        for v, (ml, pyr, ref) in enumerate(zip(layers, batch, reference_points))]
-                queries = torch.stack(outs, dim=-1)
+                p_drop = self.dropout if self.training else 0.0
+                y1 = _tf.self_attn_blocks(layers, query, pos2d, seed, salt, p_drop)
+                if all(_tf.xf_supported(ml) for ml in layers):
+                    y3 = _tf.xattn_ffn_blocks(layers, batch, y1, pos2d, torch.stack(reference_points), seed, salt, p_drop)
+                    queries = y3.permute(1, 2, 3, 0)           # (B,N,C,V): channel-major / view-minor
+                else:
+                    outs = [ml.forward_ffn(ml.forward_cross_attn(y1[v], pyr, ref, query_positions))
+                            for v, (ml, pyr, ref) in enumerate(zip(layers, batch, reference_points))]
+                    queries = torch.stack(outs, dim=-1)
                 return self.reduce(query, queries, query_positions)
         outs = [layer(query, pyr, ref, query_positions)
                 for layer, pyr, ref in zip(layers, batch, reference_points)]

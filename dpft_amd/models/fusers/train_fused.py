@@ -12,7 +12,7 @@ from typing import Dict, List
 
 import torch
 
-from dpft_amd.hip.lib import SaParams, lib, stream
+from dpft_amd.hip.lib import DecoderView, Pyramid, SaParams, lib, make_pyramid, stream
 
 _SA_SIZES = (768, 48, 256, 16, 16, 16)        # in_proj_weight, in_proj_bias, out_proj.weight, .bias, norm1.weight, .bias
 _seed_state: Dict[torch.device, torch.Tensor] = {}
@@ -100,3 +100,114 @@ def self_attn_blocks(layers, x, pos, seed, salt: int, p_drop: float):
     """y1 (V,B,Q,16) of the V MLFusion layers' self-attention blocks; x (B,Q,16), pos (Q,16)."""
     params = [t for ml in layers for t in sa_params(ml)]
     return SelfAttnBlocksFn.apply(x, pos, seed, salt, p_drop, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# deformable cross-attention + FFN block of all views (decoder_train_x.hip)
+# ---------------------------------------------------------------------------------------------------------
+_XR = dict(DLIN=0, DF=480, DPRE=496, DOUT=528, G3=544, B3=560, G2=576, B2=592, DBV=608, DVEC=624, QP=640, HD=656,
+           Y2=688, VEC=704, SAMP=720, FLOATS=848)
+
+
+def xf_supported(ml) -> bool:
+    a = ml.ms_deform_attn
+    return (sa_supported(ml) and ml.d_ffn == 32 and ml.activation == "Mish" and a.n_heads == 8
+            and a.n_points <= 4 and a.n_levels * a.n_points <= 20 and a.n_levels <= 8)
+
+
+def view_params(ml) -> List[torch.Tensor]:
+    """The 22 tensors of dpft_decoder_view, in its field order."""
+    a = ml.ms_deform_attn
+    return [ml.self_attn.in_proj_weight, ml.self_attn.in_proj_bias, ml.self_attn.out_proj.weight,
+            ml.self_attn.out_proj.bias, ml.norm1.weight, ml.norm1.bias,
+            a.sampling_offsets.weight, a.sampling_offsets.bias, a.attention_weights.weight, a.attention_weights.bias,
+            a.value_proj.weight, a.value_proj.bias, a.output_proj.weight, a.output_proj.bias,
+            ml.norm2.weight, ml.norm2.bias, ml.ffn1.weight, ml.ffn1.bias, ml.ffn2.weight, ml.ffn2.bias,
+            ml.norm3.weight, ml.norm3.bias]
+
+
+def _pack_views(params: List[torch.Tensor], V: int, n_levels, n_points, dev):
+    nv = int(lib.dpft_decoder_packed_view_floats())
+    packed = torch.empty(V * nv, dtype=torch.float32, device=dev)
+    views = (DecoderView * V)()
+    for v in range(V):
+        views[v] = DecoderView(*[t.data_ptr() for t in params[22 * v:22 * v + 22]])
+        lib.call("dpft_decoder_pack_view_f32", C.byref(views[v]), n_levels[v], n_points[v],
+                 packed.data_ptr() + v * nv * 4, stream())
+    return packed, views
+
+
+class XattnFfnBlocksFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, states, seed, salt: int, p_drop: float, n_points, y1, pos, refs, *rest):
+        V = len(states)
+        tokens, params = rest[:V], list(rest[V:])
+        params = [p if p.is_contiguous() else p.contiguous() for p in params]
+        y1, pos, refs = y1.contiguous(), pos.contiguous(), refs.contiguous()
+        _, B, Q, _ = y1.shape
+        dev = y1.device
+        n_levels = [len(s.levels) for s in states]
+        packed, views = _pack_views(params, V, n_levels, n_points, dev)
+        pyrs = (Pyramid * V)()
+        for v in range(V):
+            pyrs[v] = make_pyramid(states[v].levels)
+        npts = (C.c_int32 * V)(*n_points)
+        y3 = torch.empty_like(y1)
+        lib.call("dpft_xattn_ffn_train_fwd_f32", C.cast(pyrs, C.c_void_p), C.cast(views, C.c_void_p), packed.data_ptr(),
+                 V, C.cast(npts, C.c_void_p), y1.data_ptr(), pos.data_ptr(), refs.data_ptr(), float(p_drop),
+                 seed.data_ptr(), int(salt), y3.data_ptr(), B, Q, stream())
+        ctx.save_for_backward(y1, pos, refs, seed, packed, *params)
+        ctx.states, ctx.meta = states, (V, int(salt), float(p_drop), list(n_points), n_levels)
+        return y3
+
+    @staticmethod
+    def backward(ctx, dy3):
+        y1, pos, refs, seed, packed, *params = ctx.saved_tensors
+        V, salt, p_drop, n_points, n_levels = ctx.meta
+        states = ctx.states
+        _, B, Q, _ = y1.shape
+        dev = y1.device
+        dy3 = dy3.contiguous()
+        R, W = B * Q, _XR["FLOATS"]
+        rows = torch.empty((V, R, W), dtype=torch.float32, device=dev)
+        dy1, dqp = torch.empty_like(y1), torch.empty_like(y1)
+        dref = torch.empty_like(refs)
+        views = (DecoderView * V)()
+        pyrs = (Pyramid * V)()
+        for v in range(V):
+            views[v] = DecoderView(*[t.data_ptr() for t in params[22 * v:22 * v + 22]])
+            pyrs[v] = make_pyramid(states[v].levels, states[v].grad_buffers())
+        npts = (C.c_int32 * V)(*n_points)
+        lib.call("dpft_xattn_ffn_train_bwd_f32", C.cast(pyrs, C.c_void_p), C.cast(views, C.c_void_p), packed.data_ptr(),
+                 V, C.cast(npts, C.c_void_p), y1.data_ptr(), pos.data_ptr(), refs.data_ptr(), p_drop, seed.data_ptr(),
+                 salt, dy3.data_ptr(), dy1.data_ptr(), dqp.data_ptr(), dref.data_ptr(), rows.data_ptr(), B, Q, stream())
+        X = _XR
+        col = rows[:, :, :X["QP"]].sum(1)                                                     # (V, 640) vector gradients
+        g_oa = torch.bmm(rows[:, :, X["DLIN"]:X["DF"]].transpose(1, 2), rows[:, :, X["QP"]:X["HD"]])      # (V,480,16)
+        g_f2 = torch.bmm(rows[:, :, X["DF"]:X["DPRE"]].transpose(1, 2), rows[:, :, X["HD"]:X["Y2"]])      # (V,16,32)
+        g_f1 = torch.bmm(rows[:, :, X["DPRE"]:X["DOUT"]].transpose(1, 2), rows[:, :, X["Y2"]:X["VEC"]])   # (V,32,16)
+        g_op = torch.bmm(rows[:, :, X["DOUT"]:X["G3"]].transpose(1, 2), rows[:, :, X["VEC"]:X["SAMP"]])   # (V,16,16)
+        dvec = rows[:, :, X["DVEC"]:X["QP"]].reshape(V, R, 8, 2)
+        samp = rows[:, :, X["SAMP"]:].reshape(V, R, 8, 16)
+        g_vw = torch.einsum("vrmd,vrmc->vmdc", dvec, samp).reshape(V, 16, 16)
+        grads = []
+        for v in range(V):
+            n_off = 8 * n_levels[v] * n_points[v] * 2
+            n_att = n_off // 2
+            grads += [None] * 6
+            grads += [g_oa[v, :n_off], col[v, :n_off], g_oa[v, n_off:n_off + n_att], col[v, n_off:n_off + n_att],
+                      g_vw[v], col[v, X["DBV"]:X["DVEC"]], g_op[v], col[v, X["DOUT"]:X["G3"]],
+                      col[v, X["G2"]:X["B2"]], col[v, X["B2"]:X["DBV"]],
+                      g_f1[v], col[v, X["DPRE"]:X["DOUT"]], g_f2[v], col[v, X["DF"]:X["DPRE"]],
+                      col[v, X["G3"]:X["B3"]], col[v, X["B3"]:X["G2"]]]
+        gtok = [torch.zeros((), dtype=dy3.dtype, device=dev) for _ in range(V)]
+        return (None, None, None, None, None, dy1, dqp.sum((0, 1)), dref, *gtok, *grads)
+
+
+def xattn_ffn_blocks(layers, pyramids, y1, pos, refs, seed, salt: int, p_drop: float):
+    """y3 (V,B,Q,16); pyramids = [(PyramidState, token)] per view, refs (V,B,Q,2)."""
+    states = [p[0] for p in pyramids]
+    tokens = [p[1] for p in pyramids]
+    params = [t for ml in layers for t in view_params(ml)]
+    n_points = [ml.ms_deform_attn.n_points for ml in layers]
+    return XattnFfnBlocksFn.apply(states, seed, salt, p_drop, n_points, y1, pos, refs, *tokens, *params)

@@ -306,6 +306,30 @@ int dpft_selfattn_train_bwd_f32(const dpft_sa_params* params, int32_t V, const f
 int64_t dpft_selfattn_train_scratch_floats(int32_t B, int32_t Q, int32_t V);
 
 /* ------------------------------------------------------------------------------------------
+ * Training path of the decoder's deformable cross-attention + FFN block, all V views of one MPFusion layer:
+ *   y2 = LayerNorm2(y1 + dropout2(output_proj(MSDeformAttn(y1 + pos, ref, pyramid))))
+ *   y3 = LayerNorm3(y2 + dropout4(ffn2(dropout3(Mish(ffn1(y2))))))
+ * = MLFusion.forward_cross_attn + forward_ffn, src/dprt/models/fusers/mpfusion.py:150-229 and
+ * src/dprt/models/layers/ms_deform_attn.py:138-217.  `views` are the torch-layout parameters, `packed` the V
+ * blobs made from them by dpft_decoder_pack_view_f32 (the caller re-packs after every weight update).
+ * y1, y3, dy3, dy1, dqp are (V,B,Q,16); ref/dref (V,B,Q,2); pos (Q,16).  The backward recomputes the row's
+ * forward, scatters the pyramid gradients into pyr[v].grad[] (fp32 atomics, caller zero-fills) and writes the
+ * per-row factors of the parameter gradients into rows (V,B*Q,dpft_xattn_ffn_train_row_floats()); the column
+ * layout is documented at the top of dpft_amd/csrc/decoder_train_x.hip (XR_*) and consumed by
+ * dpft_amd/models/fusers/train_fused.py.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dpft_xattn_ffn_train_row_floats(void);
+int dpft_xattn_ffn_train_fwd_f32(const dpft_pyramid* pyr, const dpft_decoder_view* views, const float* packed,
+                                 int32_t V, const int32_t* n_points, const float* y1, const float* pos,
+                                 const float* ref, float p_drop, const int64_t* seed, int32_t salt, float* y3,
+                                 int32_t B, int32_t Q, dpft_stream_t stream);
+int dpft_xattn_ffn_train_bwd_f32(const dpft_pyramid* pyr, const dpft_decoder_view* views, const float* packed,
+                                 int32_t V, const int32_t* n_points, const float* y1, const float* pos,
+                                 const float* ref, float p_drop, const int64_t* seed, int32_t salt,
+                                 const float* dy3, float* dy1, float* dqp, float* dref, float* rows,
+                                 int32_t B, int32_t Q, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Matcher cost helper: GIoU3D of yaw-only boxes, (B,N) predictions x (B,Mg) targets.
  * boxes are (x,y,z,l,w,h,yaw) rows of 7 floats; out (B,N,Mg).
  * ---------------------------------------------------------------------------------------- */
