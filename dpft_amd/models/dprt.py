@@ -123,11 +123,12 @@ class DPRT(nn.Module):
 
     concurrent_views = True
 
-    def enable_fuser_graph(self, sample_batch: Dict[str, torch.Tensor]):
+    def enable_fuser_graph(self, sample_batch: Dict[str, torch.Tensor], grad_direct=None):
         """Capture the launch-bound fusion decoder (forward and backward) into hipGraphs for training steps
-        with the static shapes of ``sample_batch`` (dpft_amd/models/fusers/graphed.py)."""
+        with the static shapes of ``sample_batch`` (dpft_amd/models/fusers/graphed.py).  ``grad_direct``: a
+        GradBucketReducer whose bucket views the backward graph adds the parameter gradients into."""
         from dpft_amd.models.fusers.graphed import GraphedFuser
-        self.__dict__["_graphed_fuser"] = GraphedFuser(self, sample_batch)
+        self.__dict__["_graphed_fuser"] = GraphedFuser(self, sample_batch, grad_direct=grad_direct)
 
     def disable_fuser_graph(self):
         self.__dict__.pop("_graphed_fuser", None)

@@ -55,15 +55,22 @@ class _Replay(torch.autograd.Function):
         for s, a in zip(g.static_grad_outputs, grads):
             s.copy_(a) if a is not None else s.zero_()
         g.bwd_graph.replay()
-        # hand out copies: the static buffers are overwritten by the next replay
-        gi = [None if t is None else t.detach().clone() for t in g.static_grad_inputs]
         n_other = len(g.static_inputs) - 1 - g.n_levels          # shapes + projection matrices
+        # The static gradient buffers are handed out as they are: their consumers (embedding / FPN backward,
+        # gradient accumulation) run before the next replay overwrites them.
+        gi = [None if t is None else t.detach() for t in g.static_grad_inputs]
+        if g.grad_direct is not None:      # the graph already added the parameter gradients into the buckets
+            for p, t in zip(g.params, g.static_grad_inputs[g.n_levels:]):
+                if t is not None:
+                    g.grad_direct.mark_ready(p)
+            return (None, None, *gi[:g.n_levels], *([None] * (n_other + len(g.params))))
         return (None, None, *gi[:g.n_levels], *([None] * n_other), *gi[g.n_levels:])
 
 
 class GraphedFuser:
-    def __init__(self, model: nn.Module, sample_batch: Dict[str, torch.Tensor], warmup: int = 3):
+    def __init__(self, model: nn.Module, sample_batch: Dict[str, torch.Tensor], warmup: int = 3, grad_direct=None):
         self.inputs = list(model.inputs)
+        self.grad_direct = grad_direct
         was_training = model.training
         # one eval-mode pass up to the fuser (no running-stat update, no autograd) for correctly shaped samples
         model.eval()
@@ -107,6 +114,11 @@ class GraphedFuser:
         with torch.enable_grad(), torch.cuda.graph(self.bwd_graph):   # its own private pool (see module docstring)
             grads = torch.autograd.grad(self.static_outputs, diff_inputs, self.static_grad_outputs,
                                         allow_unused=True)
+            if grad_direct is not None:
+                pairs = [(grad_direct.grad_buffer(p), t) for p, t in zip(self.params, grads[self.n_levels:]) if t is not None]
+                if any(v is None for v, _ in pairs):
+                    raise RuntimeError("GraphedFuser: a decoder parameter is not owned by the gradient reducer")
+                torch._foreach_add_([v for v, _ in pairs], [t for _, t in pairs])
         self.static_grad_inputs = list(grads)
         torch.cuda.synchronize()
         # inference replay: eval mode (dropout off, MHA fast path), no autograd

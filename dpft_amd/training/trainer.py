@@ -42,7 +42,7 @@ class DataParallelTrainer:
     def enable_graphs(self, sample_data: Dict[str, torch.Tensor]):
         """Replay the launch-bound decoder from hipGraphs (static shapes of ``sample_data``)."""
         self.reducer.reset()
-        self.model.enable_fuser_graph(sample_data)
+        self.model.enable_fuser_graph(sample_data, grad_direct=self.reducer)
         self.optimizer.zero_grad(set_to_none=False)
 
     def train_step(self, data: Dict[str, torch.Tensor], labels: List[Dict[str, torch.Tensor]]):
