@@ -50,6 +50,17 @@ class SaParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("in_w", "in_b", "out_w", "out_b", "n1_w", "n1_b")]
 
 
+class HeadTrain(C.Structure):
+    _fields_ = [("y3", C.c_void_p), ("packed", C.c_void_p), ("red_w", C.c_void_p), ("head_w", (C.c_void_p * 3) * 4),
+                ("prev_center", C.c_void_p), ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
+                ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("num_classes", C.c_int32),
+                ("x", C.c_void_p), ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p),
+                ("cls", C.c_void_p), ("refs", C.c_void_p),
+                ("dx", C.c_void_p), ("dcenter", C.c_void_p), ("dsize", C.c_void_p), ("dangle", C.c_void_p),
+                ("dcls", C.c_void_p), ("drefs", C.c_void_p),
+                ("dy3", C.c_void_p), ("dcenter_prev", C.c_void_p), ("rows", C.c_void_p)]
+
+
 class DecoderFwd(C.Structure):
     _fields_ = [("B", C.c_int32), ("Q", C.c_int32), ("V", C.c_int32), ("iters", C.c_int32), ("num_classes", C.c_int32),
                 ("n_points", C.c_int32 * 4), ("packed_views", C.c_void_p), ("packed_heads", C.c_void_p),
@@ -101,6 +112,9 @@ SIGNATURES = {
     "dpft_selfattn_train_bwd_f32": (_I, [_P, _I, _P, _L, _P, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_selfattn_train_scratch_floats": (_L, [_I, _I, _I]),
     "dpft_xattn_ffn_train_row_floats": (_L, []),
+    "dpft_head_train_row_floats": (_L, []),
+    "dpft_head_train_fwd_f32": (_I, [C.POINTER(HeadTrain), _I, _I, _I, _P]),
+    "dpft_head_train_bwd_f32": (_I, [C.POINTER(HeadTrain), _I, _I, _I, _P]),
     "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _I, _I, _P]),
     "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),

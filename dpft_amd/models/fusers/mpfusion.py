@@ -115,6 +115,18 @@ class MPFusion(nn.Module):
 
     use_fused_train = True      # CUDA: self-attention blocks of all views from the fused HIP kernels (train_fused.py)
 
+    def fused_blocks_supported(self) -> bool:
+        from dpft_amd.models.fusers import train_fused as _tf
+        return self.use_fused_train and all(_tf.xf_supported(ml) for ml in self.ml_fusion_layers.values())
+
+    def forward_fused_blocks(self, query, batch, refs, pos2d, seed, salt: int):
+        """(V,B,Q,16) outputs of every view's MLFusion from the fused HIP training kernels; refs (V,B,Q,2)."""
+        from dpft_amd.models.fusers import train_fused as _tf
+        layers = list(self.ml_fusion_layers.values())
+        p_drop = self.dropout if self.training else 0.0
+        y1 = _tf.self_attn_blocks(layers, query, pos2d, seed, salt, p_drop)
+        return _tf.xattn_ffn_blocks(layers, batch, y1, pos2d, refs, seed, salt, p_drop)
+
     def forward(self, query, batch, reference_points, query_positions, pos2d=None, seed=None, salt: int = 0):
         layers = list(self.ml_fusion_layers.values())
         if self.use_fused_train and query.is_cuda and pos2d is not None and seed is not None:
@@ -166,6 +178,7 @@ class IMPFusion(nn.Module):
         return cls(**config, **kwargs)
 
     use_fused_inference = True       # eval + no_grad forward runs the fused HIP decoder when the config allows
+    use_fused_train = True           # CUDA: layers run from the fused HIP training kernels when the config allows
 
     def reset_parameters(self) -> None:
         self.q_init(self.query)
@@ -216,8 +229,20 @@ class IMPFusion(nn.Module):
         pyramids = [make_pyramid_state(list(levels.values())) for levels in batch]
         seed = None
         if query.is_cuda:
-            from dpft_amd.models.fusers.train_fused import advance_seed
-            seed = advance_seed(query.device)
+            from dpft_amd.models.fusers import train_fused as _tf
+            seed = _tf.advance_seed(query.device)
+            layers = list(self.mpfusion.values())
+            if self.use_fused_train and all(l.fused_blocks_supported() and _tf.head_supported(l, h)
+                                            for l, h in zip(layers, self.heads)):
+                # every layer = 3 fused forward launches (self attention | cross attention + FFN | reduction +
+                # heads + next reference points) with hand-written backward kernels (train_fused.py)
+                proj = _tf._Proj(projection, shape, flags)
+                pos2d = self.query_embedding.weight
+                refs = _tf.reference_points(proj, out["center"])
+                for it, (layer, head) in enumerate(zip(layers, self.heads)):
+                    y3 = layer.forward_fused_blocks(query, pyramids, refs, pos2d, seed, it)
+                    query, out, refs = _tf.head_block(layer, head, proj, y3, out["center"], it + 1 < len(layers))
+                return out
         for it, (layer, head) in enumerate(zip(self.mpfusion.values(), self.heads)):
             reference_points = [
                 self.get_reference_points(out["center"][..., :3], p[0], p[1], s, f)

@@ -12,7 +12,7 @@ from typing import Dict, List
 
 import torch
 
-from dpft_amd.hip.lib import DecoderView, Pyramid, SaParams, lib, make_pyramid, stream
+from dpft_amd.hip.lib import DecoderView, HeadTrain, Pyramid, SaParams, lib, make_pyramid, stream
 
 _SA_SIZES = (768, 48, 256, 16, 16, 16)        # in_proj_weight, in_proj_bias, out_proj.weight, .bias, norm1.weight, .bias
 _seed_state: Dict[torch.device, torch.Tensor] = {}
@@ -211,3 +211,132 @@ def xattn_ffn_blocks(layers, pyramids, y1, pos, refs, seed, salt: int, p_drop: f
     params = [t for ml in layers for t in view_params(ml)]
     n_points = [ml.ms_deform_attn.n_points for ml in layers]
     return XattnFfnBlocksFn.apply(states, seed, salt, p_drop, n_points, y1, pos, refs, *tokens, *params)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# view reduction + detection head + next reference points (decoder_train_h.hip)
+# ---------------------------------------------------------------------------------------------------------
+_HR = dict(DX=0, Y3C=16, D1=80, D2=144, DO=208, H1=272, H2=336, X=400, FLOATS=416)
+_BRANCHES = ("center", "size", "angle", "class")
+
+
+def head_supported(layer, head) -> bool:
+    from dpft_amd.models.heads.detection import LinearDetectionHead
+    return (layer.reduction == "linear" and layer.d_model == 16 and isinstance(head, LinearDetectionHead)
+            and head.num_reg_layers == 3 and head.num_cls_layers == 3 and not head.bias and head.in_channels == 16
+            and head.num_classes <= 16 and (head.dropout == 0.0 or not head.training))
+
+
+def head_params(layer, head) -> List[torch.Tensor]:
+    """reduction weight + the 12 head weights (branch-major, layers .0 .3 .6)."""
+    out = [layer.reduction_layer.weight]
+    for name in _BRANCHES:
+        seq = head.layers[name + "_head"]
+        out += [seq[0].weight, seq[3].weight, seq[6].weight]
+    return out
+
+
+class _Proj:
+    """Non-differentiable projection inputs of the reference points (per view: T, P, shape, flag)."""
+
+    def __init__(self, projection, shape, flags):
+        self.T = [t.contiguous().float() for t, _ in projection]
+        self.P = [p.contiguous().float() for _, p in projection]
+        self.shape = [s[:, :2].to(torch.int64).contiguous() for s in shape]
+        self.flags = [int(f) for f in flags]
+
+    def fill(self, h: HeadTrain):
+        for v in range(len(self.T)):
+            h.T[v], h.P[v], h.shape[v] = self.T[v].data_ptr(), self.P[v].data_ptr(), self.shape[v].data_ptr()
+            h.p_rows[v], h.has_t[v] = self.P[v].shape[1], self.flags[v]
+
+
+def reference_points(proj: _Proj, center: torch.Tensor) -> torch.Tensor:
+    """(V,B,Q,2) reference points of a center that carries no gradient (the querent output)."""
+    V = len(proj.T)
+    center = center[..., :3].detach().contiguous().float()
+    B, Q, _ = center.shape
+    refs = torch.empty((V, B, Q, 2), dtype=torch.float32, device=center.device)
+    h = HeadTrain()
+    proj.fill(h)
+    h.prev_center, h.refs, h.num_classes = center.data_ptr(), refs.data_ptr(), 1
+    lib.call("dpft_head_train_fwd_f32", C.byref(h), B, Q, V, stream())
+    return refs
+
+
+def _fill_head_weights(h: HeadTrain, weights, packed):
+    h.packed, h.red_w = packed.data_ptr(), weights[0].data_ptr()
+    for g in range(4):
+        for k in range(3):
+            h.head_w[g][k] = weights[1 + g * 3 + k].data_ptr()
+
+
+class HeadBlockFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, proj: _Proj, want_refs: bool, ncls: int, y3, prev_center, *weights):
+        ctx.set_materialize_grads(False)
+        V, B, Q, _ = y3.shape
+        dev = y3.device
+        y3 = y3.contiguous()
+        prev_center = prev_center[..., :3].contiguous()
+        weights = [w if w.is_contiguous() else w.contiguous() for w in weights]
+        packed = torch.empty(int(lib.dpft_decoder_packed_head_floats()), dtype=torch.float32, device=dev)
+        hw = (C.c_void_p * 12)(*[w.data_ptr() for w in weights[1:]])
+        lib.call("dpft_decoder_pack_head_f32", weights[0].data_ptr(), C.byref(hw), V, ncls, packed.data_ptr(), stream())
+        x = torch.empty((B, Q, 16), dtype=torch.float32, device=dev)
+        center, size = torch.empty((B, Q, 3), dtype=torch.float32, device=dev), torch.empty((B, Q, 3), dtype=torch.float32, device=dev)
+        angle, cls = torch.empty((B, Q, 2), dtype=torch.float32, device=dev), torch.empty((B, Q, ncls), dtype=torch.float32, device=dev)
+        refs = torch.empty((V, B, Q, 2) if want_refs else (0,), dtype=torch.float32, device=dev)
+        h = HeadTrain()
+        proj.fill(h)
+        _fill_head_weights(h, weights, packed)
+        h.y3, h.prev_center, h.num_classes = y3.data_ptr(), prev_center.data_ptr(), ncls
+        h.x, h.center, h.size, h.angle, h.cls = (t.data_ptr() for t in (x, center, size, angle, cls))
+        h.refs = refs.data_ptr() if want_refs else None
+        lib.call("dpft_head_train_fwd_f32", C.byref(h), B, Q, V, stream())
+        ctx.save_for_backward(y3, prev_center, packed, *weights)
+        ctx.proj, ctx.meta = proj, (ncls, want_refs)
+        return x, center, size, angle, cls, refs
+
+    @staticmethod
+    def backward(ctx, dx, dcenter, dsize, dangle, dcls, drefs):
+        y3, prev_center, packed, *weights = ctx.saved_tensors
+        ncls, want_refs = ctx.meta
+        V, B, Q, _ = y3.shape
+        dev = y3.device
+        R, W = B * Q, _HR["FLOATS"]
+        rows = torch.empty((R, W), dtype=torch.float32, device=dev)
+        dy3 = torch.empty_like(y3)
+        dcp = torch.empty((B, Q, 3), dtype=torch.float32, device=dev)
+        h = HeadTrain()
+        ctx.proj.fill(h)
+        _fill_head_weights(h, weights, packed)
+        h.y3, h.prev_center, h.num_classes = y3.data_ptr(), prev_center.data_ptr(), ncls
+        keep = [None if t is None else t.contiguous() for t in (dx, dcenter, dsize, dangle, dcls, drefs if want_refs else None)]
+        h.dx, h.dcenter, h.dsize, h.dangle, h.dcls, h.drefs = (None if t is None else t.data_ptr() for t in keep)
+        h.dy3, h.dcenter_prev, h.rows = dy3.data_ptr(), dcp.data_ptr(), rows.data_ptr()
+        lib.call("dpft_head_train_bwd_f32", C.byref(h), B, Q, V, stream())
+        X = _HR
+        g_red = rows[:, X["DX"]:X["Y3C"]].t() @ rows[:, X["Y3C"]:X["Y3C"] + 16 * V]                   # (16, 16V)
+        d1 = rows[:, X["D1"]:X["D2"]].reshape(R, 4, 16)
+        d2 = rows[:, X["D2"]:X["DO"]].reshape(R, 4, 16)
+        do = rows[:, X["DO"]:X["H1"]].reshape(R, 4, 16)
+        h1 = rows[:, X["H1"]:X["H2"]].reshape(R, 4, 16)
+        h2 = rows[:, X["H2"]:X["X"]].reshape(R, 4, 16)
+        xs = rows[:, X["X"]:]
+        g0 = torch.einsum("rgo,rk->gok", d1, xs)
+        g3 = torch.einsum("rgo,rgk->gok", d2, h1)
+        g6 = torch.einsum("rgo,rgk->gok", do, h2)
+        grads = [g_red]
+        for g, nout in enumerate((3, 3, 2, ncls)):
+            grads += [g0[g], g3[g], g6[g, :nout]]
+        return (None, None, None, dy3, dcp, *grads)
+
+
+def head_block(layer, head, proj: _Proj, y3, prev_center, want_refs: bool):
+    """-> (x, out dict, refs (V,B,Q,2) or None)."""
+    x, center, size, angle, cls, refs = HeadBlockFn.apply(proj, want_refs, head.num_classes, y3, prev_center,
+                                                         *head_params(layer, head))
+    from collections import OrderedDict
+    out = OrderedDict([("center", center), ("size", size), ("angle", angle), ("class", cls)])
+    return x, out, (refs if want_refs else None)

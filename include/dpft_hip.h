@@ -330,6 +330,36 @@ int dpft_xattn_ffn_train_bwd_f32(const dpft_pyramid* pyr, const dpft_decoder_vie
                                  int32_t B, int32_t Q, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training path of the decoder's view reduction + detection head + next reference points (one layer):
+ *   x = reduction_layer(cat_v y3[v]);  out_g = act_g(MLP_g(x));  center = out_center + prev_center;
+ *   refs[v] = reference point of `center` in view v (input of the NEXT layer's cross attention)
+ * = MPFusion 'linear' reduction (src/dprt/models/fusers/mpfusion.py:416-514), LinearDetectionHead
+ * (src/dprt/models/heads/detection.py:252-275) and IMPFusion.get_reference_points (mpfusion.py:617-696).
+ * `packed` comes from dpft_decoder_pack_head_f32.  y3 == NULL: only refs of prev_center are computed.
+ * Backward: NULL gradient inputs mean "no gradient"; rows (B*Q, dpft_head_train_row_floats()) receives the
+ * per-row factors of the weight gradients (columns HR_* in dpft_amd/csrc/decoder_train_h.hip).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dpft_head_train {
+    const float* y3;               /* (V,B,Q,16) */
+    const float* packed;           /* dpft_decoder_packed_head_floats() floats */
+    const float* red_w;            /* reduction_layer.weight (16, 16*V) */
+    const float* head_w[4][3];     /* center/size/angle/class x layers .0,.3,.6 (torch layouts) */
+    const float* prev_center;      /* (B,Q,3) */
+    const float* T[4];             /* (B,4,4) per view (may be NULL when has_t == 0) */
+    const float* P[4];             /* (B,p_rows,4) */
+    const int64_t* shape[4];       /* (B,2) = (H, W) */
+    int32_t p_rows[4], has_t[4];
+    int32_t num_classes;
+    float *x, *center, *size, *angle, *cls;      /* forward outputs (B,Q,16) (B,Q,3) (B,Q,3) (B,Q,2) (B,Q,ncls) */
+    float* refs;                                   /* (V,B,Q,2) or NULL */
+    const float *dx, *dcenter, *dsize, *dangle, *dcls, *drefs;   /* backward inputs, any may be NULL */
+    float *dy3, *dcenter_prev, *rows;              /* backward outputs */
+} dpft_head_train;
+int64_t dpft_head_train_row_floats(void);
+int dpft_head_train_fwd_f32(const dpft_head_train* h, int32_t B, int32_t Q, int32_t V, dpft_stream_t stream);
+int dpft_head_train_bwd_f32(const dpft_head_train* h, int32_t B, int32_t Q, int32_t V, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Matcher cost helper: GIoU3D of yaw-only boxes, (B,N) predictions x (B,Mg) targets.
  * boxes are (x,y,z,l,w,h,yaw) rows of 7 floats; out (B,N,Mg).
  * ---------------------------------------------------------------------------------------- */

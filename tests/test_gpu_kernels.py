@@ -460,3 +460,62 @@ def test_fused_xattn_ffn_block_dropout_consistent():
         return val
     numeric = (f(+1) - f(-1)) / (2 * eps)
     assert abs(numeric - analytic) < 5e-2 * max(1.0, abs(analytic)), (numeric, analytic)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# fused training reduction + heads + reference points (decoder_train_h.hip) vs eager modules
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,V,ncls,flags", [(2, 100, 3, 2, (0, 1, 1)), (1, 33, 2, 5, (1, 0)), (3, 64, 1, 1, (1,))])
+def test_fused_head_block_matches_eager(B, Q, V, ncls, flags):
+    from dpft_amd.models.fusers import train_fused as tf
+    from dpft_amd.models.fusers.mpfusion import IMPFusion, MPFusion
+    from dpft_amd.models.heads.detection import LinearDetectionHead
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(9)
+    layer = MPFusion(V, d_model=16, d_ffn=32, n_levels=[2] * V, n_heads=[8] * V, n_points=[2] * V, activation="Mish",
+                     norm=True, reduction="linear").to(dev)
+    head = LinearDetectionHead(16, ncls, 3, 3).to(dev)
+    y3 = (torch.randn(V, B, Q, 16, device=dev) * 0.8).requires_grad_(True)
+    prev = (torch.randn(B, Q, 3, device=dev) * torch.tensor([20.0, 10.0, 2.0], device=dev)
+            + torch.tensor([30.0, 0.0, 0.0], device=dev)).requires_grad_(True)
+    projection, shapes = [], []
+    for v in range(V):
+        T = torch.eye(4, device=dev).repeat(B, 1, 1)
+        if flags[v]:
+            T[:, :3, :3] += torch.randn(B, 3, 3, device=dev) * 0.05
+            T[:, :3, 3] = torch.randn(B, 3, device=dev)
+        else:
+            T.zero_()
+        P = torch.zeros(B, 4, 4, device=dev)
+        P[:, 0, :] = torch.tensor([4.0, 1.5, 0.3, 60.0], device=dev)
+        P[:, 1, :] = torch.tensor([0.2, 0.4, 3.0, 40.0], device=dev)
+        P[:, 2, :] = torch.tensor([0.01, 0.0, 0.0, 1.0], device=dev) if v % 2 == 0 else torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)
+        P[:, 3, 3] = 1.0
+        projection.append((T, P))
+        shapes.append(torch.tensor([[128, 256, 3]] * B, device=dev))
+    # eager
+    queries = y3.permute(1, 2, 3, 0)
+    x_ref = layer.reduce(None if False else y3[0], queries, None)
+    out_ref = head(x_ref, {"center": prev})
+    refs_ref = torch.stack([IMPFusion.get_reference_points(out_ref["center"][..., :3], projection[v][0], projection[v][1],
+                                                          shapes[v], bool(flags[v])) for v in range(V)])
+    outs_ref = [x_ref, out_ref["center"], out_ref["size"], out_ref["angle"], out_ref["class"], refs_ref]
+    gys = [torch.randn_like(t) for t in outs_ref]
+    weights = tf.head_params(layer, head)
+    gref = torch.autograd.grad(outs_ref, [y3, prev] + weights, gys)
+    # fused
+    proj = tf._Proj(projection, shapes, flags)
+    x, out, refs = tf.head_block(layer, head, proj, y3, prev, True)
+    outs = [x, out["center"], out["size"], out["angle"], out["class"], refs]
+    for a, b_, n in zip(outs, outs_ref, ["x", "center", "size", "angle", "class", "refs"]):
+        assert torch.allclose(a, b_, rtol=1e-4, atol=1e-4), (n, float((a - b_).abs().max()))
+    gout = torch.autograd.grad(outs, [y3, prev] + weights, gys)
+    for a, b_, n in zip(gout, gref, ["y3", "prev"] + [f"w{i}" for i in range(len(weights))]):
+        err = (a - b_).norm() / b_.norm().clamp_min(1e-12)
+        assert err < 5e-4, (n, float(err))
+    # reference points of a gradient-free center
+    r0 = tf.reference_points(proj, prev)
+    r0_ref = torch.stack([IMPFusion.get_reference_points(prev.detach(), projection[v][0], projection[v][1], shapes[v],
+                                                        bool(flags[v])) for v in range(V)])
+    assert torch.allclose(r0, r0_ref, rtol=1e-4, atol=1e-5)
