@@ -30,24 +30,14 @@ __device__ double poly_area(const P2* p, int n) {
     return a / 2;
 }
 
-__global__ void giou3d_yaw_kernel(const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ out,
-                                  int B, int N, int Mg) {
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (int64_t)B * N * Mg) return;
-    const int j = (int)(idx % Mg);
-    const int i = (int)((idx / Mg) % N);
-    const int b = (int)(idx / ((int64_t)Mg * N));
-    const float* pa = pred + ((int64_t)b * N + i) * 7;
-    const float* pb = gt + ((int64_t)b * Mg + j) * 7;
+// GIoU3D of two (x,y,z,l,w,h,yaw) boxes
+__device__ float giou3d_yaw_pair(const float* pa, const float* pb) {
     const double eps = 1e-4;
     auto valid = [&](const float* s) {
         const double l = s[3], w = s[4], h = s[5];
         return fmin(fmin(l * w, l * h), w * h) / 2 > eps;
     };
-    if (!(valid(pa) && valid(pb))) {  // iou.py:159,185-208: evol keeps -1 => giou = -1
-        out[idx] = -1.f;
-        return;
-    }
+    if (!(valid(pa) && valid(pb))) return -1.f;      // iou.py:159,185-208: evol keeps -1 => giou = -1
     P2 A[4], Bq[4];
     double azl, azh, bzl, bzh;
     rect_corners(pa, A, azl, azh);
@@ -90,7 +80,160 @@ __global__ void giou3d_yaw_kernel(const float* __restrict__ pred, const float* _
     const double v1 = (double)pa[3] * pa[4] * pa[5], v2 = (double)pb[3] * pb[4] * pb[5];
     const double iou = vol > 0 ? vol / (v1 + v2 - vol) : 0.0;
     const double uni = iou != 0 ? vol / iou : 0.0;
-    out[idx] = (float)(evol != 0 ? iou - (evol - uni) / evol : 0.0);
+    return (float)(evol != 0 ? iou - (evol - uni) / evol : 0.0);
+}
+
+
+__global__ void giou3d_yaw_kernel(const float* __restrict__ pred, const float* __restrict__ gt, float* __restrict__ out,
+                                  int B, int N, int Mg) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)B * N * Mg) return;
+    const int j = (int)(idx % Mg);
+    const int i = (int)((idx / Mg) % N);
+    const int b = (int)(idx / ((int64_t)Mg * N));
+    out[idx] = giou3d_yaw_pair(pred + ((int64_t)b * N + i) * 7, gt + ((int64_t)b * Mg + j) * 7);
+}
+
+// ---- Hungarian matcher cost (src/dprt/training/assigner.py:113-132), one thread per (sample, query, target) ----
+struct CostArgs {
+    const float *cls, *center, *size, *angle;      // (B,N,C) (B,N,3) (B,N,3) (B,N,2)
+    const float* gt_box;                           // (B,Mmax,8) center | size | angle
+    const int32_t* gt_id;                          // (B,Mmax) class index
+    const int32_t* counts;                         // (B)
+    float* cost;                                   // (B,N,Mmax), 0 beyond counts[b]
+    float w_class, w_center, w_size, w_angle, w_giou;
+    int B, N, Mmax, C;
+};
+__global__ void match_cost_kernel(CostArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.B * a.N * a.Mmax) return;
+    const int j = (int)(idx % a.Mmax);
+    const int64_t bn = idx / a.Mmax;
+    const int b = (int)(bn / a.N);
+    if (j >= a.counts[b]) {
+        a.cost[idx] = 0.f;
+        return;
+    }
+    const float* g = a.gt_box + ((int64_t)b * a.Mmax + j) * 8;
+    const float* ce = a.center + bn * 3;
+    const float* sz = a.size + bn * 3;
+    const float* an = a.angle + bn * 2;
+    const float pa[7] = {ce[0], ce[1], ce[2], sz[0], sz[1], sz[2], atan2f(an[0], an[1])};
+    const float pb[7] = {g[0], g[1], g[2], g[3], g[4], g[5], atan2f(g[6], g[7])};
+    const float giou = giou3d_yaw_pair(pa, pb);
+    const float l1c = fabsf(ce[0] - g[0]) + fabsf(ce[1] - g[1]) + fabsf(ce[2] - g[2]);
+    const float l1s = fabsf(sz[0] - g[3]) + fabsf(sz[1] - g[4]) + fabsf(sz[2] - g[5]);
+    const float l1a = fabsf(an[0] - g[6]) + fabsf(an[1] - g[7]);
+    float c = a.w_class * (-a.cls[bn * a.C + a.gt_id[b * a.Mmax + j]]);
+    c += a.w_center * l1c;
+    c += a.w_size * l1s;
+    c += a.w_angle * l1a;
+    c += a.w_giou * (-giou);
+    a.cost[idx] = c;
+}
+
+// ---- SetCriterion + Loss (src/dprt/training/loss.py:17-60 focal, :176-373 criterion, :486-564 reduction) ----
+// One thread per (sample, query).  Terms: 0 total_class, 1 object_class, 2 center, 3 size, 4 angle; every sample's
+// term is weighted and divided by B (reduction 'mean'); samples without targets contribute 0.
+struct LossArgs {
+    const float *cls, *center, *size, *angle;
+    const float* gt_box;        // (B,Mmax,8)
+    const float* gt_onehot;     // (B,Mmax,C)
+    const int32_t* match;       // (B,Mmax,2) (query i, target j) in assignment order
+    const int32_t* counts;
+    const float* gout;          // (5) upstream gradient of the batch-reduced terms (backward)
+    float* losses;              // (5) accumulated (caller zero-fills)            (forward)
+    float *dcls, *dcenter, *dsize, *dangle;                                     // (backward)
+    float w[5];
+    float alpha;
+    int B, N, Mmax, C;
+};
+__device__ __forceinline__ void focal_term(float x, float t, float alpha, float& loss, float& dldx) {
+    const float ce = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
+    const float pt = x * t + (1.f - x) * (1.f - t);       // raw logits, as in the reference (loss.py:44)
+    const float om = 1.f - pt;
+    const float at = alpha >= 0.f ? alpha * t + (1.f - alpha) * (1.f - t) : 1.f;
+    loss = at * ce * om * om;
+    const float sg = 1.f / (1.f + expf(-x));
+    dldx = at * ((sg - t) * om * om - ce * 2.f * om * (2.f * t - 1.f));
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void set_loss_kernel(LossArgs a) {
+    __shared__ float red[5][4];
+    const int64_t bn = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    float part[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+    if (bn < (int64_t)a.B * a.N) {
+        const int b = (int)(bn / a.N), n = (int)(bn - (int64_t)b * a.N);
+        const int M = a.counts[b];
+        const int C = a.C;
+        float g[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) g[k] = BWD ? a.gout[k] * a.w[k] / (float)a.B : a.w[k] / (float)a.B;
+        int kk = -1;
+        for (int k = 0; k < M; ++k)
+            if (a.match[((int64_t)b * a.Mmax + k) * 2] == n) kk = k;
+        const int jj = kk >= 0 ? a.match[((int64_t)b * a.Mmax + kk) * 2 + 1] : -1;
+        const float* x = a.cls + bn * C;
+        const float invM = M > 0 ? 1.f / (float)M : 0.f;
+        // total_class over every query (one-hot row: background unless matched; matched rows take the kk-th target
+        // row -- assignment order, loss.py:305-306), object_class over the matched ones
+        for (int c = 0; c < C; ++c) {
+            float dl = 0.f;
+            if (M > 0) {
+                const float t = kk >= 0 ? a.gt_onehot[((int64_t)b * a.Mmax + kk) * C + c] : (c == 0 ? 1.f : 0.f);
+                float l, d;
+                focal_term(x[c], t, a.alpha, l, d);
+                part[0] += l * invM * g[0];
+                dl += d * invM * g[0];
+                if (kk >= 0) {
+                    const float t2 = a.gt_onehot[((int64_t)b * a.Mmax + jj) * C + c];
+                    focal_term(x[c], t2, a.alpha, l, d);
+                    const float sc = (float)a.N * invM * invM * g[1];
+                    part[1] += l * sc;
+                    dl += d * sc;
+                }
+            }
+            if (BWD) a.dcls[bn * C + c] = dl;
+        }
+        const float* gb = kk >= 0 ? a.gt_box + ((int64_t)b * a.Mmax + jj) * 8 : nullptr;
+        for (int d = 0; d < 3; ++d) {
+            float dc = 0.f, ds = 0.f;
+            if (gb) {
+                const float e1 = a.center[bn * 3 + d] - gb[d], e2 = a.size[bn * 3 + d] - gb[3 + d];
+                const float s1 = invM / 3.f * g[2], s2 = invM / 3.f * g[3];
+                part[2] += fabsf(e1) * s1;
+                part[3] += fabsf(e2) * s2;
+                dc = (e1 > 0.f ? 1.f : (e1 < 0.f ? -1.f : 0.f)) * s1;
+                ds = (e2 > 0.f ? 1.f : (e2 < 0.f ? -1.f : 0.f)) * s2;
+            }
+            if (BWD) {
+                a.dcenter[bn * 3 + d] = dc;
+                a.dsize[bn * 3 + d] = ds;
+            }
+        }
+        for (int d = 0; d < 2; ++d) {
+            float da = 0.f;
+            if (gb) {
+                const float e = a.angle[bn * 2 + d] - gb[6 + d];
+                const float s = invM / 2.f * g[4];
+                part[4] += fabsf(e) * s;
+                da = (e > 0.f ? 1.f : (e < 0.f ? -1.f : 0.f)) * s;
+            }
+            if (BWD) a.dangle[bn * 2 + d] = da;
+        }
+    }
+    if (!BWD) {
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            float v = part[k];
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) v += __shfl_xor(v, o);
+            if (lane == 0) red[k][wv] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 5) atomicAdd(a.losses + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+    }
 }
 
 }  // namespace dpft
@@ -104,4 +247,58 @@ extern "C" int dpft_giou3d_yaw_f32(const float* pred, const float* gt, float* ou
     hipLaunchKernelGGL(giou3d_yaw_kernel, dim3(cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream, pred, gt, out, B,
                        N, Mg);
     return check_launch("giou3d_yaw");
+}
+
+extern "C" int dpft_match_cost_f32(const float* cls, const float* center, const float* size, const float* angle,
+                                   const float* gt_box, const int32_t* gt_id, const int32_t* counts, const float* weights5,
+                                   float* cost, int32_t B, int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream) {
+    DPFT_REQUIRE(cls && center && size && angle && gt_box && gt_id && counts && weights5 && cost, "match_cost: null argument");
+    DPFT_REQUIRE(B > 0 && N > 0 && Mmax > 0 && C > 0, "match_cost: non-positive sizes");
+    CostArgs a;
+    a.cls = cls; a.center = center; a.size = size; a.angle = angle; a.gt_box = gt_box; a.gt_id = gt_id; a.counts = counts;
+    a.cost = cost; a.w_class = weights5[0]; a.w_center = weights5[1]; a.w_size = weights5[2]; a.w_angle = weights5[3];
+    a.w_giou = weights5[4]; a.B = B; a.N = N; a.Mmax = Mmax; a.C = C;
+    const int64_t total = (int64_t)B * N * Mmax;
+    hipLaunchKernelGGL(match_cost_kernel, dim3(cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream, a);
+    return check_launch("match_cost");
+}
+
+static int loss_fill(LossArgs& a, const float* cls, const float* center, const float* size, const float* angle,
+                     const float* gt_box, const float* gt_onehot, const int32_t* match, const int32_t* counts,
+                     const float* weights5, float alpha, int B, int N, int Mmax, int C) {
+    DPFT_REQUIRE(cls && center && size && angle && gt_box && gt_onehot && match && counts && weights5, "set_loss: null argument");
+    DPFT_REQUIRE(B > 0 && N > 0 && Mmax > 0 && C > 0, "set_loss: non-positive sizes");
+    memset(&a, 0, sizeof(a));
+    a.cls = cls; a.center = center; a.size = size; a.angle = angle; a.gt_box = gt_box; a.gt_onehot = gt_onehot;
+    a.match = match; a.counts = counts; a.alpha = alpha; a.B = B; a.N = N; a.Mmax = Mmax; a.C = C;
+    for (int k = 0; k < 5; ++k) a.w[k] = weights5[k];
+    return DPFT_OK;
+}
+
+extern "C" int dpft_set_loss_fwd_f32(const float* cls, const float* center, const float* size, const float* angle,
+                                     const float* gt_box, const float* gt_onehot, const int32_t* match,
+                                     const int32_t* counts, const float* weights5, float alpha, float* losses5,
+                                     int32_t B, int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream) {
+    LossArgs a;
+    int rc = loss_fill(a, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, B, N, Mmax, C);
+    if (rc) return rc;
+    DPFT_REQUIRE(losses5, "set_loss_fwd: null output");
+    a.losses = losses5;
+    DPFT_REQUIRE(hipMemsetAsync(losses5, 0, 5 * sizeof(float), (hipStream_t)stream) == hipSuccess, "set_loss_fwd: memset failed");
+    hipLaunchKernelGGL(set_loss_kernel<false>, dim3(cdiv((int64_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("set_loss_fwd");
+}
+
+extern "C" int dpft_set_loss_bwd_f32(const float* cls, const float* center, const float* size, const float* angle,
+                                     const float* gt_box, const float* gt_onehot, const int32_t* match,
+                                     const int32_t* counts, const float* weights5, float alpha, const float* gout5,
+                                     float* dcls, float* dcenter, float* dsize, float* dangle, int32_t B, int32_t N,
+                                     int32_t Mmax, int32_t C, dpft_stream_t stream) {
+    LossArgs a;
+    int rc = loss_fill(a, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, B, N, Mmax, C);
+    if (rc) return rc;
+    DPFT_REQUIRE(gout5 && dcls && dcenter && dsize && dangle, "set_loss_bwd: null argument");
+    a.gout = gout5; a.dcls = dcls; a.dcenter = dcenter; a.dsize = dsize; a.dangle = dangle;
+    hipLaunchKernelGGL(set_loss_kernel<true>, dim3(cdiv((int64_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("set_loss_bwd");
 }

@@ -118,6 +118,9 @@ SIGNATURES = {
     "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _I, _I, _P]),
     "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
+    "dpft_match_cost_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _P, _I, _I, _I, _I, _P]),
+    "dpft_set_loss_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _I, _I, _I, _I, _P]),
+    "dpft_set_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),

@@ -136,6 +136,42 @@ class SetCriterion(nn.Module):
                 for name, fn in self.losses.items()}
 
 
+class _SetLossFn(torch.autograd.Function):
+    """dpft_set_loss_fwd/bwd_f32: the five batch-reduced, weighted criterion terms for fixed assignments."""
+
+    @staticmethod
+    def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha):
+        import ctypes as C
+        from dpft_amd.hip.lib import lib, stream
+        B, N, ncls = cls.shape
+        Mmax = gt_box.shape[1]
+        losses = torch.empty(5, dtype=torch.float32, device=cls.device)
+        w = (C.c_float * 5)(*weights5)
+        lib.call("dpft_set_loss_fwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
+                 losses.data_ptr(), B, N, Mmax, ncls, stream())
+        ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts)
+        ctx.meta = (weights5, float(alpha))
+        return losses
+
+    @staticmethod
+    def backward(ctx, gout):
+        import ctypes as C
+        from dpft_amd.hip.lib import lib, stream
+        cls, center, size, angle, gt_box, gt_onehot, match, counts = ctx.saved_tensors
+        weights5, alpha = ctx.meta
+        B, N, ncls = cls.shape
+        Mmax = gt_box.shape[1]
+        gout = gout.contiguous().float()
+        dcls, dcenter, dsize, dangle = (torch.empty_like(t) for t in (cls, center, size, angle))
+        w = (C.c_float * 5)(*weights5)
+        lib.call("dpft_set_loss_bwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), alpha,
+                 gout.data_ptr(), dcls.data_ptr(), dcenter.data_ptr(), dsize.data_ptr(), dangle.data_ptr(), B, N, Mmax,
+                 ncls, stream())
+        return dcls, dcenter, dsize, dangle, None, None, None, None, None, None
+
+
 class Loss(nn.modules.loss._Loss):
     def __init__(self, anassigner: nn.Module = None, criterion: nn.Module = None, loss_weights: Dict[str, float] = None,
                  reduction: str = "mean", **kwargs):
@@ -155,7 +191,64 @@ class Loss(nn.modules.loss._Loss):
         return cls(anassigner=HungarianAnassigner.from_config(config), criterion=SetCriterion(),
                    loss_weights=config.get("loss_weights"), reduction=config.get("reduction", "mean"))
 
+    use_fused = True      # CUDA: matcher cost, criterion and its gradient from 3 HIP kernels (dpft_amd/csrc/misc.hip)
+    _TERMS = ("total_class", "object_class", "center", "size", "angle")
+
+    def _fused_ok(self, inputs) -> bool:
+        return (self.use_fused and inputs["class"].is_cuda and self.reduction == "mean"
+                and isinstance(self.anassigner, HungarianAnassigner) and isinstance(self.criterion, SetCriterion)
+                and set(self.loss_weights) <= set(self._TERMS) and inputs["class"].dtype == torch.float32)
+
+    def forward_fused(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
+        """Same values as ``forward_eager`` from three launches + the host assignment (one D2H, one H2D copy)."""
+        import ctypes as C
+        from torch.nn.utils.rnn import pad_sequence
+        from dpft_amd.hip.lib import lib, stream
+        cls, center = inputs["class"].contiguous(), inputs["center"].contiguous()
+        size, angle = inputs["size"].contiguous(), inputs["angle"].contiguous()
+        B, N, ncls = cls.shape
+        dev = cls.device
+        counts = [int(t["gt_class"].shape[0]) if all(v.numel() for v in t.values()) else 0 for t in targets]
+        if max(counts) == 0:
+            zero = torch.zeros((), device=dev, dtype=cls.dtype, requires_grad=True)
+            return zero * 1.0, {k: zero for k in self.loss_weights}
+        Mmax = max(counts)
+        empty8, emptyc = cls.new_zeros((0, 8)), cls.new_zeros((0, ncls))
+        boxes = [torch.cat((t["gt_center"], t["gt_size"], t["gt_angle"]), -1).float() if m else empty8
+                 for t, m in zip(targets, counts)]
+        gt_box = pad_sequence(boxes, batch_first=True).contiguous()                          # (B,Mmax,8)
+        gt_onehot = pad_sequence([t["gt_class"].float() if m else emptyc for t, m in zip(targets, counts)],
+                                 batch_first=True).contiguous()                              # (B,Mmax,C)
+        gt_id = gt_onehot.argmax(-1).to(torch.int32).contiguous()
+        counts_t = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
+        aw = self.anassigner.loss_weights
+        cw = (C.c_float * 5)(aw["total_class"], aw["center"], aw["size"], aw["angle"], self.anassigner.giou_weight)
+        cost = torch.empty((B, N, Mmax), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            lib.call("dpft_match_cost_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+                     gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
+                     ncls, stream())
+        host = cost.cpu().numpy()                                                             # the one sync of the step
+        match = np.full((B, Mmax, 2), -1, dtype=np.int32)
+        for b, m in enumerate(counts):
+            if m:
+                i, j = linear_sum_assignment(host[b, :, :m])
+                match[b, :len(i), 0], match[b, :len(i), 1] = i, j
+                counts[b] = len(i)           # min(N, m) assigned pairs
+        match_t = torch.from_numpy(match).to(dev, non_blocking=True)
+        counts_m = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
+        weights5 = tuple(float(self.loss_weights.get(k, 0.0)) for k in self._TERMS)
+        losses5 = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75)
+        batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}
+        total = torch.stack(tuple(batch_losses.values())).sum(dim=-1)
+        return total, batch_losses
+
     def forward(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
+        if self._fused_ok(inputs):
+            return self.forward_fused(inputs, targets)
+        return self.forward_eager(inputs, targets)
+
+    def forward_eager(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
         """-> (total_loss, {name: batch-reduced loss}) exactly like loss.py:486-564."""
         dev, dtype = inputs["class"].device, inputs["class"].dtype
         matches = self.anassigner(inputs, targets)

@@ -366,6 +366,31 @@ int dpft_head_train_bwd_f32(const dpft_head_train* h, int32_t B, int32_t Q, int3
 int dpft_giou3d_yaw_f32(const float* pred, const float* gt, float* out, int32_t B, int32_t N,
                         int32_t Mg, dpft_stream_t stream);
 
+/* Whole matcher cost (src/dprt/training/assigner.py:113-132) in one launch:
+ * cost[b,n,j] = w0*(-cls[b,n,gt_id[b,j]]) + w1*L1(center) + w2*L1(size) + w3*L1(angle) - w4*GIoU3D, 0 for j >= counts[b].
+ * gt_box (B,Mmax,8) = center | size | angle(2); weights5 is a HOST array. */
+int dpft_match_cost_f32(const float* cls, const float* center, const float* size, const float* angle,
+                        const float* gt_box, const int32_t* gt_id, const int32_t* counts,
+                        const float* weights5, float* cost, int32_t B, int32_t N, int32_t Mmax, int32_t C,
+                        dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * SetCriterion + batch reduction 'mean' (src/dprt/training/loss.py:17-60 focal loss with the raw-logit p_t,
+ * :176-373 criterion, :486-564 weighting / reduction) for given assignments.
+ * losses5 = batch-reduced, weighted (total_class, object_class, center, size, angle); match (B,Mmax,2) int32 =
+ * (query, target) pairs in assignment order; weights5 (HOST array) in the same term order; gout5 (DEVICE) = upstream
+ * gradient per term.  The backward writes d(sum_k gout5[k]*losses5[k]) / d{cls,center,size,angle}.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_set_loss_fwd_f32(const float* cls, const float* center, const float* size, const float* angle,
+                          const float* gt_box, const float* gt_onehot, const int32_t* match,
+                          const int32_t* counts, const float* weights5, float alpha, float* losses5,
+                          int32_t B, int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
+int dpft_set_loss_bwd_f32(const float* cls, const float* center, const float* size, const float* angle,
+                          const float* gt_box, const float* gt_onehot, const int32_t* match,
+                          const int32_t* counts, const float* weights5, float alpha, const float* gout5,
+                          float* dcls, float* dcenter, float* dsize, float* dangle, int32_t B, int32_t N,
+                          int32_t Mmax, int32_t C, dpft_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW (torch.optim.AdamW semantics: decoupled decay, bias correction, no amsgrad),
  * the optimizer the reference builds at src/dprt/training/trainer.py:233 / optimizer.py:6-7.

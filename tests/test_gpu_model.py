@@ -251,6 +251,14 @@ def test_loss_and_matcher_match_oracle():
     total.backward()
     for k in out:
         close(dev_out[k].grad, ref_out[k].grad, rtol=1e-4, what=f"dloss/d{k}")
+    # the fused kernels (default on the GPU) against the torch-op path of the same module
+    assert loss_fn._fused_ok(dev_out)
+    eag_out = {k: v.to(DEV).requires_grad_(True) for k, v in out.items()}
+    e_total, e_losses = loss_fn.forward_eager(eag_out, dev_labels)
+    e_total.backward()
+    close(total, e_total, rtol=1e-5, what="fused vs eager total")
+    for k in out:
+        close(dev_out[k].grad, eag_out[k].grad, rtol=1e-4, what=f"fused vs eager dloss/d{k}")
 
 
 def test_fused_adamw_matches_torch():
