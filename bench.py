@@ -178,6 +178,7 @@ def main():
                 "frac": tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
                 "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family)",
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * tot_t / max(n_launch, 1),
+                "event_bracket_overhead_us_subtracted": 1e3 * float(ops.lib.dpft_profile_overhead_ms()),
                 "conv_ms_per_step": 1e3 * tot_t, "algorithmic_gflop_per_step": tot_f / 1e9,
                 "per_kind_tflops": {k: v[0] / v[1] / 1e12 for k, v in per_kind.items()}}
 

@@ -1170,12 +1170,40 @@ extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t
     return check_launch("bias_grad");
 }
 
+static float g_prof_overhead_ms = 0.f;      // elapsed time of an EMPTY event bracket (subtracted from every record)
+
 extern "C" int dpft_profile_start(void) {
     for (auto& r : g_prof) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     g_prof.clear();
+    // calibrate the bracket itself: two back-to-back event records cost a few us of queue time that is not the
+    // kernel's (rocprofv3's per-kernel durations do not contain it)
+    {
+        hipStream_t st;
+        if (hipStreamCreate(&st) == hipSuccess) {
+            float samples[15];
+            int n = 0;
+            for (int i = 0; i < 15; ++i) {
+                hipEvent_t a, b;
+                if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) break;
+                (void)hipEventRecord(a, st);
+                (void)hipEventRecord(b, st);
+                float ms = 0.f;
+                if (hipEventSynchronize(b) == hipSuccess && hipEventElapsedTime(&ms, a, b) == hipSuccess) samples[n++] = ms;
+                (void)hipEventDestroy(a);
+                (void)hipEventDestroy(b);
+            }
+            (void)hipStreamDestroy(st);
+            if (n > 0) {
+                std::sort(samples, samples + n);
+                g_prof_overhead_ms = samples[n / 2];
+            }
+        }
+    }
     g_prof_on = true;
     return DPFT_OK;
 }
+
+extern "C" float dpft_profile_overhead_ms(void) { return g_prof_overhead_ms; }
 
 extern "C" int32_t dpft_profile_stop(void) {
     g_prof_on = false;
@@ -1191,6 +1219,7 @@ extern "C" int dpft_profile_get(int32_t i, int32_t* kind, double* flops, float* 
         set_error("profile_get: events not complete (synchronise the stream first)");
         return DPFT_ERR_LAUNCH;
     }
+    *ms = fmaxf(*ms - g_prof_overhead_ms, 0.f);
     memcpy(shape7, r.shape, sizeof(r.shape));
     return DPFT_OK;
 }

@@ -406,6 +406,8 @@ int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, 
  * ---------------------------------------------------------------------------------------- */
 int dpft_profile_start(void);
 int32_t dpft_profile_stop(void);                 /* -> number of recorded launches */
+float dpft_profile_overhead_ms(void);            /* elapsed time of an empty event bracket, calibrated by
+                                                    dpft_profile_start and already subtracted by dpft_profile_get */
 /* kind 0 fwd / 1 dgrad / 2 wgrad; flops = algorithmic 2*M*K*kh*kw*C; ms = event-timed duration;
  * shape7 = B,H,W,C,K,k,stride.  The stream must have been synchronised. */
 int dpft_profile_get(int32_t i, int32_t* kind, double* flops, float* ms, int32_t* shape7);
