@@ -51,8 +51,20 @@ struct ResnetPlan {
     size_t g_off[2];
     size_t gmax;            // floats of the largest activation gradient
     size_t o_dy, o_da, o_dd, o_wt, o_sums;   // backward scratch offsets (floats)
+    size_t o_dy2;           // second dy buffer: weight gradients run on a side stream while the data path moves on
     int g_cur;
     bool g_valid;
+    // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
+    int dyi = 0;
+    ~ResnetPlan() {
+        if (side) (void)hipStreamDestroy(side);
+        if (ev_ready) (void)hipEventDestroy(ev_ready);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        for (auto& e : ev_done)
+            if (e) (void)hipEventDestroy(e);
+    }
 };
 
 static size_t align64(size_t f) { return (f + 63) & ~(size_t)63; }
@@ -176,12 +188,13 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     wmax = std::max(wmax, nelem_w(p->c0.d));
     p->bwd_floats = off;   // start of scratch
     p->o_dy = take(gmax);
+    p->o_dy2 = take(gmax);
     p->o_da = take(gmax);
     p->o_dd = take(gmax);
     p->o_wt = take(wmax);
     p->o_sums = take(2 * 2048);
     p->ws_bytes = wsb;
-    p->arena_bytes = off * sizeof(float) + wsb + 256;
+    p->arena_bytes = off * sizeof(float) + 2 * wsb + 384;      // two split-K workspaces (main / side stream)
     p->g_valid = false;
     p->g_cur = 0;
     return (int64_t)(intptr_t)p;
@@ -239,7 +252,7 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
     DPFT_REQUIRE(p && x && tables && arena, "resnet_forward: null argument");
     Tables T{tables};
     float* A = (float*)arena;
-    void* ws = (char*)arena + (p->arena_bytes - p->ws_bytes - 128);
+    void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
     const bool tr = train != 0;
     const float* xa = x;
     if (p->adj.w >= 0) {
@@ -278,38 +291,86 @@ static int bn_backward(const float* y, const float* dout, const float* out, cons
     return dpft_bn_bwd_apply_f32(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, st);
 }
 
-static int block_backward(const ResnetPlan* p, const BlockPlan& b, const Tables& T, float* A, void* ws, const float* gp,
-                          float* dx, dpft_stream_t st) {
-    float* dyb = A + p->o_dy;
+// Weight gradients do not feed the rest of the backward, so they run on the plan's side stream while the main
+// stream continues with the data-gradient chain (mid/late layers launch < 2 workgroups per CU: two kernels in
+// flight share the chip).  dy buffers alternate (dy / dy2 / dyd) and each has an event "last wgrad that read it
+// is done" which the main stream waits on before overwriting the buffer.
+struct SideCtx {
+    ResnetPlan* p;
+    hipStream_t main;
+    void* ws2;
+    int init() {
+        if (!p->side) {
+            DPFT_REQUIRE(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess, "resnet_backward: side stream");
+            DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
+            DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
+            for (auto& e : p->ev_done)
+                DPFT_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
+        }
+        return DPFT_OK;
+    }
+    // main stream is about to overwrite dy buffer `slot`
+    int acquire(int slot) {
+        DPFT_REQUIRE(hipStreamWaitEvent(main, p->ev_done[slot], 0) == hipSuccess, "resnet_backward: wait event");
+        return DPFT_OK;
+    }
+    // dy buffer `slot` is complete on the main stream: launch the weight gradient that reads it on the side stream
+    int wgrad(int slot, const dpft_conv_desc* d, const float* x, const float* dy, const float* pro, int relu, float* dw) {
+        DPFT_REQUIRE(hipEventRecord(p->ev_ready, main) == hipSuccess, "resnet_backward: record event");
+        DPFT_REQUIRE(hipStreamWaitEvent(p->side, p->ev_ready, 0) == hipSuccess, "resnet_backward: wait event");
+        RC(dpft_conv2d_nhwc_wgrad_f32(d, x, dy, pro, relu, dw, ws2, (dpft_stream_t)p->side));
+        DPFT_REQUIRE(hipEventRecord(p->ev_done[slot], p->side) == hipSuccess, "resnet_backward: record event");
+        return DPFT_OK;
+    }
+    // everything queued on the side stream is ordered before what follows on the main stream
+    int join() {
+        DPFT_REQUIRE(hipEventRecord(p->ev_join, p->side) == hipSuccess, "resnet_backward: record event");
+        DPFT_REQUIRE(hipStreamWaitEvent(main, p->ev_join, 0) == hipSuccess, "resnet_backward: wait event");
+        return DPFT_OK;
+    }
+};
+
+static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, float* A, void* ws, SideCtx& sc,
+                          const float* gp, float* dx, dpft_stream_t st) {
+    float* dyv[2] = {A + p->o_dy, A + p->o_dy2};
     float* dab = A + p->o_da;
     float* dyd = A + p->o_dd;
     float* wt = A + p->o_wt;
     float* sums = A + p->o_sums;
     const int planes = b.c1.d.K, K3 = b.c3.d.K, inC = b.c1.d.C;
     const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
+    int& cur = p->dyi;
     // bn3 (+ the residual ReLU mask taken from the block output)
-    RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyb, T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st));
-    RC(dpft_conv2d_nhwc_wgrad_f32(&b.c3.d, A + b.y2, dyb, A + b.p2, 1, T.dw(b.c3.w), ws, st));
+    RC(sc.acquire(cur));
+    RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st));
+    RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
     RC(dpft_weight_transpose_f32(T.w(b.c3.w), wt, K3, 1, planes, st));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyb, wt, dab, 0, ws, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyv[cur], wt, dab, 0, ws, st));
+    cur ^= 1;
     // bn2 (fused-ReLU mask recomputed from its BN block)
-    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyb, T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st));
-    RC(dpft_conv2d_nhwc_wgrad_f32(&b.c2.d, A + b.y1, dyb, A + b.p1, 1, T.dw(b.c2.w), ws, st));
+    RC(sc.acquire(cur));
+    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st));
+    RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
     RC(dpft_weight_transpose_f32(T.w(b.c2.w), wt, planes, 9, planes, st));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyb, wt, dab, 0, ws, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyv[cur], wt, dab, 0, ws, st));
+    cur ^= 1;
     // bn1
-    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyb, T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st));
-    RC(dpft_conv2d_nhwc_wgrad_f32(&b.c1.d, A + b.x, dyb, nullptr, 0, T.dw(b.c1.w), ws, st));
+    RC(sc.acquire(cur));
+    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyv[cur], T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st));
+    RC(sc.wgrad(cur, &b.c1.d, A + b.x, dyv[cur], nullptr, 0, T.dw(b.c1.w)));
     if (b.has_ds) {
+        RC(sc.acquire(2));
         RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st));
-        RC(dpft_conv2d_nhwc_wgrad_f32(&b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w), ws, st));
+        RC(sc.wgrad(2, &b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w)));
         RC(dpft_weight_transpose_f32(T.w(b.cd.w), wt, K3, 1, inC, st));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt, dx, 0, ws, st));
     } else {
         RC(dpft_relu_bwd_f32(gp, A + b.out, dx, M2 * K3, st));      // identity branch: dz = dout * (out > 0)
     }
     RC(dpft_weight_transpose_f32(T.w(b.c1.w), wt, planes, 1, inC, st));
-    return dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyb, wt, dx, 1, ws, st);
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt, dx, 1, ws, st));
+    cur ^= 1;
+    return DPFT_OK;
 }
 
 }  // namespace dpft
@@ -324,7 +385,9 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
     DPFT_REQUIRE(stage >= 0 && stage < p->desc.n_layers, "resnet_backward: bad stage %d", stage);
     Tables T{tables};
     float* A = (float*)arena;
-    void* ws = (char*)arena + (p->arena_bytes - p->ws_bytes - 128);
+    void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
+    SideCtx sc{p, (hipStream_t)st, (char*)arena + (p->arena_bytes - p->ws_bytes - 128)};
+    RC(sc.init());
     const size_t out_n = (size_t)p->out_shape[stage][0] * p->out_shape[stage][1] * p->out_shape[stage][2] * p->out_shape[stage][3];
     const float* gp;
     if (!p->g_valid) {
@@ -343,23 +406,26 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         const BlockPlan& b = p->blocks[i];
         if (b.layer != stage) continue;
         float* dx = A + p->g_off[p->g_cur ^ 1];
-        RC(block_backward(p, b, T, A, ws, gp, dx, st));
+        RC(block_backward(p, b, T, A, ws, sc, gp, dx, st));
         p->g_cur ^= 1;
         gp = dx;
     }
     p->g_valid = true;
     if (stage == 0) {
         // stem: maxpool + ReLU + bn1 + conv1 (+ the 1x1 adjustment conv of the radar views)
-        float* dyb = A + p->o_dy;
         float* dab = A + p->o_da;
         float* wt = A + p->o_wt;
         float* sums = A + p->o_sums;
         const dpft_conv_desc& d0 = p->c0.d;
         const int64_t M0 = (int64_t)d0.B * d0.OH * d0.OW;
+        const int slot = p->dyi;
+        float* dyb = A + (slot ? p->o_dy2 : p->o_dy);
         RC(dpft_bn_relu_maxpool_bwd_f32(A + p->y0, A + p->p0, gp, dab, d0.B, d0.OH, d0.OW, 64, p->PH, p->PW, st));
+        RC(sc.acquire(slot));
         RC(bn_backward(A + p->y0, dab, nullptr, nullptr, A + p->p0, T.gamma(p->bn0), sums, dyb, T.dgamma(p->bn0), T.dbeta(p->bn0), M0, 64, st));
         const float* xa = p->adj.w >= 0 ? A + p->xa : x;
-        RC(dpft_conv2d_nhwc_wgrad_f32(&d0, xa, dyb, nullptr, 0, T.dw(p->c0.w), ws, st));
+        RC(sc.wgrad(slot, &d0, xa, dyb, nullptr, 0, T.dw(p->c0.w)));
+        p->dyi ^= 1;
         if (p->adj.w >= 0) {
             RC(dpft_weight_transpose_f32(T.w(p->c0.w), wt, 64, 49, 3, st));
             RC(dpft_conv2d_nhwc_dgrad_f32(&d0, dyb, wt, dab, 0, ws, st));
@@ -367,5 +433,5 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         }
         p->g_valid = false;
     }
-    return DPFT_OK;
+    return sc.join();      // parameter gradients of this stage are complete for whatever follows on `st`
 }
