@@ -3,6 +3,7 @@
 // (reference call sites: src/dprt/models/backbones/resnet.py:54-55, src/dprt/models/necks/fpn.py:39-43)
 // and the in-place sinusoidal embedding add (src/dprt/models/embeddings/sinusoidal.py:107-108).
 #include "common.h"
+#include <stdlib.h>
 
 #include <algorithm>
 
@@ -229,15 +230,16 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                              const float* __restrict__ outp, const float* __restrict__ mbnp,
                                                              const float* __restrict__ bnp, float* __restrict__ sums,
-                                                             int64_t M, int K, int rows_per_block) {
+                                                             int64_t M, int K, int rows_per_block, int slab) {
     __shared__ float red0[256 * 4];
     __shared__ float red1[256 * 4];
     const int K4 = K / 4;
-    // slab of up to 256 float4-chunks of channels per blockIdx.y
-    const int kc = min(K4 - (int)blockIdx.y * 256, 256);
+    // slab of up to `slab` float4-chunks of channels per blockIdx.y (narrow slabs = many row groups per block =
+    // few atomics per block and low contention per accumulator)
+    const int kc = min(K4 - (int)blockIdx.y * slab, slab);
     const int groups = 256 / kc;
     const int cl = threadIdx.x % kc, g = threadIdx.x / kc;
-    const int c4 = blockIdx.y * 256 + cl;
+    const int c4 = blockIdx.y * slab + cl;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = min(M, r0 + rows_per_block);
     f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
@@ -512,14 +514,17 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
     hipStream_t st = (hipStream_t)stream;
     (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * K, st);
     const int K4 = K / 4;
-    const int slabs = cdiv(K4, 256);
-    const int kc = std::min(K4, 256);
-    const int groups = 256 / kc;
-    const int want_blocks = std::max(1, (kNumCU * 2) / slabs);
-    int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 8, (M + want_blocks - 1) / want_blocks);
+    // Tuned on MI355X (tools/bn_bench.py): 128 B wide channel slabs (8 float4) => 32 row groups per block and only
+    // 64 accumulators per block; at most 64 blocks per slab keeps the fp32 atomics on one accumulator <= 64-deep
+    // (the first version -- every block covering all K channels, 512 blocks -- spent most of its time in atomics).
+    const int slab = std::min(K4, 8);
+    const int slabs = cdiv(K4, slab);
+    const int groups = 256 / slab;
+    const int want_blocks = std::min(64, std::max(1, (kNumCU * 4) / slabs));
+    int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 4, (M + want_blocks - 1) / want_blocks);
     dim3 grid(cdiv(M, rows_per_block), slabs);
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
-                       (int)rows_per_block);
+                       (int)rows_per_block, slab);
     return check_launch("bn_bwd_reduce");
 }
 
