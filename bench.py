@@ -157,9 +157,13 @@ def main():
     roof, per_kind = None, {}
     if rank == 0:
         torch.cuda.synchronize()
+        # one serialized step (no concurrent view streams, no side-stream weight gradients): every conv launch is
+        # bracketed by HIP events and runs alone, so its duration is the kernel's, not its share of a busy device
+        trainer.model.concurrent_views = False
         ops.profile_start()
         trainer.train_step(data, labels)
         recs = ops.profile_collect()
+        trainer.model.concurrent_views = True
         tot_f, tot_t = 0.0, 0.0
         shapes = {}
         for kind, flops, dt, shape in recs:
@@ -174,8 +178,13 @@ def main():
                 for key, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f}\n")
         n_launch = sum(k[2] for k in per_kind.values())
+        traffic = None      # HBM bytes per conv launch from the committed PMC passes (tools/pmc_traffic.sh)
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic_pmc.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                traffic = json.load(f).get("traffic_bytes_per_launch")
         roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+                "frac": tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
                 "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family)",
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * tot_t / max(n_launch, 1),
                 "event_bracket_overhead_us_subtracted": 1e3 * float(ops.lib.dpft_profile_overhead_ms()),

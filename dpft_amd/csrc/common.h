@@ -13,6 +13,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace dpft {
 
 void set_error(const char* fmt, ...);
+bool profiling_active();      // conv.hip: true between dpft_profile_start / dpft_profile_stop
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

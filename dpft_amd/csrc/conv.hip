@@ -844,6 +844,7 @@ struct ProfRec {
     int shape[7];        // B,H,W,C,K,k,stride
 };
 static bool g_prof_on = false;
+bool profiling_active() { return g_prof_on; }      // resnet_plan: keep everything on one stream while timing
 static std::vector<ProfRec> g_prof;
 
 struct ProfScope {

@@ -316,6 +316,8 @@ struct SideCtx {
     }
     // dy buffer `slot` is complete on the main stream: launch the weight gradient that reads it on the side stream
     int wgrad(int slot, const dpft_conv_desc* d, const float* x, const float* dy, const float* pro, int relu, float* dw) {
+        if (profiling_active())      // per-launch event timing wants each kernel alone on the device
+            return dpft_conv2d_nhwc_wgrad_f32(d, x, dy, pro, relu, dw, ws2, (dpft_stream_t)main);
         DPFT_REQUIRE(hipEventRecord(p->ev_ready, main) == hipSuccess, "resnet_backward: record event");
         DPFT_REQUIRE(hipStreamWaitEvent(p->side, p->ev_ready, 0) == hipSuccess, "resnet_backward: wait event");
         RC(dpft_conv2d_nhwc_wgrad_f32(d, x, dy, pro, relu, dw, ws2, (dpft_stream_t)p->side));
