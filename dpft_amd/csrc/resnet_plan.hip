@@ -17,6 +17,7 @@ namespace dpft {
 struct ConvRef {
     dpft_conv_desc d;
     int w;  // index into the conv table
+    size_t wt = 0;  // float offset (inside the wt region) of this conv's transposed weights during its stage's backward
 };
 
 struct BlockPlan {
@@ -56,12 +57,13 @@ struct ResnetPlan {
     bool g_valid;
     // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
     hipStream_t side = nullptr;
-    hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr;
+    hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr, ev_wt = nullptr;
     int dyi = 0;
     ~ResnetPlan() {
         if (side) (void)hipStreamDestroy(side);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_wt) (void)hipEventDestroy(ev_wt);
         for (auto& e : ev_done)
             if (e) (void)hipEventDestroy(e);
     }
@@ -179,13 +181,21 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     p->gmax = gmax;
     p->g_off[0] = take(gmax);
     p->g_off[1] = take(gmax);
-    // scratch: dy (gmax) + da (gmax) + dyd (gmax) + weight transpose (max weight) + bn sums
-    size_t wmax = 0;
-    for (auto& b : p->blocks) {
-        wmax = std::max(wmax, nelem_w(b.c1.d)); wmax = std::max(wmax, nelem_w(b.c2.d)); wmax = std::max(wmax, nelem_w(b.c3.d));
-        if (b.has_ds) wmax = std::max(wmax, nelem_w(b.cd.d));
+    // scratch: dy (2 x gmax) + da (gmax) + dyd (gmax) + transposed weights of one whole stage + bn sums.  The
+    // transposes of a stage are queued on the side stream at the start of that stage's backward (they only depend on
+    // the weights), so they are off the data-gradient chain.
+    size_t wmax = nelem_w(p->c0.d);
+    for (int li = 0; li < p->desc.n_layers; ++li) {
+        size_t acc = 0;
+        for (auto& b : p->blocks) {
+            if (b.layer != li) continue;
+            b.c1.wt = acc; acc += align64(nelem_w(b.c1.d));
+            b.c2.wt = acc; acc += align64(nelem_w(b.c2.d));
+            b.c3.wt = acc; acc += align64(nelem_w(b.c3.d));
+            if (b.has_ds) { b.cd.wt = acc; acc += align64(nelem_w(b.cd.d)); }
+        }
+        wmax = std::max(wmax, acc);
     }
-    wmax = std::max(wmax, nelem_w(p->c0.d));
     p->bwd_floats = off;   // start of scratch
     p->o_dy = take(gmax);
     p->o_dy2 = take(gmax);
@@ -304,6 +314,7 @@ struct SideCtx {
             DPFT_REQUIRE(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess, "resnet_backward: side stream");
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
+            DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_wt, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
             for (auto& e : p->ev_done)
                 DPFT_REQUIRE(hipEventCreateWithFlags(&e, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
         }
@@ -324,6 +335,26 @@ struct SideCtx {
         DPFT_REQUIRE(hipEventRecord(p->ev_done[slot], p->side) == hipSuccess, "resnet_backward: record event");
         return DPFT_OK;
     }
+    // transposed copies [I][kh][kw][O] of every conv weight of `stage` (the dgrad operand) on the side stream; the
+    // main stream waits for them once.  The previous stage's dgrads (main stream) must be done with the region first.
+    int transposes(const Tables& T, float* wt_base, int stage) {
+        hipStream_t ts = profiling_active() ? main : p->side;
+        if (ts != main) {
+            DPFT_REQUIRE(hipEventRecord(p->ev_ready, main) == hipSuccess, "resnet_backward: record event");
+            DPFT_REQUIRE(hipStreamWaitEvent(ts, p->ev_ready, 0) == hipSuccess, "resnet_backward: wait event");
+        }
+        for (auto& b : p->blocks) {
+            if (b.layer != stage) continue;
+            const ConvRef* cs[4] = {&b.c3, &b.c2, &b.c1, b.has_ds ? &b.cd : nullptr};
+            for (const ConvRef* c : cs)
+                if (c) RC(dpft_weight_transpose_f32(T.w(c->w), wt_base + c->wt, c->d.K, c->d.kh * c->d.kw, c->d.C, (dpft_stream_t)ts));
+        }
+        if (ts != main) {
+            DPFT_REQUIRE(hipEventRecord(p->ev_wt, ts) == hipSuccess, "resnet_backward: record event");
+            DPFT_REQUIRE(hipStreamWaitEvent(main, p->ev_wt, 0) == hipSuccess, "resnet_backward: wait event");
+        }
+        return DPFT_OK;
+    }
     // everything queued on the side stream is ordered before what follows on the main stream
     int join() {
         DPFT_REQUIRE(hipEventRecord(p->ev_join, p->side) == hipSuccess, "resnet_backward: record event");
@@ -339,22 +370,20 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     float* dyd = A + p->o_dd;
     float* wt = A + p->o_wt;
     float* sums = A + p->o_sums;
-    const int planes = b.c1.d.K, K3 = b.c3.d.K, inC = b.c1.d.C;
+    const int planes = b.c1.d.K, K3 = b.c3.d.K;
     const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
     int& cur = p->dyi;
     // bn3 (+ the residual ReLU mask taken from the block output)
     RC(sc.acquire(cur));
     RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st));
     RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
-    RC(dpft_weight_transpose_f32(T.w(b.c3.w), wt, K3, 1, planes, st));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyv[cur], wt, dab, 0, ws, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyv[cur], wt + b.c3.wt, dab, 0, ws, st));
     cur ^= 1;
     // bn2 (fused-ReLU mask recomputed from its BN block)
     RC(sc.acquire(cur));
     RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st));
     RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
-    RC(dpft_weight_transpose_f32(T.w(b.c2.w), wt, planes, 9, planes, st));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyv[cur], wt, dab, 0, ws, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyv[cur], wt + b.c2.wt, dab, 0, ws, st));
     cur ^= 1;
     // bn1
     RC(sc.acquire(cur));
@@ -364,13 +393,11 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
         RC(sc.acquire(2));
         RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st));
         RC(sc.wgrad(2, &b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w)));
-        RC(dpft_weight_transpose_f32(T.w(b.cd.w), wt, K3, 1, inC, st));
-        RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt, dx, 0, ws, st));
+        RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt + b.cd.wt, dx, 0, ws, st));
     } else {
         RC(dpft_relu_bwd_f32(gp, A + b.out, dx, M2 * K3, st));      // identity branch: dz = dout * (out > 0)
     }
-    RC(dpft_weight_transpose_f32(T.w(b.c1.w), wt, planes, 1, inC, st));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt, dx, 1, ws, st));
+    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st));
     cur ^= 1;
     return DPFT_OK;
 }
@@ -404,6 +431,7 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         if (dout) RC(dpft_add_inplace_f32(A + p->g_off[p->g_cur], dout, (int64_t)out_n, st));
         gp = A + p->g_off[p->g_cur];
     }
+    RC(sc.transposes(T, A + p->o_wt, stage));
     for (int i = (int)p->blocks.size() - 1; i >= 0; --i) {
         const BlockPlan& b = p->blocks[i];
         if (b.layer != stage) continue;
