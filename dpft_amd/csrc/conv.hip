@@ -53,7 +53,22 @@ struct IgemmArgs {
     int mtiles, ntiles, splits, ksteps, ksteps_per_split;
     int pro_relu;
     int accumulate;   // y += result (dgrad into an existing gradient)
+    // dgrad of a strided conv as one launch per output-pixel parity class (sub_step = stride > 1): rows enumerate the
+    // sub_oh x sub_ow output pixels (oh, ow) = (sub_step*i + sub_ph, sub_step*j + sub_pw) and only the taps
+    // r = sub_r0 + sub_step*k, s = sub_s0 + sub_step*l can hit them (all others fall between the dy samples).
+    // A plain launch over all pixels and taps would spend stride^2 = 4x the MFMA work on structural zeros.
+    int sub_step, sub_ph, sub_pw, sub_oh, sub_ow, sub_r0, sub_s0, sub_nr, sub_ns;
 };
+
+// output row (GEMM row m) -> pixel index of the output tensor
+__device__ __forceinline__ size_t out_pixel(const IgemmArgs& a, int m) {
+    if (a.sub_step <= 1) return (size_t)m;
+    const int per = a.sub_oh * a.sub_ow;
+    const int b = m / per;
+    const int rem = m - b * per;
+    const int i = rem / a.sub_ow, j = rem - i * a.sub_ow;
+    return ((size_t)b * a.OH + (size_t)i * a.sub_step + a.sub_ph) * a.OW + (size_t)j * a.sub_step + a.sub_pw;
+}
 
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: store accumulators (+bias), optional split-K partial, optional BN tile stats
@@ -145,7 +160,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 const int row = idx / C4, c4 = idx - row * C4;
                 old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N)
-                    old[it] = *reinterpret_cast<const f32x4*>(out + (size_t)(m0 + row) * a.N + n0 + c4 * 4);
+                    old[it] = *reinterpret_cast<const f32x4*>(out + out_pixel(a, m0 + row) * a.N + n0 + c4 * 4);
             }
         }
 #pragma unroll
@@ -156,7 +171,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
                 if (add_bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + c4 * 4);
                 if (accum) v += old[it];
-                *reinterpret_cast<f32x4*>(out + (size_t)(m0 + row) * a.N + n0 + c4 * 4) = v;
+                *reinterpret_cast<f32x4*>(out + out_pixel(a, m0 + row) * a.N + n0 + c4 * 4) = v;
             }
         }
     } else {
@@ -165,7 +180,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             if (m0 + row < a.M && n0 + c < a.N) {
                 float v = Cs[row * LDC + c];
                 if (add_bias) v += a.bias[n0 + c];
-                float* o = out + (size_t)(m0 + row) * a.N + n0 + c;
+                float* o = out + out_pixel(a, m0 + row) * a.N + n0 + c;
                 if (accum) v += *o;
                 *o = v;
             }
@@ -204,7 +219,9 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     const int chunk = tid & 15, rowl = tid >> 4;
     int a_bh[AP], a_bw[AP];
     const float* a_base[AP];
-    const int ohw = a.OH * a.OW;
+    const bool sub = DGRAD && a.sub_step > 1;
+    const int roww = sub ? a.sub_ow : a.OW;
+    const int ohw = sub ? a.sub_oh * a.sub_ow : a.OH * a.OW;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + rowl + 16 * i;
@@ -212,7 +229,11 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         const int mm = ok ? m : 0;
         const int b = mm / ohw;
         const int rem = mm - b * ohw;
-        const int oh = rem / a.OW, ow = rem - oh * a.OW;
+        int oh = rem / roww, ow = rem - oh * roww;
+        if (sub) {
+            oh = oh * a.sub_step + a.sub_ph;
+            ow = ow * a.sub_step + a.sub_pw;
+        }
         if (!DGRAD) {
             a_bh[i] = ok ? oh * a.stride - a.pad : -(1 << 28);
             a_bw[i] = ow * a.stride - a.pad;
@@ -243,7 +264,16 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         constexpr int sidx = decltype(S)::value;
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BKV;
-        const int r = tap / a.kw, s = tap - r * a.kw;
+        int r, s;
+        if (sub) {
+            const int ri = tap / a.sub_ns;
+            r = a.sub_r0 + a.sub_step * ri;
+            s = a.sub_s0 + a.sub_step * (tap - ri * a.sub_ns);
+        } else {
+            r = tap / a.kw;
+            s = tap - r * a.kw;
+        }
+        const size_t koff = (size_t)(r * a.kw + s) * a.C + c0;      // == kt * BKV when every tap is visited
         if (PRO) {
             p_mu[sidx] = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
             p_sc[sidx] = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
@@ -282,7 +312,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         a_valid[sidx] = valid;
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-            rbv[sidx][i] = *reinterpret_cast<const f32x4*>(b_base[i] + (size_t)kt * BKV);   // rows >= N: clamped row, zeroed at store
+            rbv[sidx][i] = *reinterpret_cast<const f32x4*>(b_base[i] + koff);   // rows >= N: clamped row, zeroed at store
     };
     auto store_tile = [&](auto S) {
         constexpr int sidx = decltype(S)::value;
@@ -1068,6 +1098,36 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     ProfScope prof(1, d, st);
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
+    if (d->stride > 1 && (a.C % BKV) == 0) {
+        // one launch per output-pixel parity class, each over the taps that can reach it (see IgemmArgs::sub_*)
+        const int sp = d->stride, cpt = a.C / BKV;
+        bool empty_class = false;
+        for (int ph = 0; ph < sp; ++ph)
+            for (int pw = 0; pw < sp; ++pw) {
+                const int r0 = (ph + d->pad) % sp, s0 = (pw + d->pad) % sp;
+                if (r0 >= d->kh || s0 >= d->kw) empty_class = true;
+            }
+        if (empty_class && !accumulate)      // pixels no tap reaches (1x1 stride-2: three of four) are plain zeros
+            DPFT_REQUIRE(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)a.B * a.OH * a.OW * a.N, st) == hipSuccess,
+                         "conv dgrad: memset failed");
+        for (int ph = 0; ph < sp; ++ph)
+            for (int pw = 0; pw < sp; ++pw) {
+                const int r0 = (ph + d->pad) % sp, s0 = (pw + d->pad) % sp;
+                if (r0 >= d->kh || s0 >= d->kw || ph >= a.OH || pw >= a.OW) continue;
+                IgemmArgs q = a;
+                q.sub_step = sp; q.sub_ph = ph; q.sub_pw = pw;
+                q.sub_oh = (a.OH - ph + sp - 1) / sp; q.sub_ow = (a.OW - pw + sp - 1) / sp;
+                q.sub_r0 = r0; q.sub_s0 = s0;
+                q.sub_nr = (d->kh - r0 + sp - 1) / sp; q.sub_ns = (d->kw - s0 + sp - 1) / sp;
+                q.M = a.B * q.sub_oh * q.sub_ow;
+                q.ksteps = q.sub_nr * q.sub_ns * cpt;
+                TileChoice tq = choose_tile(q.M, q.N, q.C, q.ksteps);
+                tq.splits = 1;
+                rc = launch_igemm<true>(q, tq, false, st);
+                if (rc) return rc;
+            }
+        return DPFT_OK;
+    }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
