@@ -1007,6 +1007,48 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     return check_launch("conv igemm");
 }
 
+}  // namespace dpft
+#include "conv16_kernels.h"
+namespace dpft {
+
+// thin-channel fast paths (conv16_kernels.h); `handled` tells the caller whether the launch was taken
+static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
+                      hipStream_t st, bool& handled) {
+    handled = false;
+    if (!workspace) return DPFT_OK;
+    if (conv16_matches(d)) {
+        handled = true;
+        const int nb = conv16_wgrad_blocks(d);
+        Wgrad16Args a{x, dy, (float*)workspace, d->B, d->H, d->W, cdiv(d->W, 4), (long)d->B * d->H * cdiv(d->W, 4)};
+        hipLaunchKernelGGL(wgrad16_3x3_kernel, dim3(nb), dim3(256), 0, st, a);
+        int rc = check_launch("conv16 wgrad");
+        if (rc) return rc;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(2304, 1024)), dim3(256), 0, st, (const float*)workspace,
+                           (const float*)nullptr, dw, (int64_t)2304, 16, nb, 0);
+        return check_launch("conv16 wgrad reduce");
+    }
+    if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) {
+        const long M = (long)d->B * d->H * d->W;
+        const int nb = (int)std::max<long>(1, std::min<long>(kNumCU * 2, M / 1024));
+        const int kc = d->K * d->C;
+#define THIN_1X1(K_, C_)                                                                                     \
+    if (d->K == K_ && d->C == C_) {                                                                          \
+        handled = true;                                                                                      \
+        hipLaunchKernelGGL((wgrad1x1_small_kernel<K_, C_>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M); \
+    }
+        THIN_1X1(16, 3) else THIN_1X1(16, 6) else THIN_1X1(3, 6)
+#undef THIN_1X1
+        if (handled) {
+            int rc = check_launch("thin 1x1 wgrad");
+            if (rc) return rc;
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace,
+                               (const float*)nullptr, dw, (int64_t)kc, d->C, nb, 0);
+            return check_launch("thin 1x1 wgrad reduce");
+        }
+    }
+    return DPFT_OK;
+}
+
 static int check_desc(const dpft_conv_desc* d) {
     DPFT_REQUIRE(d != nullptr, "conv: null descriptor");
     DPFT_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->K > 0, "conv: non-positive dims");
@@ -1028,6 +1070,8 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
     if (check_desc(d) != DPFT_OK) return -1;
     // worst case over fwd / dgrad / wgrad split-K partials
     int64_t best = 0;
+    if (conv16_matches(d)) best = std::max<int64_t>(best, (int64_t)conv16_wgrad_blocks(d) * 2304 * 4);
+    if (d->kh == 1 && d->kw == 1 && d->K <= 16 && d->C <= 8) best = std::max<int64_t>(best, (int64_t)kNumCU * 2 * d->K * d->C * 4);
     {
         IgemmArgs a; fill_igemm(a, d, false);
         TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
@@ -1063,6 +1107,7 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
     DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(0, d, st);
+    if (conv16_matches(d) && !pro_bn && !stats) return conv16_forward(d, x, w, bias, y, st);
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
     a.pro = pro_bn; a.pro_relu = pro_relu;
@@ -1096,6 +1141,7 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     DPFT_REQUIRE(dy && w_t && dx, "conv dgrad: null tensor");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(1, d, st);
+    if (conv16_matches(d)) return conv16_dgrad(d, dy, w_t, dx, accumulate, st);
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
     if (d->stride > 1 && (a.C % BKV) == 0) {
@@ -1151,6 +1197,11 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     DPFT_REQUIRE(x && dy && dw, "conv wgrad: null tensor");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(2, d, st);
+    if (!pro_bn) {
+        bool handled = false;
+        rc = thin_wgrad(d, x, dy, dw, workspace, st, handled);
+        if (rc || handled) return rc;
+    }
     WgradArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy; a.dw = dw; a.pro = pro_bn; a.pro_relu = pro_relu;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.OH = d->OH; a.OW = d->OW; a.K = d->K;
