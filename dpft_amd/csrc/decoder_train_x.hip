@@ -38,6 +38,7 @@ struct Pyr5g {
     const float* level[DPFT_MAX_LEVELS];
     float* grad[DPFT_MAX_LEVELS];
     int H[DPFT_MAX_LEVELS], W[DPFT_MAX_LEVELS];
+    int rep[DPFT_MAX_LEVELS];      // gradient replicas (>= 1)
     int L;
 };
 struct XfArgs {
@@ -348,7 +349,9 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
         const int H = pyr.H[l], W = pyr.W[l];
         const int64_t lb = (int64_t)b * H * W * DC + j * 2;
         const float* base = pyr.level[l] + lb;
-        float* gbase = pyr.grad[l] + lb;
+        // tiny levels: replica (row % R) of the gradient buffer, so that the fp32 atomics of 1600 rows x 8 heads do
+        // not serialise on a few hundred addresses
+        float* gbase = pyr.grad[l] + (int64_t)(bq % pyr.rep[l]) * a.B * H * W * DC + lb;
         for (int p = 0; p < P; ++p) {
             const int lp = l * P + p;
             const float ox = offp[lp * 2 + 0], oy = offp[lp * 2 + 1];
@@ -462,6 +465,7 @@ static int xf_fill(XfArgs& a, const dpft_pyramid* pyr, const dpft_decoder_view* 
             DPFT_REQUIRE(p->level[l] && p->H[l] > 0 && p->W[l] > 0, "xattn_ffn_train: view %d level %d is invalid", v, l);
             DPFT_REQUIRE(!need_grad || p->grad[l], "xattn_ffn_train: view %d level %d has no gradient buffer", v, l);
             a.pyr[v].level[l] = p->level[l]; a.pyr[v].grad[l] = p->grad[l];
+            a.pyr[v].rep[l] = p->grad_replicas[l] > 1 ? p->grad_replicas[l] : 1;
             a.pyr[v].H[l] = p->H[l]; a.pyr[v].W[l] = p->W[l];
         }
         a.P[v] = P;

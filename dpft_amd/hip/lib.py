@@ -26,7 +26,8 @@ class ConvDesc(C.Structure):
 
 class Pyramid(C.Structure):
     _fields_ = [("level", C.c_void_p * MAX_LEVELS), ("grad", C.c_void_p * MAX_LEVELS),
-                ("H", C.c_int32 * MAX_LEVELS), ("W", C.c_int32 * MAX_LEVELS), ("L", C.c_int32)]
+                ("H", C.c_int32 * MAX_LEVELS), ("W", C.c_int32 * MAX_LEVELS), ("L", C.c_int32),
+                ("grad_replicas", C.c_int32 * MAX_LEVELS)]
 
 
 class ResnetDesc(C.Structure):
@@ -187,6 +188,7 @@ def make_desc(B, H, W, Cin, K, kh, kw, stride, pad) -> ConvDesc:
 
 
 def make_pyramid(levels: Sequence[torch.Tensor], grads: Optional[Sequence[torch.Tensor]] = None) -> Pyramid:
+    """grads[i] with one more leading dimension than levels[i] is a replicated buffer (R,B,H,W,C)."""
     p = Pyramid()
     p.L = len(levels)
     for i, l in enumerate(levels):
@@ -194,4 +196,5 @@ def make_pyramid(levels: Sequence[torch.Tensor], grads: Optional[Sequence[torch.
         p.level[i] = l.data_ptr()
         p.H[i], p.W[i] = l.shape[1], l.shape[2]
         p.grad[i] = grads[i].data_ptr() if grads is not None else None
+        p.grad_replicas[i] = grads[i].shape[0] if grads is not None and grads[i].dim() == l.dim() + 1 else 0
     return p

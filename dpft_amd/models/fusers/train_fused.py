@@ -176,7 +176,7 @@ class XattnFfnBlocksFn(torch.autograd.Function):
         pyrs = (Pyramid * V)()
         for v in range(V):
             views[v] = DecoderView(*[t.data_ptr() for t in params[22 * v:22 * v + 22]])
-            pyrs[v] = make_pyramid(states[v].levels, states[v].grad_buffers())
+            pyrs[v] = make_pyramid(states[v].levels, states[v].replicated_grad_buffers())
         npts = (C.c_int32 * V)(*n_points)
         lib.call("dpft_xattn_ffn_train_bwd_f32", C.cast(pyrs, C.c_void_p), C.cast(views, C.c_void_p), packed.data_ptr(),
                  V, C.cast(npts, C.c_void_p), y1.data_ptr(), pos.data_ptr(), refs.data_ptr(), p_drop, seed.data_ptr(),

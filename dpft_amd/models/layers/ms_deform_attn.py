@@ -50,14 +50,33 @@ class PyramidState:
     cross-attention call of the pass + lazily zero-initialised gradient buffers that all of those
     calls accumulate into (fp32 atomics), handed to autograd exactly once by ``_PyramidHub``."""
 
+    REPLICAS = 32            # gradient replicas of tiny levels (see dpft_pyramid.grad_replicas)
+    TINY_PIXELS = 256        # levels with H*W <= this are replicated
+
     def __init__(self, levels: Sequence[torch.Tensor]):
         self.levels = [l.detach().contiguous() for l in levels]
         self.grads = None
+        self.rep = None
 
     def grad_buffers(self) -> List[torch.Tensor]:
         if self.grads is None:
             self.grads = [torch.zeros_like(l) for l in self.levels]
         return self.grads
+
+    def replicated_grad_buffers(self) -> List[torch.Tensor]:
+        """Like grad_buffers(), but tiny levels come as (R,B,H,W,C) replica stacks that `finish()` folds back."""
+        g = self.grad_buffers()
+        if self.rep is None:
+            self.rep = [torch.zeros((self.REPLICAS,) + tuple(l.shape), dtype=l.dtype, device=l.device)
+                        if l.shape[1] * l.shape[2] <= self.TINY_PIXELS else None for l in self.levels]
+        return [r if r is not None else t for r, t in zip(self.rep, g)]
+
+    def finish(self):
+        if self.rep is not None and self.grads is not None:
+            for g, r in zip(self.grads, self.rep):
+                if r is not None:
+                    g.add_(r.sum(0))
+        self.rep = None
 
 
 class _PyramidHub(Function):
@@ -69,6 +88,7 @@ class _PyramidHub(Function):
 
     @staticmethod
     def backward(ctx, gtoken):
+        ctx.state.finish()
         g = ctx.state.grads
         ctx.state.grads = None
         return (None, *(g if g is not None else [None] * ctx.n))

@@ -211,6 +211,10 @@ typedef struct dpft_pyramid {
     float* grad[DPFT_MAX_LEVELS];        /* same shapes, accumulated into (backward only) */
     int32_t H[DPFT_MAX_LEVELS], W[DPFT_MAX_LEVELS];
     int32_t L;
+    /* grad_replicas[l] = R > 1: grad[l] is (R,B,H_l,W_l,C) and every query row adds into replica (row % R); the
+     * caller sums the replicas.  Spreads the fp32 atomics of tiny levels (a 2x4 radar level would otherwise take
+     * ~6000 serialized adds per address).  0 or 1 = plain buffer.  Honoured by dpft_xattn_ffn_train_bwd_f32. */
+    int32_t grad_replicas[DPFT_MAX_LEVELS];
 } dpft_pyramid;
 
 /* Fused sample-then-project cross attention (C = M*D <= 64, L*P <= 32):
