@@ -306,13 +306,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ bnp, const float* __restrict__ gamma,
                                                             const float* __restrict__ sums, float* __restrict__ dy,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            int64_t n4, int K, float invM) {
+                                                            int64_t n4, int K, float invM, float* __restrict__ zero_buf,
+                                                            int zero_n) {
     const int K4 = K / 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < K; c += blockDim.x) {
             if (dbeta) dbeta[c] = sums[c];
             if (dgamma) dgamma[c] = sums[K + c];
         }
+        // ping-pong accumulators of the launch plan: clear the buffer the NEXT reduction will add into
+        for (int c = threadIdx.x; c < zero_n; c += blockDim.x) zero_buf[c] = 0.f;
     }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % K4) * 4;
@@ -510,9 +513,16 @@ extern "C" int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* bnp,
 extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const float* out,
                                       const float* mask_bnp, const float* bnp, float* sums, int64_t M,
                                       int32_t K, dpft_stream_t stream) {
+    DPFT_REQUIRE(sums && K > 0, "bn_bwd_reduce: bad arguments");
+    DPFT_REQUIRE(hipMemsetAsync(sums, 0, sizeof(float) * 2 * K, (hipStream_t)stream) == hipSuccess, "bn_bwd_reduce: memset failed");
+    return dpft::bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, stream);
+}
+
+// `sums` (2K floats) must already be zero (the launch plan keeps two buffers and lets each apply pass clear the other)
+int dpft::bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out, const float* mask_bnp,
+                                  const float* bnp, float* sums, int64_t M, int32_t K, dpft_stream_t stream) {
     DPFT_REQUIRE(y && dout && bnp && sums && M > 0 && K > 0 && K % 4 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = (hipStream_t)stream;
-    (void)hipMemsetAsync(sums, 0, sizeof(float) * 2 * K, st);
     const int K4 = K / 4;
     // Tuned on MI355X (tools/bn_bench.py): 128 B wide channel slabs (8 float4) => 32 row groups per block and only
     // 64 accumulators per block; at most 64 blocks per slab keeps the fp32 atomics on one accumulator <= 64-deep
@@ -532,10 +542,16 @@ extern "C" int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const fl
                                      const float* mask_bnp, const float* bnp, const float* gamma,
                                      const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
                                      int32_t K, dpft_stream_t stream) {
+    return dpft::bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, nullptr, 0, stream);
+}
+
+int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp,
+                               const float* bnp, const float* gamma, const float* sums, float* dy, float* dgamma,
+                               float* dbeta, int64_t M, int32_t K, float* zero_buf, int32_t zero_n, dpft_stream_t stream) {
     DPFT_REQUIRE(y && dout && bnp && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = M * K / 4;
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                       mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M);
+                       mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n);
     return check_launch("bn_bwd_apply");
 }
 

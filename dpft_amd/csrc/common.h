@@ -13,6 +13,13 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace dpft {
 
 void set_error(const char* fmt, ...);
+int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
+                        const float* res_mask, void* workspace, dpft_stream_t stream);      // conv.hip
+int bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
+                            float* sums, int64_t M, int32_t K, dpft_stream_t stream);                       // bn.hip
+int bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
+                         const float* gamma, const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
+                         int32_t K, float* zero_buf, int32_t zero_n, dpft_stream_t stream);                // bn.hip
 bool profiling_active();      // conv.hip: true between dpft_profile_start / dpft_profile_stop
 
 inline int check_launch(const char* what) {

@@ -53,6 +53,10 @@ struct IgemmArgs {
     int mtiles, ntiles, splits, ksteps, ksteps_per_split;
     int pro_relu;
     int accumulate;   // y += result (dgrad into an existing gradient)
+    // residual variant of `accumulate`: y = result + (res_mask > 0 ? res_src : 0) -- the identity branch of a
+    // bottleneck (dz = dout * (out > 0), src/.../resnet block) folded into the conv1 data gradient
+    const float* res_src;
+    const float* res_mask;
     // dgrad of a strided conv as one launch per output-pixel parity class (sub_step = stride > 1): rows enumerate the
     // sub_oh x sub_ow output pixels (oh, ow) = (sub_step*i + sub_ph, sub_step*j + sub_pw) and only the taps
     // r = sub_r0 + sub_step*k, s = sub_s0 + sub_step*l can hit them (all others fall between the dy samples).
@@ -153,14 +157,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         constexpr int C4 = BN / 4;
         constexpr int ITER = BM * C4 / 256;
         f32x4 old[ITER];
-        if (accum) {
+        const bool resid = (a.res_src != nullptr) && (a.partial == nullptr);
+        if (accum || resid) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + it * 256;
                 const int row = idx / C4, c4 = idx - row * C4;
                 old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (m0 + row < a.M && n0 + c4 * 4 < a.N)
-                    old[it] = *reinterpret_cast<const f32x4*>(out + out_pixel(a, m0 + row) * a.N + n0 + c4 * 4);
+                if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
+                    const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c4 * 4;
+                    if (resid) {
+                        const f32x4 g = *reinterpret_cast<const f32x4*>(a.res_src + off);
+                        const f32x4 o = *reinterpret_cast<const f32x4*>(a.res_mask + off);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) old[it][e] = o[e] > 0.f ? g[e] : 0.f;
+                    } else {
+                        old[it] = *reinterpret_cast<const f32x4*>(out + off);
+                    }
+                }
             }
         }
 #pragma unroll
@@ -170,7 +184,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
                 if (add_bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + c4 * 4);
-                if (accum) v += old[it];
+                if (accum || resid) v += old[it];
                 *reinterpret_cast<f32x4*>(out + out_pixel(a, m0 + row) * a.N + n0 + c4 * 4) = v;
             }
         }
@@ -180,8 +194,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             if (m0 + row < a.M && n0 + c < a.N) {
                 float v = Cs[row * LDC + c];
                 if (add_bias) v += a.bias[n0 + c];
-                float* o = out + out_pixel(a, m0 + row) * a.N + n0 + c;
-                if (accum) v += *o;
+                const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c;
+                float* o = out + off;
+                if (a.res_src != nullptr && a.partial == nullptr) v += a.res_mask[off] > 0.f ? a.res_src[off] : 0.f;
+                else if (accum) v += *o;
                 *o = v;
             }
         }
@@ -564,6 +580,17 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, const fl
             y[i + e] = s;
         }
     }
+}
+
+// split-K reduce with the masked residual: y = sum_s partial[s] + (mask > 0 ? src : 0)
+__global__ void splitk_reduce_residual_kernel(const float* __restrict__ partial, const float* __restrict__ src,
+                                              const float* __restrict__ mask, float* __restrict__ y, int64_t MN,
+                                              int splits) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= MN) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += partial[(size_t)k * MN + i];
+    y[i] = s + (mask[i] > 0.f ? src[i] : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1185,6 +1212,34 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
         const int64_t MN = (int64_t)a.M * a.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 1024)), dim3(256), 0, st, a.partial, (const float*)nullptr, dx, MN, a.N, t.splits, accumulate);
         rc = check_launch("conv dgrad split-K reduce");
+    }
+    return rc;
+}
+
+// dx = dgrad(dy) + (res_mask > 0 ? res_src : 0): stride-1 data gradient with the identity-branch ReLU backward folded
+// into the epilogue (internal: used by the ResNet launch plan)
+int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
+                              const float* res_mask, void* workspace, dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(dy && w_t && dx && res_src && res_mask, "conv dgrad residual: null tensor");
+    DPFT_REQUIRE(d->stride == 1 && !conv16_matches(d), "conv dgrad residual: stride-1 bottleneck convs only");
+    hipStream_t st = (hipStream_t)stream;
+    ProfScope prof(1, d, st);
+    IgemmArgs a; fill_igemm(a, d, true);
+    a.x = dy; a.w = w_t; a.y = dx; a.res_src = res_src; a.res_mask = res_mask;
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (t.splits > 1) {
+        DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
+        a.partial = (float*)workspace;
+    }
+    rc = launch_igemm<true>(a, t, false, st);
+    if (rc) return rc;
+    if (t.splits > 1) {
+        const int64_t MN = (int64_t)a.M * a.N;
+        hipLaunchKernelGGL(splitk_reduce_residual_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, st, a.partial, res_src,
+                           res_mask, dx, MN, t.splits);
+        rc = check_launch("conv dgrad split-K residual reduce");
     }
     return rc;
 }

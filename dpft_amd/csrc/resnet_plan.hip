@@ -202,7 +202,7 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     p->o_da = take(gmax);
     p->o_dd = take(gmax);
     p->o_wt = take(wmax);
-    p->o_sums = take(2 * 2048);
+    p->o_sums = take(2 * 2 * 2048);      // two ping-pong BN-backward accumulators
     p->ws_bytes = wsb;
     p->arena_bytes = off * sizeof(float) + 2 * wsb + 384;      // two split-K workspaces (main / side stream)
     p->g_valid = false;
@@ -294,11 +294,21 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
 
 namespace dpft {
 
+// BN backward = reduce (atomics into `sums`) + apply.  The plan keeps TWO 2*2048-float accumulators: the reduction of
+// call k adds into buffer k % 2 (all zero: cleared by the apply pass of call k - 1, or by the stage-start memset) and the
+// apply pass of call k clears buffer (k + 1) % 2 -- no memset launch per BatchNorm layer.
+struct BnSums {
+    float* buf[2];
+    int cur;
+};
 static int bn_backward(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
-                       const float* gamma, float* sums, float* dy, float* dgamma, float* dbeta, int64_t M, int K,
+                       const float* gamma, BnSums& bs, float* dy, float* dgamma, float* dbeta, int64_t M, int K,
                        dpft_stream_t st) {
-    RC(dpft_bn_bwd_reduce_f32(y, dout, out, mask_bnp, bnp, sums, M, K, st));
-    return dpft_bn_bwd_apply_f32(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, st);
+    float* sums = bs.buf[bs.cur];
+    float* other = bs.buf[bs.cur ^ 1];
+    bs.cur ^= 1;
+    RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, st));
+    return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, st);
 }
 
 // Weight gradients do not feed the rest of the backward, so they run on the plan's side stream while the main
@@ -364,12 +374,11 @@ struct SideCtx {
 };
 
 static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, float* A, void* ws, SideCtx& sc,
-                          const float* gp, float* dx, dpft_stream_t st) {
+                          BnSums& sums, const float* gp, float* dx, dpft_stream_t st) {
     float* dyv[2] = {A + p->o_dy, A + p->o_dy2};
     float* dab = A + p->o_da;
     float* dyd = A + p->o_dd;
     float* wt = A + p->o_wt;
-    float* sums = A + p->o_sums;
     const int planes = b.c1.d.K, K3 = b.c3.d.K;
     const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
     int& cur = p->dyi;
@@ -394,10 +403,11 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
         RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st));
         RC(sc.wgrad(2, &b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w)));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt + b.cd.wt, dx, 0, ws, st));
+        RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st));
     } else {
-        RC(dpft_relu_bwd_f32(gp, A + b.out, dx, M2 * K3, st));      // identity branch: dz = dout * (out > 0)
+        // identity branch dz = dout * (out > 0) folded into the epilogue of the conv1 data gradient
+        RC(conv_dgrad_residual(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, gp, A + b.out, ws, st));
     }
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st));
     cur ^= 1;
     return DPFT_OK;
 }
@@ -431,12 +441,14 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         if (dout) RC(dpft_add_inplace_f32(A + p->g_off[p->g_cur], dout, (int64_t)out_n, st));
         gp = A + p->g_off[p->g_cur];
     }
+    BnSums sums{{A + p->o_sums, A + p->o_sums + 2 * 2048}, 0};
+    RC((int)hipMemsetAsync(sums.buf[0], 0, 2 * 2 * 2048 * sizeof(float), (hipStream_t)st));
     RC(sc.transposes(T, A + p->o_wt, stage));
     for (int i = (int)p->blocks.size() - 1; i >= 0; --i) {
         const BlockPlan& b = p->blocks[i];
         if (b.layer != stage) continue;
         float* dx = A + p->g_off[p->g_cur ^ 1];
-        RC(block_backward(p, b, T, A, ws, sc, gp, dx, st));
+        RC(block_backward(p, b, T, A, ws, sc, sums, gp, dx, st));
         p->g_cur ^= 1;
         gp = dx;
     }
@@ -445,7 +457,6 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         // stem: maxpool + ReLU + bn1 + conv1 (+ the 1x1 adjustment conv of the radar views)
         float* dab = A + p->o_da;
         float* wt = A + p->o_wt;
-        float* sums = A + p->o_sums;
         const dpft_conv_desc& d0 = p->c0.d;
         const int64_t M0 = (int64_t)d0.B * d0.OH * d0.OW;
         const int slot = p->dyi;
