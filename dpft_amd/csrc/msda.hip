@@ -68,7 +68,6 @@ __global__ __launch_bounds__(256) void msda_bwd_kernel(const float* __restrict__
     if (idx >= total) return;
     int64_t t = idx;
     const int m = (int)(t % M); t /= M;
-    t /= Lq;
     const int b = (int)(t / Lq);
     const int64_t lp = idx * L * P;
     const float* go = gout + idx * D;
