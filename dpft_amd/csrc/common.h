@@ -20,6 +20,14 @@ int bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out,
 int bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                          const float* gamma, const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
                          int32_t K, float* zero_buf, int32_t zero_n, dpft_stream_t stream);                // bn.hip
+struct BnEvalBatch {      // eval-mode BN blocks of up to 16 layers (bn.hip)
+    const float *gamma[16], *beta[16], *rm[16], *rv[16];
+    float* out[16];
+    int K[16];
+    int n;
+    float eps;
+};
+int bn_eval_params_batch(const BnEvalBatch& batch, dpft_stream_t stream);
 bool profiling_active();      // conv.hip: true between dpft_profile_start / dpft_profile_stop
 
 inline int check_launch(const char* what) {

@@ -251,7 +251,33 @@ static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* 
     if (train)
         return dpft_bn_finalize_f32(stats, tiles, rows, M, K, T.gamma(bn), T.beta(bn), p->desc.eps, p->desc.momentum,
                                     T.rm(bn), T.rv(bn), bnp, st);
-    return dpft_bn_eval_params_f32(T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), p->desc.eps, K, bnp, st);
+    return DPFT_OK;      // eval: every BN block was produced up front by eval_bn_blocks()
+}
+
+// eval mode: the BN blocks only depend on parameters/buffers -- all of them in ceil(n_bn / 16) launches
+static int eval_bn_blocks(const ResnetPlan* p, const Tables& T, float* A, dpft_stream_t st) {
+    BnEvalBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    batch.eps = p->desc.eps;
+    auto push = [&](int bn, int K, size_t off) -> int {
+        const int i = batch.n++;
+        batch.gamma[i] = T.gamma(bn); batch.beta[i] = T.beta(bn); batch.rm[i] = T.rm(bn); batch.rv[i] = T.rv(bn);
+        batch.out[i] = A + off; batch.K[i] = K;
+        if (batch.n == 16) {
+            RC(bn_eval_params_batch(batch, st));
+            batch.n = 0;
+        }
+        return DPFT_OK;
+    };
+    RC(push(p->bn0, 64, p->p0));
+    for (const BlockPlan& b : p->blocks) {
+        RC(push(b.bn1, b.c1.d.K, b.p1));
+        RC(push(b.bn2, b.c2.d.K, b.p2));
+        RC(push(b.bn3, b.c3.d.K, b.p3));
+        if (b.has_ds) RC(push(b.bnd, b.cd.d.K, b.pd));
+    }
+    if (batch.n > 0) RC(bn_eval_params_batch(batch, st));
+    return DPFT_OK;
 }
 
 }  // namespace dpft
@@ -264,6 +290,7 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
     float* A = (float*)arena;
     void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
     const bool tr = train != 0;
+    if (!tr) RC(eval_bn_blocks(p, T, A, st));
     const float* xa = x;
     if (p->adj.w >= 0) {
         RC(dpft_conv2d_nhwc_fwd_f32(&p->adj.d, x, T.w(p->adj.w), nullptr, nullptr, 0, A + p->xa, nullptr, ws, st));
