@@ -171,6 +171,59 @@ def test_dprt_eval_forward_matches_oracle():
     assert torch.equal(out["class"].argmax(-1).cpu(), ref["class"].argmax(-1))
 
 
+def test_dprt_eval_forward_full_size_matches_oracle():
+    """BASELINE.json configs[1] at its real sizes (camera 512x910 ResNet-101, radar 256x107 / 37x107 ResNet-50),
+    batch 1: fused inference path vs the oracle on the same weights; plus a batch-composition property at batch 4
+    (eval-mode outputs of a sample do not depend on its batch mates -- every kernel tiling changes with B)."""
+    from dpft_amd.configs import load_config
+    from dpft_amd.synthetic import make_batch
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(21)
+    cfg = copy.deepcopy(load_config("kradar"))
+    model = _build(cfg, g)
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in state_dict_f64(model).items()}
+    batch4 = make_batch(cfg["model"]["inputs"], 4, seed=5)
+    batch1 = {k: v[1:2].contiguous() for k, v in batch4.items()}
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = O.dprt_forward(sd, cfg, batch1, train=False)
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out1 = model({k: v.to(DEV) for k, v in batch1.items()})
+        out4 = model({k: v.to(DEV) for k, v in batch4.items()})
+    for k in out1:
+        close(out1[k], ref[k], rtol=2e-4, atol_scale=2e-4, what=f"full-size eval out {k}")
+        close(out4[k][1:2], out1[k], rtol=2e-4, atol_scale=2e-4, what=f"batch-composition {k}")
+    assert torch.equal(out1["class"].argmax(-1).cpu(), ref["class"].argmax(-1))
+
+
+def test_full_size_train_backward_repeatable_and_linear():
+    """Size-independent properties at BASELINE.json's full sizes (batch 4): the backward is a linear map of the
+    cotangent and repeats (side-stream weight gradients, split-K slabs and atomics only reorder fp32 sums)."""
+    from dpft_amd.configs import load_config
+    from dpft_amd.synthetic import make_batch
+    g = torch.Generator().manual_seed(22)
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["fuser"]["dropout"] = 0.0
+    model = _build(cfg, g).to(DEV).train()
+    batch = {k: v.to(DEV) for k, v in make_batch(cfg["model"]["inputs"], 4, seed=6).items()}
+    cots = None
+
+    def grads(scale):
+        nonlocal cots
+        model.zero_grad(set_to_none=True)
+        out = model(batch)
+        if cots is None:
+            cots = {k: torch.randn(v.shape, generator=g).to(DEV) for k, v in out.items()}
+        (scale * sum((out[k] * cots[k]).sum() for k in out)).backward()
+        return {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+    g1, g2, g3 = grads(1.0), grads(1.0), grads(2.0)
+    assert len(g1) > 300 and g1.keys() == g2.keys() == g3.keys()
+    worst_rep = max(rel_l2(g2[n], g1[n]) for n in g1 if float(g1[n].norm()) > 0)
+    worst_lin = max(rel_l2(g3[n], 2.0 * g1[n]) for n in g1 if float(g1[n].norm()) > 0)
+    print(f"full-size backward: repeat rel-L2 {worst_rep:.2e}, linearity rel-L2 {worst_lin:.2e}")
+    assert worst_rep < 2e-4 and worst_lin < 2e-4
+
+
 def test_dprt_train_forward_backward_matches_oracle():
     from dpft_amd.synthetic import make_batch
     from oracle import dprt_oracle as O
