@@ -122,6 +122,9 @@ SIGNATURES = {
     "dpft_match_cost_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "dpft_resize_bilinear_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_resize_bilinear_nhwc_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "dpft_scale_clip_f32": (_I, [_P, _P, _L, _F, _F, _F, _F, _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),
     "dpft_profile_overhead_ms": (_F, []),

@@ -396,6 +396,20 @@ int dpft_set_loss_bwd_f32(const float* cls, const float* center, const float* si
                           int32_t Mmax, int32_t C, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Input preprocessing on the device (the reference does it per sample in DataLoader workers):
+ * camera frame resize = torchvision.transforms.functional.resize(bilinear, no antialias) on the HWC frame
+ * (src/dprt/datasets/kradar/dataset.py:319-341), from fp32 or straight from the decoded u8 bytes; radar map scaling
+ * (v - in_lo) / (in_hi - in_lo) * (out_hi - out_lo) + out_lo clipped to [out_lo, out_hi] (dataset.py:295-317 with
+ * in = (min_power, max_power) = (100, 200), out = (0, 255)).  NHWC in and out.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_resize_bilinear_nhwc_f32(const float* src, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd,
+                                  int32_t Wd, int32_t C, dpft_stream_t stream);
+int dpft_resize_bilinear_nhwc_u8(const uint8_t* src, float* dst, int32_t B, int32_t Hs, int32_t Ws, int32_t Hd,
+                                 int32_t Wd, int32_t C, dpft_stream_t stream);
+int dpft_scale_clip_f32(const float* x, float* y, int64_t n, float in_lo, float in_hi, float out_lo,
+                        float out_hi, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW (torch.optim.AdamW semantics: decoupled decay, bias correction, no amsgrad),
  * the optimizer the reference builds at src/dprt/training/trainer.py:233 / optimizer.py:6-7.
  * chunks: device array of {float* p; const float* g; float* m; float* v; int32 n; int32 tensor}

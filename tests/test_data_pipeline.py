@@ -1,0 +1,124 @@
+"""Input pipeline: host logic on CPU, device transforms + prefetch on the GPU."""
+import pytest
+import torch
+
+from dpft_amd.data import (GpuPreprocessor, PrefetchLoader, ShardedSampler, SyntheticRawDataset, listed_collating,
+                           load_listed, resized_output_size)
+
+
+def test_resized_output_size_follows_torchvision_rule():
+    assert resized_output_size(720, 1280, 512) == (512, 910)          # config/kradar.json image_size on a K-Radar frame
+    assert resized_output_size(1280, 720, 512) == (910, 512)
+    assert resized_output_size(720, 1280, (300, 400)) == (300, 400)
+    assert resized_output_size(100, 100, [64]) == (64, 64)
+
+
+@pytest.mark.parametrize("n,world,drop", [(103, 4, True), (103, 4, False), (16, 1, True), (7, 8, False)])
+def test_sharded_sampler_partitions_every_epoch(n, world, drop):
+    shards = [ShardedSampler(n, r, world, shuffle=True, seed=5, drop_last=drop) for r in range(world)]
+    for epoch in (0, 1):
+        got = []
+        for s in shards:
+            s.set_epoch(epoch)
+            idx = list(s)
+            assert len(idx) == len(s)
+            got += idx
+        if drop:
+            assert len(set(got)) == len(got) == (n // world) * world        # disjoint, nothing twice
+        else:
+            assert set(got) == set(range(n))                                # full cover (with wrap-around padding)
+    a, b = ShardedSampler(n, 0, world, seed=5), ShardedSampler(n, 0, world, seed=5)
+    assert list(a) == list(b)
+    b.set_epoch(3)
+    assert world >= n or list(a) != list(b)
+    assert list(ShardedSampler(10, 1, 2, shuffle=False)) == [1, 3, 5, 7, 9]
+    with pytest.raises(ValueError):
+        ShardedSampler(10, 2, 2)
+
+
+def test_listed_collating_contract():
+    ds = SyntheticRawDataset(4, seed=1, raw_shapes={"camera_mono": (24, 32, 3)})
+    inputs, targets = listed_collating([ds[0], ds[1], ds[2]])
+    assert inputs["camera_mono"].shape == (3, 24, 32, 3) and inputs["camera_mono"].dtype == torch.uint8
+    assert inputs["radar_bev"].shape == (3, 256, 107, 6)
+    assert inputs["camera_mono_shape"].tolist() == [[24, 32, 3]] * 3
+    assert isinstance(targets, list) and len(targets) == 3 and set(targets[0]) == {"gt_center", "gt_size", "gt_angle", "gt_class"}
+    assert torch.equal(ds[2][0]["radar_front"], ds[2][0]["radar_front"])      # deterministic per index
+
+
+def test_prefetch_loader_cpu_passthrough_and_errors():
+    ds = SyntheticRawDataset(6, seed=2, raw_shapes={"camera_mono": (24, 32, 3)})
+    cfg = {"train": {"batch_size": 2, "shuffle": False}, "computing": {"workers": 0}}
+    loader, sampler = load_listed(ds, cfg, device="cpu")
+    batches = list(loader)
+    assert len(batches) == 3 and len(loader) == 3
+    assert batches[1][0]["camera_mono"].shape == (2, 24, 32, 3)
+
+    def bad():
+        yield batches[0]
+        raise RuntimeError("decode failed")
+    with pytest.raises(RuntimeError, match="decode failed"):
+        list(PrefetchLoader(bad(), "cpu"))
+
+
+def _ref_resize(x, size):
+    import torch.nn.functional as F
+    return F.interpolate(x.float().permute(0, 3, 1, 2), size=size, mode="bilinear", align_corners=False).permute(0, 2, 3, 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,size", [((2, 720, 1280, 3), 512), ((1, 37, 53, 3), (64, 91)), ((2, 90, 60, 1), 40)])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.uint8])
+def test_gpu_resize_matches_torch_bilinear(shape, size, dtype):
+    from dpft_amd.data.preprocess import resize_bilinear
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 256, shape, generator=g, dtype=torch.uint8)
+    x = x if dtype == torch.uint8 else x.float() + torch.rand(shape, generator=g)
+    out_size = resized_output_size(shape[1], shape[2], size)
+    ref = _ref_resize(x, out_size)
+    out = resize_bilinear(x.cuda(), out_size).cpu()
+    assert out.shape == ref.shape
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-3), float((out - ref).abs().max())      # values up to 256
+
+
+@pytest.mark.gpu
+def test_gpu_radar_scaling_is_bit_exact():
+    from dpft_amd.data.preprocess import scale_clip
+    g = torch.Generator().manual_seed(4)
+    v = 60.0 + torch.rand(3, 256, 107, 6, generator=g) * 180.0
+    ref = torch.clip((v - 100.0) / (200.0 - 100.0) * (255 - 0) + 0, 0, 255)         # dataset.py:307-315
+    assert torch.equal(scale_clip(v.cuda()).cpu(), ref)
+
+
+@pytest.mark.gpu
+def test_gpu_pipeline_feeds_a_train_step():
+    """raw synthetic samples -> sharded sampler -> collate -> pinned upload + GPU transforms -> model-ready batch."""
+    from dpft_amd.configs import load_config
+    import copy
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["train"]["batch_size"] = 2
+    cfg["computing"] = dict(cfg.get("computing", {}), workers=0)
+    ds = SyntheticRawDataset(8, seed=9, raw_shapes={"camera_mono": (180, 320, 3), "radar_bev": (128, 43, 6)})
+    pre = GpuPreprocessor(image_size=128)
+    loader, sampler = load_listed(ds, cfg, device="cuda:0", rank=1, world=2, preprocessor=pre, seed=1)
+    sampler.set_epoch(0)
+    seen = list(sampler)
+    batches = list(loader)
+    assert len(batches) == 2
+    batch, labels = batches[0]
+    assert batch["camera_mono"].shape == (2, 128, 227, 3) and batch["camera_mono"].dtype == torch.float32
+    assert batch["camera_mono_shape"].tolist() == [[180, 320, 3]] * 2           # recorded before the resize
+    assert float(batch["radar_bev"].min()) >= 0.0 and float(batch["radar_bev"].max()) <= 255.0
+    # same values as preprocessing the collated host batch directly
+    host_in, _ = listed_collating([ds[i] for i in seen[:2]])
+    direct = pre({k: v.cuda() for k, v in host_in.items()})
+    for k in direct:
+        assert torch.equal(direct[k], batch[k]), k
+    assert all(v.is_cuda for v in labels[0].values())
+    # and the model trains on it
+    from dpft_amd.models import build
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device("cuda", 0))
+    loss, _ = tr.train_step(batch, labels)
+    assert torch.isfinite(loss)
