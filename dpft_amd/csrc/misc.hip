@@ -30,9 +30,10 @@ __device__ double poly_area(const P2* p, int n) {
     return a / 2;
 }
 
-// GIoU3D of two (x,y,z,l,w,h,yaw) boxes
-__device__ float giou3d_yaw_pair(const float* pa, const float* pb) {
+// GIoU3D (return value) and IoU3D (*iou_out, may be null) of two (x,y,z,l,w,h,yaw) boxes
+__device__ float giou3d_yaw_pair(const float* pa, const float* pb, float* iou_out = nullptr) {
     const double eps = 1e-4;
+    if (iou_out) *iou_out = 0.f;
     auto valid = [&](const float* s) {
         const double l = s[3], w = s[4], h = s[5];
         return fmin(fmin(l * w, l * h), w * h) / 2 > eps;
@@ -80,6 +81,7 @@ __device__ float giou3d_yaw_pair(const float* pa, const float* pb) {
     const double v1 = (double)pa[3] * pa[4] * pa[5], v2 = (double)pb[3] * pb[4] * pb[5];
     const double iou = vol > 0 ? vol / (v1 + v2 - vol) : 0.0;
     const double uni = iou != 0 ? vol / iou : 0.0;
+    if (iou_out) *iou_out = (float)iou;
     return (float)(evol != 0 ? iou - (evol - uni) / evol : 0.0);
 }
 
@@ -130,6 +132,158 @@ __global__ void match_cost_kernel(CostArgs a) {
     c += a.w_angle * l1a;
     c += a.w_giou * (-giou);
     a.cost[idx] = c;
+}
+
+// ---- per-step detection metrics (src/dprt/evaluation/metric.py: mAP3D :16-151, mGIoU3D :154-253) --------------------
+// Pair pass: IoU3D / GIoU3D of every (prediction, target) pair of a sample.  Metric pass: one block per sample.
+// Both metrics reduce to a handful of per-class counts (see the comments in detection_metric_kernel): the reference's
+// precision/recall "interpolation" is a straight line through the FIRST and LAST point of the curve
+// (src/dprt/utils/misc.py:43-83), so no sort / scan of the 400 predictions is needed -- only the most confident row, the
+// set of matched rows and three counters per class.
+struct MetricArgs {
+    const float *cls, *center, *size, *angle;      // (B,N,C) (B,N,3) (B,N,3) (B,N,2)
+    const float* gt_box;                           // (B,Mmax,8)
+    const float* gt_onehot;                        // (B,Mmax,C)
+    const int32_t* counts;                         // (B)
+    float* pair;                                   // (B,N,Mmax,2): iou, giou
+    float* out;                                    // (B,2): mAP, mGIoU of each sample
+    float thr;
+    int nelem;
+    int B, N, Mmax, C;
+};
+__global__ void metric_pair_kernel(MetricArgs a) {
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (int64_t)a.B * a.N * a.Mmax) return;
+    const int j = (int)(idx % a.Mmax);
+    const int64_t bn = idx / a.Mmax;
+    const int b = (int)(bn / a.N);
+    float iou = 0.f, giou = -1.f;
+    if (j < a.counts[b]) {
+        const float* g = a.gt_box + ((int64_t)b * a.Mmax + j) * 8;
+        const float* ce = a.center + bn * 3;
+        const float* sz = a.size + bn * 3;
+        const float* an = a.angle + bn * 2;
+        const float pa[7] = {ce[0], ce[1], ce[2], sz[0], sz[1], sz[2], atan2f(an[0], an[1])};
+        const float pb[7] = {g[0], g[1], g[2], g[3], g[4], g[5], atan2f(g[6], g[7])};
+        giou = giou3d_yaw_pair(pa, pb, &iou);
+    }
+    a.pair[idx * 2 + 0] = iou;
+    a.pair[idx * 2 + 1] = giou;
+}
+
+constexpr int kMetricMaxN = 1024, kMetricMaxM = 256, kMetricMaxC = 16;
+
+__device__ __forceinline__ int argmax_row(const float* x, int n, int stride) {
+    int best = 0;
+    for (int i = 1; i < n; ++i)
+        if (x[(size_t)i * stride] > x[(size_t)best * stride]) best = i;
+    return best;
+}
+
+__global__ __launch_bounds__(256) void detection_metric_kernel(MetricArgs a) {
+    __shared__ int label[kMetricMaxN];          // argmax class of every prediction
+    __shared__ int gt_label[kMetricMaxM];
+    __shared__ int best[kMetricMaxM];           // per target column: most confident matching prediction (or -1)
+    __shared__ float colmax[kMetricMaxM];       // per target column: max GIoU over the predictions of the class
+    __shared__ int present[kMetricMaxC];
+    __shared__ float ap[kMetricMaxC], gi[kMetricMaxC];
+    __shared__ int s_row0, s_nmask, s_nR, s_row0_in_R;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int N = a.N, C = a.C, M = a.counts[b];
+    const float* cls = a.cls + (size_t)b * N * C;
+    const float* pair = a.pair + (size_t)b * N * a.Mmax * 2;
+    for (int c = tid; c < C; c += 256) present[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 256) {
+        const int l = argmax_row(cls + (size_t)i * C, C, 1);
+        label[i] = l;
+        atomicOr(&present[l], 1);
+    }
+    for (int j = tid; j < M; j += 256) {
+        const int l = argmax_row(a.gt_onehot + ((size_t)b * a.Mmax + j) * C, C, 1);
+        gt_label[j] = l;
+        atomicOr(&present[l], 1);
+    }
+    __syncthreads();
+    for (int l = 0; l < C; ++l) {
+        if (tid == 0) { s_nmask = 0; s_nR = 0; s_row0_in_R = 0; }
+        __syncthreads();
+        // most confident prediction of the whole sample for this class score (first row of the sorted order)
+        if (tid == 0) s_row0 = argmax_row(cls + l, N, C);
+        int cnt = 0;
+        for (int i = tid; i < N; i += 256) cnt += label[i] == l;
+        if (cnt) atomicAdd(&s_nmask, cnt);
+        // per target: the most confident prediction of class l with IoU > thr (the row torch.max picks in the sorted
+        // candidate mask, metric.py:103-113) and the best GIoU over the predictions of class l (:229-233)
+        for (int j = tid; j < M; j += 256) {
+            int bi = -1;
+            float bs = 0.f, gm = -1.f;
+            if (gt_label[j] == l) {
+                for (int i = 0; i < N; ++i) {
+                    if (label[i] != l) continue;
+                    const float iou = pair[((size_t)i * a.Mmax + j) * 2 + 0], gg = pair[((size_t)i * a.Mmax + j) * 2 + 1];
+                    gm = fmaxf(gm, gg);
+                    const float sc = cls[(size_t)i * C + l];
+                    if (iou > a.thr && (bi < 0 || sc > bs)) { bi = i; bs = sc; }
+                }
+            }
+            best[j] = bi;
+            colmax[j] = gm;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int npos = 0, nR = 0, row0_in_R = 0;
+            float gsum = 0.f;
+            for (int j = 0; j < M; ++j) {
+                npos += gt_label[j] == l;
+                gsum += colmax[j];
+                if (best[j] < 0) continue;
+                bool dup = false;
+                for (int k = 0; k < j; ++k) dup = dup || best[k] == best[j];
+                nR += dup ? 0 : 1;
+                row0_in_R |= best[j] == s_row0;
+            }
+            const int row0 = s_row0;
+            // ---- average precision: straight line through the first and last precision/recall point ----
+            const float tp0 = row0_in_R ? 1.f : 0.f;
+            const float fp0 = (label[row0] == l && !row0_in_R) ? 1.f : 0.f;
+            const float p0 = (tp0 + fp0 != 0.f) ? tp0 / (fp0 + tp0) : 0.f;
+            const float TP = (float)nR, FP = (float)(s_nmask - nR);
+            const float p1 = (TP + FP != 0.f) ? TP / (FP + TP) : 0.f;
+            const float r0 = npos == 0 ? 1.f : tp0 / (float)npos, r1 = npos == 0 ? 1.f : TP / (float)npos;
+            const bool flat = fabsf(r1 - r0) <= 1e-8f;
+            const float step = 1.f / (float)(a.nelem - 1);
+            float sum = 0.f;
+            for (int k = 0; k < a.nelem; ++k) {
+                const float x = k < a.nelem / 2 ? step * (float)k : 1.f - step * (float)(a.nelem - k - 1);   // torch.linspace
+                float y = flat ? 0.f : p0 + (x - r0) * (p1 - p0) / (r1 - r0);
+                if (x < r0) y = p0;
+                if (x > r1) y = 0.f;
+                sum += y * 1.f / (float)(a.nelem - 1);
+            }
+            ap[l] = sum;
+            // ---- class GIoU: mean over ALL target columns of the best GIoU (-1 for other-class columns) ----
+            float gv = -1.f;
+            if (npos == 0) gv = 1.f;
+            if (M > 0 && N > 0 && s_nmask > 0 && npos > 0) gv = gsum / (float)M;
+            gi[l] = gv;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        // contributing classes: the present labels without the SMALLEST present one (metric.py:141,243)
+        int first = -1, nsel = 0, anynz = 0;
+        float s_ap = 0.f, s_gi = 0.f;
+        for (int c = 0; c < C; ++c) {
+            if (!present[c]) continue;
+            if (first < 0) { first = c; continue; }
+            ++nsel; anynz |= c != 0;
+            s_ap += ap[c]; s_gi += gi[c];
+        }
+        const bool none = nsel == 0 || !anynz;
+        a.out[b * 2 + 0] = none ? 1.f : s_ap / (float)nsel;
+        a.out[b * 2 + 1] = none ? 1.f : s_gi / (float)nsel;
+    }
 }
 
 // ---- SetCriterion + Loss (src/dprt/training/loss.py:17-60 focal, :176-373 criterion, :486-564 reduction) ----
@@ -301,4 +455,22 @@ extern "C" int dpft_set_loss_bwd_f32(const float* cls, const float* center, cons
     a.gout = gout5; a.dcls = dcls; a.dcenter = dcenter; a.dsize = dsize; a.dangle = dangle;
     hipLaunchKernelGGL(set_loss_kernel<true>, dim3(cdiv((int64_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("set_loss_bwd");
+}
+
+extern "C" int dpft_detection_metrics_f32(const float* cls, const float* center, const float* size, const float* angle,
+                                          const float* gt_box, const float* gt_onehot, const int32_t* counts,
+                                          float threshold, int32_t nelem, float* scratch, float* out, int32_t B,
+                                          int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream) {
+    DPFT_REQUIRE(cls && center && size && angle && gt_box && gt_onehot && counts && scratch && out, "detection_metrics: null argument");
+    DPFT_REQUIRE(B > 0 && N > 0 && N <= kMetricMaxN && Mmax > 0 && Mmax <= kMetricMaxM && C > 0 && C <= kMetricMaxC && nelem >= 2,
+                 "detection_metrics: sizes out of range (N <= %d, Mmax <= %d, C <= %d)", kMetricMaxN, kMetricMaxM, kMetricMaxC);
+    MetricArgs a;
+    a.cls = cls; a.center = center; a.size = size; a.angle = angle; a.gt_box = gt_box; a.gt_onehot = gt_onehot;
+    a.counts = counts; a.pair = scratch; a.out = out; a.thr = threshold; a.nelem = nelem; a.B = B; a.N = N; a.Mmax = Mmax; a.C = C;
+    const int64_t total = (int64_t)B * N * Mmax;
+    hipLaunchKernelGGL(metric_pair_kernel, dim3(cdiv(total, 128)), dim3(128), 0, (hipStream_t)stream, a);
+    int rc = check_launch("detection_metrics pairs");
+    if (rc) return rc;
+    hipLaunchKernelGGL(detection_metric_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("detection_metrics");
 }

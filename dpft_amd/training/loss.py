@@ -136,148 +136,25 @@ class SetCriterion(nn.Module):
                 for name, fn in self.losses.items()}
 
 
-class _SetLossFn(torch.autograd.Function):
-    """dpft_set_loss_fwd/bwd_f32: the five batch-reduced, weighted criterion terms for fixed assignments."""
 
-    @staticmethod
-    def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha):
-        import ctypes as C
-        from dpft_amd.hip.lib import lib, stream
-        B, N, ncls = cls.shape
-        Mmax = gt_box.shape[1]
-        losses = torch.empty(5, dtype=torch.float32, device=cls.device)
-        w = (C.c_float * 5)(*weights5)
-        lib.call("dpft_set_loss_fwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
-                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
-                 losses.data_ptr(), B, N, Mmax, ncls, stream())
-        ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts)
-        ctx.meta = (weights5, float(alpha))
-        return losses
-
-    @staticmethod
-    def backward(ctx, gout):
-        import ctypes as C
-        from dpft_amd.hip.lib import lib, stream
-        cls, center, size, angle, gt_box, gt_onehot, match, counts = ctx.saved_tensors
-        weights5, alpha = ctx.meta
-        B, N, ncls = cls.shape
-        Mmax = gt_box.shape[1]
-        gout = gout.contiguous().float()
-        dcls, dcenter, dsize, dangle = (torch.empty_like(t) for t in (cls, center, size, angle))
-        w = (C.c_float * 5)(*weights5)
-        lib.call("dpft_set_loss_bwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
-                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), alpha,
-                 gout.data_ptr(), dcls.data_ptr(), dcenter.data_ptr(), dsize.data_ptr(), dangle.data_ptr(), B, N, Mmax,
-                 ncls, stream())
-        return dcls, dcenter, dsize, dangle, None, None, None, None, None, None
-
-
-class Loss(nn.modules.loss._Loss):
-    def __init__(self, anassigner: nn.Module = None, criterion: nn.Module = None, loss_weights: Dict[str, float] = None,
-                 reduction: str = "mean", **kwargs):
-        super().__init__()
-        if reduction not in {"none", "mean", "sum"}:
-            raise ValueError(f"Invalid Value for arg 'reduction': '{reduction}'")
-        if anassigner is None or criterion is None:
-            raise ValueError("dpft_amd Loss: the hot path is HungarianAnassigner + SetCriterion (every reference config)")
-        self.anassigner, self.criterion = anassigner, criterion
-        self.loss_weights = loss_weights if loss_weights is not None else {}
-        self.reduction = reduction
-
-    @classmethod
-    def from_config(cls, config: Dict[str, Any]) -> "Loss":
-        if "hungarian" not in config.get("anassigner", "").lower() or config.get("criterion") != "SetCriterion":
-            raise ValueError("dpft_amd Loss supports anassigner=HungarianAnassigner, criterion=SetCriterion")
-        return cls(anassigner=HungarianAnassigner.from_config(config), criterion=SetCriterion(),
-                   loss_weights=config.get("loss_weights"), reduction=config.get("reduction", "mean"))
-
-    use_fused = True      # CUDA: matcher cost, criterion and its gradient from 3 HIP kernels (dpft_amd/csrc/misc.hip)
-    _TERMS = ("total_class", "object_class", "center", "size", "angle")
-
-    def _fused_ok(self, inputs) -> bool:
-        return (self.use_fused and inputs["class"].is_cuda and self.reduction == "mean"
-                and isinstance(self.anassigner, HungarianAnassigner) and isinstance(self.criterion, SetCriterion)
-                and set(self.loss_weights) <= set(self._TERMS) and inputs["class"].dtype == torch.float32)
-
-    def forward_fused(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
-        """Same values as ``forward_eager`` from three launches + the host assignment (one D2H, one H2D copy)."""
-        import ctypes as C
-        from torch.nn.utils.rnn import pad_sequence
-        from dpft_amd.hip.lib import lib, stream
-        cls, center = inputs["class"].contiguous(), inputs["center"].contiguous()
-        size, angle = inputs["size"].contiguous(), inputs["angle"].contiguous()
-        B, N, ncls = cls.shape
-        dev = cls.device
-        counts = [int(t["gt_class"].shape[0]) if all(v.numel() for v in t.values()) else 0 for t in targets]
-        if max(counts) == 0:
-            zero = torch.zeros((), device=dev, dtype=cls.dtype, requires_grad=True)
-            return zero * 1.0, {k: zero for k in self.loss_weights}
-        Mmax = max(counts)
-        empty8, emptyc = cls.new_zeros((0, 8)), cls.new_zeros((0, ncls))
-        boxes = [torch.cat((t["gt_center"], t["gt_size"], t["gt_angle"]), -1).float() if m else empty8
-                 for t, m in zip(targets, counts)]
-        gt_box = pad_sequence(boxes, batch_first=True).contiguous()                          # (B,Mmax,8)
-        gt_onehot = pad_sequence([t["gt_class"].float() if m else emptyc for t, m in zip(targets, counts)],
-                                 batch_first=True).contiguous()                              # (B,Mmax,C)
-        gt_id = gt_onehot.argmax(-1).to(torch.int32).contiguous()
-        counts_t = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
-        aw = self.anassigner.loss_weights
-        cw = (C.c_float * 5)(aw["total_class"], aw["center"], aw["size"], aw["angle"], self.anassigner.giou_weight)
-        cost = torch.empty((B, N, Mmax), dtype=torch.float32, device=dev)
-        with torch.no_grad():
-            lib.call("dpft_match_cost_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
-                     gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
-                     ncls, stream())
-        host = cost.cpu().numpy()                                            # the one sync of the step
-        dev = cost.device
-        result = []
-        for b, m in enumerate(counts):
-            if not m:
-                result.append(None)
-                continue
-            i, j = linear_sum_assignment(host[b, :, :m])
-            result.append((torch.as_tensor(np.ascontiguousarray(i), dtype=torch.int64).to(dev, non_blocking=True),
-                           torch.as_tensor(np.ascontiguousarray(j), dtype=torch.int64).to(dev, non_blocking=True)))
-        return result
-
-
-class SetCriterion(nn.Module):
-    """Per-sample criterion (the reference always calls it with a batch dimension of 1, loss.py:532-540)."""
-
-    def __init__(self):
-        super().__init__()
-        self.losses = {"total_class": "total_focal_loss", "object_class": "object_focal_loss", "center": "l1_loss",
-                       "size": "l1_loss", "angle": "l1_loss"}
-        self.loss_inputs = {"total_class": ["class"], "object_class": ["class"], "center": ["center"],
-                            "size": ["size"], "angle": ["angle"]}
-
-    @staticmethod
-    def total_focal_loss(inputs, targets, i, j):
-        N, C = inputs.shape
-        M = j.numel()
-        one_hot = torch.zeros((N, C), dtype=inputs.dtype, device=inputs.device)
-        one_hot[:, 0] = 1.0
-        one_hot[i] = targets                      # scatter_ with src=targets in assignment order (loss.py:305-306)
-        loss = focal_loss(inputs, one_hot, reduction="none")
-        return (loss.mean(0).sum() / M) * N
-
-    @staticmethod
-    def object_focal_loss(inputs, targets, i, j):
-        N = inputs.shape[0]
-        M = j.numel()
-        loss = focal_loss(inputs[i], targets[j], reduction="none")
-        return (loss.mean(0).sum() / M) * N
-
-    @staticmethod
-    def l1_loss(inputs, targets, i, j):
-        return F.l1_loss(inputs[i], targets[j], reduction="mean")
-
-    def forward(self, inputs: Dict[str, torch.Tensor], targets: Dict[str, torch.Tensor],
-                indices: Tuple[torch.Tensor, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        i, j = indices
-        return {name: getattr(self, fn)(torch.cat([inputs[k] for k in self.loss_inputs[name]], -1),
-                                        torch.cat([targets[f"gt_{k}"] for k in self.loss_inputs[name]], -1), i, j)
-                for name, fn in self.losses.items()}
+def pack_targets(targets: List[Dict[str, torch.Tensor]], counts: List[int], ncls: int, dev):
+    """List of per-sample label dicts -> padded device tensors for the HIP loss / metric kernels:
+    gt_box (B,Mmax,8) = center | size | angle, gt_onehot (B,Mmax,C), gt_id (B,Mmax) int32, counts (B) int32."""
+    from torch.nn.utils.rnn import pad_sequence
+    Mmax = max(max(counts), 1)
+    empty8 = torch.zeros((0, 8), dtype=torch.float32, device=dev)
+    emptyc = torch.zeros((0, ncls), dtype=torch.float32, device=dev)
+    boxes = [torch.cat((t["gt_center"], t["gt_size"], t["gt_angle"]), -1).float() if m else empty8
+             for t, m in zip(targets, counts)]
+    gt_box = pad_sequence(boxes, batch_first=True).contiguous()
+    gt_onehot = pad_sequence([t["gt_class"].float() if m else emptyc for t, m in zip(targets, counts)],
+                             batch_first=True).contiguous()
+    if gt_box.shape[1] < Mmax:                      # every sample empty
+        gt_box = torch.zeros((len(targets), Mmax, 8), dtype=torch.float32, device=dev)
+        gt_onehot = torch.zeros((len(targets), Mmax, ncls), dtype=torch.float32, device=dev)
+    gt_id = gt_onehot.argmax(-1).to(torch.int32).contiguous()
+    counts_t = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
+    return gt_box, gt_onehot, gt_id, counts_t, Mmax
 
 
 class _SetLossFn(torch.autograd.Function):
@@ -346,7 +223,6 @@ class Loss(nn.modules.loss._Loss):
     def forward_fused(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
         """Same values as ``forward_eager`` from three launches + the host assignment (one D2H, one H2D copy)."""
         import ctypes as C
-        from torch.nn.utils.rnn import pad_sequence
         from dpft_amd.hip.lib import lib, stream
         cls, center = inputs["class"].contiguous(), inputs["center"].contiguous()
         size, angle = inputs["size"].contiguous(), inputs["angle"].contiguous()
@@ -356,15 +232,7 @@ class Loss(nn.modules.loss._Loss):
         if max(counts) == 0:
             zero = torch.zeros((), device=dev, dtype=cls.dtype, requires_grad=True)
             return zero * 1.0, {k: zero for k in self.loss_weights}
-        Mmax = max(counts)
-        empty8, emptyc = cls.new_zeros((0, 8)), cls.new_zeros((0, ncls))
-        boxes = [torch.cat((t["gt_center"], t["gt_size"], t["gt_angle"]), -1).float() if m else empty8
-                 for t, m in zip(targets, counts)]
-        gt_box = pad_sequence(boxes, batch_first=True).contiguous()                          # (B,Mmax,8)
-        gt_onehot = pad_sequence([t["gt_class"].float() if m else emptyc for t, m in zip(targets, counts)],
-                                 batch_first=True).contiguous()                              # (B,Mmax,C)
-        gt_id = gt_onehot.argmax(-1).to(torch.int32).contiguous()
-        counts_t = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
+        gt_box, gt_onehot, gt_id, counts_t, Mmax = pack_targets(targets, counts, ncls, dev)
         aw = self.anassigner.loss_weights
         cw = (C.c_float * 5)(aw["total_class"], aw["center"], aw["size"], aw["angle"], self.anassigner.giou_weight)
         cost = torch.empty((B, N, Mmax), dtype=torch.float32, device=dev)

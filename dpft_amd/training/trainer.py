@@ -23,6 +23,11 @@ class DataParallelTrainer:
         self.device = device
         train = config["train"]
         self.loss_fn = build_loss(train)
+        # the reference evaluates mAP3D / mGIoU3D in every training step (trainer.py:134); optional here
+        self.eval_fn = None
+        if config.get("evaluate", {}).get("metrics"):
+            from dpft_amd.evaluation import build_metric
+            self.eval_fn = build_metric(config["evaluate"])
         opt = dict(train["optimizer"])
         name = opt.pop("name")
         self.world = dist.get_world_size() if dist.is_initialized() else 1
@@ -45,7 +50,9 @@ class DataParallelTrainer:
         self.model.enable_fuser_graph(sample_data, grad_direct=self.reducer)
         self.optimizer.zero_grad(set_to_none=False)
 
-    def train_step(self, data: Dict[str, torch.Tensor], labels: List[Dict[str, torch.Tensor]]):
+    def train_step(self, data: Dict[str, torch.Tensor], labels: List[Dict[str, torch.Tensor]], with_metrics: bool = False):
+        """One step of CentralizedTrainer.train_one_epoch (trainer.py:122-136).  ``with_metrics`` also evaluates the
+        configured detection metrics on the step's outputs (two more launches) and returns them as a third value."""
         self.model.train()
         self.reducer.reset()                               # zero_grad (grads live in the buckets)
         output = self.model(data)
@@ -61,6 +68,8 @@ class DataParallelTrainer:
             if isinstance(self.optimizer, FusedAdamW):
                 self.optimizer.set_active(self.reducer.seen_ids())
             self.optimizer.step()
+        if with_metrics and self.eval_fn is not None:
+            return loss.detach(), {k: v.detach() for k, v in losses.items()}, self.eval_fn(output, labels)
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
 
     @torch.no_grad()

@@ -410,6 +410,17 @@ int dpft_scale_clip_f32(const float* x, float* y, int64_t n, float in_lo, float 
                         float out_hi, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-step detection metrics of the reference's train / validation loops (src/dprt/training/trainer.py:134,
+ * src/dprt/evaluation/metric.py): mAP3D (IoU threshold, nelem-point "interpolated" curve, :16-151) and mGIoU3D
+ * (:154-253) of every sample, on padded targets.  out (B,2) = (mAP, mGIoU) per sample (the caller applies the batch
+ * reduction); scratch holds 2*B*N*Mmax floats (IoU, GIoU of every pair).  N <= 1024, Mmax <= 256, C <= 16.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_detection_metrics_f32(const float* cls, const float* center, const float* size, const float* angle,
+                               const float* gt_box, const float* gt_onehot, const int32_t* counts,
+                               float threshold, int32_t nelem, float* scratch, float* out, int32_t B,
+                               int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW (torch.optim.AdamW semantics: decoupled decay, bias correction, no amsgrad),
  * the optimizer the reference builds at src/dprt/training/trainer.py:233 / optimizer.py:6-7.
  * chunks: device array of {float* p; const float* g; float* m; float* v; int32 n; int32 tensor}

@@ -207,6 +207,55 @@ def main():
     lx["enclosing"] = bbox.get_minimum_enclosing_box_corners(c2, corners)
     lx["enclosing_vol"] = bbox.get_box_volume_from_corners(lx["enclosing"].flatten(0, 2))
     np.savez(os.path.join(OUT, "loss.npz"), **_np(lx))
+    # ---- per-step detection metrics (src/dprt/evaluation/metric.py) from the reference's own classes; the absent
+    # pytorch3d.box3d_overlap is bound to the oracle's exact yaw-only geometry (parity unpinned for that call) ----
+    import dprt.utils.iou as ref_iou
+    from dprt.evaluation.metric import build_metric
+    from oracle.metric_oracle import box3d_overlap_from_corners
+    ref_iou.box3d_overlap = box3d_overlap_from_corners
+    metric = build_metric(cfg["evaluate"])
+    gm = torch.Generator().manual_seed(77)
+    mx = {}
+    cases = [(3, 40, (3, 5, 2)), (2, 25, (0, 4)), (2, 30, (6, 1)), (1, 12, (2,))]
+    for ci, (B, N, counts) in enumerate(cases):
+        gts = []
+        for M in counts:
+            c = torch.stack((5 + torch.rand(M, generator=gm) * 40, -6 + torch.rand(M, generator=gm) * 12,
+                             -1 + torch.rand(M, generator=gm) * 2), -1)
+            sz = torch.stack((3.5 + torch.rand(M, generator=gm), 1.6 + torch.rand(M, generator=gm) * 0.5,
+                              1.4 + torch.rand(M, generator=gm) * 0.5), -1)
+            yaw = (torch.rand(M, generator=gm) * 2 - 1) * 3.1
+            cls = torch.zeros(M, 2)
+            cls[torch.arange(M), (torch.rand(M, generator=gm) > (0.15 if ci != 2 else 1.5)).long()] = 1.0
+            gts.append(dict(gt_center=c, gt_size=sz, gt_angle=torch.stack((torch.sin(yaw), torch.cos(yaw)), -1),
+                            gt_class=cls))
+        out = {"center": torch.zeros(B, N, 3), "size": torch.zeros(B, N, 3), "angle": torch.zeros(B, N, 2),
+               "class": torch.randn(B, N, 2, generator=gm)}
+        for b, gt in enumerate(gts):           # predictions: jittered copies of the targets + clutter
+            M = gt["gt_center"].shape[0]
+            out["center"][b] = torch.stack((5 + torch.rand(N, generator=gm) * 40, -6 + torch.rand(N, generator=gm) * 12,
+                                            -1 + torch.rand(N, generator=gm) * 2), -1)
+            out["size"][b] = torch.stack((3.5 + torch.rand(N, generator=gm), 1.6 + torch.rand(N, generator=gm) * 0.5,
+                                          1.4 + torch.rand(N, generator=gm) * 0.5), -1)
+            yaw = (torch.rand(N, generator=gm) * 2 - 1) * 3.1
+            out["angle"][b] = torch.stack((torch.sin(yaw), torch.cos(yaw)), -1)
+            for j in range(M):
+                for rep in range(2):
+                    i = int(torch.randint(0, N, (1,), generator=gm))
+                    out["center"][b, i] = gt["gt_center"][j] + torch.randn(3, generator=gm) * (0.15 + 0.5 * rep)
+                    out["size"][b, i] = gt["gt_size"][j] * (1 + torch.randn(3, generator=gm) * 0.05)
+                    out["angle"][b, i] = gt["gt_angle"][j]
+                    out["class"][b, i] = gt["gt_class"][j] * 3 + torch.randn(2, generator=gm) * 0.5
+            out["size"][b, 0] = 0.0                # a degenerate prediction
+        ref = metric(out, gts)
+        for k, v in out.items():
+            mx[f"c{ci}_{k}"] = v
+        for b, gt in enumerate(gts):
+            for k, v in gt.items():
+                mx[f"c{ci}_t{b}_{k}"] = v
+        mx[f"c{ci}_mAP"], mx[f"c{ci}_mGIoU"] = ref["mAP"], ref["mGIoU"]
+        mx[f"c{ci}_B"] = np.asarray(B)
+    np.savez(os.path.join(OUT, "metric.npz"), **_np(mx))
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")

@@ -163,3 +163,21 @@ def test_giou_yaw_basic():
     # degenerate (zero size) prediction => -1 like the reference's validity mask
     g3 = O.giou3d_yaw(c[:1], torch.tensor([[0.0, 2, 2]]), a[:1], c[:1], s[:1], a[:1])
     assert float(g3[0, 0]) == -1.0
+
+
+def test_metric_oracle_matches_reference_golden(golden):
+    """oracle/metric_oracle.py vs the reference's mAP3D / mGIoU3D / Metric outputs (tests/golden/metric.npz)."""
+    from oracle import metric_oracle as MO
+    g = golden("metric.npz")
+    ci = 0
+    while f"c{ci}_class" in g:
+        B = int(g[f"c{ci}_B"])
+        out = {k: torch.from_numpy(g[f"c{ci}_{k}"]) for k in ("center", "size", "angle", "class")}
+        tgts = [{k: torch.from_numpy(g[f"c{ci}_t{b}_{k}"]) for k in ("gt_center", "gt_size", "gt_angle", "gt_class")}
+                for b in range(B)]
+        res = MO.metric_forward(out, tgts)
+        for k in ("mAP", "mGIoU"):
+            ref = float(g[f"c{ci}_{k}"])
+            assert abs(float(res[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), (ci, k, float(res[k]), ref)
+        ci += 1
+    assert ci == 4
