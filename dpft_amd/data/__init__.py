@@ -3,3 +3,4 @@ prefetch with an upload stream, and the per-sample online transforms (radar scal
 from dpft_amd.data.loader import PrefetchLoader, ShardedSampler, listed_collating, load_listed   # noqa: F401
 from dpft_amd.data.preprocess import GpuPreprocessor, resized_output_size                        # noqa: F401
 from dpft_amd.data.synthetic_raw import SyntheticRawDataset                                      # noqa: F401
+from dpft_amd.data.radar_projection import doppler_raster, radar_projection                      # noqa: F401

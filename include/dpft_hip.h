@@ -421,6 +421,18 @@ int dpft_detection_metrics_f32(const float* cls, const float* center, const floa
                                int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Radar tesseract -> RA / EA feature maps: KRadarProcessor.get_radar_data,
+ * src/dprt/datasets/kradar/processor.py:588-633.  tesseract (D,R,E,A) linear power; doppler_raster (D);
+ * ra (R,A,6), ea (E,A,6) = (rcs max, rcs median, rcs var, doppler peak, doppler centre, doppler var); the EA map
+ * folds the range bins [r_lo, r_hi) (reference: 4, 252).  scratch: dpft_radar_projection_scratch_floats(D,R,E,A);
+ * D <= 64, folded axes <= 256 elements.
+ * ---------------------------------------------------------------------------------------- */
+int64_t dpft_radar_projection_scratch_floats(int32_t D, int32_t R, int32_t E, int32_t A);
+int dpft_radar_projection_f32(const float* tesseract, const float* doppler_raster, float* ra, float* ea,
+                              float* scratch, int32_t D, int32_t R, int32_t E, int32_t A, int32_t r_lo,
+                              int32_t r_hi, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Fused multi-tensor AdamW (torch.optim.AdamW semantics: decoupled decay, bias correction, no amsgrad),
  * the optimizer the reference builds at src/dprt/training/trainer.py:233 / optimizer.py:6-7.
  * chunks: device array of {float* p; const float* g; float* m; float* v; int32 n; int32 tensor}

@@ -256,6 +256,22 @@ def main():
         mx[f"c{ci}_mAP"], mx[f"c{ci}_mGIoU"] = ref["mAP"], ref["mGIoU"]
         mx[f"c{ci}_B"] = np.asarray(B)
     np.savez(os.path.join(OUT, "metric.npz"), **_np(mx))
+
+    # ---- radar tesseract -> RA / EA maps from the reference's KRadarProcessor.get_radar_data (processor.py:588-633)
+    # on a seeded synthetic tesseract (only the outputs are stored; the test regenerates the input from the seed) ----
+    from dprt.datasets.kradar.processor import KRadarProcessor
+    from dprt.datasets.kradar.utils import radar_info
+    proc = KRadarProcessor.__new__(KRadarProcessor)
+    proc._dtype = np.float32
+    rx = {"doppler_raster": np.asarray(radar_info.doppler_raster, dtype=np.float64)}
+    for ci, (E, A, seed) in enumerate([(5, 6, 11), (3, 9, 12)]):
+        rs = np.random.RandomState(seed)
+        tess = (10.0 ** (rs.rand(64, 256, E, A) * 12.0 + 4.0)).astype(np.float32)       # 40 .. 160 dB
+        proc.get_radar_tesseract = lambda filename, t=tess: t
+        ra, ea = proc.get_radar_data("synthetic")
+        rx[f"c{ci}_shape"], rx[f"c{ci}_seed"] = np.asarray([E, A]), np.asarray(seed)
+        rx[f"c{ci}_ra"], rx[f"c{ci}_ea"] = ra, ea
+    np.savez(os.path.join(OUT, "radar_projection.npz"), **rx)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")

@@ -74,6 +74,9 @@ def install():
 
     _mod("MultiScaleDeformableAttention", ms_deform_attn_forward=ms_deform_attn_forward,
          ms_deform_attn_backward=ms_deform_attn_backward)
+    # dataset-preparation imports of dprt.datasets.kradar.processor (only its numpy reductions are exercised)
+    _mod("cv2")
+    _mod("pypcd", pypcd=_mod("pypcd.pypcd"))
     p3 = _mod("pytorch3d")
     p3.ops = _mod("pytorch3d.ops", box3d_overlap=_Placeholder)
     _mod("torch.utils.tensorboard", SummaryWriter=_Placeholder)

@@ -122,3 +122,60 @@ def test_gpu_pipeline_feeds_a_train_step():
     tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device("cuda", 0))
     loss, _ = tr.train_step(batch, labels)
     assert torch.isfinite(loss)
+
+
+def test_doppler_raster_matches_reference_table():
+    import numpy as np, os
+    from dpft_amd.data import doppler_raster
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "radar_projection.npz"))
+    assert np.array_equal(doppler_raster(64).numpy(), g["doppler_raster"].astype(np.float32))
+
+
+def _tesseract(E, A, seed):
+    import numpy as np
+    rs = np.random.RandomState(seed)
+    return (10.0 ** (rs.rand(64, 256, E, A) * 12.0 + 4.0)).astype(np.float32)
+
+
+def _check_projection(ra, ea, ra_ref, ea_ref):
+    import numpy as np
+    # order statistics and the raster lookup are exact given the dB values; dB differs by <= 2 ulp between log10f and
+    # numpy, variances are sums of squares of ~1e2 dB values
+    for got, ref in ((ra, ra_ref), (ea, ea_ref)):
+        np.testing.assert_allclose(got[..., [0, 1, 4]], ref[..., [0, 1, 4]], rtol=2e-6, atol=1e-5)
+        # peak-doppler bin: identical except where two doppler bins tie within the dB rounding (argmax of equal peaks)
+        flips = float(np.mean(got[..., 3] != ref[..., 3].astype(np.float32)))
+        assert flips <= 2e-3, flips
+        np.testing.assert_allclose(got[..., [2, 5]], ref[..., [2, 5]], rtol=2e-4, atol=1e-3)
+
+
+@pytest.mark.gpu
+def test_gpu_radar_projection_matches_reference_golden():
+    import numpy as np, os
+    from dpft_amd.data import radar_projection
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "radar_projection.npz"))
+    for ci in range(2):
+        E, A = [int(v) for v in g[f"c{ci}_shape"]]
+        t = torch.from_numpy(_tesseract(E, A, int(g[f"c{ci}_seed"]))).cuda()
+        ra, ea = radar_projection(t, torch.from_numpy(g["doppler_raster"]).float())
+        _check_projection(ra.cpu().numpy(), ea.cpu().numpy(), g[f"c{ci}_ra"], g[f"c{ci}_ea"])
+
+
+@pytest.mark.gpu
+def test_gpu_radar_projection_full_size_matches_oracle():
+    """The real cube size (64,256,37,107) against the numpy oracle, plus a size-independent property: permuting the
+    doppler bins permutes nothing but the peak-doppler channel."""
+    import numpy as np
+    from dpft_amd.data import doppler_raster, radar_projection
+    from oracle import radar_oracle as RO
+    t = _tesseract(37, 107, 5)
+    ra_ref, ea_ref = RO.radar_projection(t, doppler_raster(64).double().numpy())
+    td = torch.from_numpy(t).cuda()
+    ra, ea = radar_projection(td)
+    assert ra.shape == (256, 107, 6) and ea.shape == (37, 107, 6)
+    _check_projection(ra.cpu().numpy(), ea.cpu().numpy(), ra_ref, ea_ref)
+    perm = torch.randperm(64, generator=torch.Generator().manual_seed(1))
+    ra_p, ea_p = radar_projection(td[perm.cuda()])
+    for ch in (0, 1, 2, 4, 5):
+        np.testing.assert_allclose(ra_p[..., ch].cpu().numpy(), ra[..., ch].cpu().numpy(), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(ea_p[..., ch].cpu().numpy(), ea[..., ch].cpu().numpy(), rtol=1e-5, atol=1e-4)

@@ -181,3 +181,20 @@ def test_metric_oracle_matches_reference_golden(golden):
             assert abs(float(res[k]) - ref) <= 1e-5 * max(1.0, abs(ref)), (ci, k, float(res[k]), ref)
         ci += 1
     assert ci == 4
+
+
+def synthetic_tesseract(E, A, seed):
+    rs = np.random.RandomState(seed)
+    return (10.0 ** (rs.rand(64, 256, E, A) * 12.0 + 4.0)).astype(np.float32)
+
+
+def test_radar_projection_oracle_matches_reference_golden(golden):
+    """oracle/radar_oracle.py vs KRadarProcessor.get_radar_data outputs (tests/golden/radar_projection.npz)."""
+    from oracle import radar_oracle as RO
+    g = golden("radar_projection.npz")
+    for ci in range(2):
+        E, A = [int(v) for v in g[f"c{ci}_shape"]]
+        ra, ea = RO.radar_projection(synthetic_tesseract(E, A, int(g[f"c{ci}_seed"])), g["doppler_raster"])
+        np.testing.assert_allclose(ra, g[f"c{ci}_ra"], rtol=1e-6, atol=1e-6)
+        np.testing.assert_allclose(ea, g[f"c{ci}_ea"], rtol=1e-6, atol=1e-6)
+        assert ra.shape == (256, A, 6) and ea.shape == (E, A, 6)
