@@ -1272,8 +1272,8 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     int64_t tiles;
     if (vec) {
         if (d->K <= 32) { bmn = 32; bnc = 128; }
-        else if (d->K >= 128 && d->C >= 128) { bmn = 128; bnc = 128; }
-        else { bmn = 64; bnc = 64; }
+        else if (d->K >= 128 && d->C >= 128 && (int64_t)cdiv(d->K, 128) * cdiv(d->C, 128) * a.taps >= 8) { bmn = 128; bnc = 128; }
+        else { bmn = 64; bnc = 64; }      // also when 128x128 would leave < 8 output tiles to split over
         a.ktiles = cdiv(d->K, bmn);
         a.ctiles = cdiv(d->C, bnc);
         tiles = (int64_t)a.ktiles * a.ctiles * a.taps;
@@ -1283,13 +1283,31 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         a.ctiles = cdiv(a.J, 64);
         tiles = (int64_t)a.ktiles * a.ctiles;
     }
-    // enough pixel-splits to fill the chip; partial slabs bounded by 64 MiB (and by the workspace contract)
-    int splits = (int)((kNumCU * 2 + tiles - 1) / tiles);
+    // Pixel-splits: the grid should be ONE full round of workgroups -- 256 for the 128x128 tile, 512 (two per CU) for
+    // the smaller ones -- and never spill a few workgroups into another round (tools/wgrad_sweep.sh: 36 tiles x 15
+    // splits = 540 workgroups ran 25 % slower than 36 x 14 = 504 or 36 x 7 = 252).  Partial slabs are bounded by
+    // 64 MiB (and by the workspace contract).
+    const int round_wgs = (vec && bmn == 128) ? kNumCU : kNumCU * 2;
+    int splits = (int)std::max<int64_t>(1, round_wgs / tiles);
+    {   // when one round would stay badly filled (e.g. 144 tiles), fill two rounds instead
+        const int s2 = (int)std::max<int64_t>(1, 2 * round_wgs / tiles);
+        const double f1 = (double)tiles * splits / round_wgs, f2 = (double)tiles * s2 / (2.0 * round_wgs);
+        if (f1 < 0.8 && f2 > f1 + 0.1) splits = s2;
+    }
     const int64_t wbytes = (int64_t)d->K * a.J * 4;
     const int max_splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, (64ll << 20) / wbytes));
     if (splits > max_splits) splits = max_splits;
     while (splits > 1 && a.psteps / splits < 4) --splits;
     if (splits < 1) splits = 1;
+    if (const char* f = getenv("DPFT_FORCE_WGRAD")) {      // tuning aid: "tile,splits" (tile 128 | 64 for the vec kernel)
+        int tb, sp;
+        if (vec && sscanf(f, "%d,%d", &tb, &sp) == 2 && (tb == 128 || tb == 64)) {
+            bmn = tb; bnc = tb;
+            a.ktiles = cdiv(d->K, bmn); a.ctiles = cdiv(d->C, bnc);
+            tiles = (int64_t)a.ktiles * a.ctiles * a.taps;
+            splits = std::max(1, std::min(sp, max_splits));
+        }
+    }
     if (splits > 1 && !workspace) splits = 1;
     a.splits = splits;
     a.psteps_per_split = cdiv(a.psteps, splits);
