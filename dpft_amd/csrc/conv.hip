@@ -582,6 +582,27 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, const fl
     }
 }
 
+// weight-gradient slabs: many splits (up to 512) of a result that can be as small as 64 x 64 -- the slab index is
+// spread over PARTS lanes per output chunk (the serial walk above needs `splits` dependent trips per thread)
+template <int PARTS>
+__global__ __launch_bounds__(256) void splitk_reduce_wide_kernel(const float* __restrict__ partial, float* __restrict__ y,
+                                                                 int64_t MN, int splits) {
+    constexpr int CH = 256 / PARTS;      // float4 chunks per block
+    __shared__ f32x4 red[256];
+    const int ch = threadIdx.x % CH, part = threadIdx.x / CH;
+    const int64_t i = ((int64_t)blockIdx.x * CH + ch) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < MN)
+        for (int k = part; k < splits; k += PARTS) s += *reinterpret_cast<const f32x4*>(partial + (size_t)k * MN + i);
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (part == 0 && i < MN) {
+#pragma unroll
+        for (int q = 1; q < PARTS; ++q) s += red[q * CH + ch];
+        *reinterpret_cast<f32x4*>(y + i) = s;
+    }
+}
+
 // split-K reduce with the masked residual: y = sum_s partial[s] + (mask > 0 ? src : 0)
 __global__ void splitk_reduce_residual_kernel(const float* __restrict__ partial, const float* __restrict__ src,
                                               const float* __restrict__ mask, float* __restrict__ y, int64_t MN,
@@ -1050,8 +1071,7 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
         hipLaunchKernelGGL(wgrad16_3x3_kernel, dim3(nb), dim3(256), 0, st, a);
         int rc = check_launch("conv16 wgrad");
         if (rc) return rc;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(2304, 1024)), dim3(256), 0, st, (const float*)workspace,
-                           (const float*)nullptr, dw, (int64_t)2304, 16, nb, 0);
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(2304, 16)), dim3(256), 0, st, (const float*)workspace, dw, 2304, nb);
         return check_launch("conv16 wgrad reduce");
     }
     if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) {
@@ -1063,13 +1083,16 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
         handled = true;                                                                                      \
         hipLaunchKernelGGL((wgrad1x1_small_kernel<K_, C_>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M); \
     }
-        THIN_1X1(16, 3) else THIN_1X1(16, 6) else THIN_1X1(3, 6)
+        if (d->K == 16 && (d->C == 3 || d->C == 6)) {
+            handled = true;
+            if (d->C == 3) hipLaunchKernelGGL((wgrad1x1_k16_kernel<3>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M);
+            else hipLaunchKernelGGL((wgrad1x1_k16_kernel<6>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M);
+        } else THIN_1X1(3, 6)
 #undef THIN_1X1
         if (handled) {
             int rc = check_launch("thin 1x1 wgrad");
             if (rc) return rc;
-            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace,
-                               (const float*)nullptr, dw, (int64_t)kc, d->C, nb, 0);
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(kc, 16)), dim3(256), 0, st, (const float*)workspace, dw, kc, nb);
             return check_launch("thin 1x1 wgrad reduce");
         }
     }
@@ -1331,7 +1354,12 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     if (rc) return rc;
     if (splits > 1) {
         const int64_t n = (int64_t)d->K * a.J;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, st, a.partial, (const float*)nullptr, dw, n, 4, splits, 0);
+        if ((n & 3) == 0 && splits >= 16) {
+            if (n / 4 <= (int64_t)kNumCU * 64) hipLaunchKernelGGL(splitk_reduce_wide_kernel<16>, dim3(cdiv(n / 4, 16)), dim3(256), 0, st, a.partial, dw, n, splits);
+            else hipLaunchKernelGGL(splitk_reduce_wide_kernel<4>, dim3(cdiv(n / 4, 64)), dim3(256), 0, st, a.partial, dw, n, splits);
+        } else {
+            hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(n, 1024)), dim3(256), 0, st, a.partial, (const float*)nullptr, dw, n, 4, splits, 0);
+        }
         rc = check_launch("conv wgrad split-K reduce");
     }
     return rc;
