@@ -187,6 +187,20 @@ def stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+# Kernels that update parameters through raw pointers (dpft_adamw_f32) do not touch torch's per-tensor version
+# counters; anything that caches a function of the weights (the inference decoder's packed blobs) keys on this too.
+_weights_generation = 0
+
+
+def note_weights_changed() -> None:
+    global _weights_generation
+    _weights_generation += 1
+
+
+def weights_generation() -> int:
+    return _weights_generation
+
+
 def make_desc(B, H, W, Cin, K, kh, kw, stride, pad) -> ConvDesc:
     OH = (H + 2 * pad - kh) // stride + 1
     OW = (W + 2 * pad - kw) // stride + 1

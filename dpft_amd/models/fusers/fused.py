@@ -9,7 +9,7 @@ from typing import Dict, List, Tuple
 import torch
 from torch import nn
 
-from dpft_amd.hip.lib import DecoderFwd, DecoderView, Pyramid, lib, make_pyramid, stream
+from dpft_amd.hip.lib import DecoderFwd, DecoderView, Pyramid, lib, make_pyramid, stream, weights_generation
 
 
 def supported(fuser: nn.Module) -> bool:
@@ -48,7 +48,7 @@ class FusedDecoder:
     def _build(self):
         """(Re)pack the parameters into the kernels' transposed blobs whenever a weight changed."""
         f = self.fuser
-        key = tuple((p.data_ptr(), p._version) for p in f.parameters())
+        key = (weights_generation(),) + tuple((p.data_ptr(), p._version) for p in f.parameters())
         if key == self._key:
             return
         V, I = f.m_views, f.i_iter

@@ -7,7 +7,7 @@ from __future__ import annotations
 import numpy as np
 import torch
 
-from dpft_amd.hip.lib import lib, ptr, stream
+from dpft_amd.hip.lib import lib, note_weights_changed, ptr, stream
 
 CHUNK = 16384
 
@@ -77,6 +77,7 @@ class FusedAdamW(torch.optim.Optimizer):
             lib.call("dpft_adamw_f32", ptr(t["chunks"]), t["n_chunks"], ptr(t["active"]) if ids is not None else None,
                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                      self._step, stream())
+        note_weights_changed()                             # in-place through raw pointers: no _version bump
         return None
 
 

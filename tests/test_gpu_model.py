@@ -382,6 +382,33 @@ def test_graphed_decoder_step_equals_eager_step():
     assert errs[0][0] < 5e-3, errs[:6]
 
 
+def test_eval_after_fused_optimizer_steps_uses_updated_weights():
+    """The fused AdamW kernel writes parameters through raw pointers (no torch version bump): the inference decoder's
+    packed weight blobs must still be rebuilt, i.e. eval after training == the eager decoder on the current weights."""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    cfg["train"]["optimizer"]["lr"] = 1e-3                 # large steps: stale blobs would be far off
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=9, shapes=SHAPES, device=DEV)
+    labels = make_labels(2, seed=9, device=DEV)
+    torch.manual_seed(0)
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+    tr.model.eval()
+    with torch.no_grad():
+        before = {k: v.clone() for k, v in tr.model(batch).items()}      # builds (and caches) the packed blobs
+    for _ in range(3):
+        tr.train_step(batch, labels)
+    tr.model.eval()
+    with torch.no_grad():
+        out = {k: v.clone() for k, v in tr.model(batch).items()}
+        tr.model.fuser.use_fused_inference = False
+        ref = tr.model(batch)
+    assert float((out["center"] - before["center"]).abs().max()) > 1e-3, "training did not change the outputs"
+    for k in ref:
+        close(out[k], ref[k], rtol=1e-4, atol_scale=1e-4, what=f"eval after training {k}")
+
+
 @pytest.mark.parametrize("bsz", [1, 3, 4])      # different self-attention tilings (queries per block)
 def test_fused_inference_decoder_equals_eager_decoder(bsz):
     """eval + no_grad forward through the fused HIP decoder kernels == the eager (torch-op) decoder."""
