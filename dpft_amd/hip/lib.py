@@ -127,6 +127,7 @@ SIGNATURES = {
     "dpft_scale_clip_f32": (_I, [_P, _P, _L, _F, _F, _F, _F, _P]),
     "dpft_detection_metrics_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _I, _P, _P, _I, _I, _I, _I, _P]),
     "dpft_radar_projection_scratch_floats": (_L, [_I, _I, _I, _I]),
+    "dpft_export_select_f32": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _P, _I, _I, _I, _P]),
     "dpft_radar_projection_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),

@@ -421,6 +421,19 @@ int dpft_detection_metrics_f32(const float* cls, const float* center, const floa
                                int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * K-Radar export selection: KRadarExporter._construct_objects
+ * (src/dprt/evaluation/exporters/kradar.py:231-294) for all B samples and T <= 8 confidence thresholds at once.
+ * cls (B,N,C) raw scores, center (B,N,3), size (B,N,3), angle (B,N,2)=[sin,cos]; conf_thrs is a HOST array of T
+ * floats.  An object survives threshold t iff  argmax(cls)-1 >= 0  &  max(cls) >= thr_t  &  0<x<72, -6.4<y<6.4,
+ * -2<z<6, -50<yaw<50 (:268-277).  rows (B,T,N,8) receives the survivors in candidate order as
+ * [category, h, w, l, y, z, x, theta] (the non-constant columns of :283-292), counts (B,T) their number;
+ * mask (B,N) (optional, may be NULL) bit t = survived threshold t.  One block per sample.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_export_select_f32(const float* cls, const float* center, const float* size, const float* angle,
+                           const float* conf_thrs, int32_t T, float* rows, int32_t* counts, uint8_t* mask,
+                           int32_t B, int32_t N, int32_t C, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Radar tesseract -> RA / EA feature maps: KRadarProcessor.get_radar_data,
  * src/dprt/datasets/kradar/processor.py:588-633.  tesseract (D,R,E,A) linear power; doppler_raster (D);
  * ra (R,A,6), ea (E,A,6) = (rcs max, rcs median, rcs var, doppler peak, doppler centre, doppler var); the EA map

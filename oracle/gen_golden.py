@@ -272,6 +272,59 @@ def main():
         rx[f"c{ci}_shape"], rx[f"c{ci}_seed"] = np.asarray([E, A]), np.asarray(seed)
         rx[f"c{ci}_ra"], rx[f"c{ci}_ea"] = ra, ea
     np.savez(os.path.join(OUT, "radar_projection.npz"), **rx)
+    # ---- K-Radar exporter: file trees written by the reference's own KRadarExporter (exporters/kradar.py) ----
+    import tempfile
+    from dprt.evaluation.exporters.kradar import KRadarExporter
+    ex, trees = {}, {}
+    kradar_cats = {"Sedan": 0, "Bus or Truck": -1, "Motorcycle": -1, "Bicycle": -1, "Bicycle Group": -1,
+                   "Pedestrian": -1, "Pedestrian Group": -1, "Background": -1}          # config/kradar.json data.categories
+    for ci, (B, N, ncls, cats, counts, steps) in enumerate([(2, 50, 8, None, (0, 6), (0,)),
+                                                            (3, 400, 2, kradar_cats, (5, 1, 9), (0, 3))]):
+        ge = torch.Generator().manual_seed(300 + ci)
+        exporter = KRadarExporter(categories=cats)
+        with tempfile.TemporaryDirectory() as dst:
+            for si, step in enumerate(steps):
+                out = {"class": torch.randn(B, N, ncls, generator=ge) * 0.6,
+                       "center": torch.stack((-5 + torch.rand(B, N, generator=ge) * 85, -8 + torch.rand(B, N, generator=ge) * 16,
+                                              -3 + torch.rand(B, N, generator=ge) * 10), -1),
+                       "size": torch.stack((3.5 + torch.rand(B, N, generator=ge), 1.6 + torch.rand(B, N, generator=ge) * 0.5,
+                                            1.4 + torch.rand(B, N, generator=ge) * 0.5), -1)}
+                yaw = (torch.rand(B, N, generator=ge) * 2 - 1) * 3.1
+                out["angle"] = torch.stack((torch.sin(yaw), torch.cos(yaw)), -1)
+                out["class"][:, 3] = out["class"][:, 3, :1]                 # a tie between all classes -> background
+                out["center"][:, 5, 0] = 72.0                              # exactly on the FoV bound -> excluded
+                out["class"][0, 7] = torch.tensor([0.1] + [0.3] * (ncls - 1))     # confidence == a threshold, tie among objects
+                if ci == 0:
+                    out["class"][1] -= 2.0                                 # sample 1: nothing survives 0.9 (dummy line)
+                tgts = []
+                for b in range(B):
+                    M = counts[b]
+                    c = torch.stack((2 + torch.rand(M, generator=ge) * 80, -7 + torch.rand(M, generator=ge) * 14,
+                                     -1 + torch.rand(M, generator=ge) * 2), -1)
+                    sz = torch.stack((3.5 + torch.rand(M, generator=ge), 1.6 + torch.rand(M, generator=ge) * 0.5,
+                                      1.4 + torch.rand(M, generator=ge) * 0.5), -1)
+                    ya = (torch.rand(M, generator=ge) * 2 - 1) * 3.1
+                    cl = torch.zeros(M, ncls)
+                    cl[torch.arange(M), torch.randint(0, ncls, (M,), generator=ge)] = 1.0
+                    desc = torch.tensor([int(torch.randint(0, 9, (1,), generator=ge)), int(torch.randint(0, 2, (1,), generator=ge)),
+                                         int(torch.randint(0, 7, (1,), generator=ge))])
+                    tgts.append(dict(gt_center=c, gt_size=sz, gt_angle=torch.stack((torch.sin(ya), torch.cos(ya)), -1),
+                                     gt_class=cl, description=desc))
+                exporter(out, tgts, step, dst)
+                for k, v in out.items():
+                    ex[f"c{ci}_s{si}_{k}"] = v
+                for b, t in enumerate(tgts):
+                    for k, v in t.items():
+                        ex[f"c{ci}_s{si}_t{b}_{k}"] = v
+            tree = {}
+            for root, _, files in os.walk(dst):
+                for f in files:
+                    full = os.path.join(root, f)
+                    tree[os.path.relpath(full, dst).replace(os.sep, "/")] = open(full).read()
+        trees[f"c{ci}"] = {"B": B, "ncls": ncls, "categories": cats, "steps": list(steps), "tree": tree}
+    np.savez_compressed(os.path.join(OUT, "export.npz"), **_np(ex))
+    with open(os.path.join(OUT, "export.json"), "w") as f:
+        json.dump(trees, f, sort_keys=True)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")

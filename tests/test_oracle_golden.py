@@ -198,3 +198,37 @@ def test_radar_projection_oracle_matches_reference_golden(golden):
         np.testing.assert_allclose(ra, g[f"c{ci}_ra"], rtol=1e-6, atol=1e-6)
         np.testing.assert_allclose(ea, g[f"c{ci}_ea"], rtol=1e-6, atol=1e-6)
         assert ra.shape == (256, A, 6) and ea.shape == (E, A, 6)
+
+
+def export_cases(golden):
+    """(case dict from export.json, [(outputs, targets, step), ...]) for every exporter golden case."""
+    import json
+    import os
+    g = golden("export.npz")
+    with open(os.path.join(os.path.dirname(__file__), "golden", "export.json")) as f:
+        trees = json.load(f)
+    for name, case in sorted(trees.items()):
+        calls = []
+        for si, step in enumerate(case["steps"]):
+            out = {k: torch.from_numpy(g[f"{name}_s{si}_{k}"]) for k in ("class", "center", "size", "angle")}
+            tgts = [{k: torch.from_numpy(g[f"{name}_s{si}_t{b}_{k}"])
+                     for k in ("gt_center", "gt_size", "gt_angle", "gt_class", "description")} for b in range(case["B"])]
+            calls.append((out, tgts, step))
+        yield case, calls
+
+
+def test_export_oracle_matches_reference_golden(golden):
+    """oracle/export_oracle.py vs the file trees the reference's KRadarExporter wrote (tests/golden/export.json)."""
+    from oracle import export_oracle as EO
+    n = 0
+    for case, calls in export_cases(golden):
+        tree = {}
+        for out, tgts, step in calls:
+            for path, text in EO.export_tree(out, tgts, step, categories=case["categories"]).items():
+                tree[path] = tree.get(path, "") + text
+        assert sorted(tree) == sorted(case["tree"]), set(tree) ^ set(case["tree"])
+        for path, text in case["tree"].items():
+            assert tree[path] == text, path
+        assert any("dummy" in t for t in case["tree"].values())          # the placeholder path is exercised
+        n += 1
+    assert n == 2
