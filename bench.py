@@ -108,11 +108,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: dpft_amd has no CPU path")
+    # test hook (tests/test_gpu_distributed.py): all ranks on ONE device over gloo -- RCCL refuses two ranks per GPU
+    one_device = os.environ.get("DPFT_BENCH_ONE_DEVICE_GLOO") == "1"
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=device)
+        if one_device:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from dpft_amd.configs import load_config
@@ -155,15 +162,17 @@ def main():
 
     # ---- roofline of the dominant kernel family: fp32 MFMA implicit-GEMM convolutions --------------
     roof, per_kind = None, {}
+    # one serialized step (no concurrent view streams, no side-stream weight gradients): every conv launch is
+    # bracketed by HIP events and runs alone, so its duration is the kernel's, not its share of a busy device.
+    # EVERY rank takes the step (it contains the gradient all-reduce); only rank 0 records.
+    torch.cuda.synchronize()
+    trainer.model.concurrent_views = False
     if rank == 0:
-        torch.cuda.synchronize()
-        # one serialized step (no concurrent view streams, no side-stream weight gradients): every conv launch is
-        # bracketed by HIP events and runs alone, so its duration is the kernel's, not its share of a busy device
-        trainer.model.concurrent_views = False
         ops.profile_start()
-        trainer.train_step(data, labels)
-        recs = ops.profile_collect()
-        trainer.model.concurrent_views = True
+    trainer.train_step(data, labels)
+    recs = ops.profile_collect() if rank == 0 else []
+    trainer.model.concurrent_views = True
+    if rank == 0:
         tot_f, tot_t = 0.0, 0.0
         shapes = {}
         for kind, flops, dt, shape in recs:
@@ -253,6 +262,7 @@ def main():
         }
         print(json.dumps(line))
     if world > 1:
+        dist.barrier()                    # rank 0 is still measuring (decoder roofline) when the others get here
         dist.destroy_process_group()
 
 

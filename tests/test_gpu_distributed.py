@@ -21,3 +21,26 @@ def test_two_ranks_one_gpu_stay_in_sync(graphs):
     res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     assert "dp2 gloo-on-GPU OK" in res.stdout
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_launch_line():
+    """The driver's N>1 launch line of bench.py (torch.distributed.run, one JSON line from rank 0), with both ranks on
+    this box's single GPU over gloo (DPFT_BENCH_ONE_DEVICE_GLOO): every rank must pass through every collective --
+    including the profiled step after the timed region -- and the line must carry the whole-job aggregate."""
+    import json
+    env = dict(os.environ, DPFT_BENCH_ONE_DEVICE_GLOO="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    port = 29750 + (os.getpid() % 200)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3",
+           "--warmup", "2", "--latency-reps", "5"]
+    res = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["config"]["global_batch"] == 8 and line["config"]["parallelism"] == "dp2"
+    assert abs(line["value"] - 8 / (line["ms_per_step"] * 1e-3)) < 1e-6 * line["value"]
+    assert line["roofline"]["bound"] == "mfma" and 0 < line["roofline"]["frac"] < 1
+    assert line["cpu_baseline"] is None          # the CPU leg is an N=1 measurement
