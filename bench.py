@@ -187,6 +187,13 @@ def main():
                 for key, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f}\n")
         n_launch = sum(k[2] for k in per_kind.values())
+        # two more views of the same launch log: FLOP-weighted mean of the per-shape rates (SURVEY 8d wording), and
+        # the camera encoder alone (94 % of the FLOPs; the radar encoders' tiny GEMMs are launch-bound and, in the
+        # real step, hidden behind the camera on their own streams -- in this serialized step they count in full)
+        flop_weighted = sum(v[0] * (v[0] / v[1]) for v in shapes.values()) / max(tot_f, 1.0)
+        cam_w = {910, 455, 228, 114, 57, 29}          # widths of the camera feature maps (input of the conv)
+        cam = [v for key, v in shapes.items() if key[3] in cam_w]
+        cam_f, cam_t = sum(v[0] for v in cam), sum(v[1] for v in cam)
         traffic = None      # HBM bytes per conv launch from the committed PMC passes (tools/pmc_traffic.sh)
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic_pmc.json")
         if os.path.exists(pmc):
@@ -198,7 +205,10 @@ def main():
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * tot_t / max(n_launch, 1),
                 "event_bracket_overhead_us_subtracted": 1e3 * float(ops.lib.dpft_profile_overhead_ms()),
                 "conv_ms_per_step": 1e3 * tot_t, "algorithmic_gflop_per_step": tot_f / 1e9,
-                "per_kind_tflops": {k: v[0] / v[1] / 1e12 for k, v in per_kind.items()}}
+                "per_kind_tflops": {k: v[0] / v[1] / 1e12 for k, v in per_kind.items()},
+                "frac_flop_weighted": flop_weighted / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                "frac_camera_encoder": (cam_f / cam_t / 1e12 / PEAK_F32_MFMA_TFLOPS) if cam_t > 0 else None,
+                "camera_encoder_share_of_conv_time": (cam_t / tot_t) if tot_t > 0 else None}
 
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
     fwd_mean, fwd_std = trainer.inference_time(data, warmup=5, reps=args.latency_reps)
