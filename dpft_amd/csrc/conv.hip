@@ -582,6 +582,61 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, const fl
     }
 }
 
+// split-K reduce of a forward conv WITH the BatchNorm tile statistics of the reduced output (what the non-split kernel's
+// epilogue produces): one launch instead of reduce + bn_stats on the radar encoders' small maps, where every dependent
+// launch costs more than the work in it.  block = one statistics tile (tile_rows <= 128 rows) x 64 columns;
+// thread = one float4 column chunk x every 16th row.  N % 64 == 0.
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const float* __restrict__ partial, float* __restrict__ y,
+                                                                  float* __restrict__ stats, int64_t M, int N, int splits,
+                                                                  int tile_rows) {
+    __shared__ f32x4 red[16][16];
+    __shared__ f32x4 smean[16];
+    const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int tile = blockIdx.x, c = blockIdx.y * 64 + cl * 4;
+    const int64_t r0 = (int64_t)tile * tile_rows, MN = M * N;
+    const int cnt = (int)min((int64_t)tile_rows, M - r0);
+    f32x4 v[8];
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int r = rg + i * 16;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (r < cnt) {
+            const int64_t o = (r0 + r) * N + c;
+            f32x4 a = *reinterpret_cast<const f32x4*>(partial + o);
+            for (int k = 1; k < splits; ++k) a += *reinterpret_cast<const f32x4*>(partial + (size_t)k * MN + o);
+            *reinterpret_cast<f32x4*>(y + o) = a;
+            v[i] = a;
+            sum += a;
+        }
+    }
+    red[rg][cl] = sum;
+    __syncthreads();
+    if (rg == 0) {
+        f32x4 t = red[0][cl];
+        for (int i = 1; i < 16; ++i) t += red[i][cl];
+        smean[cl] = t * (1.0f / (float)cnt);
+    }
+    __syncthreads();
+    const f32x4 mean = smean[cl];
+    f32x4 m2 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+        if (rg + i * 16 < cnt) {
+            const f32x4 dlt = v[i] - mean;
+            m2 += dlt * dlt;
+        }
+    __syncthreads();
+    red[rg][cl] = m2;
+    __syncthreads();
+    if (rg == 0) {
+        f32x4 t = red[0][cl];
+        for (int i = 1; i < 16; ++i) t += red[i][cl];
+        *reinterpret_cast<f32x4*>(stats + ((size_t)tile * 2 + 0) * N + c) = mean;
+        *reinterpret_cast<f32x4*>(stats + ((size_t)tile * 2 + 1) * N + c) = t;
+    }
+}
+
 // weight-gradient slabs: many splits (up to 512) of a result that can be as small as 64 x 64 -- the slab index is
 // spread over PARTS lanes per output chunk (the serial walk above needs `splits` dependent trips per thread)
 template <int PARTS>
@@ -873,6 +928,49 @@ __global__ __launch_bounds__(256) void wgrad_gen_kernel(WgradArgs a) {
             const int n = n0 + wm * 32 + 4 * (lane >> 5) + (q & 3) + 8 * (q >> 2);
             if (n < a.K) out[(size_t)n * a.J + jj] = acc[q];
         }
+    }
+}
+
+// Data gradient of a conv whose INPUT has <= 4 channels (the 7x7/2 stems behind the radar encoders' 6->3 adjust conv):
+// as an implicit GEMM this has N = 3 (padded to a 32-wide tile) and, at stride 2, three of four taps invalid per pixel
+// -- 2.5 TF.  Here one thread owns one input pixel, walks only the taps that reach it and dots dy's K channels
+// (float4 loads) with the transposed weights held in LDS.  w_t is [C][taps][K]; K % 4 == 0; taps * C * K floats <= 40 KB.
+template <int CIN>
+__global__ __launch_bounds__(256) void thin_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w_t,
+                                                         float* __restrict__ dx, int B, int H, int W, int OH, int OW,
+                                                         int K, int kh, int kw, int stride, int pad, int accumulate) {
+    extern __shared__ float wl[];      // [CIN][taps][K]
+    const int taps = kh * kw, nw = CIN * taps * K;
+    for (int i = threadIdx.x * 4; i < nw; i += 256 * 4) *reinterpret_cast<f32x4*>(wl + i) = *reinterpret_cast<const f32x4*>(w_t + i);
+    __syncthreads();
+    const int64_t pix = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (pix >= (int64_t)B * H * W) return;
+    const int iw = (int)(pix % W), ih = (int)((pix / W) % H), b = (int)(pix / ((int64_t)W * H));
+    float acc[CIN];
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) acc[c] = 0.f;
+    for (int r = (ih + pad) % stride; r < kh; r += stride) {
+        const int oh = (ih + pad - r) / stride;
+        if (ih + pad - r < 0 || oh >= OH) continue;
+        for (int q = (iw + pad) % stride; q < kw; q += stride) {
+            const int ow = (iw + pad - q) / stride;
+            if (iw + pad - q < 0 || ow >= OW) continue;
+            const float* g = dy + (((int64_t)b * OH + oh) * OW + ow) * K;
+            const float* wt = wl + (r * kw + q) * K;
+            for (int k = 0; k < K; k += 4) {
+                const f32x4 gv = *reinterpret_cast<const f32x4*>(g + k);
+#pragma unroll
+                for (int c = 0; c < CIN; ++c) {
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(wt + c * taps * K + k);
+                    acc[c] += gv[0] * wv[0] + gv[1] * wv[1] + gv[2] * wv[2] + gv[3] * wv[3];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < CIN; ++c) {
+        float* o = dx + pix * CIN + c;
+        *o = accumulate ? *o + acc[c] : acc[c];
     }
 }
 
@@ -1173,6 +1271,11 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
     if (rc) return rc;
     if (t.splits > 1) {
         const int64_t MN = (int64_t)a.M * a.N;
+        if (stats && !bias && (a.N % 64) == 0 && t.bm <= 128) {      // reduce + per-tile (mean, M2) in one launch
+            hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(cdiv(a.M, t.bm), a.N / 64), dim3(256), 0, st, a.partial, y,
+                               stats, (int64_t)a.M, a.N, t.splits, t.bm);
+            return check_launch("conv fwd split-K reduce + stats");
+        }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 1024)), dim3(256), 0, st, a.partial, bias, y, MN, a.N, t.splits, 0);
         rc = check_launch("conv fwd split-K reduce");
         if (rc) return rc;
@@ -1192,9 +1295,28 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(1, d, st);
     if (conv16_matches(d)) return conv16_dgrad(d, dy, w_t, dx, accumulate, st);
+    if (d->C <= 4 && d->K % 4 == 0 && (size_t)d->C * d->kh * d->kw * d->K * 4 <= 40960 && ((d->C * d->kh * d->kw * d->K) % 4) == 0) {
+        const size_t lds = (size_t)d->C * d->kh * d->kw * d->K * 4;
+        const dim3 grid(cdiv((int64_t)d->B * d->H * d->W, 256));
+#define THIN_DGRAD(CI)                                                                                                  \
+    hipLaunchKernelGGL(thin_dgrad_kernel<CI>, grid, dim3(256), lds, st, dy, w_t, dx, d->B, d->H, d->W, d->OH, d->OW, \
+                       d->K, d->kh, d->kw, d->stride, d->pad, accumulate)
+        switch (d->C) {
+            case 1: THIN_DGRAD(1); break;
+            case 2: THIN_DGRAD(2); break;
+            case 3: THIN_DGRAD(3); break;
+            default: THIN_DGRAD(4); break;
+        }
+#undef THIN_DGRAD
+        return check_launch("conv dgrad (thin input)");
+    }
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
-    if (d->stride > 1 && (a.C % BKV) == 0) {
+    // Parity classes pay when each class fills the chip on its own (4x fewer MFMAs); on small maps (radar encoders) the
+    // stride^2 classes are stride^2 dependent launches of a few workgroups with the whole tap x channel loop inside
+    // (170 us for a 4x16x7 map) -- there one split-K launch over all taps is ~6x faster despite the wasted taps.
+    const int64_t class_wgs = (int64_t)cdiv((int64_t)a.B * cdiv(a.OH, d->stride) * cdiv(a.OW, d->stride), 64) * cdiv(a.N, 64);
+    if (d->stride > 1 && (a.C % BKV) == 0 && (class_wgs >= kNumCU / 2 || !workspace)) {
         // one launch per output-pixel parity class, each over the taps that can reach it (see IgemmArgs::sub_*)
         const int sp = d->stride, cpt = a.C / BKV;
         bool empty_class = false;
@@ -1320,7 +1442,17 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     const int64_t wbytes = (int64_t)d->K * a.J * 4;
     const int max_splits = (int)std::max<int64_t>(1, std::min<int64_t>(512, (64ll << 20) / wbytes));
     if (splits > max_splits) splits = max_splits;
-    while (splits > 1 && a.psteps / splits < 4) --splits;
+    if (splits > 1 && a.psteps / splits < 4) {
+        // Few pixels (radar encoders: 84 ... 1800): a workgroup would get under four pixel steps, so its fixed costs and
+        // the partial slabs decide.  tools/wgrad_small_sweep.sh: the 64x64 tile with about one workgroup per CU wins
+        // by 2-4x over fewer, fatter workgroups (448 pixels, 256->1024: 11.9 us vs 48.3 us unsplit 128x128 tiles).
+        if (vec && bmn == 128) {
+            bmn = 64; bnc = 64;
+            a.ktiles = cdiv(d->K, bmn); a.ctiles = cdiv(d->C, bnc);
+            tiles = (int64_t)a.ktiles * a.ctiles * a.taps;
+        }
+        splits = (int)std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(kNumCU / tiles, a.psteps), max_splits));
+    }
     if (splits < 1) splits = 1;
     if (const char* f = getenv("DPFT_FORCE_WGRAD")) {      // tuning aid: "tile,splits" (tile 128 | 64 for the vec kernel)
         int tb, sp;

@@ -36,6 +36,10 @@ CONV_CASES = [
     (4, 8, 4, 512, 512, 3, 1, 1),       # radar layer4: split-K
     (4, 16, 7, 1024, 256, 1, 1, 0),     # small M, long K
     (1, 128, 228, 64, 256, 1, 1, 0),    # big M
+    (4, 64, 114, 128, 128, 3, 2, 1),    # stride 2 on a big map: one dgrad launch per pixel parity class
+    (4, 64, 114, 256, 512, 1, 2, 0),    # 1x1 stride 2 on a big map: parity classes with empty ones (memset)
+    (4, 256, 107, 3, 64, 7, 2, 3),      # radar BEV stem at its real size: thin-input dgrad kernel
+    (2, 20, 17, 2, 32, 5, 3, 2),        # thin-input dgrad, stride 3, two input channels
 ]
 
 
