@@ -217,8 +217,7 @@ class _BodyFn(torch.autograd.Function):
             lib.call("dpft_resnet_backward_stage", plan.handle, li, ptr(st["x"]), C.byref(st["tables"]),
                      ptr(st["arena"]), ptr(d), stream())
             if direct is not None:                       # this stage's gradients are in the DP buckets: release them
-                for p_ in stage_params[li]:
-                    direct.mark_ready(p_)
+                direct.mark_ready_many(stage_params[li])
         grads = {}
         if direct is None:
             for c, g in zip(st["convs"], st["conv_g"]):

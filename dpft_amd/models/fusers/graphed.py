@@ -60,9 +60,7 @@ class _Replay(torch.autograd.Function):
         # gradient accumulation) run before the next replay overwrites them.
         gi = [None if t is None else t.detach() for t in g.static_grad_inputs]
         if g.grad_direct is not None:      # the graph already added the parameter gradients into the buckets
-            for p, t in zip(g.params, g.static_grad_inputs[g.n_levels:]):
-                if t is not None:
-                    g.grad_direct.mark_ready(p)
+            g.grad_direct.mark_ready_many(g.params_with_grad)
             return (None, None, *gi[:g.n_levels], *([None] * (n_other + len(g.params))))
         return (None, None, *gi[:g.n_levels], *([None] * n_other), *gi[g.n_levels:])
 
@@ -120,6 +118,7 @@ class GraphedFuser:
                     raise RuntimeError("GraphedFuser: a decoder parameter is not owned by the gradient reducer")
                 torch._foreach_add_([v for v, _ in pairs], [t for _, t in pairs])
         self.static_grad_inputs = list(grads)
+        self.params_with_grad = [p for p, t in zip(self.params, grads[self.n_levels:]) if t is not None]
         torch.cuda.synchronize()
         # inference replay: eval mode (dropout off, MHA fast path), no autograd
         self.flat.eval()

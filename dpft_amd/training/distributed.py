@@ -103,6 +103,28 @@ class GradBucketReducer:
         if bi is not None:
             self._mark(bi, p)
 
+    def mark_ready_many(self, params):
+        """``mark_ready`` for a whole list at once (a replayed decoder graph hands over ~250 gradients): the per-bucket
+        bookkeeping and the current-stream lookup happen once per bucket instead of once per parameter -- this runs on
+        the host right after the step's only device sync, while the GPU has nothing queued."""
+        touched = {}
+        for p in params:
+            bi = self._index.get(id(p))
+            if bi is None:
+                continue
+            b = self.buckets[bi]
+            if id(p) in b["seen"]:
+                continue
+            b["seen"].add(id(p))
+            b["ready"] += 1
+            touched[bi] = b
+        for b in touched.values():
+            if b["flat"].is_cuda:
+                st = torch.cuda.current_stream(b["flat"].device)
+                b["streams"][st.cuda_stream] = st
+            if b["ready"] == len(b["params"]) and not b["fired"]:
+                self._fire(b)
+
     def _hook(self, p):
         bi = self._index[id(p)]
         b = self.buckets[bi]
