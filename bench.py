@@ -144,7 +144,13 @@ def main():
         torch.cuda.synchronize()
 
     if not args.no_graphs:
-        trainer.enable_graphs(data)
+        try:
+            trainer.enable_graphs(data)
+        except Exception as e:          # keep the measurement valid (same work, eager launches) rather than abort the rank
+            print(f"[bench] rank {rank}: decoder graph capture failed ({type(e).__name__}: {e}); running ungraphed",
+                  file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
+            trainer.model.disable_fuser_graph()
     for _ in range(args.warmup):
         trainer.train_step(data, labels)
     sync()

@@ -19,6 +19,11 @@ import torch
 from torch import nn
 
 
+# Other threads of the process (the RCCL watchdog of torch.distributed polls its events) must not invalidate a capture
+# in progress: only this thread's calls are checked.
+CAPTURE_MODE = "thread_local"
+
+
 class _FlatFuser(nn.Module):
     """Tensor-only signature around IMPFusion.forward."""
 
@@ -105,11 +110,11 @@ class GraphedFuser:
         torch.cuda.synchronize()
 
         self.fwd_graph = torch.cuda.CUDAGraph()
-        with torch.enable_grad(), torch.cuda.graph(self.fwd_graph):
+        with torch.enable_grad(), torch.cuda.graph(self.fwd_graph, capture_error_mode=CAPTURE_MODE):
             self.static_outputs = self.flat(*static)
         self.static_grad_outputs = [torch.zeros_like(o) for o in self.static_outputs]
         self.bwd_graph = torch.cuda.CUDAGraph()
-        with torch.enable_grad(), torch.cuda.graph(self.bwd_graph):   # its own private pool (see module docstring)
+        with torch.enable_grad(), torch.cuda.graph(self.bwd_graph, capture_error_mode=CAPTURE_MODE):   # its own private pool (see module docstring)
             grads = torch.autograd.grad(self.static_outputs, diff_inputs, self.static_grad_outputs,
                                         allow_unused=True)
             if grad_direct is not None:
@@ -131,7 +136,7 @@ class GraphedFuser:
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             self.eval_graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.eval_graph):
+            with torch.cuda.graph(self.eval_graph, capture_error_mode=CAPTURE_MODE):
                 self.eval_outputs = self.flat(*self.eval_inputs)
         torch.cuda.synchronize()
         self.flat.train()

@@ -46,6 +46,9 @@ class DataParallelTrainer:
 
     def enable_graphs(self, sample_data: Dict[str, torch.Tensor]):
         """Replay the launch-bound decoder from hipGraphs (static shapes of ``sample_data``)."""
+        if self.world > 1:                    # no collective (parameter broadcast) may still be in flight during a capture
+            dist.barrier()
+        torch.cuda.synchronize()
         self.reducer.reset()
         self.model.enable_fuser_graph(sample_data, grad_direct=self.reducer)
         self.optimizer.zero_grad(set_to_none=False)
