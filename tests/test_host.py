@@ -36,6 +36,22 @@ def test_cabi_argument_errors_are_reported():
     assert rc != 0 and b"M=8" in lib.dpft_last_error()
 
 
+def test_every_compute_entry_rejects_null_arguments():
+    """Error behaviour of the boundary: every compute entry validates its arguments before touching the device and
+    reports DPFT_ERR_ARG + a message through dpft_last_error() (no GPU needed; run in a child process because a missing
+    check would be a crash)."""
+    import subprocess
+    import sys
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "cabi_null_probe.py")], capture_output=True,
+                         text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    got = json.loads(res.stdout.strip().splitlines()[-1])
+    assert len(got) >= 44, sorted(got)
+    for name, (rc, err) in got.items():
+        assert rc == -1, (name, rc, err)                       # DPFT_ERR_ARG
+        assert err and ":" in err, (name, err)                 # "<entry>: what was wrong"
+
+
 def test_state_dict_layout_matches_reference_naming():
     from dpft_amd.configs import load_config
     from dpft_amd.models import build
