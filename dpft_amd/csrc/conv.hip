@@ -217,7 +217,10 @@ __device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt
 // ---------------------------------------------------------------------------------------------
 // vector path: C % 32 == 0 (every bottleneck conv); float4 global loads, b128 LDS fragments
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO>
+// LIN = false: data gradient of a strided conv over ALL taps in one launch (small maps, see dpft_conv2d_nhwc_dgrad_f32):
+// the source pixel is (oh + pad - r) / stride where that divides, not linear in the tap -- only that instantiation
+// carries the divisions.
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true>
 __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
     constexpr int AP = BM / 16, BP = BN / 16;      // 16 rows x 16 chunks (of 16 B) per loader pass
@@ -233,11 +236,24 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     const int m0 = mt * BM, n0 = nt * BN;
 
     const int chunk = tid & 15, rowl = tid >> 4;
-    int a_bh[AP], a_bw[AP];
-    const float* a_base[AP];
+    // ---- operand addressing --------------------------------------------------------------------------------------
+    // fp32 "MFMA" runs on the vector ALUs of gfx950 (its peak IS the vector fp32 peak; tools/probes/mfma_valu_overlap:
+    // MFMA + VALU time add up, at any occupancy), so every address / mask / clamp instruction of the loader is paid in
+    // matrix throughput.  The loader therefore costs no vector instruction per K-step:
+    //  * raw buffer loads: the hardware range check returns 0 for an offset beyond the tensor, which serves the zero
+    //    padding, rows >= M and weight rows >= N without clamps, selects or a zeroing pass;
+    //  * one 32-bit byte offset per loader row, recomputed only when the filter tap changes (every C/64 steps), from
+    //    per-row filter-row / filter-column validity bits built once; the channel offset of the step travels in the
+    //    scalar soffset.
     const bool sub = DGRAD && a.sub_step > 1;
+    constexpr bool lin = LIN;      // source pixel is linear in the tap: forward, stride-1 dgrad, parity-class dgrad
     const int roww = sub ? a.sub_ow : a.OW;
     const int ohw = sub ? a.sub_oh * a.sub_ow : a.OH * a.OW;
+    const int ntap_s = sub ? a.sub_ns : a.kw;
+    const int ntap_r = sub ? a.sub_nr : a.kh;      // kh, kw <= 8 (host side)
+    constexpr unsigned OOB = 0x80000000u;
+    int a_h0[AP], a_w0[AP], a_row[AP];      // tap-origin pixel (may lie outside the image) and its element offset
+    unsigned a_mask[AP];                    // which filter rows / columns read a real pixel (see below)
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
         const int m = m0 + rowl + 16 * i;
@@ -246,28 +262,81 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         const int b = mm / ohw;
         const int rem = mm - b * ohw;
         int oh = rem / roww, ow = rem - oh * roww;
-        if (sub) {
-            oh = oh * a.sub_step + a.sub_ph;
-            ow = ow * a.sub_step + a.sub_pw;
-        }
+        int h0, w0;
         if (!DGRAD) {
-            a_bh[i] = ok ? oh * a.stride - a.pad : -(1 << 28);
-            a_bw[i] = ow * a.stride - a.pad;
+            h0 = oh * a.stride - a.pad;
+            w0 = ow * a.stride - a.pad;
+        } else if (sub) {      // (oh,ow) = sub-grid index; source row = index + q0 - tap index (see IgemmArgs::sub_*)
+            h0 = oh + (a.sub_ph + a.pad - a.sub_r0) / a.sub_step;
+            w0 = ow + (a.sub_pw + a.pad - a.sub_s0) / a.sub_step;
         } else {
-            a_bh[i] = ok ? oh + a.pad : -(1 << 28);
-            a_bw[i] = ow + a.pad;
+            h0 = oh + a.pad;
+            w0 = ow + a.pad;
         }
-        a_base[i] = a.x + (size_t)b * a.H * a.W * a.C + chunk * 4;
+        a_h0[i] = h0; a_w0[i] = w0;
+        a_row[i] = lin ? ((b * a.H + h0) * a.W + w0) * a.C : b * a.H * a.W * a.C;
+        // tap validity is separable: bits 0..7 = filter rows that land inside the image, bits 8..15 = filter columns
+        unsigned mask = 0;
+        for (int ri = 0; ri < ntap_r; ++ri) {
+            int hi;
+            bool v = ok;
+            if (!DGRAD) hi = h0 + ri;
+            else if (lin) hi = h0 - ri;
+            else {
+                const int th = h0 - ri;
+                hi = th / a.stride;
+                v = v && th >= 0 && hi * a.stride == th;
+            }
+            mask |= (v && (unsigned)hi < (unsigned)a.H) ? (1u << ri) : 0u;
+        }
+        for (int si = 0; si < ntap_s; ++si) {
+            int wi;
+            bool v = ok;
+            if (!DGRAD) wi = w0 + si;
+            else if (lin) wi = w0 - si;
+            else {
+                const int tw = w0 - si;
+                wi = tw / a.stride;
+                v = v && tw >= 0 && wi * a.stride == tw;
+            }
+            mask |= (v && (unsigned)wi < (unsigned)a.W) ? (256u << si) : 0u;
+        }
+        a_mask[i] = mask;
     }
-    const float* b_base[BP];
-    bool b_ok[BP];
+    unsigned b_off[BP];      // byte offset of weight row n (+ this lane's 16-byte chunk); OOB for rows >= N
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
         const int n = n0 + rowl + 16 * i;
-        b_ok[i] = n < a.N;
-        b_base[i] = a.w + (size_t)(b_ok[i] ? n : 0) * a.Ktot + chunk * 4;
+        b_off[i] = n < a.N ? (unsigned)(n * a.Ktot + chunk * 4) * 4u : OOB;
     }
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.N * a.Ktot * 4, 0x00020000);
     const int cpt = a.C / BKV;  // K-steps per filter tap
+    unsigned a_off[AP];         // byte offsets of the current tap (OOB where the tap misses the image)
+    unsigned a_valid_tap = 0;   // bit i: row i of the current tap is a real pixel
+    int cur_tap = -1;
+    auto set_tap = [&](int tap) {
+        const int ri = tap / ntap_s, si = tap - ri * ntap_s;
+        const int tapoff = (DGRAD ? -1 : 1) * (ri * a.W + si) * a.C;      // linear case
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bool v = ((a_mask[i] >> ri) & (a_mask[i] >> (8 + si)) & 1u) != 0;
+            int e;
+            if (lin) {
+                e = a_row[i] + tapoff;
+            } else {
+                const int hi = (a_h0[i] - ri) / a.stride, wi = (a_w0[i] - si) / a.stride;
+                e = a_row[i] + (hi * a.W + wi) * a.C;
+            }
+            a_off[i] = v ? (unsigned)(e + chunk * 4) * 4u : OOB;
+            valid |= v ? (1u << i) : 0u;
+        }
+        a_valid_tap = valid;
+        cur_tap = tap;
+    };
 
     // Raw operand registers of the next DEPTH K-steps (register ring).  Loads are issued two steps ahead:
     // under load HBM/L2 latency exceeds one step of MFMA work, and a wait right behind the MFMAs stalls every
@@ -280,79 +349,49 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         constexpr int sidx = decltype(S)::value;
         const int tap = kt / cpt;
         const int c0 = (kt - tap * cpt) * BKV;
-        int r, s;
+        if (tap != cur_tap) set_tap(tap);      // uniform
+        int r, s_;
         if (sub) {
             const int ri = tap / a.sub_ns;
             r = a.sub_r0 + a.sub_step * ri;
-            s = a.sub_s0 + a.sub_step * (tap - ri * a.sub_ns);
+            s_ = a.sub_s0 + a.sub_step * (tap - ri * a.sub_ns);
         } else {
             r = tap / a.kw;
-            s = tap - r * a.kw;
+            s_ = tap - r * a.kw;
         }
-        const size_t koff = (size_t)(r * a.kw + s) * a.C + c0;      // == kt * BKV when every tap is visited
+        const int koff = (r * a.kw + s_) * a.C + c0;      // == kt * BKV when every tap is visited
         if (PRO) {
             p_mu[sidx] = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
             p_sc[sidx] = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
             p_sh[sidx] = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
         }
-        unsigned valid = 0;
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            int hi, wi;
-            bool v;
-            if (!DGRAD) {
-                hi = a_bh[i] + r;
-                wi = a_bw[i] + s;
-                v = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            } else {
-                const int th = a_bh[i] - r, tw = a_bw[i] - s;
-                v = th >= 0 && tw >= 0;
-                if (a.stride == 1) {
-                    hi = th;
-                    wi = tw;
-                } else {
-                    hi = th / a.stride;
-                    wi = tw / a.stride;
-                    v = v && (hi * a.stride == th) && (wi * a.stride == tw);
-                }
-                v = v && hi < a.H && wi < a.W;
-            }
-            // unconditional load from a clamped (always valid) address; invalid rows are zeroed when the set is
-            // written to LDS.  No control flow around the loads => the compiler can keep counted vmcnt waits and
-            // the ring really stays two steps deep.
-            hi = min(max(hi, 0), a.H - 1);
-            wi = min(max(wi, 0), a.W - 1);
-            ra[sidx][i] = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * a.W + wi) * a.C + c0);
-            valid |= v ? (1u << i) : 0u;
-        }
-        a_valid[sidx] = valid;
+        for (int i = 0; i < AP; ++i)
+            ra[sidx][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_off[i], c0 * 4, 0));
+        a_valid[sidx] = a_valid_tap;
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-            rbv[sidx][i] = *reinterpret_cast<const f32x4*>(b_base[i] + koff);   // rows >= N: clamped row, zeroed at store
+            rbv[sidx][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_off[i], koff * 4, 0));
     };
+    const bool pro_mask = a.kh * a.kw > 1 || a.pad > 0;      // padding exists: BN(0) != 0 must be forced back to 0
     auto store_tile = [&](auto S) {
         constexpr int sidx = decltype(S)::value;
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             f32x4 val = ra[sidx][i];
-            const bool v = (a_valid[sidx] >> i) & 1u;
+            if (PRO) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float t = val[e];
-                if (PRO) {
-                    t = fmaf(t - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
-                    t = a.pro_relu ? fmaxf(t, 0.f) : t;
+                for (int e = 0; e < 4; ++e) {
+                    float t = fmaf(val[e] - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
+                    val[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
                 }
-                val[e] = v ? t : 0.f;
+                if (pro_mask && !((a_valid[sidx] >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
             }
             *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
         }
 #pragma unroll
-        for (int i = 0; i < BP; ++i) {
-            f32x4 val = rbv[sidx][i];
-            if (!b_ok[i]) val = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = val;
-        }
+        for (int i = 0; i < BP; ++i)
+            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
     };
 
     // NACC > 1 = K-interleaved partial accumulators per 32x32 block (summed in the epilogue) to break the
@@ -1129,12 +1168,26 @@ static void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t 
 
 template <bool DGRAD>
 static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t st) {
-    a.mtiles = cdiv(a.M, t.bm);
-    a.ntiles = cdiv(a.N, t.bn);
+    if (t.vec) {      // the vector loader keeps a 32-bit tap mask per row and 32-bit buffer offsets
+        DPFT_REQUIRE(a.kh <= 8 && a.kw <= 8, "conv: the C %% 64 == 0 path supports filters up to 8x8 (%dx%d)", a.kh, a.kw);
+        DPFT_REQUIRE((int64_t)a.B * a.H * a.W * a.C < (1ll << 29) && (int64_t)a.N * a.Ktot < (1ll << 29),
+                     "conv: operand larger than 2 GiB");
+    }
+    const bool nonlin = DGRAD && t.vec && a.stride > 1 && a.sub_step <= 1;
+    const int bm = nonlin ? 64 : t.bm, bn = nonlin ? 64 : t.bn;
+    a.mtiles = cdiv(a.M, bm);
+    a.ntiles = cdiv(a.N, bn);
     a.splits = t.splits;
     a.ksteps_per_split = cdiv(a.ksteps, a.splits);
     const int nwg = a.mtiles * a.ntiles * a.splits;
     dim3 grid(nwg), block(256);
+    if (nonlin) {
+        if constexpr (DGRAD) {
+            constexpr size_t lds = (size_t)(64 + 64) * LDK * sizeof(float);
+            launch_lds(igemm_vec_kernel<64, 64, 2, 2, true, false, false>, grid, block, lds, st, a);
+        }
+        return check_launch("conv igemm (strided dgrad, all taps)");
+    }
 #define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
     do {                                                                                      \
         constexpr size_t lds = (size_t)(BM_ + BN_) * LDK * sizeof(float);                     \
