@@ -765,33 +765,51 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
 
     f32x4 ry[YP], rx[XP];
     unsigned x_valid = 0;
-    auto load_tile = [&](int ps) {
-        const int p0 = ps * BKP;
+    // Loader without divisions (see igemm_vec_kernel: every vector instruction here is paid in matrix throughput): raw
+    // buffer loads, dy rows at fixed per-lane offsets + a scalar pixel offset, and for x a (b, oh, ow) triple per loader
+    // row that is decomposed once and then ADVANCED by the 64 pixels of a step with two carries.
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    unsigned y_voff[YP];
 #pragma unroll
-        for (int i = 0; i < YP; ++i) {
-            const int p = p0 + yrow + i * YRP;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (y_ok && p < a.M) v = *reinterpret_cast<const f32x4*>(a.dy + (size_t)p * a.K + n0 + ych * 4);
-            ry[i] = v;
-        }
-        x_valid = 0;
+    for (int i = 0; i < YP; ++i) y_voff[i] = y_ok ? (unsigned)((yrow + i * YRP) * a.K + n0 + ych * 4) * 4u : OOB;
+    int xb[XP], xoh[XP], xow[XP];      // pixel of loader row i in the NEXT step to be loaded
+    {
+        const int p_first = (split * a.psteps_per_split) * BKP;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const int p = p0 + xrow + i * XRP;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (x_ok && p < a.M) {
-                const int b = p / ohw;
-                const int rem = p - b * ohw;
-                const int oh = rem / a.OW, ow = rem - oh * a.OW;
-                const int hi = oh * a.stride - a.pad + r, wi = ow * a.stride - a.pad + s;
-                if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
-                    v = *reinterpret_cast<const f32x4*>(
-                        a.x + (((size_t)b * a.H + hi) * a.W + wi) * a.C + c0 + xch * 4);
-                    x_valid |= 1u << i;
-                }
-            }
-            rx[i] = v;
+            const int p = p_first + xrow + i * XRP;
+            xb[i] = p / ohw;
+            const int rem = p - xb[i] * ohw;
+            xoh[i] = rem / a.OW;
+            xow[i] = rem - xoh[i] * a.OW;
         }
+    }
+    const int adv_b = BKP / ohw, adv_rem = BKP - adv_b * ohw;      // one step = adv_b images + adv_oh rows + adv_ow pixels
+    const int adv_oh = adv_rem / a.OW, adv_ow = adv_rem - adv_oh * a.OW;
+    const int x_lane = (c0 + xch * 4);
+    auto load_tile = [&](int ps) {      // called once per step, in step order
+        const int soff_y = ps * BKP * a.K * 4;
+#pragma unroll
+        for (int i = 0; i < YP; ++i)
+            ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, (int)y_voff[i], soff_y, 0));
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int hi = xoh[i] * a.stride - a.pad + r, wi = xow[i] * a.stride - a.pad + s;
+            const bool v = x_ok && xb[i] < a.B && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const unsigned e = ((((unsigned)xb[i] * a.H + hi) * a.W + wi) * a.C + x_lane) * 4u;      // garbage where !v
+            rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? e : OOB), 0, 0));
+            valid |= v ? (1u << i) : 0u;
+            // advance to the next step's pixel
+            int ow = xow[i] + adv_ow, oh = xoh[i] + adv_oh, b = xb[i] + adv_b;
+            if (ow >= a.OW) { ow -= a.OW; ++oh; }
+            if (oh >= a.OH) { oh -= a.OH; ++b; }
+            xow[i] = ow; xoh[i] = oh; xb[i] = b;
+        }
+        x_valid = valid;
     };
     auto store_tile = [&]() {
 #pragma unroll
@@ -801,13 +819,12 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         for (int i = 0; i < XP; ++i) {
             f32x4 v = rx[i];
             if (PRO) {      // producer BN+ReLU applied after the MFMAs of the current step (see igemm_vec_kernel)
-                const bool ok = (x_valid >> i) & 1u;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
-                    t = a.pro_relu ? fmaxf(t, 0.f) : t;
-                    v[e] = ok ? t : 0.f;
+                    const float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
+                    v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
                 }
+                if (!((x_valid >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // padding / pixel tail: BN(0) != 0
             }
             *reinterpret_cast<f32x4*>(&Xs[(xrow + i * XRP) * BNc + xch * 4]) = v;
         }
@@ -1466,6 +1483,8 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     const bool vec = (d->C % 32 == 0) && (d->K % 4 == 0);
     a.psteps = cdiv(a.M, vec ? BKP : BK);
     DPFT_REQUIRE(!(pro && !vec), "conv wgrad: fused prologue needs C %% 32 == 0");
+    DPFT_REQUIRE(!vec || ((int64_t)a.M * a.K < (1ll << 29) && (int64_t)a.B * a.H * a.W * a.C < (1ll << 29)),
+                 "conv wgrad: operand larger than 2 GiB");
     int bmn, bnc;
     int64_t tiles;
     if (vec) {
