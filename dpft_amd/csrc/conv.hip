@@ -415,24 +415,33 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, DEPTH - 1>;      // == S0 when DEPTH == 1
 
+    // The fragments of K-group kg+1 are read from LDS BEFORE the MFMAs of group kg are issued (two register sets;
+    // sched_barrier keeps the order -- left alone the scheduler reads a group right before its use, and the wave then
+    // waits out the LDS latency with nothing in the pipe).
     auto compute = [&]() {
-#pragma unroll
-        for (int kg = 0; kg < BKV / 8; ++kg) {
-            f32x4 af[RB], bf[CB];
+        f32x4 af[2][RB], bf[2][CB];
+        auto frags = [&](int set, int kg) {
 #pragma unroll
             for (int i = 0; i < RB; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDK + kg * 8);
+                af[set][i] = *reinterpret_cast<const f32x4*>(a_frag + i * 32 * LDK + kg * 8);
 #pragma unroll
             for (int j = 0; j < CB; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDK + kg * 8);
+                bf[set][j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDK + kg * 8);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int kg = 0; kg < BKV / 8; ++kg) {
+            if (kg + 1 < BKV / 8) frags((kg + 1) & 1, kg + 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
-                        accp[e % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][e], bf[j][e],
+                        accp[e % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][i][e], bf[kg & 1][j][e],
                                                                                     accp[e % NACC][i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
@@ -850,18 +859,28 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     for (int ps = ps_begin; ps < ps_end; ++ps) {
         const bool more = ps + 1 < ps_end;
         if (more) load_tile(ps + 1);
+        {   // fragments of pixel pair kk+PF are read before the MFMAs of pair kk are issued (see igemm_vec_kernel)
+            constexpr int PF = 2, NS = PF + 1;
+            float av[NS][RB], bv[NS][CB];
+            auto frags = [&](int set, int kk) {
 #pragma unroll
-        for (int kk = 0; kk < BKP / 2; ++kk) {
-            float av[RB], bv[CB];
+                for (int i = 0; i < RB; ++i) av[set][i] = y_frag[kk * 2 * BMn + i * 32];
 #pragma unroll
-            for (int i = 0; i < RB; ++i) av[i] = y_frag[kk * 2 * BMn + i * 32];
+                for (int j = 0; j < CB; ++j) bv[set][j] = x_frag[kk * 2 * BNc + j * 32];
+            };
 #pragma unroll
-            for (int j = 0; j < CB; ++j) bv[j] = x_frag[kk * 2 * BNc + j * 32];
+            for (int q = 0; q < PF; ++q) frags(q, q);
 #pragma unroll
-            for (int i = 0; i < RB; ++i)
+            for (int kk = 0; kk < BKP / 2; ++kk) {
+                if (kk + PF < BKP / 2) frags((kk + PF) % NS, kk + PF);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < CB; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % NS][i], bv[kk % NS][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         __syncthreads();
         if (more) store_tile();
