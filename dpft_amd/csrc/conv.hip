@@ -240,8 +240,9 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     // fp32 "MFMA" runs on the vector ALUs of gfx950 (its peak IS the vector fp32 peak; tools/probes/mfma_valu_overlap:
     // MFMA + VALU time add up, at any occupancy), so every address / mask / clamp instruction of the loader is paid in
     // matrix throughput.  The loader therefore costs no vector instruction per K-step:
-    //  * raw buffer loads: the hardware range check returns 0 for an offset beyond the tensor, which serves the zero
-    //    padding, rows >= M and weight rows >= N without clamps, selects or a zeroing pass;
+    //  * raw buffer loads: the hardware range check returns 0 for an offset beyond the tensor (voffset + soffset are
+    //    both checked on gfx950, dword by dword: tools/probes/buffer_range.hip), which serves the zero padding, rows
+    //    >= M and weight rows >= N without clamps, selects or a zeroing pass;
     //  * one 32-bit byte offset per loader row, recomputed only when the filter tap changes (every C/64 steps), from
     //    per-row filter-row / filter-column validity bits built once; the channel offset of the step travels in the
     //    scalar soffset.
