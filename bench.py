@@ -26,6 +26,7 @@ import torch
 import torch.distributed as dist
 
 PEAK_F32_MFMA_TFLOPS = 157.3       # /opt/skills/guides/MI355X_MICROARCH.md, chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (same table); only used by --dtype bf16
 
 
 def parse():
@@ -37,6 +38,9 @@ def parse():
     ap.add_argument("--config", default="kradar")
     ap.add_argument("--latency-reps", type=int, default=30, help="event-timed eval forwards for fwd ms/frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="f32 = the reference's arithmetic (BASELINE metric, default); bf16 = mixed precision of "
+                         "BASELINE.json configs[4]: bf16 operands / fp32 accumulation in the conv GEMMs")
     ap.add_argument("--no-graphs", action="store_true", help="do not replay the decoder from hipGraphs")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-steps", type=int, default=1)
@@ -129,6 +133,8 @@ def main():
     from dpft_amd.training.trainer import DataParallelTrainer
 
     cfg = load_config(args.config)
+    if args.dtype == "bf16":
+        cfg["computing"]["conv_compute"] = "bf16"
     torch.manual_seed(cfg["computing"]["seed"])
     model = build("dprt", cfg)
     trainer = DataParallelTrainer(model, cfg, device)
@@ -205,15 +211,18 @@ def main():
         if os.path.exists(pmc):
             with open(pmc) as f:
                 traffic = json.load(f).get("traffic_bytes_per_launch")
-        roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": tot_f / tot_t / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": traffic,
+        # mixed precision: priced against the dense bf16 MFMA peak although the operands still arrive as fp32 (the
+        # kernels are then bound by that fp32 operand path, not by the matrix pipe)
+        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": tot_f / tot_t / 1e12 / peak, "traffic": traffic if args.dtype == "f32" else None,
                 "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family)",
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * tot_t / max(n_launch, 1),
                 "event_bracket_overhead_us_subtracted": 1e3 * float(ops.lib.dpft_profile_overhead_ms()),
                 "conv_ms_per_step": 1e3 * tot_t, "algorithmic_gflop_per_step": tot_f / 1e9,
                 "per_kind_tflops": {k: v[0] / v[1] / 1e12 for k, v in per_kind.items()},
-                "frac_flop_weighted": flop_weighted / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                "frac_camera_encoder": (cam_f / cam_t / 1e12 / PEAK_F32_MFMA_TFLOPS) if cam_t > 0 else None,
+                "frac_flop_weighted": flop_weighted / 1e12 / peak,
+                "frac_camera_encoder": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
                 "camera_encoder_share_of_conv_time": (cam_t / tot_t) if tot_t > 0 else None}
 
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
@@ -267,11 +276,14 @@ def main():
         line = {
             "metric": "training samples/sec (K-Radar C+R, bs4/GPU)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config}.json full C+R dual-perspective fusion train step, batch {B}/GPU "
                                    "(camera 512x910x3 ResNet-101, radar BEV 256x107x6 + front 37x107x6 ResNet-50, "
                                    "FPN->16ch, IMPFusion 4 it x 3 views, Hungarian set loss, AdamW)",
-                       "global_batch": world * B, "parallelism": f"dp{world}"},
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "precision": "fp32 (reference arithmetic)" if args.dtype == "f32" else
+                                    "mixed: bf16 operands / fp32 accumulation in the forward + data-gradient conv GEMMs, "
+                                    "everything else fp32 (BASELINE.json configs[4])"},
             "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,
             "loss": float(loss),
             "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,

@@ -35,6 +35,9 @@ constexpr int BK = 32;        // generic path K-step
 constexpr int BKV = 64;       // vector path K-step: one barrier pair per 2048+ MFMA cycles, and the register
                               // prefetch of the next step has that long to land (HBM/L2 latency under load)
 constexpr int LDK = BKV + 4;  // vector path: padded LDS row (272 B = 17 x 16 B: odd slot stride, conflict-free b128)
+constexpr int LDKH = BKV + 8; // bf16 tiles (mixed-precision mode): 144-byte rows
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDG = BK + 1;   // generic path: odd pad, ds_read_b32 fragments
 constexpr int BKP = 64;       // wgrad vector path: pixels per step
 
@@ -220,7 +223,9 @@ __device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt
 // LIN = false: data gradient of a strided conv over ALL taps in one launch (small maps, see dpft_conv2d_nhwc_dgrad_f32):
 // the source pixel is (oh + pad - r) / stride where that divides, not linear in the tap -- only that instantiation
 // carries the divisions.
-template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true>
+// BF16 = true (mixed-precision mode, dpft_conv_set_compute): the operands are rounded to bf16 (RNE) when a tile is written
+// to LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulation); tensors in memory stay fp32.
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false>
 __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
     constexpr int AP = BM / 16, BP = BN / 16;      // 16 rows x 16 chunks (of 16 B) per loader pass
@@ -228,6 +233,9 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // (BM + BN) * LDK floats
     float* As = smem;
     float* Bs = smem + BM * LDK;
+    // bf16 tiles: rows of 64 + 8 halfs (144 B: 16 consecutive rows start in 16 different 16-byte bank groups)
+    __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+    __bf16* Bh = Ah + BM * LDKH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -401,11 +409,14 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                 }
                 if (pro_mask && !((a_valid[sidx] >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
+            if (BF16) *reinterpret_cast<bf16x4*>(&Ah[(rowl + 16 * i) * LDKH + chunk * 4]) = __builtin_convertvector(val, bf16x4);
+            else *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
         }
 #pragma unroll
-        for (int i = 0; i < BP; ++i)
-            *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
+        for (int i = 0; i < BP; ++i) {
+            if (BF16) *reinterpret_cast<bf16x4*>(&Bh[(rowl + 16 * i) * LDKH + chunk * 4]) = __builtin_convertvector(rbv[sidx][i], bf16x4);
+            else *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
+        }
     };
 
     // NACC > 1 = K-interleaved partial accumulators per 32x32 block (summed in the epilogue) to break the
@@ -432,7 +443,30 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     // The fragments of K-group kg+1 are read from LDS BEFORE the MFMAs of group kg are issued (two register sets;
     // sched_barrier keeps the order -- left alone the scheduler reads a group right before its use, and the wave then
     // waits out the LDS latency with nothing in the pipe).
-    auto compute = [&]() {
+    const __bf16* a_fragh = Ah + (wm * RB * 32 + (lane & 31)) * LDKH + (lane >> 5) * 8;
+    const __bf16* b_fragh = Bh + (wn * CB * 32 + (lane & 31)) * LDKH + (lane >> 5) * 8;
+    auto compute_bf16 = [&]() {      // 4 K-groups of 16: lane l holds k = 8 * (l / 32) .. + 7 of row / column l % 32
+        bf16x8 af[2][RB], bf[2][CB];
+        auto frags = [&](int set, int kg) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) af[set][i] = *reinterpret_cast<const bf16x8*>(a_fragh + i * 32 * LDKH + kg * 16);
+#pragma unroll
+            for (int j = 0; j < CB; ++j) bf[set][j] = *reinterpret_cast<const bf16x8*>(b_fragh + j * 32 * LDKH + kg * 16);
+        };
+        frags(0, 0);
+#pragma unroll
+        for (int kg = 0; kg < BKV / 16; ++kg) {
+            if (kg + 1 < BKV / 16) frags((kg + 1) & 1, kg + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+                    accp[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kg & 1][i], bf[kg & 1][j], accp[0][i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto compute_f32 = [&]() {
         f32x4 af[2][RB], bf[2][CB];
         auto frags = [&](int set, int kg) {
 #pragma unroll
@@ -457,6 +491,11 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                                                                                     accp[e % NACC][i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
+    };
+
+    auto compute = [&]() {
+        if constexpr (BF16) compute_bf16();
+        else compute_f32();
     };
 
     // tile t (relative to kt_begin) lives in register set t % DEPTH
@@ -1216,6 +1255,10 @@ static void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t 
     hipLaunchKernelGGL(kernel, grid, block, lds, st, args);
 }
 
+// 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 operands / fp32 accumulation in the forward and data-gradient
+// GEMMs of the C % 64 == 0 convs (BASELINE.json configs[4], "bf16 mixed precision"); process-wide, set between launches
+static int g_conv_bf16 = 0;
+
 template <bool DGRAD>
 static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t st) {
     if (t.vec) {      // the vector loader keeps a 32-bit tap mask per row and 32-bit buffer offsets
@@ -1241,7 +1284,10 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
 #define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
     do {                                                                                      \
         constexpr size_t lds = (size_t)(BM_ + BN_) * LDK * sizeof(float);                     \
-        if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>, grid, block, lds, st, a); \
+        if (g_conv_bf16) {                                                                    \
+            if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true>, grid, block, lds, st, a); \
+            else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true>, grid, block, lds, st, a);      \
+        } else if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>, grid, block, lds, st, a); \
         else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false>, grid, block, lds, st, a);      \
     } while (0)
     if (t.vec) {
@@ -1341,6 +1387,14 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
     }
     return best;
 }
+
+extern "C" int dpft_conv_set_compute(int32_t mode) {
+    DPFT_REQUIRE(mode == 0 || mode == 1, "conv_set_compute: mode 0 (fp32) or 1 (bf16 operands, fp32 accumulation), got %d", mode);
+    dpft::g_conv_bf16 = mode;
+    return DPFT_OK;
+}
+
+extern "C" int32_t dpft_conv_get_compute() { return dpft::g_conv_bf16; }
 
 extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows) {
     if (check_desc(d) != DPFT_OK) return -1;

@@ -81,6 +81,8 @@ SIGNATURES = {
     "dpft_last_error": (C.c_char_p, []),
     "dpft_conv2d_workspace_bytes": (_L, [_DESC]),
     "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
+    "dpft_conv_set_compute": (_I, [_I]),
+    "dpft_conv_get_compute": (_I, []),
     "dpft_conv2d_nhwc_fwd_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_dgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P]),
     "dpft_conv2d_nhwc_wgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P, _P]),

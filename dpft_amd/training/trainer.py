@@ -21,6 +21,11 @@ class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, config: Dict[str, Any], device, bucket_mb: int = 64):
         self.model = model.to(device)
         self.device = device
+        # optional mixed precision (BASELINE.json configs[4]): config["computing"]["conv_compute"] = "bf16" runs the
+        # forward / data-gradient conv GEMMs with bf16 operands and fp32 accumulation; default = the reference's fp32
+        if torch.device(device).type == "cuda":
+            from dpft_amd.hip import ops as _ops
+            _ops.conv_set_compute(config.get("computing", {}).get("conv_compute", "fp32"))
         train = config["train"]
         self.loss_fn = build_loss(train)
         # the reference evaluates mAP3D / mGIoU3D in every training step (trainer.py:134); optional here

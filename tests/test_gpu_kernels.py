@@ -101,6 +101,49 @@ def test_conv_fwd_dgrad_wgrad(case, fused):
     close((acc - base).permute(0, 3, 1, 2), xa.grad, rtol=1e-3, atol_scale=1e-4, what="conv dgrad accumulate")
 
 
+@pytest.mark.parametrize("case", [(4, 32, 57, 256, 256, 3, 1, 1), (2, 13, 11, 128, 128, 3, 2, 1), (2, 21, 17, 64, 96, 1, 1, 0),
+                                  (4, 64, 114, 128, 128, 3, 2, 1), (4, 16, 7, 1024, 256, 1, 1, 0), (1, 128, 228, 64, 256, 1, 1, 0)])
+def test_conv_bf16_operand_mode(case):
+    """Mixed-precision mode (dpft_conv_set_compute(1)): forward (+ fused BN prologue, + tile statistics) and data gradient
+    with bf16 operands / fp32 accumulation vs the fp64 reference: relative L2 error of a bf16-rounded product sum
+    (2^-9 per operand, averaged over the reduction), and the mode really is a different arithmetic than fp32."""
+    ops = _ops()
+    B, H, W, C, K, k, stride, pad = case
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, H, W, C, generator=g)
+    w = (torch.randn(K, C, k, k, generator=g) / (C * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    pro = (torch.stack((torch.randn(C, generator=g) * 0.5, torch.rand(C, generator=g) + 0.5,
+                        torch.randn(C, generator=g) * 0.3, torch.ones(C))), True)
+    xa, wd, yref = _conv_ref(x, w, None, stride, pad, pro)
+    cv = ops.conv_problem(B, H, W, C, K, k, k, stride, pad)
+    w_dev = w.to(DEV).permute(0, 2, 3, 1)
+    dy = torch.randn(yref.shape, generator=g, dtype=torch.float64)
+    (yref * dy).sum().backward()
+    dy_nhwc = dy.permute(0, 2, 3, 1).contiguous().float().to(DEV)
+    wt = ops.weight_transpose(w_dev)
+    res = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.conv_set_compute(mode)
+            assert ops.conv_get_compute() == mode
+            y, stats = ops.conv_fwd(cv, x.to(DEV), w_dev, pro=(pro[0].to(DEV), True), want_stats=True)
+            dx = ops.conv_dgrad(cv, dy_nhwc, wt)
+            res[mode] = (y.double().cpu().permute(0, 3, 1, 2), dx.double().cpu().permute(0, 3, 1, 2), stats)
+    finally:
+        ops.conv_set_compute("fp32")
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    e_y32, e_y16 = rel(res["fp32"][0], yref.detach()), rel(res["bf16"][0], yref.detach())
+    e_d32, e_d16 = rel(res["fp32"][1], xa.grad), rel(res["bf16"][1], xa.grad)
+    print(f"conv {case}: fwd rel-L2 fp32 {e_y32:.1e} bf16 {e_y16:.1e}; dgrad fp32 {e_d32:.1e} bf16 {e_d16:.1e}")
+    assert e_y32 < 1e-5 and e_d32 < 1e-5
+    assert 1e-4 < e_y16 < 6e-3 and e_d16 < 6e-3, (e_y16, e_d16)      # (all-tap strided dgrads of small maps stay fp32)
+    # tile statistics are computed from the bf16-mode output itself (consistent with what the BN backward will see)
+    yb = res["bf16"][0].permute(0, 2, 3, 1).reshape(-1, K)
+    rows = cv.tile_rows
+    t0 = yb[:rows].float()
+    close(res["bf16"][2][0, 0].cpu(), t0.mean(0), rtol=1e-4, atol_scale=1e-4, what="tile-0 mean in bf16 mode")
+
+
 def test_bias_grad_and_transpose():
     ops = _ops()
     g = torch.Generator().manual_seed(3)

@@ -41,6 +41,8 @@ def run(spec, reps=20, pro=True, stats=True):
 
 
 if __name__ == "__main__":
+    if os.environ.get("DPFT_COMPUTE"):      # fp32 | bf16
+        ops.conv_set_compute(os.environ["DPFT_COMPUTE"])
     specs = sys.argv[1:] or DEFAULT
     for sp in specs:
         run(sp)
