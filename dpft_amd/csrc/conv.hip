@@ -790,8 +790,12 @@ struct WgradArgs {
     int J;            // generic path: taps*C
 };
 
-template <int BMn, int BNc, int WGM, int WGN, bool PRO>
+// BF16 = true (mixed-precision mode, 128 x 128 tile only): both operands are rounded to bf16 and TRANSPOSED on their
+// way into LDS ([channel][pixel], so that a lane finds the 8 consecutive reduction indices v_mfma_f32_32x32x16_bf16
+// wants); see store_tile.
+template <int BMn, int BNc, int WGM, int WGN, bool PRO, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
+    static_assert(!BF16 || (BMn == 128 && BNc == 128), "bf16 weight gradient: 128 x 128 tile only");
     constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
     constexpr int YCH = BMn / 4, XCH = BNc / 4;        // float4 chunks per pixel row
     constexpr int YRP = 256 / YCH, XRP = 256 / XCH;    // pixel rows per pass
@@ -834,15 +838,19 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    // pixel (within the step) of loader pass i: fp32 -- row + i * rows-per-pass; bf16 -- passes 2k, 2k+1 are ADJACENT pixels
+    // (they share one 32-bit LDS word of the transposed tile)
+    auto ypix = [&](int i) { return BF16 ? 2 * YRP * (i >> 1) + 2 * yrow + (i & 1) : yrow + i * YRP; };
+    auto xpix = [&](int i) { return BF16 ? 2 * XRP * (i >> 1) + 2 * xrow + (i & 1) : xrow + i * XRP; };
     unsigned y_voff[YP];
 #pragma unroll
-    for (int i = 0; i < YP; ++i) y_voff[i] = y_ok ? (unsigned)((yrow + i * YRP) * a.K + n0 + ych * 4) * 4u : OOB;
+    for (int i = 0; i < YP; ++i) y_voff[i] = y_ok ? (unsigned)(ypix(i) * a.K + n0 + ych * 4) * 4u : OOB;
     int xb[XP], xoh[XP], xow[XP];      // pixel of loader row i in the NEXT step to be loaded
     {
         const int p_first = (split * a.psteps_per_split) * BKP;
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
-            const int p = p_first + xrow + i * XRP;
+            const int p = p_first + xpix(i);
             xb[i] = p / ohw;
             const int rem = p - xb[i] * ohw;
             xoh[i] = rem / a.OW;
@@ -873,22 +881,51 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         }
         x_valid = valid;
     };
-    auto store_tile = [&]() {
+    // bf16 tiles: [channel][pixel], rows of WLD = 76 halfs (152 B = 38 words).  A lane owns 4 channels x 2 adjacent pixels
+    // per pass pair = four 32-bit words in four rows; in the e-th of its four writes it takes channel (e + ych / 8) % 4, and
+    // with the 38-word pitch the 64 lanes of a wave then hit 64 different banks (brute-forced; any plain order is 8-way
+    // conflicted because the lanes of a wave differ in the CHANNEL chunk, i.e. by whole rows).
+    constexpr int WLD = 76;
+    __bf16* Yh = reinterpret_cast<__bf16*>(smem);
+    __bf16* Xh = Yh + BMn * WLD;
+    auto rot4 = [](f32x4 v, int r) {      // v[(e + r) & 3] at position e, r per lane
+        f32x4 t = (r & 1) ? f32x4{v[1], v[2], v[3], v[0]} : v;
+        return (r & 2) ? f32x4{t[2], t[3], t[0], t[1]} : t;
+    };
+    auto store_pair = [&](__bf16* T, int ch, int rowp, f32x4 v0, f32x4 v1) {      // pixels 2 * rowp', 2 * rowp' + 1
+        const int r = (ch >> 3) & 3;
+        const f32x4 a0 = rot4(v0, r), a1 = rot4(v1, r);
 #pragma unroll
-        for (int i = 0; i < YP; ++i)
-            *reinterpret_cast<f32x4*>(&Ys[(yrow + i * YRP) * BMn + ych * 4]) = ry[i];
+        for (int e = 0; e < 4; ++e) {
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const bf16x2 pk = __builtin_convertvector((__attribute__((ext_vector_type(2))) float){a0[e], a1[e]}, bf16x2);
+            *reinterpret_cast<bf16x2*>(&T[(ch * 4 + ((e + r) & 3)) * WLD + rowp]) = pk;
+        }
+    };
+    auto pro4 = [&](f32x4 v, int i) {
+        if (PRO) {      // producer BN+ReLU applied after the MFMAs of the current step (see igemm_vec_kernel)
 #pragma unroll
-        for (int i = 0; i < XP; ++i) {
-            f32x4 v = rx[i];
-            if (PRO) {      // producer BN+ReLU applied after the MFMAs of the current step (see igemm_vec_kernel)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
-                    v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
-                }
-                if (!((x_valid >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // padding / pixel tail: BN(0) != 0
+            for (int e = 0; e < 4; ++e) {
+                const float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
+                v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
             }
-            *reinterpret_cast<f32x4*>(&Xs[(xrow + i * XRP) * BNc + xch * 4]) = v;
+            if (!((x_valid >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // padding / pixel tail: BN(0) != 0
+        }
+        return v;
+    };
+    auto store_tile = [&]() {
+        if constexpr (BF16) {
+#pragma unroll
+            for (int i = 0; i < YP; i += 2) store_pair(Yh, ych, ypix(i), ry[i], ry[i + 1]);
+#pragma unroll
+            for (int i = 0; i < XP; i += 2) store_pair(Xh, xch, xpix(i), pro4(rx[i], i), pro4(rx[i + 1], i + 1));
+        } else {
+#pragma unroll
+            for (int i = 0; i < YP; ++i)
+                *reinterpret_cast<f32x4*>(&Ys[(yrow + i * YRP) * BMn + ych * 4]) = ry[i];
+#pragma unroll
+            for (int i = 0; i < XP; ++i)
+                *reinterpret_cast<f32x4*>(&Xs[(xrow + i * XRP) * BNc + xch * 4]) = pro4(rx[i], i);
         }
     };
 
@@ -912,7 +949,33 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     for (int ps = ps_begin; ps < ps_end; ++ps) {
         const bool more = ps + 1 < ps_end;
         if (more) load_tile(ps + 1);
-        {   // fragments of pixel pair kk+PF are read before the MFMAs of pair kk are issued (see igemm_vec_kernel)
+        if constexpr (BF16) {      // 4 groups of 16 pixels; lane l: channel l % 32, pixels 8 * (l / 32) .. + 7 of the group
+            const __bf16* yf = Yh + (wm * RB * 32 + (lane & 31)) * WLD + (lane >> 5) * 8;
+            const __bf16* xf = Xh + (wn * CB * 32 + (lane & 31)) * WLD + (lane >> 5) * 8;
+            auto frag8 = [](const __bf16* q) {      // rows are 8-byte, not 16-byte aligned (152-byte pitch): two b64 reads
+                const bf16x4 lo = *reinterpret_cast<const bf16x4*>(q), hi = *reinterpret_cast<const bf16x4*>(q + 4);
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+            bf16x8 ay[2][RB], bx[2][CB];
+            auto frags = [&](int set, int kg) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) ay[set][i] = frag8(yf + i * 32 * WLD + kg * 16);
+#pragma unroll
+                for (int j = 0; j < CB; ++j) bx[set][j] = frag8(xf + j * 32 * WLD + kg * 16);
+            };
+            frags(0, 0);
+#pragma unroll
+            for (int kg = 0; kg < BKP / 16; ++kg) {
+                if (kg + 1 < BKP / 16) frags((kg + 1) & 1, kg + 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay[kg & 1][i], bx[kg & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {   // fragments of pixel pair kk+PF are read before the MFMAs of pair kk are issued (see igemm_vec_kernel)
             constexpr int PF = 2, NS = PF + 1;
             float av[NS][RB], bv[NS][CB];
             auto frags = [&](int set, int kk) {
@@ -1634,7 +1697,10 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, st, a);     \
     } while (0)
-        if (bmn == 128) LAUNCH_WG(128, 128, 2, 2);
+        if (bmn == 128 && g_conv_bf16) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
+            if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true>), grid, block, 0, st, a);
+        } else if (bmn == 128) LAUNCH_WG(128, 128, 2, 2);
         else if (bmn == 64) LAUNCH_WG(64, 64, 2, 2);
         else LAUNCH_WG(32, 128, 1, 4);
 #undef LAUNCH_WG

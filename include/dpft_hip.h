@@ -63,10 +63,11 @@ int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d);
  * *tile_rows receives the tile height so the caller can recover per-tile counts. */
 int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows);
 
-/* Arithmetic of the forward / data-gradient GEMMs of every conv with C % 64 == 0 (process-wide; call between launches):
+/* Arithmetic of the forward / data-gradient GEMMs of every conv with C % 64 == 0 and of the 128 x 128-tiled weight
+ * gradients (process-wide; call between launches):
  *   0  fp32 operands, fp32 accumulation -- the reference's arithmetic (config/kradar.json "dtype": "float32"), default;
  *   1  operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16); tensors in
- *      memory, BatchNorm, weight gradients, optimizer stay fp32 ("bf16 mixed precision", BASELINE.json configs[4]).
+ *      memory, BatchNorm, the small weight gradients, optimizer stay fp32 ("bf16 mixed precision", BASELINE.json configs[4]).
  * Returns DPFT_ERR_ARG for any other value. */
 int dpft_conv_set_compute(int32_t mode);
 int32_t dpft_conv_get_compute(void);

@@ -128,7 +128,9 @@ def test_conv_bf16_operand_mode(case):
             assert ops.conv_get_compute() == mode
             y, stats = ops.conv_fwd(cv, x.to(DEV), w_dev, pro=(pro[0].to(DEV), True), want_stats=True)
             dx = ops.conv_dgrad(cv, dy_nhwc, wt)
-            res[mode] = (y.double().cpu().permute(0, 3, 1, 2), dx.double().cpu().permute(0, 3, 1, 2), stats)
+            dw = ops.conv_wgrad(cv, x.to(DEV), dy_nhwc, pro=(pro[0].to(DEV), True))
+            res[mode] = (y.double().cpu().permute(0, 3, 1, 2), dx.double().cpu().permute(0, 3, 1, 2), stats,
+                         dw.double().cpu().permute(0, 3, 1, 2))
     finally:
         ops.conv_set_compute("fp32")
     rel = lambda a, b: float((a - b).norm() / b.norm())
@@ -137,6 +139,9 @@ def test_conv_bf16_operand_mode(case):
     print(f"conv {case}: fwd rel-L2 fp32 {e_y32:.1e} bf16 {e_y16:.1e}; dgrad fp32 {e_d32:.1e} bf16 {e_d16:.1e}")
     assert e_y32 < 1e-5 and e_d32 < 1e-5
     assert 1e-4 < e_y16 < 6e-3 and e_d16 < 6e-3, (e_y16, e_d16)      # (all-tap strided dgrads of small maps stay fp32)
+    e_w32, e_w16 = rel(res["fp32"][3], wd.grad), rel(res["bf16"][3], wd.grad)
+    print(f"   wgrad rel-L2 fp32 {e_w32:.1e} bf16 {e_w16:.1e}")
+    assert e_w32 < 1e-5 and e_w16 < 6e-3, (e_w32, e_w16)             # (only the 128 x 128-tiled problems switch to bf16)
     # tile statistics are computed from the bf16-mode output itself (consistent with what the BN backward will see)
     yb = res["bf16"][0].permute(0, 2, 3, 1).reshape(-1, K)
     rows = cv.tile_rows

@@ -7,6 +7,8 @@ from dpft_amd.models import build
 from dpft_amd.synthetic import make_batch, make_labels
 from dpft_amd.training.trainer import DataParallelTrainer
 cfg = load_config("kradar")
+if os.environ.get("COMPUTE"):      # fp32 | bf16 (mixed-precision mode of the conv GEMMs)
+    cfg["computing"]["conv_compute"] = os.environ["COMPUTE"]
 torch.manual_seed(int(os.environ.get("SEED", "0")))
 dev = torch.device("cuda", 0)
 tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
