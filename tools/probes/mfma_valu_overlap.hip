@@ -4,12 +4,14 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int MODE, int NV>
+template <int MODE, int NV, bool BF = false>
 __global__ __launch_bounds__(256) void probe(float* out, int iters, unsigned seed) {
     f32x16 acc[4];
     for (int q = 0; q < 4; ++q) for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
     float a = threadIdx.x * 0.001f, b = 1.0f;
+    bf16x8 ab; for (int e = 0; e < 8; ++e) ab[e] = (__bf16)(a + e);
     unsigned v[8];
     for (int q = 0; q < 8; ++q) v[q] = seed + threadIdx.x * (q + 1);
     for (int it = 0; it < iters; ++it) {
@@ -17,7 +19,7 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, unsigned see
         for (int g = 0; g < 8; ++g) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                if (MODE != 2) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0);
+                if (MODE != 2) { if (BF) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ab, ab, acc[q], 0, 0, 0); else acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[q], 0, 0, 0); }
                 if (MODE == 1 || MODE == 2) {
 #pragma unroll
                     for (int n = 0; n < NV; ++n) v[n & 7] = v[n & 7] * 1664525u + v[(n + 1) & 7];
@@ -39,14 +41,14 @@ __global__ __launch_bounds__(256) void probe(float* out, int iters, unsigned see
 }
 
 static int g_blocks = 256;
-template <int MODE, int NV>
+template <int MODE, int NV, bool BF = false>
 static float run(float* out, const char* what) {
     const int iters = 2000;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    probe<MODE, NV><<<g_blocks, 256>>>(out, 10, 1u);
+    probe<MODE, NV, BF><<<g_blocks, 256>>>(out, 10, 1u);
     hipEventRecord(e0);
-    probe<MODE, NV><<<g_blocks, 256>>>(out, iters, 1u);
+    probe<MODE, NV, BF><<<g_blocks, 256>>>(out, iters, 1u);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0.f;
@@ -72,6 +74,10 @@ int main() {
     run<2, 12>(out, "VALU only");
     run<1, 12>(out, "MFMA + VALU after each MFMA");
     run<3, 12>(out, "MFMA x4 then VALU x4*NV");
+    run<0, 0, true>(out, "bf16 32x32x16 MFMA only");
+    run<1, 2, true>(out, "bf16 MFMA + VALU after each MFMA");
+    run<1, 4, true>(out, "bf16 MFMA + VALU after each MFMA");
+    run<1, 8, true>(out, "bf16 MFMA + VALU after each MFMA");
     }
     return 0;
 }
