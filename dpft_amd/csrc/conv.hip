@@ -225,8 +225,15 @@ __device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt
 // carries the divisions.
 // BF16 = true (mixed-precision mode, dpft_conv_set_compute): the operands are rounded to bf16 (RNE) when a tile is written
 // to LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulation); tensors in memory stay fp32.
-template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false>
+// X3 = true (with BF16; experimental mode 2): every fp32 operand value is split into three bf16 terms a = a1 + a2 + a3
+// (each the RNE rounding of what the previous ones left: 3 x 8 = 24 mantissa bits) kept in three LDS planes, and a
+// product sum uses the six term products of weight >= 2^-16: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, all exact in the
+// bf16 MFMA, accumulated in fp32 -- fp32-grade results from the matrix cores, which (unlike the fp32 MFMA) do not share
+// the vector ALUs (tools/probes/mfma_valu_overlap.hip): 6 x 32 instead of 8 x 64 cycles per 16 reduction indices.
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
+    static_assert(!X3 || BF16, "the split mode builds on the bf16 path");
+    constexpr int PLANE = (BM + BN) * LDKH;      // halfs per bf16 plane (split mode: 3 planes)
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
     constexpr int AP = BM / 16, BP = BN / 16;      // 16 rows x 16 chunks (of 16 B) per loader pass
     static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1, "bad tile");
@@ -395,6 +402,17 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         for (int i = 0; i < BP; ++i)
             rbv[sidx][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_off[i], koff * 4, 0));
     };
+    auto store_bf16 = [&](__bf16* dst, f32x4 v) {      // one plane (rounded), or three planes (split)
+        const bf16x4 t1 = __builtin_convertvector(v, bf16x4);
+        *reinterpret_cast<bf16x4*>(dst) = t1;
+        if constexpr (X3) {
+            const f32x4 r1 = v - __builtin_convertvector(t1, f32x4);
+            const bf16x4 t2 = __builtin_convertvector(r1, bf16x4);
+            *reinterpret_cast<bf16x4*>(dst + PLANE) = t2;
+            const f32x4 r2 = r1 - __builtin_convertvector(t2, f32x4);
+            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = __builtin_convertvector(r2, bf16x4);
+        }
+    };
     const bool pro_mask = a.kh * a.kw > 1 || a.pad > 0;      // padding exists: BN(0) != 0 must be forced back to 0
     auto store_tile = [&](auto S) {
         constexpr int sidx = decltype(S)::value;
@@ -409,12 +427,12 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                 }
                 if (pro_mask && !((a_valid[sidx] >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
             }
-            if (BF16) *reinterpret_cast<bf16x4*>(&Ah[(rowl + 16 * i) * LDKH + chunk * 4]) = __builtin_convertvector(val, bf16x4);
+            if (BF16) store_bf16(&Ah[(rowl + 16 * i) * LDKH + chunk * 4], val);
             else *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            if (BF16) *reinterpret_cast<bf16x4*>(&Bh[(rowl + 16 * i) * LDKH + chunk * 4]) = __builtin_convertvector(rbv[sidx][i], bf16x4);
+            if (BF16) store_bf16(&Bh[(rowl + 16 * i) * LDKH + chunk * 4], rbv[sidx][i]);
             else *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
         }
     };
@@ -466,6 +484,45 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
     };
+    // Split mode: six term products per 32x32 block and K-group.  Back-to-back MFMAs on ONE accumulator wait out the full
+    // MFMA latency (measured: the naive chain of six ran at 1/3 of the matrix rate), so the terms are issued term-major
+    // over the blocks of the wave and, where a wave owns fewer than four blocks, spread over three accumulator sets
+    // (by magnitude: a1b1 | a1b2 + a2b1 | a1b3 + a2b2 + a3b1 -- which also adds the small terms among themselves first).
+    constexpr int NSET = X3 ? ((RB * CB >= 4) ? 1 : 3) : 1;
+    f32x16 accx[NSET][RB][CB];
+    if constexpr (X3 && NSET > 1) {
+#pragma unroll
+        for (int q = 1; q < NSET; ++q)
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) accx[q][i][j][r] = 0.f;
+    }
+    auto compute_x3 = [&]() {
+        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 0, 0, 1, 1, 2}, TS[6] = {2, 1, 0, 2, 1, 2};
+#pragma unroll
+        for (int kg = 0; kg < BKV / 16; ++kg) {
+            bf16x8 af[3][RB], bf[3][CB];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int i = 0; i < RB; ++i) af[t][i] = *reinterpret_cast<const bf16x8*>(a_fragh + t * PLANE + i * 32 * LDKH + kg * 16);
+#pragma unroll
+                for (int j = 0; j < CB; ++j) bf[t][j] = *reinterpret_cast<const bf16x8*>(b_fragh + t * PLANE + j * 32 * LDKH + kg * 16);
+            }
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int j = 0; j < CB; ++j) {
+                        f32x16& c = (NSET == 1 || TS[t] == 0) ? accp[0][i][j] : accx[NSET == 1 ? 0 : TS[t]][i][j];
+                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], c, 0, 0, 0);
+                    }
+        }
+    };
     auto compute_f32 = [&]() {
         f32x4 af[2][RB], bf[2][CB];
         auto frags = [&](int set, int kg) {
@@ -494,7 +551,8 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     };
 
     auto compute = [&]() {
-        if constexpr (BF16) compute_bf16();
+        if constexpr (X3) compute_x3();
+        else if constexpr (BF16) compute_bf16();
         else compute_f32();
     };
 
@@ -528,6 +586,12 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         }
     }
     f32x16 (&acc)[RB][CB] = accp[0];
+    if constexpr (X3 && NSET > 1) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i)
+#pragma unroll
+            for (int j = 0; j < CB; ++j) acc[i][j] += accx[1][i][j] + accx[2][i][j];
+    }
     if (NACC == 2) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -1347,7 +1411,11 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
 #define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
     do {                                                                                      \
         constexpr size_t lds = (size_t)(BM_ + BN_) * LDK * sizeof(float);                     \
-        if (g_conv_bf16) {                                                                    \
+        if (g_conv_bf16 == 2) {                                                               \
+            constexpr size_t lds3 = std::max(lds, (size_t)3 * (BM_ + BN_) * LDKH * 2);        \
+            if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true, true>, grid, block, lds3, st, a); \
+            else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true, true>, grid, block, lds3, st, a);      \
+        } else if (g_conv_bf16) {                                                             \
             if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true>, grid, block, lds, st, a); \
             else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true>, grid, block, lds, st, a);      \
         } else if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>, grid, block, lds, st, a); \
@@ -1452,7 +1520,7 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
 }
 
 extern "C" int dpft_conv_set_compute(int32_t mode) {
-    DPFT_REQUIRE(mode == 0 || mode == 1, "conv_set_compute: mode 0 (fp32) or 1 (bf16 operands, fp32 accumulation), got %d", mode);
+    DPFT_REQUIRE(mode >= 0 && mode <= 2, "conv_set_compute: mode 0 (fp32), 1 (bf16 operands) or 2 (3 x bf16 split), got %d", mode);
     dpft::g_conv_bf16 = mode;
     return DPFT_OK;
 }
@@ -1697,7 +1765,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, st, a);     \
     } while (0)
-        if (bmn == 128 && g_conv_bf16) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
+        if (bmn == 128 && g_conv_bf16 == 1) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
             if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true>), grid, block, 0, st, a);
         } else if (bmn == 128) LAUNCH_WG(128, 128, 2, 2);

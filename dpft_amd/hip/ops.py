@@ -17,11 +17,11 @@ _ws_cache = {}
 def conv_set_compute(mode: str) -> None:
     """"fp32" (the reference's arithmetic, default) or "bf16" (bf16 operands / fp32 accumulation in the forward and
     data-gradient GEMMs of the C % 64 == 0 convs; BASELINE.json configs[4])."""
-    lib.call("dpft_conv_set_compute", {"fp32": 0, "bf16": 1}[mode])
+    lib.call("dpft_conv_set_compute", {"fp32": 0, "bf16": 1, "bf16x3": 2}[mode])
 
 
 def conv_get_compute() -> str:
-    return ("fp32", "bf16")[int(lib.dpft_conv_get_compute())]
+    return ("fp32", "bf16", "bf16x3")[int(lib.dpft_conv_get_compute())]
 
 
 def profile_start():

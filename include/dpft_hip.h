@@ -68,6 +68,9 @@ int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows);
  *   0  fp32 operands, fp32 accumulation -- the reference's arithmetic (config/kradar.json "dtype": "float32"), default;
  *   1  operands rounded to bf16 (RNE) on their way into LDS, fp32 accumulation (v_mfma_f32_32x32x16_bf16); tensors in
  *      memory, BatchNorm, the small weight gradients, optimizer stay fp32 ("bf16 mixed precision", BASELINE.json configs[4]).
+ *   2  (experimental, forward / data gradient only) every operand value split into three bf16 terms on its way into
+ *      LDS and the six term products of weight >= 2^-16 accumulated in fp32 on the bf16 matrix cores: fp32-grade
+ *      results (measured 2-3e-7 relative L2 error vs fp64, the fp32 MFMA path 6-8e-7), 10-15 % faster than mode 0.
  * Returns DPFT_ERR_ARG for any other value. */
 int dpft_conv_set_compute(int32_t mode);
 int32_t dpft_conv_get_compute(void);

@@ -123,7 +123,7 @@ def test_conv_bf16_operand_mode(case):
     wt = ops.weight_transpose(w_dev)
     res = {}
     try:
-        for mode in ("fp32", "bf16"):
+        for mode in ("fp32", "bf16", "bf16x3"):
             ops.conv_set_compute(mode)
             assert ops.conv_get_compute() == mode
             y, stats = ops.conv_fwd(cv, x.to(DEV), w_dev, pro=(pro[0].to(DEV), True), want_stats=True)
@@ -141,6 +141,11 @@ def test_conv_bf16_operand_mode(case):
     assert 1e-4 < e_y16 < 6e-3 and e_d16 < 6e-3, (e_y16, e_d16)      # (all-tap strided dgrads of small maps stay fp32)
     e_w32, e_w16 = rel(res["fp32"][3], wd.grad), rel(res["bf16"][3], wd.grad)
     print(f"   wgrad rel-L2 fp32 {e_w32:.1e} bf16 {e_w16:.1e}")
+    # experimental mode 2: every operand value as three bf16 terms, six term products on the bf16 matrix cores -- at
+    # least as close to the fp64 result as the fp32 MFMA path
+    e_y3, e_d3 = rel(res["bf16x3"][0], yref.detach()), rel(res["bf16x3"][1], xa.grad)
+    print(f"   3 x bf16 split: fwd {e_y3:.1e} dgrad {e_d3:.1e}")
+    assert e_y3 < max(1e-6, 1.2 * e_y32) and e_d3 < max(1e-6, 1.2 * e_d32), (e_y3, e_d3)
     assert e_w32 < 1e-5 and e_w16 < 6e-3, (e_w32, e_w16)             # (only the 128 x 128-tiled problems switch to bf16)
     # tile statistics are computed from the bf16-mode output itself (consistent with what the BN backward will see)
     yb = res["bf16"][0].permute(0, 2, 3, 1).reshape(-1, K)
