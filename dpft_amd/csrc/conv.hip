@@ -854,12 +854,12 @@ struct WgradArgs {
     int J;            // generic path: taps*C
 };
 
-// BF16 = true (mixed-precision mode, 128 x 128 tile only): both operands are rounded to bf16 and TRANSPOSED on their
+// BF16 = true (mixed-precision mode, square tiles): both operands are rounded to bf16 and TRANSPOSED on their
 // way into LDS ([channel][pixel], so that a lane finds the 8 consecutive reduction indices v_mfma_f32_32x32x16_bf16
 // wants); see store_tile.
 template <int BMn, int BNc, int WGM, int WGN, bool PRO, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
-    static_assert(!BF16 || (BMn == 128 && BNc == 128), "bf16 weight gradient: 128 x 128 tile only");
+    static_assert(!BF16 || (BMn == BNc && (BMn == 128 || BMn == 64)), "bf16 weight gradient: 128 x 128 and 64 x 64 tiles");
     constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
     constexpr int YCH = BMn / 4, XCH = BNc / 4;        // float4 chunks per pixel row
     constexpr int YRP = 256 / YCH, XRP = 256 / XCH;    // pixel rows per pass
@@ -949,7 +949,8 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     // per pass pair = four 32-bit words in four rows; in the e-th of its four writes it takes channel (e + ych / 8) % 4, and
     // with the 38-word pitch the 64 lanes of a wave then hit 64 different banks (brute-forced; any plain order is 8-way
     // conflicted because the lanes of a wave differ in the CHANNEL chunk, i.e. by whole rows).
-    constexpr int WLD = 76;
+    constexpr int WLD = BMn == 128 ? 76 : 72;      // 64 x 64 tile (16 channel chunks per pixel row): 36 words, order (e + ych / 4) % 4
+    constexpr int RSH = BMn == 128 ? 3 : 2;
     __bf16* Yh = reinterpret_cast<__bf16*>(smem);
     __bf16* Xh = Yh + BMn * WLD;
     auto rot4 = [](f32x4 v, int r) {      // v[(e + r) & 3] at position e, r per lane
@@ -957,7 +958,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         return (r & 2) ? f32x4{t[2], t[3], t[0], t[1]} : t;
     };
     auto store_pair = [&](__bf16* T, int ch, int rowp, f32x4 v0, f32x4 v1) {      // pixels 2 * rowp', 2 * rowp' + 1
-        const int r = (ch >> 3) & 3;
+        const int r = (ch >> RSH) & 3;
         const f32x4 a0 = rot4(v0, r), a1 = rot4(v1, r);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -1768,6 +1769,9 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         if (bmn == 128 && g_conv_bf16 == 1) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
             if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true>), grid, block, 0, st, a);
+        } else if (bmn == 64 && g_conv_bf16 == 1) {
+            if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<64, 64, 2, 2, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((wgrad_vec_kernel<64, 64, 2, 2, false, true>), grid, block, 0, st, a);
         } else if (bmn == 128) LAUNCH_WG(128, 128, 2, 2);
         else if (bmn == 64) LAUNCH_WG(64, 64, 2, 2);
         else LAUNCH_WG(32, 128, 1, 4);
