@@ -34,6 +34,11 @@ def test_cabi_argument_errors_are_reported():
     assert b"inconsistent" in lib.dpft_last_error()
     rc = lib.dpft_xattn_fwd_f32(None, None, None, None, None, None, None, None, None, 1, 1, 4, 4, 4, None)
     assert rc != 0 and b"M=8" in lib.dpft_last_error()
+    # compute-mode switch: 0 fp32 (default) | 1 bf16 operands | 2 three-term bf16 split; anything else is rejected
+    assert lib.dpft_conv_get_compute() == 0
+    assert lib.dpft_conv_set_compute(3) == -1 and b"conv_set_compute" in lib.dpft_last_error()
+    assert lib.dpft_conv_set_compute(1) == 0 and lib.dpft_conv_get_compute() == 1
+    assert lib.dpft_conv_set_compute(0) == 0 and lib.dpft_conv_get_compute() == 0
 
 
 def test_every_compute_entry_rejects_null_arguments():
