@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--config", default="kradar")
     ap.add_argument("--latency-reps", type=int, default=30, help="event-timed eval forwards for fwd ms/frame")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="f32 = the reference's arithmetic (BASELINE metric, default); bf16 = mixed precision of "
                          "BASELINE.json configs[4]: bf16 operands / fp32 accumulation in the conv GEMMs")
     ap.add_argument("--no-graphs", action="store_true", help="do not replay the decoder from hipGraphs")
@@ -135,6 +135,8 @@ def main():
     cfg = load_config(args.config)
     if args.dtype == "bf16":
         cfg["computing"]["conv_compute"] = "bf16"
+    elif args.dtype == "f32x3":      # experimental: fp32 operands as three bf16 terms on the bf16 matrix cores
+        cfg["computing"]["conv_compute"] = "bf16x3"
     torch.manual_seed(cfg["computing"]["seed"])
     model = build("dprt", cfg)
     trainer = DataParallelTrainer(model, cfg, device)
@@ -213,7 +215,7 @@ def main():
                 traffic = json.load(f).get("traffic_bytes_per_launch")
         # mixed precision: priced against the dense bf16 MFMA peak although the operands still arrive as fp32 (the
         # kernels are then bound by that fp32 operand path, not by the matrix pipe)
-        peak = PEAK_F32_MFMA_TFLOPS if args.dtype == "f32" else PEAK_BF16_MFMA_TFLOPS
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": tot_f / tot_t / 1e12 / peak, "traffic": traffic if args.dtype == "f32" else None,
                 "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family)",
@@ -281,9 +283,11 @@ def main():
                                    "(camera 512x910x3 ResNet-101, radar BEV 256x107x6 + front 37x107x6 ResNet-50, "
                                    "FPN->16ch, IMPFusion 4 it x 3 views, Hungarian set loss, AdamW)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "precision": "fp32 (reference arithmetic)" if args.dtype == "f32" else
-                                    "mixed: bf16 operands / fp32 accumulation in the forward + data-gradient conv GEMMs, "
-                                    "everything else fp32 (BASELINE.json configs[4])"},
+                       "precision": {"f32": "fp32 (reference arithmetic)",
+                                     "bf16": "mixed: bf16 operands / fp32 accumulation in the conv GEMMs, everything else "
+                                             "fp32 (BASELINE.json configs[4])",
+                                     "f32x3": "experimental: fp32 conv operands as three bf16 terms, six term products "
+                                              "on the bf16 matrix cores, fp32 accumulation"}[args.dtype]},
             "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,
             "loss": float(loss),
             "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,

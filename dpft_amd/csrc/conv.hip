@@ -857,15 +857,17 @@ struct WgradArgs {
 // BF16 = true (mixed-precision mode, square tiles): both operands are rounded to bf16 and TRANSPOSED on their
 // way into LDS ([channel][pixel], so that a lane finds the 8 consecutive reduction indices v_mfma_f32_32x32x16_bf16
 // wants); see store_tile.
-template <int BMn, int BNc, int WGM, int WGN, bool PRO, bool BF16 = false>
+template <int BMn, int BNc, int WGM, int WGN, bool PRO, bool BF16 = false, bool X3 = false>
 __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
+    static_assert(!X3 || (BF16 && BMn == 128), "split weight gradient: 128 x 128 tile, on top of the bf16 path");
     static_assert(!BF16 || (BMn == BNc && (BMn == 128 || BMn == 64)), "bf16 weight gradient: 128 x 128 and 64 x 64 tiles");
     constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
     constexpr int YCH = BMn / 4, XCH = BNc / 4;        // float4 chunks per pixel row
     constexpr int YRP = 256 / YCH, XRP = 256 / XCH;    // pixel rows per pass
     constexpr int YP = BKP / YRP, XP = BKP / XRP;
     static_assert(WGM * WGN == 4 && YP >= 1 && XP >= 1, "bad wgrad tile");
-    __shared__ __attribute__((aligned(16))) float smem[BKP * (BMn + BNc)];
+    constexpr int SMEM_FLOATS = X3 ? 3 * (BMn + BNc) * 76 / 2 : BKP * (BMn + BNc);      // split mode: three bf16 planes
+    __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* Ys = smem;
     float* Xs = smem + BKP * BMn;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -951,6 +953,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     // conflicted because the lanes of a wave differ in the CHANNEL chunk, i.e. by whole rows).
     constexpr int WLD = BMn == 128 ? 76 : 72;      // 64 x 64 tile (16 channel chunks per pixel row): 36 words, order (e + ych / 4) % 4
     constexpr int RSH = BMn == 128 ? 3 : 2;
+    constexpr int WPLANE = (BMn + BNc) * WLD;      // halfs per plane (split mode)
     __bf16* Yh = reinterpret_cast<__bf16*>(smem);
     __bf16* Xh = Yh + BMn * WLD;
     auto rot4 = [](f32x4 v, int r) {      // v[(e + r) & 3] at position e, r per lane
@@ -963,8 +966,18 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-            const bf16x2 pk = __builtin_convertvector((__attribute__((ext_vector_type(2))) float){a0[e], a1[e]}, bf16x2);
-            *reinterpret_cast<bf16x2*>(&T[(ch * 4 + ((e + r) & 3)) * WLD + rowp]) = pk;
+            typedef float f32x2_ __attribute__((ext_vector_type(2)));
+            f32x2_ v = {a0[e], a1[e]};
+            __bf16* dst = &T[(ch * 4 + ((e + r) & 3)) * WLD + rowp];
+            const bf16x2 t1 = __builtin_convertvector(v, bf16x2);
+            *reinterpret_cast<bf16x2*>(dst) = t1;
+            if constexpr (X3) {      // three-term split (see igemm_vec_kernel), planes WPLANE halfs apart
+                v -= __builtin_convertvector(t1, f32x2_);
+                const bf16x2 t2 = __builtin_convertvector(v, bf16x2);
+                *reinterpret_cast<bf16x2*>(dst + WPLANE) = t2;
+                v -= __builtin_convertvector(t2, f32x2_);
+                *reinterpret_cast<bf16x2*>(dst + 2 * WPLANE) = __builtin_convertvector(v, bf16x2);
+            }
         }
     };
     auto pro4 = [&](f32x4 v, int i) {
@@ -1021,6 +1034,27 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(q), hi = *reinterpret_cast<const bf16x4*>(q + 4);
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             };
+            if constexpr (X3) {      // six term products per block, term-major over the wave's four blocks
+                constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 0, 0, 1, 1, 2};
+#pragma unroll
+                for (int kg = 0; kg < BKP / 16; ++kg) {
+                    bf16x8 ay3[3][RB], bx3[3][CB];
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                        for (int i = 0; i < RB; ++i) ay3[t][i] = frag8(yf + t * WPLANE + i * 32 * WLD + kg * 16);
+#pragma unroll
+                        for (int j = 0; j < CB; ++j) bx3[t][j] = frag8(xf + t * WPLANE + j * 32 * WLD + kg * 16);
+                    }
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int i = 0; i < RB; ++i)
+#pragma unroll
+                            for (int j = 0; j < CB; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay3[TA[t]][i], bx3[TB[t]][j], acc[i][j], 0, 0, 0);
+                }
+            }
             bf16x8 ay[2][RB], bx[2][CB];
             auto frags = [&](int set, int kg) {
 #pragma unroll
@@ -1028,9 +1062,9 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < CB; ++j) bx[set][j] = frag8(xf + j * 32 * WLD + kg * 16);
             };
-            frags(0, 0);
+            if constexpr (!X3) frags(0, 0);
 #pragma unroll
-            for (int kg = 0; kg < BKP / 16; ++kg) {
+            for (int kg = 0; kg < (X3 ? 0 : BKP / 16); ++kg) {
                 if (kg + 1 < BKP / 16) frags((kg + 1) & 1, kg + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1385,7 +1419,12 @@ static void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t 
 
 // 0 = fp32 MFMA (the reference's arithmetic), 1 = bf16 operands / fp32 accumulation in the forward and data-gradient
 // GEMMs of the C % 64 == 0 convs (BASELINE.json configs[4], "bf16 mixed precision"); process-wide, set between launches
-static int g_conv_bf16 = 0;
+static int initial_compute_mode() {      // DPFT_CONV_COMPUTE=fp32|bf16|bf16x3 presets the mode (tests, sweeps)
+    const char* e = getenv("DPFT_CONV_COMPUTE");
+    if (!e) return 0;
+    return !strcmp(e, "bf16") ? 1 : (!strcmp(e, "bf16x3") ? 2 : 0);
+}
+static int g_conv_bf16 = initial_compute_mode();
 
 template <bool DGRAD>
 static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t st) {
@@ -1766,7 +1805,10 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, st, a);     \
     } while (0)
-        if (bmn == 128 && g_conv_bf16 == 1) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
+        if (bmn == 128 && g_conv_bf16 == 2) {      // split mode: 117 KB of LDS (three bf16 planes)
+            if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true, true>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true, true>), grid, block, 0, st, a);
+        } else if (bmn == 128 && g_conv_bf16 == 1) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
             if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true>), grid, block, 0, st, a);
         } else if (bmn == 64 && g_conv_bf16 == 1) {

@@ -143,9 +143,9 @@ def test_conv_bf16_operand_mode(case):
     print(f"   wgrad rel-L2 fp32 {e_w32:.1e} bf16 {e_w16:.1e}")
     # experimental mode 2: every operand value as three bf16 terms, six term products on the bf16 matrix cores -- at
     # least as close to the fp64 result as the fp32 MFMA path
-    e_y3, e_d3 = rel(res["bf16x3"][0], yref.detach()), rel(res["bf16x3"][1], xa.grad)
-    print(f"   3 x bf16 split: fwd {e_y3:.1e} dgrad {e_d3:.1e}")
-    assert e_y3 < max(1e-6, 1.2 * e_y32) and e_d3 < max(1e-6, 1.2 * e_d32), (e_y3, e_d3)
+    e_y3, e_d3, e_w3 = rel(res["bf16x3"][0], yref.detach()), rel(res["bf16x3"][1], xa.grad), rel(res["bf16x3"][3], wd.grad)
+    print(f"   3 x bf16 split: fwd {e_y3:.1e} dgrad {e_d3:.1e} wgrad {e_w3:.1e}")
+    assert e_y3 < max(1e-6, 1.2 * e_y32) and e_d3 < max(1e-6, 1.2 * e_d32) and e_w3 < max(1e-6, 1.2 * e_w32), (e_y3, e_d3, e_w3)
     assert e_w32 < 1e-5 and e_w16 < 6e-3, (e_w32, e_w16)             # (the 32 x 128-tiled problems, K <= 32, stay fp32)
     # tile statistics are computed from the bf16-mode output itself (consistent with what the BN backward will see)
     yb = res["bf16"][0].permute(0, 2, 3, 1).reshape(-1, K)
