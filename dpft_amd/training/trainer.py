@@ -25,7 +25,8 @@ class DataParallelTrainer:
         # forward / data-gradient conv GEMMs with bf16 operands and fp32 accumulation; default = the reference's fp32
         if torch.device(device).type == "cuda":
             from dpft_amd.hip import ops as _ops
-            _ops.conv_set_compute(config.get("computing", {}).get("conv_compute", "fp32"))
+            import os
+            _ops.conv_set_compute(config.get("computing", {}).get("conv_compute") or os.environ.get("DPFT_CONV_COMPUTE", "fp32"))
         train = config["train"]
         self.loss_fn = build_loss(train)
         # the reference evaluates mAP3D / mGIoU3D in every training step (trainer.py:134); optional here
