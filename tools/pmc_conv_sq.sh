@@ -1,7 +1,7 @@
 # SQ wave-cycle breakdown of the conv kernels on the layer3 problems (one PMC pass, 8 SQ counters)
 cd /tmp && export TMPDIR=/tmp
 S="fwd:4,32,57,256,256,3,1 dgrad:4,32,57,256,256,3,1 wgrad:4,32,57,256,256,3,1 fwd:4,32,57,256,1024,1,1 dgrad:4,128,228,64,64,3,1 wgrad:4,32,57,1024,256,1,1"
-timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_sq -- python /root/repo/tools/conv_bench.py $S </dev/null > /tmp/pmc_sq.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d /tmp/pmc_sq -- env DPFT_COMPUTE=${DPFT_COMPUTE:-fp32} python /root/repo/tools/conv_bench.py $S </dev/null > /tmp/pmc_sq.log 2>&1
 tail -8 /tmp/pmc_sq.log
 python - <<'PY'
 import csv, glob, collections, re
