@@ -1,3 +1,2 @@
-"""Evaluation-side pieces: the per-step metrics, the K-Radar exporter and the evaluation loop."""
-from dpft_amd.evaluation.evaluator import CentralizedEvaluator, build_evaluator   # noqa: F401
+"""Evaluation-side pieces: the per-step metrics, and the K-Radar exporter."""
 from dpft_amd.evaluation.metric import Metric, build_metric   # noqa: F401

@@ -80,56 +80,3 @@ def test_exporter_argument_errors(tmp_path):
         KRadarExporter.select(z, torch.zeros(1, 4, 3), torch.zeros(1, 4, 3), z, [0.5])
     with pytest.raises(ValueError):
         KRadarExporter.select(z.to(DEV), torch.zeros(1, 4, 3).to(DEV), torch.zeros(1, 4, 3).to(DEV), z.to(DEV), [0.1] * 9)
-
-
-def test_evaluator_end_to_end(tmp_path):
-    """dprt.evaluate's loop on a saved checkpoint: metrics + export of every batch, latency protocol, complexity."""
-    import copy
-    from dpft_amd.configs import load_config
-    from dpft_amd.evaluation import build_evaluator
-    from dpft_amd.models import build
-    from dpft_amd.synthetic import make_batch, make_labels
-    from oracle import export_oracle as EO
-    from oracle import metric_oracle as MO
-    cfg = copy.deepcopy(load_config("kradar"))
-    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
-    shapes = {"camera_mono": (96, 160, 3), "radar_bev": (128, 43, 6), "radar_front": (37, 107, 6)}
-    torch.manual_seed(3)
-    model = build("dprt", cfg)
-    with torch.no_grad():                                               # some confident foreground predictions
-        model.fuser.heads[-1].layers["class_head"][-1].weight.mul_(8.0)
-    ckpt = tmp_path / "20240101-000000_checkpoint_0007.pt"
-    torch.save(model, str(ckpt))
-    loader = []
-    for i in range(2):
-        labels = make_labels(2, seed=20 + i)
-        for b, lab in enumerate(labels):
-            lab["description"] = torch.tensor([(i + b) % 9, b % 2, (2 * i + b) % 7])
-        loader.append((make_batch(cfg["model"]["inputs"], 2, seed=30 + i, shapes=shapes), labels))
-    ev = build_evaluator(cfg)
-    ev.evaluate(str(ckpt), loader, str(tmp_path / "out"))
-    dst = tmp_path / "out" / "20240101-000000"
-    scalars = [__import__("json").loads(l) for l in open(dst / "scalars.jsonl")]
-    tags = {s["tag"] for s in scalars}
-    assert {"test/mAP", "test/mGIoU", "test/Inference_time_mean_ms", "test/Inference_time_std_ms", "test/FLOPS",
-            "test/MACS", "test/Parameters"} <= tags
-    assert all(s["step"] == 7 for s in scalars)
-    by = {s["tag"]: s["value"] for s in scalars}
-    assert by["test/FLOPS"] > 1e9 and by["test/MACS"] * 2 == by["test/FLOPS"]
-    assert by["test/Parameters"] == sum(p.numel() for p in model.parameters())
-    # the exported tree and the epoch metrics equal the oracle's on the model's own outputs
-    model = model.to(DEV).eval()
-    tree, acc = {}, {"mAP": 0.0, "mGIoU": 0.0}
-    for i, (data, labels) in enumerate(loader):
-        with torch.no_grad():
-            out = {k: v.cpu() for k, v in model(to_dev(data)).items()}
-        for path, text in EO.export_tree(out, labels, i * len(labels), categories=cfg["data"].get("categories")).items():
-            tree[path] = tree.get(path, "") + text
-        for k, v in MO.metric_forward(out, labels).items():
-            acc[k] += float(v) / len(loader)
-    got = {p: t for p, t in read_tree(str(dst)).items() if p.startswith("exports/")}
-    assert sorted(got) == sorted(tree)
-    for path, text in tree.items():
-        assert got[path] == text, path
-    for k in acc:
-        assert abs(by[f"test/{k}"] - acc[k]) < 1e-5, (k, by[f"test/{k}"], acc[k])
