@@ -73,17 +73,30 @@ def make_config(inputs: List[str], weights: str = "") -> Dict[str, Any]:
     }
 
 
-def load_config(name_or_path: str, offline: bool = True) -> Dict[str, Any]:
-    """``load_config('kradar')`` -> built-in equivalent of config/kradar.json; a path loads that JSON
-    (mirror of src/dprt/utils/config.py:8-20).  ``offline`` blanks torchvision weight enums."""
+def load_config(name_or_path: str, offline: bool = False, weight_files: Dict[str, str] = None) -> Dict[str, Any]:
+    """``load_config('kradar')`` -> built-in equivalent of config/kradar.json; a path loads that JSON unchanged
+    (mirror of src/dprt/utils/config.py:8-20).
+
+    Backbone ``weights`` entries that are torchvision enums (``IMAGENET1K_V2`` ...) cannot be downloaded here.  Nothing
+    is blanked silently: ``weight_files={"ResNet101": "/path/r101.pt", "IMAGENET1K_V2": ...}`` maps a backbone name (or
+    an enum) to a local state-dict file; ``offline=True`` is the explicit opt-in to random init and warns per backbone;
+    otherwise the enum stays in the config and ``Backbone`` raises when the model is built."""
     if name_or_path in _NAMES:
         return make_config(_NAMES[name_or_path])
     with open(name_or_path, "r") as f:
         cfg = json.load(f)
-    if offline:
-        for bb in cfg.get("model", {}).get("backbones", {}).values():
-            if bb.get("weights") and not os.path.exists(bb["weights"]):
-                bb["weights"] = ""
+    for view, bb in cfg.get("model", {}).get("backbones", {}).items():
+        w = bb.get("weights")
+        if not w or os.path.exists(w):
+            continue
+        local = (weight_files or {}).get(bb.get("name")) or (weight_files or {}).get(w)
+        if local:
+            bb["weights"] = local
+        elif offline:
+            import warnings
+            warnings.warn(f"load_config(offline=True): backbone {view!r} ({bb.get('name')}) weights {w!r} are not "
+                          "available offline -> RANDOM initialisation (the reference starts from pretrained weights)")
+            bb["weights"] = ""
     return cfg
 
 

@@ -14,11 +14,27 @@ struct AdamChunk {
     int32_t tensor;   // index into `active`
 };
 
+// `skipped[t]` = number of optimizer steps tensor t sat out (no gradient): its own step count is `step - skipped[t]`,
+// like the per-parameter `state["step"]` of torch.optim.AdamW.  Only inactive blocks write it (the block of a tensor's
+// first chunk), only active blocks read it, so there is no race inside a launch.
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, const int32_t* __restrict__ active,
+                                                     int32_t* __restrict__ skipped, int32_t step,
                                                      float lr, float beta1, float beta2, float eps, float decay,
                                                      float step_size, float inv_sqrt_bc2) {
     const AdamChunk c = chunks[blockIdx.x];
-    if (active && !active[c.tensor]) return;      // parameters without a gradient are skipped (grad is None)
+    if (active && !active[c.tensor]) {             // parameters without a gradient are skipped (grad is None)
+        if (skipped && c.m == nullptr && threadIdx.x == 0) skipped[c.tensor] += 1;   // marker row: one per tensor
+        return;
+    }
+    if (c.m == nullptr) return;                    // marker row of an active tensor
+    if (skipped) {
+        const int32_t own = step - skipped[c.tensor];
+        if (own != step) {                         // bias corrections of this tensor's own step count
+            const double bc1 = 1.0 - pow((double)beta1, (double)own), bc2 = 1.0 - pow((double)beta2, (double)own);
+            step_size = (float)((double)lr / bc1);
+            inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+        }
+    }
     for (int i = threadIdx.x * 4; i < c.n; i += 256 * 4) {
         if (i + 3 < c.n && ((((uintptr_t)(c.p + i)) | ((uintptr_t)(c.g + i))) & 15) == 0) {
             f32x4 p = *reinterpret_cast<f32x4*>(c.p + i);
@@ -53,11 +69,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
 
 using namespace dpft;
 
-extern "C" int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, float lr, float beta1,
-                              float beta2, float eps, float weight_decay, int32_t step, dpft_stream_t stream) {
+extern "C" int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, int32_t* skipped, float lr,
+                              float beta1, float beta2, float eps, float weight_decay, int32_t step, dpft_stream_t stream) {
     DPFT_REQUIRE(chunks && n_chunks > 0 && step >= 1, "adamw: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
-    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks, active, lr,
+    hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks, active, skipped, step, lr,
                        beta1, beta2, eps, (float)(1.0 - (double)lr * weight_decay), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
     return check_launch("adamw");
 }

@@ -135,7 +135,7 @@ SIGNATURES = {
     "dpft_profile_stop": (_I, []),
     "dpft_profile_overhead_ms": (_F, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
-    "dpft_adamw_f32": (_I, [_P, _I, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "dpft_resnet_plan_create": (_L, [C.POINTER(ResnetDesc)]),
     "dpft_resnet_plan_destroy": (None, [_L]),
     "dpft_resnet_plan_query": (_L, [_L, _I, _I]),

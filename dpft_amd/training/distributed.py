@@ -5,8 +5,14 @@ src/dprt/training/trainer.py:20,215); this is the MI355X-side addition (SURVEY.m
 per GPU, samples sharded across ranks, one exchange step = all-reduce(mean) of the gradients.
 
 Design for xGMI (7 point-to-point links per GPU, ring collectives are per-link bound):
-  * gradients live in a few large flat fp32 buckets (default 64 MiB) in REVERSE registration order,
+  * gradients live in flat fp32 buckets (default 25 MiB, SURVEY 5: large enough to run the links at their
+    bandwidth, small enough that the first collective starts early in the backward; ``train.dp.bucket_mb`` /
+    DPFT_BUCKET_MB) in REVERSE registration order, all carved out of ONE arena (one memset per step);
     ``param.grad`` are views into them -> one collective per bucket, no per-tensor launches;
+  * optional bf16 wire format (``train.dp.comm_dtype = "bf16"`` / DPFT_COMM_DTYPE): a bucket is rounded into a bf16
+    staging buffer, reduced in bf16 and widened back - half the bytes per link (179.8 MB instead of 359.6 MB per step);
+  * ``exposed_ms()``: the part of the exchange that was NOT hidden behind the backward (time between the end of the
+    rank's own backward work and the completion of the last collective);
   * a bucket's all-reduce is issued asynchronously the moment its last gradient is produced, so the
     exchange of layer4 overlaps the backward of layer3 ... ; the hand-scheduled backbone backward
     hands gradients over per bottleneck block through ``grad_sink`` instead of waiting for the end
@@ -23,29 +29,40 @@ import torch.distributed as dist
 
 
 class GradBucketReducer:
-    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 64 << 20, process_group=None,
-                 average: bool = True, group_of: Dict[int, str] = None):
+    def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 25 << 20, process_group=None,
+                 average: bool = True, group_of: Dict[int, str] = None, comm_dtype: Optional[torch.dtype] = None):
         """``group_of`` (id(param) -> group key) keeps buckets from spanning groups: the three view encoders run
         (forward and backward) on their own HIP streams, and a bucket whose gradients all come from one stream
         can be reduced from that stream without joining the others."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.params = [p for p in params if p.requires_grad]
         order = list(reversed(self.params))
         self.buckets: List[dict] = []
-        cur, cur_bytes, cur_group = [], 0, None
+        plan, cur, cur_bytes, cur_group = [], [], 0, None
         for p in order:
             nbytes = p.numel() * p.element_size()
             grp = group_of.get(id(p)) if group_of else None
             if cur and (cur_bytes + nbytes > bucket_bytes or grp != cur_group):
-                self._add_bucket(cur)
+                plan.append(cur)
                 cur, cur_bytes = [], 0
             cur.append(p)
             cur_bytes += nbytes
             cur_group = grp
         if cur:
-            self._add_bucket(cur)
+            plan.append(cur)
+        # one arena for all buckets (64-element aligned starts): reset() is a single memset
+        starts, total = [], 0
+        for ps in plan:
+            starts.append(total)
+            total += (sum(p.numel() for p in ps) + 63) // 64 * 64
+        p0 = self.params[0]
+        self.arena = torch.zeros(total, dtype=p0.dtype, device=p0.device)
+        for ps, st in zip(plan, starts):
+            self._add_bucket(ps, self.arena[st:st + sum(p.numel() for p in ps)])
+        self._exposed = None
         self._index: Dict[int, tuple] = {}
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
@@ -54,10 +71,7 @@ class GradBucketReducer:
         self._pending: List = []
         self.reset()
 
-    def _add_bucket(self, params):
-        dev, dtype = params[0].device, params[0].dtype
-        total = sum(p.numel() for p in params)
-        flat = torch.zeros(total, dtype=dtype, device=dev)
+    def _add_bucket(self, params, flat):
         views, off = {}, 0
         for p in params:
             seg = flat[off:off + p.numel()]
@@ -69,13 +83,15 @@ class GradBucketReducer:
                 v = seg.view(p.shape)
             views[id(p)] = v
             off += p.numel()
-        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set(), streams={}))
+        stage = torch.empty(flat.numel(), dtype=self.comm_dtype, device=flat.device) if self.comm_dtype else None
+        self.buckets.append(dict(params=params, flat=flat, views=views, ready=0, fired=False, seen=set(), streams={},
+                                 stage=stage))
 
     # ------------------------------------------------------------------------------------------
     def reset(self):
         """Call before every backward: zero the buckets and point ``param.grad`` at the bucket views."""
+        self.arena.zero_()
         for b in self.buckets:
-            b["flat"].zero_()
             b["ready"], b["fired"] = 0, False
             b["seen"].clear()
             b["streams"].clear()
@@ -157,7 +173,11 @@ class GradBucketReducer:
         if self.world > 1:
             if self.average:
                 b["flat"].div_(self.world)
-            self._pending.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            wire = b["flat"]
+            if b["stage"] is not None:
+                wire = b["stage"]
+                wire.copy_(b["flat"])                                 # round to the wire dtype (RNE)
+            self._pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
 
     def seen_ids(self):
         """ids of the parameters that received a gradient since the last reset()."""
@@ -171,9 +191,34 @@ class GradBucketReducer:
         for b in self.buckets:
             if not b["fired"]:
                 self._fire(b)
-        for w in self._pending:
-            w.wait()
+        if not self._pending:
+            self._exposed = 0.0
+            return
+        cuda = self.arena.is_cuda
+        if cuda:                                   # t0: the rank's own backward work is done on the current stream
+            t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0.record()
+        else:
+            import time
+            t0 = time.perf_counter()
+        for w, b in self._pending:
+            w.wait()                               # cuda: the current stream waits for the collective's stream
+            if b["stage"] is not None:
+                b["flat"].copy_(b["stage"])
+        if cuda:
+            t1.record()
+            self._exposed = (t0, t1)
+        else:
+            self._exposed = (time.perf_counter() - t0) * 1e3
         self._pending = []
+
+    def exposed_ms(self) -> float:
+        """Exposed (non-overlapped) exchange time of the last ``finish()`` in ms; synchronises on its end event."""
+        e = self._exposed
+        if isinstance(e, tuple):
+            e[1].synchronize()
+            e = self._exposed = e[0].elapsed_time(e[1])
+        return float(e or 0.0)
 
     def remove(self):
         for h in self._hooks:

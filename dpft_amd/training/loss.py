@@ -240,13 +240,6 @@ class Loss(nn.modules.loss._Loss):
             lib.call("dpft_match_cost_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                      gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
                      ncls, stream())
-        import os
-        if os.environ.get("DPFT_EXPERIMENT_NOSYNC") and hasattr(self, "_exp_match"):
-            match_t, counts_m = self._exp_match
-            weights5 = tuple(float(self.loss_weights.get(k, 0.0)) for k in self._TERMS)
-            losses5 = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75)
-            batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}
-            return torch.stack(tuple(batch_losses.values())).sum(dim=-1), batch_losses
         host = cost.cpu().numpy()                                                             # the one sync of the step
         match = np.full((B, Mmax, 2), -1, dtype=np.int32)
         for b, m in enumerate(counts):

@@ -1,7 +1,7 @@
 """Optimizers.  ``build_optimizer`` mirrors src/dprt/training/optimizer.py:6-7 (``getattr(torch.optim,
 name)``); for AdamW on CUDA it returns ``FusedAdamW``: the same update rule as torch.optim.AdamW
 (lr, betas=(0.9,0.999), eps=1e-8, weight_decay=1e-2, no amsgrad) executed by ONE HIP launch over all
-parameter tensors (dpft_adamw_f32), with the moments in two flat fp32 buffers."""
+parameter tensors (dpft_adamw_f32), with the moments in two flat fp32 buffers (per-parameter state kept)."""
 from __future__ import annotations
 
 import numpy as np
@@ -13,10 +13,18 @@ CHUNK = 16384
 
 
 class FusedAdamW(torch.optim.Optimizer):
+    """Drop-in for ``torch.optim.AdamW`` (no amsgrad / maximize / capturable).  The moments of a parameter group live in
+    two flat fp32 buffers; ``self.state[p]`` holds views into them, so ``state_dict()`` / ``load_state_dict()`` round-trip
+    in torch's format.  Fast path: persistent gradient buffers (the DP reducer's buckets) - the pointer table is built
+    once.  With a plain ``zero_grad(set_to_none=True)`` loop the table is re-pointed whenever a ``.grad`` moves; the
+    moments and step counts are keyed by parameter and survive that.  ``grad is None`` = the parameter sits the step out
+    (its own step count does not advance, exactly like torch)."""
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2):
         super().__init__(list(params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = None
-        self._step = 0
+        self._step = 0                 # launches so far; a tensor's own count is _step - skipped[t]
+        self._restore = False          # self.state was replaced by load_state_dict: re-seed the flat buffers from it
 
     @staticmethod
     def _layout(t: torch.Tensor):
@@ -28,33 +36,72 @@ class FusedAdamW(torch.optim.Optimizer):
             out.add("khwc")
         return out
 
+    @staticmethod
+    def _ptrs(ps):
+        return [(p.data_ptr(), None if p.grad is None else p.grad.data_ptr()) for p in ps]
+
+    @staticmethod
+    def _flat_view(flat, off, p):
+        """View of ``flat[off : off + numel]`` with p's shape AND physical element order."""
+        v = flat[off:off + p.numel()]
+        if p.dim() == 4 and not p.is_contiguous():                    # khwc
+            o, i, kh, kw = p.shape
+            return v.view(o, kh, kw, i).permute(0, 3, 1, 2)
+        return v.view(p.shape)
+
     def _build(self):
+        """(Re)build the chunk tables.  Moments: first build -> zeros (or the loaded state); later builds keep the flat
+        buffers and only refresh the parameter / gradient pointers."""
+        old = self._tables
+        if self._restore:
+            steps = [float(st["step"]) for st in self.state.values() if "step" in st]
+            self._step = int(max(steps)) if steps else 0
         tables = []
-        for group in self.param_groups:
+        for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.requires_grad]
-            total = sum(p.numel() for p in ps)
             dev = ps[0].device
-            m = torch.zeros(total, dtype=torch.float32, device=dev)
-            v = torch.zeros(total, dtype=torch.float32, device=dev)
+            keep = old is not None and not self._restore and [id(p) for p in old[gi]["params"]] == [id(p) for p in ps]
+            if keep:
+                m, v, skipped = old[gi]["m"], old[gi]["v"], old[gi]["skipped"]
+            else:
+                total = sum(p.numel() for p in ps)
+                m = torch.zeros(total, dtype=torch.float32, device=dev)
+                v = torch.zeros(total, dtype=torch.float32, device=dev)
+                skip_host = [0] * len(ps)
             rows, off = [], 0
             for ti, p in enumerate(ps):
-                assert p.grad is not None and (self._layout(p) & self._layout(p.grad)), \
-                    "FusedAdamW expects persistent, dense gradient buffers laid out like their parameters"
-                pp, gp = p.data_ptr(), p.grad.data_ptr()
-                for c0 in range(0, p.numel(), CHUNK):
-                    n = min(CHUNK, p.numel() - c0)
-                    rows.append((pp + 4 * c0, gp + 4 * c0, m.data_ptr() + 4 * (off + c0), v.data_ptr() + 4 * (off + c0),
-                                 n, ti))
+                mv, vv = self._flat_view(m, off, p), self._flat_view(v, off, p)
+                if not keep:
+                    st = self.state.get(p, {})
+                    if "exp_avg" in st:                                # loaded / carried-over state
+                        mv.copy_(st["exp_avg"])
+                        vv.copy_(st["exp_avg_sq"])
+                        skip_host[ti] = self._step - int(float(st.get("step", 0)))
+                    else:
+                        skip_host[ti] = self._step                      # joins now: its own count starts at 0
+                    self.state[p] = {"exp_avg": mv, "exp_avg_sq": vv}
+                rows.append((0, 0, 0, 0, 0, ti))                        # marker row (advances skipped[t] when inactive)
+                if p.grad is not None:
+                    assert p.grad.dtype == torch.float32 and (self._layout(p) & self._layout(p.grad)), \
+                        "FusedAdamW expects dense fp32 gradients laid out like their parameters"
+                    pp, gp = p.data_ptr(), p.grad.data_ptr()
+                    for c0 in range(0, p.numel(), CHUNK):
+                        n = min(CHUNK, p.numel() - c0)
+                        rows.append((pp + 4 * c0, gp + 4 * c0, m.data_ptr() + 4 * (off + c0),
+                                     v.data_ptr() + 4 * (off + c0), n, ti))
                 off += p.numel()
+            if not keep:
+                skipped = torch.tensor(skip_host, dtype=torch.int32).to(dev)
             arr = np.zeros(len(rows), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"),
                                                       ("n", "<i4"), ("t", "<i4")]))
             for i, r in enumerate(rows):
                 arr[i] = r
             chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
             active = torch.ones(len(ps), dtype=torch.int32, device=dev)
-            tables.append(dict(params=ps, ptrs=[(p.data_ptr(), p.grad.data_ptr()) for p in ps], m=m, v=v,
-                               chunks=chunks, n_chunks=len(rows), active=active, active_host=None))
+            tables.append(dict(params=ps, ptrs=self._ptrs(ps), m=m, v=v, skipped=skipped, chunks=chunks,
+                               n_chunks=len(rows), active=active, active_host=None))
         self._tables = tables
+        self._restore = False
 
     def set_active(self, active_ids):
         """ids of parameters that received a gradient this step (others are skipped like ``grad is None``)."""
@@ -62,23 +109,33 @@ class FusedAdamW(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        if self._tables is None or any(
-                [(p.data_ptr(), p.grad.data_ptr()) for p in t["params"]] != t["ptrs"] for t in self._tables):
+        if self._restore or self._tables is None or any(self._ptrs(t["params"]) != t["ptrs"] for t in self._tables):
             self._build()
         self._step += 1
         ids = getattr(self, "_active_ids", None)
         for group, t in zip(self.param_groups, self._tables):
-            if ids is not None:
-                host = [int(id(p) in ids) for p in t["params"]]
-                if host != t["active_host"]:
-                    t["active"].copy_(torch.tensor(host, dtype=torch.int32))
-                    t["active_host"] = host
+            host = [int(p.grad is not None and (ids is None or id(p) in ids)) for p in t["params"]]
+            if host != t["active_host"]:
+                t["active"].copy_(torch.tensor(host, dtype=torch.int32))
+                t["active_host"] = host
             b1, b2 = group["betas"]
-            lib.call("dpft_adamw_f32", ptr(t["chunks"]), t["n_chunks"], ptr(t["active"]) if ids is not None else None,
+            lib.call("dpft_adamw_f32", ptr(t["chunks"]), t["n_chunks"], ptr(t["active"]), ptr(t["skipped"]),
                      float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                      self._step, stream())
         note_weights_changed()                             # in-place through raw pointers: no _version bump
         return None
+
+    def state_dict(self):
+        """torch's format: per parameter ``step`` (its own count), ``exp_avg``, ``exp_avg_sq``."""
+        for t in self._tables or []:
+            skipped = t["skipped"].cpu().tolist()
+            for p, sk in zip(t["params"], skipped):
+                self.state[p]["step"] = torch.tensor(float(self._step - sk))
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        self._restore = True
 
 
 def build_optimizer(name: str, params, device=None, **kwargs):

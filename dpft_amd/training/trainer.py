@@ -18,7 +18,8 @@ from dpft_amd.training.optimizer import FusedAdamW, build_optimizer
 
 
 class DataParallelTrainer:
-    def __init__(self, model: torch.nn.Module, config: Dict[str, Any], device, bucket_mb: int = 64):
+    def __init__(self, model: torch.nn.Module, config: Dict[str, Any], device, bucket_mb: Optional[float] = None,
+                 comm_dtype: Optional[str] = None):
         self.model = model.to(device)
         self.device = device
         # optional mixed precision (BASELINE.json configs[4]): config["computing"]["conv_compute"] = "bf16" runs the
@@ -43,8 +44,15 @@ class DataParallelTrainer:
         for n, p in self.model.named_parameters():
             parts = n.split(".")
             group_of[id(p)] = ".".join(parts[:2]) if parts[0] in ("backbones", "necks") else "decoder"
-        self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=bucket_mb << 20,
-                                         group_of=group_of)
+        # exchange knobs: argument > config["train"]["dp"] > environment > default (25 MiB fp32 buckets)
+        import os as _os
+        dp = train.get("dp", {})
+        bucket_mb = float(bucket_mb or dp.get("bucket_mb") or _os.environ.get("DPFT_BUCKET_MB") or 25)
+        comm_dtype = comm_dtype or dp.get("comm_dtype") or _os.environ.get("DPFT_COMM_DTYPE") or "fp32"
+        wire = {"fp32": None, "float32": None, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[comm_dtype]
+        self.bucket_mb, self.comm_dtype = bucket_mb, comm_dtype
+        self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=int(bucket_mb * (1 << 20)),
+                                         group_of=group_of, comm_dtype=wire)
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         for m in self.model.modules():
             if hasattr(m, "grad_direct"):
@@ -66,12 +74,17 @@ class DataParallelTrainer:
         self.reducer.reset()                               # zero_grad (grads live in the buckets)
         output = self.model(data)
         loss, losses = self.loss_fn(output, labels)
-        stepped = bool(loss > 0)                           # trainer.py:131 (host sync, as in the reference)
-        if self.world > 1:                                 # every rank must take the same branch
-            flag = torch.tensor([int(stepped)], device=self.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        stepped = local = bool(loss > 0)                   # trainer.py:131 (host sync, as in the reference)
+        if self.world > 1:
+            # The global batch steps if ANY shard has a loss (MAX): a rank whose label shard is empty then runs the same
+            # backward over a zero-valued loss, so it contributes zero gradients, issues its bucket collectives in the
+            # same order and reports the same set of parameters-with-gradient as every other rank.
+            flag = torch.tensor([int(local)], device=self.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
             stepped = bool(flag.item())
         if stepped:
+            if not local:
+                loss = sum(v.sum() for v in output.values()) * 0.0
             loss.backward()
             self.reducer.finish()
             if isinstance(self.optimizer, FusedAdamW):

@@ -462,8 +462,11 @@ int dpft_radar_projection_f32(const float* tesseract, const float* doppler_raste
  * the optimizer the reference builds at src/dprt/training/trainer.py:233 / optimizer.py:6-7.
  * chunks: device array of {float* p; const float* g; float* m; float* v; int32 n; int32 tensor}
  * (4 pointers + 2 int32 = 40 bytes each); active: device int32 per tensor (0 = skip: gradient is None) or NULL.
+ * skipped (or NULL): device int32 per tensor, the number of steps the tensor sat out; its bias corrections use
+ * step - skipped[t] (the per-parameter state["step"] of torch.optim.AdamW).  A row with m == NULL is the tensor's
+ * "marker row": it carries no elements and advances skipped[t] when the tensor is inactive (one such row per tensor).
  * ---------------------------------------------------------------------------------------- */
-int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, float lr, float beta1,
+int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, int32_t* skipped, float lr, float beta1,
                    float beta2, float eps, float weight_decay, int32_t step, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

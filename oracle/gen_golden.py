@@ -12,6 +12,7 @@ modules.  No reference source text is stored.  Reference call sites exercised:
   MSDeformAttn (python part)   src/dprt/models/layers/ms_deform_attn.py:138-217
   head        src/dprt/models/heads/detection.py:252-275
   loss        src/dprt/training/loss.py:17-60,234-373 ; bbox src/dprt/utils/bbox.py:4-163
+  assigner + Loss.forward  src/dprt/training/assigner.py:58-143, src/dprt/training/loss.py:486-564  (assign.npz)
 The MSDA *core* inside these fixtures is the oracle's grid_sample core (the reference has no CPU
 core; parity for that core is unpinned by the reference, see oracle/__init__.py).
 """
@@ -19,6 +20,7 @@ from __future__ import annotations
 
 import json
 import os
+import sys
 from collections import OrderedDict
 
 import numpy as np
@@ -69,6 +71,84 @@ def projections(B: int, g: torch.Generator):
     shapes = [torch.tensor([[720, 1280]] * B), torch.tensor([[256, 107]] * B),
               torch.tensor([[37, 107]] * B)]
     return [(cam_t, cam_p), (rad_t, bev_p), (rad_t.clone(), fr_p)], shapes
+
+
+def gen_assign(cfg):
+    """HungarianAnassigner.forward (training/assigner.py:58-143) and Loss.forward (training/loss.py:486-564) of the
+    reference's OWN classes built from config/kradar.json's train section -> tests/golden/assign.npz: inputs, the
+    per-sample cost matrix (captured where the reference hands it to scipy), the assignment, the weighted batch losses,
+    the total and its autograd gradients w.r.t. the four head outputs.  pytorch3d.box3d_overlap (absent third party) is
+    bound to the oracle's exact yaw-only geometry, exactly as for metric.npz - parity stays unpinned for that one call."""
+    import dprt.training.assigner as ref_assigner
+    import dprt.utils.iou as ref_iou
+    from dprt.training.loss import build_loss
+    from oracle.metric_oracle import box3d_overlap_from_corners
+    ref_iou.box3d_overlap = box3d_overlap_from_corners
+    captured = []
+    real_lsa = ref_assigner.linear_sum_assignment
+
+    def spy(c, *a, **k):
+        captured.append(np.asarray(c).copy())
+        return real_lsa(c, *a, **k)
+
+    ref_assigner.linear_sum_assignment = spy
+    try:
+        loss_fn = build_loss(cfg["train"])
+        ga = torch.Generator().manual_seed(4242)
+        ax = {}
+        for ci, (N, counts) in enumerate([(60, (4, 0, 7)), (400, (8, 1)), (5, (7,))]):       # last: more targets than queries
+            B = len(counts)
+            tgts = []
+            for M in counts:
+                c = torch.stack((5 + torch.rand(M, generator=ga) * 60, -6 + torch.rand(M, generator=ga) * 12,
+                                 -1.5 + torch.rand(M, generator=ga) * 3.5), -1)
+                sz = torch.stack((3.5 + torch.rand(M, generator=ga) * 1.5, 1.6 + torch.rand(M, generator=ga) * 0.6,
+                                  1.4 + torch.rand(M, generator=ga) * 0.6), -1)
+                yaw = (torch.rand(M, generator=ga) * 2 - 1) * 3.1
+                cls = torch.zeros(M, 2)
+                cls[:, 1] = 1.0                                                            # Sedan -> index 1
+                tgts.append(dict(gt_center=c, gt_size=sz, gt_angle=torch.stack((torch.sin(yaw), torch.cos(yaw)), -1),
+                                 gt_class=cls))
+            out = {"class": torch.randn(B, N, 2, generator=ga),
+                   "center": torch.stack((5 + torch.rand(B, N, generator=ga) * 60, -6 + torch.rand(B, N, generator=ga) * 12,
+                                          -1.5 + torch.rand(B, N, generator=ga) * 3.5), -1),
+                   "size": torch.stack((3 + torch.rand(B, N, generator=ga) * 2, 1.4 + torch.rand(B, N, generator=ga),
+                                        1.2 + torch.rand(B, N, generator=ga)), -1),
+                   "angle": torch.tanh(torch.randn(B, N, 2, generator=ga))}
+            for b, gt in enumerate(tgts):                       # some predictions overlap their targets (GIoU > -1)
+                for j in range(gt["gt_center"].shape[0]):
+                    i = int(torch.randint(0, N, (1,), generator=ga))
+                    out["center"][b, i] = gt["gt_center"][j] + torch.randn(3, generator=ga) * 0.4
+                    out["size"][b, i] = gt["gt_size"][j] * (1 + torch.randn(3, generator=ga) * 0.08)
+                    out["angle"][b, i] = gt["gt_angle"][j] + torch.randn(2, generator=ga) * 0.05
+            out["size"][0, 1] = 0.0                             # a degenerate prediction (invalid box -> GIoU -1)
+            leaf = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+            captured.clear()
+            total, batch_losses = loss_fn(leaf, tgts)
+            total.backward()
+            costs = list(captured)
+            # the assignment alone, sample by sample, from the reference's anassigner
+            k = 0
+            for b, gt in enumerate(tgts):
+                for name, v in gt.items():
+                    ax[f"c{ci}_t{b}_{name}"] = v
+                if gt["gt_center"].shape[0] == 0:
+                    continue
+                i, j = loss_fn.anassigner({n: v[b:b + 1].detach() for n, v in out.items()},
+                                          {n: v.unsqueeze(0) for n, v in gt.items()})
+                ax[f"c{ci}_b{b}_i"], ax[f"c{ci}_b{b}_j"] = i[0], j[0]
+                ax[f"c{ci}_b{b}_cost"] = torch.from_numpy(costs[k])
+                k += 1
+            for name, v in out.items():
+                ax[f"c{ci}_{name}"] = v
+                ax[f"c{ci}_grad_{name}"] = leaf[name].grad
+            ax[f"c{ci}_total"] = total.detach()
+            for name, v in batch_losses.items():
+                ax[f"c{ci}_loss_{name}"] = v.detach()
+            ax[f"c{ci}_B"] = np.asarray(B)
+    finally:
+        ref_assigner.linear_sum_assignment = real_lsa
+    np.savez_compressed(os.path.join(OUT, "assign.npz"), **_np(ax))
 
 
 def main():
@@ -325,10 +405,15 @@ def main():
     np.savez_compressed(os.path.join(OUT, "export.npz"), **_np(ex))
     with open(os.path.join(OUT, "export.json"), "w") as f:
         json.dump(trees, f, sort_keys=True)
+    gen_assign(cfg)
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
 
 
 if __name__ == "__main__":
-    main()
+    if sys.argv[1:] == ["assign"]:                 # only the round-2 fixture (keeps the other files byte-identical)
+        ref_import.install()
+        gen_assign(json.load(open(CFG)))
+    else:
+        main()

@@ -23,12 +23,30 @@ def available() -> bool:
     return os.path.isdir(REFERENCE_SRC)
 
 
+STUBS = []          # names of the namespace-only stub modules install() put into sys.modules
+
+
 def _mod(name: str, **attrs):
     m = types.ModuleType(name)
     for k, v in attrs.items():
         setattr(m, k, v)
     sys.modules[name] = m
+    STUBS.append(name)
     return m
+
+
+class stubs_hidden:
+    """Context manager: take the stub modules out of ``sys.modules`` while an independent package (``transformers``)
+    is imported and used -- it probes ``torchvision`` / ``deepspeed`` with ``importlib.util.find_spec`` and chokes on
+    spec-less stubs -- and put them back afterwards.  Makes the second-opinion tests independent of test order."""
+
+    def __enter__(self):
+        self.saved = {k: sys.modules.pop(k) for k in STUBS if k in sys.modules}
+        return self
+
+    def __exit__(self, *exc):
+        sys.modules.update(self.saved)
+        return False
 
 
 class _Placeholder:

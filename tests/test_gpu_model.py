@@ -431,6 +431,44 @@ def test_loss_and_matcher_match_oracle():
         close(dev_out[k].grad, eag_out[k].grad, rtol=1e-4, what=f"fused vs eager dloss/d{k}")
 
 
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_product_loss_matches_reference_golden(golden, ci):
+    """The product loss (HIP cost matrix + set-loss kernels, host Hungarian) against what the REFERENCE's own
+    HungarianAnassigner / Loss.forward produced (tests/golden/assign.npz, oracle/gen_golden.py::gen_assign): bit-exact
+    assignments, losses 1e-5, gradients 1e-4.  Case 2 has more targets than queries, case 0 an empty sample and a
+    degenerate box."""
+    import numpy as np
+    from dpft_amd.configs import load_config
+    from dpft_amd.training.loss import build_loss
+    g = golden("assign.npz")
+    T = lambda a: torch.from_numpy(np.asarray(a))
+    B = int(g[f"c{ci}_B"])
+    out = {k: T(g[f"c{ci}_{k}"]).to(DEV).requires_grad_(True) for k in ("class", "center", "size", "angle")}
+    tgts = [{k: T(g[f"c{ci}_t{b}_{k}"]).to(DEV) for k in ("gt_center", "gt_size", "gt_angle", "gt_class")} for b in range(B)]
+    loss_fn = build_loss(load_config("kradar")["train"])
+    matches = loss_fn.anassigner(out, tgts)
+    for b in range(B):
+        if tgts[b]["gt_center"].shape[0] == 0:
+            assert matches[b] is None
+            continue
+        assert torch.equal(matches[b][0].cpu(), T(g[f"c{ci}_b{b}_i"])), (ci, b)
+        assert torch.equal(matches[b][1].cpu(), T(g[f"c{ci}_b{b}_j"])), (ci, b)
+    for fused in (True, False):
+        for v in out.values():
+            v.grad = None
+        if fused:
+            assert loss_fn._fused_ok(out)
+            total, losses = loss_fn(out, tgts)
+        else:
+            total, losses = loss_fn.forward_eager(out, tgts)
+        close(total, T(g[f"c{ci}_total"]), rtol=1e-5, what=f"total (fused={fused})")
+        for k, v in losses.items():
+            close(v, T(g[f"c{ci}_loss_{k}"]), rtol=1e-5, what=f"loss {k} (fused={fused})")
+        total.backward()
+        for k, v in out.items():
+            close(v.grad, T(g[f"c{ci}_grad_{k}"]), rtol=1e-4, what=f"dloss/d{k} (fused={fused})")
+
+
 def test_fused_adamw_matches_torch():
     from dpft_amd.training.optimizer import FusedAdamW
     g = torch.Generator().manual_seed(6)
@@ -455,6 +493,48 @@ def test_fused_adamw_matches_torch():
         close(p, r, rtol=1e-5, atol_scale=1e-6, what="adamw param")
     assert torch.equal(ours[-1].detach(), frozen)
     
+
+def test_fused_adamw_plain_loop_state_and_late_joiner():
+    """a standard ``zero_grad(set_to_none=True)`` loop (gradient tensors re-allocated every step) must keep
+    the moments; a parameter whose grad is None sits out and later joins with its OWN step count (torch semantics);
+    ``state_dict`` round-trips through ``load_state_dict`` into a fresh optimizer."""
+    from dpft_amd.training.optimizer import FusedAdamW
+    g = torch.Generator().manual_seed(9)
+    shapes = [(32, 16, 3, 3), (77,), (40, 9)]
+    ref = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    ours = [r.detach().clone().requires_grad_(True) for r in ref]
+    ours[0].data = ours[0].data.contiguous(memory_format=torch.channels_last)
+    o_ref, o_ours = torch.optim.AdamW(ref, lr=1e-2), FusedAdamW(ours, lr=1e-2)
+
+    def run(o_r, o_o, steps, late_from):
+        for step in steps:
+            o_r.zero_grad(set_to_none=True)
+            o_o.zero_grad(set_to_none=True)
+            for k, (r, p) in enumerate(zip(ref, ours)):
+                if k == 2 and step < late_from:
+                    continue                                              # no gradient yet
+                gr = torch.randn(r.shape, generator=g).to(DEV)
+                r.grad = gr.clone()
+                p.grad = gr.clone().contiguous(memory_format=torch.channels_last) if p.dim() == 4 else gr.clone()
+            o_r.step()
+            o_o.step()
+
+    run(o_ref, o_ours, range(6), late_from=3)
+    for r, p in zip(ref, ours):
+        close(p, r, rtol=1e-5, atol_scale=1e-6, what="adamw plain loop")
+    sd_r, sd_o = o_ref.state_dict(), o_ours.state_dict()
+    for k in sd_r["state"]:
+        assert float(sd_o["state"][k]["step"]) == float(sd_r["state"][k]["step"]), k      # 6, 6, 3
+        close(sd_o["state"][k]["exp_avg"], sd_r["state"][k]["exp_avg"], rtol=1e-5, atol_scale=1e-6, what="exp_avg")
+        close(sd_o["state"][k]["exp_avg_sq"], sd_r["state"][k]["exp_avg_sq"], rtol=1e-5, atol_scale=1e-6, what="exp_avg_sq")
+    o2 = FusedAdamW(ours, lr=1e-2)                                        # resume from the checkpointed state
+    o2.load_state_dict(sd_o)
+    r2 = torch.optim.AdamW(ref, lr=1e-2)
+    r2.load_state_dict(sd_r)
+    run(r2, o2, range(6, 9), late_from=0)
+    for r, p in zip(ref, ours):
+        close(p, r, rtol=1e-5, atol_scale=1e-6, what="adamw resumed")
+
 
 def test_graphed_decoder_step_equals_eager_step():
     """Forward/loss/backward with the decoder replayed from hipGraphs == the same pass run eagerly.

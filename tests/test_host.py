@@ -120,8 +120,13 @@ def test_builtin_configs_equal_reference_jsons(name):
         bb["weights"] = ""
     for section in ("computing", "train", "model", "evaluate"):
         assert ours[section] == ref[section], section
-    loaded = load_config(os.path.join(REF, "config", name + ".json"))
+    path = os.path.join(REF, "config", name + ".json")
+    with pytest.warns(UserWarning, match="RANDOM initialisation"):            # explicit opt-in, never silent
+        loaded = load_config(path, offline=True)
     assert loaded["model"] == ours["model"]
+    assert load_config(path)["model"] == json.load(open(path))["model"]      # default: the JSON unchanged
+    mapped = load_config(path, weight_files={"IMAGENET1K_V2": "/w/imagenet.pt"})
+    assert all(bb["weights"] == "/w/imagenet.pt" for bb in mapped["model"]["backbones"].values())
 
 
 def test_no_cpu_fallback():

@@ -127,25 +127,84 @@ def test_msda_core_vs_scalar_restatement():
     torch.testing.assert_close(a, b, rtol=1e-12, atol=1e-12)
 
 
+def _hidden_stubs():
+    """transformers probes torchvision / deepspeed with find_spec and chokes on the reference-import stubs another test
+    may have installed; hide them while it is imported and used (order-independent, VERDICT r1 weak #3)."""
+    from oracle import ref_import
+    return ref_import.stubs_hidden()
+
+
 def test_msda_core_vs_transformers():
     """Independent second opinion (this container only): transformers' pure-PyTorch MSDA."""
-    try:
-        from transformers.models.deformable_detr.modeling_deformable_detr import (
-            MultiScaleDeformableAttention as HFMSDA)
-    except Exception:
-        pytest.skip("transformers MSDA not importable")
-    gen = torch.Generator().manual_seed(1)
-    shapes = [(6, 9), (3, 5)]
-    N, M, D, Lq, L, P = 2, 4, 2, 5, 2, 3
-    S = sum(h * w for h, w in shapes)
-    value = torch.randn(N, S, M, D, generator=gen)
-    loc = torch.rand(N, Lq, M, L, P, 2, generator=gen)
-    attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=gen), -1).view(N, Lq, M, L, P)
-    try:
-        ref = HFMSDA().forward(value, torch.tensor(shapes), shapes, torch.tensor([0, 54]), loc, attn, 64)
-    except Exception as e:  # API drift
-        pytest.skip(f"transformers MSDA signature differs: {e}")
+    with _hidden_stubs():
+        try:
+            from transformers.models.deformable_detr.modeling_deformable_detr import (
+                MultiScaleDeformableAttention as HFMSDA)
+        except ImportError:
+            pytest.skip("transformers MSDA not importable")
+        gen = torch.Generator().manual_seed(1)
+        shapes = [(6, 9), (3, 5)]
+        N, M, D, Lq, L, P = 2, 4, 2, 5, 2, 3
+        S = sum(h * w for h, w in shapes)
+        value = torch.randn(N, S, M, D, generator=gen)
+        loc = torch.rand(N, Lq, M, L, P, 2, generator=gen)
+        attn = torch.softmax(torch.randn(N, Lq, M, L * P, generator=gen), -1).view(N, Lq, M, L, P)
+        try:
+            ref = HFMSDA().forward(value, torch.tensor(shapes), shapes, torch.tensor([0, 54]), loc, attn, 64)
+        except TypeError as e:  # API drift
+            pytest.skip(f"transformers MSDA signature differs: {e}")
     torch.testing.assert_close(O.msda_core(value, shapes, loc, attn), ref, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("name,train", [("resnet50", False), ("resnet50", True), ("resnet101", False)])
+def test_resnet_body_vs_transformers(name, train):
+    """Independent second opinion for the torchvision ResNet restatement (third party, parity unpinned by the reference;
+    SURVEY 4 / VERDICT r1 weak #3): transformers' ResNetModel (bottleneck, v1.5 = stride on the 3x3 conv,
+    ``downsample_in_bottleneck=False``) with the SAME weights mapped name by name; all four stage outputs, eval-mode
+    running statistics and train-mode batch statistics."""
+    with _hidden_stubs():
+        try:
+            from transformers import ResNetConfig, ResNetModel
+        except ImportError:
+            pytest.skip("transformers ResNet not importable")
+        depths = O.RESNET_DEPTHS[name]
+        hf = ResNetModel(ResNetConfig(num_channels=3, embedding_size=64, hidden_sizes=[256, 512, 1024, 2048],
+                                      depths=list(depths), layer_type="bottleneck", hidden_act="relu",
+                                      downsample_in_bottleneck=False))
+        g = torch.Generator().manual_seed(11)
+        hsd = hf.state_dict()
+        for k, v in hsd.items():                                   # non-trivial affine + running statistics
+            if k.endswith("running_var") or k.endswith("normalization.weight"):
+                v.copy_(torch.rand(v.shape, generator=g) * 0.5 + 0.75)
+            elif k.endswith("running_mean") or k.endswith("normalization.bias"):
+                v.copy_(torch.randn(v.shape, generator=g) * 0.1)
+        sd = {}
+
+        def bn(dst, src):
+            for f in ("weight", "bias", "running_mean", "running_var"):
+                sd[f"{dst}.{f}"] = hsd[f"{src}.normalization.{f}"]
+
+        sd["body.conv1.weight"] = hsd["embedder.embedder.convolution.weight"]
+        bn("body.bn1", "embedder.embedder")
+        for s, nb in enumerate(depths):
+            for b in range(nb):
+                src, dst = f"encoder.stages.{s}.layers.{b}", f"body.layer{s + 1}.{b}"
+                for c in range(3):
+                    sd[f"{dst}.conv{c + 1}.weight"] = hsd[f"{src}.layer.{c}.convolution.weight"]
+                    bn(f"{dst}.bn{c + 1}", f"{src}.layer.{c}")
+                if f"{src}.shortcut.convolution.weight" in hsd:
+                    sd[f"{dst}.downsample.0.weight"] = hsd[f"{src}.shortcut.convolution.weight"]
+                    bn(f"{dst}.downsample.1", f"{src}.shortcut")
+        assert sum(v.numel() for k, v in sd.items()) == sum(v.numel() for k, v in hsd.items() if "num_batches" not in k)
+        x = torch.rand(2, 3, 64, 96, generator=g) * 255.0          # raw 0..255 inputs like the dataset's
+        hf.train(train)
+        with torch.no_grad():
+            ref = hf(x, output_hidden_states=True).hidden_states[1:]   # [0] = embedder output (after the max-pool)
+            ours = O.resnet_body(x, sd, "body", depths, train=train)
+    assert len(ref) == 4
+    for k, r in zip("1234", ref):
+        assert ours[k].shape == r.shape
+        torch.testing.assert_close(ours[k], r, rtol=1e-4, atol=1e-4 * float(r.abs().max()))
 
 
 def test_giou_yaw_basic():
@@ -232,3 +291,37 @@ def test_export_oracle_matches_reference_golden(golden):
         assert any("dummy" in t for t in case["tree"].values())          # the placeholder path is exercised
         n += 1
     assert n == 2
+
+
+KRADAR_LOSS_WEIGHTS = {"total_class": 1.0, "object_class": 0.0, "center": 1.0, "size": 1.0, "angle": 1.0}
+
+
+def _assign_case(g, ci):
+    B = int(g[f"c{ci}_B"])
+    out = {k: T(g[f"c{ci}_{k}"]) for k in ("class", "center", "size", "angle")}
+    tgts = [{k: T(g[f"c{ci}_t{b}_{k}"]) for k in ("gt_center", "gt_size", "gt_angle", "gt_class")} for b in range(B)]
+    return B, out, tgts
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2])
+def test_hungarian_and_loss_forward_match_reference_golden(golden, ci):
+    """the oracle's cost matrix, assignment, weighted batch losses, total and input gradients vs the
+    reference's own HungarianAnassigner.forward (assigner.py:58-143) and Loss.forward (loss.py:486-564) -- empty
+    targets, a degenerate box and more targets than queries included."""
+    g = golden("assign.npz")
+    B, out, tgts = _assign_case(g, ci)
+    for b, tgt in enumerate(tgts):
+        if tgt["gt_center"].shape[0] == 0:
+            assert f"c{ci}_b{b}_i" not in g
+            continue
+        i, j, C = O.hungarian({k: v[b] for k, v in out.items()}, tgt, KRADAR_LOSS_WEIGHTS)
+        close(C, g[f"c{ci}_b{b}_cost"], rtol=1e-5, atol_scale=1e-6)
+        assert torch.equal(i, T(g[f"c{ci}_b{b}_i"])) and torch.equal(j, T(g[f"c{ci}_b{b}_j"]))     # bit-exact indices
+    leaf = {k: v.clone().requires_grad_(True) for k, v in out.items()}
+    total, batch_losses = O.loss_forward(leaf, tgts, KRADAR_LOSS_WEIGHTS)
+    close(total, g[f"c{ci}_total"], rtol=1e-5, atol_scale=1e-6)
+    for k, v in batch_losses.items():
+        close(v, g[f"c{ci}_loss_{k}"], rtol=1e-5, atol_scale=1e-6)
+    total.backward()
+    for k in out:
+        close(leaf[k].grad, g[f"c{ci}_grad_{k}"], rtol=1e-5, atol_scale=1e-6)
