@@ -104,6 +104,25 @@ def cpu_baseline_subprocess(args):
                 "sample": f"timed out after {args.cpu_timeout}s for {args.cpu_steps} step(s) at batch {args.cpu_batch}"}
 
 
+def decoder_runner(m, data):
+    """-> (run, feats): ``run()`` = exactly one dpft_decoder_forward_f32 call (the fused inference decoder of one
+    IMPFusion.forward) on the encoded pyramids of ``data``.  Also used by tools/decoder_only.py for the PMC passes."""
+    m.eval()
+    with torch.no_grad():
+        feats = m._encode_views(data)
+        proj = m._get_projetions(m.inputs, data)
+        shp = [data[f"{i}_shape"][:, :2] for i in m.inputs]
+        flags = m.fuser.transformation_flags(proj)
+        c0 = m.querent(data)
+        vb = [feats[i] for i in m.inputs]
+        m.fuser(batch=vb, shape=shp, projection=proj, out=c0, has_transformation=flags)   # builds the fused decoder
+        fd = m.fuser.__dict__.get("_fused_decoder")
+        if not fd:
+            raise RuntimeError("the fused HIP decoder is not active for this configuration")
+        fd.prepare(vb, shp, proj, c0, flags)
+    return fd.launch, feats
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
@@ -239,20 +258,8 @@ def main():
     dec = None
     if rank == 0:
         m = trainer.model
-        m.eval()
         with torch.no_grad():
-            feats = m._encode_views(data)
-            proj = m._get_projetions(m.inputs, data)
-            shp = [data[f"{i}_shape"][:, :2] for i in m.inputs]
-            flags = m.fuser.transformation_flags(proj)
-            c0 = m.querent(data)
-            vb = [feats[i] for i in m.inputs]
-            m.fuser(batch=vb, shape=shp, projection=proj, out=c0, has_transformation=flags)   # builds the fused decoder
-            fd = m.fuser.__dict__.get("_fused_decoder")
-            if not fd:
-                raise RuntimeError("the fused HIP decoder is not active for this configuration")
-            fd.prepare(vb, shp, proj, c0, flags)
-            run = fd.launch               # exactly one dpft_decoder_forward_f32 call (8 kernel launches)
+            run, feats = decoder_runner(m, data)
             for _ in range(5):
                 run()
             reps = max(args.latency_reps, 20)

@@ -1310,7 +1310,8 @@ struct ProfRec {
     int shape[7];        // B,H,W,C,K,k,stride
 };
 static bool g_prof_on = false;
-bool profiling_active() { return g_prof_on; }      // resnet_plan: keep everything on one stream while timing
+static bool g_serialize = false;                   // dpft_profile_serialize: one stream, no event brackets
+bool profiling_active() { return g_prof_on || g_serialize; }   // resnet_plan: keep everything on one stream while timing
 static std::vector<ProfRec> g_prof;
 
 struct ProfScope {
@@ -1888,6 +1889,11 @@ extern "C" int dpft_profile_start(void) {
 }
 
 extern "C" float dpft_profile_overhead_ms(void) { return g_prof_overhead_ms; }
+
+extern "C" int dpft_profile_serialize(int32_t on) {
+    g_serialize = on != 0;
+    return DPFT_OK;
+}
 
 extern "C" int32_t dpft_profile_stop(void) {
     g_prof_on = false;

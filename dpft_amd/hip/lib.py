@@ -133,6 +133,7 @@ SIGNATURES = {
     "dpft_radar_projection_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_profile_start": (_I, []),
     "dpft_profile_stop": (_I, []),
+    "dpft_profile_serialize": (_I, [_I]),
     "dpft_profile_overhead_ms": (_F, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
     "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P]),

@@ -15,7 +15,15 @@ def build(model: str, *args, **kwargs):
 
 def load(checkpoint: str, *args, **kwargs) -> Tuple[torch.nn.Module, int, str]:
     """``<timestamp>_checkpoint_<epoch>.pt`` -> (module, epoch, timestamp).  Whole-module pickles
-    need ``weights_only=False`` on torch >= 2.6."""
+    need ``weights_only=False`` on torch >= 2.6.
+
+    Accepts this package's own ``torch.save(model)`` files AND the reference's (classes of ``dprt.*`` / ``torchvision.*``,
+    e.g. the published checkpoints): those are rebuilt as ``dpft_amd`` modules from the pickled tensors and
+    hyper-parameters (dpft_amd/models/checkpoint.py)."""
+    from dpft_amd.models import checkpoint as _ck
     filename = os.path.splitext(os.path.basename(checkpoint))[0]
     timestamp, _, epoch = filename.split("_")
-    return torch.load(checkpoint, weights_only=False), int(epoch), timestamp
+    obj = _ck.read_foreign(checkpoint)
+    if isinstance(obj, _ck.ForeignModule):
+        return _ck.load_reference_checkpoint(obj, kwargs.get("config")), int(epoch), timestamp
+    return obj, int(epoch), timestamp

@@ -113,7 +113,8 @@ class SetCriterion(nn.Module):
         M = j.numel()
         one_hot = torch.zeros((N, C), dtype=inputs.dtype, device=inputs.device)
         one_hot[:, 0] = 1.0
-        one_hot[i] = targets                      # scatter_ with src=targets in assignment order (loss.py:305-306)
+        one_hot[i] = targets[:i.numel()]          # scatter_ with src=targets in assignment order (loss.py:305-306);
+                                                  # more targets than queries: scatter_ reads the first len(i) rows
         loss = focal_loss(inputs, one_hot, reduction="none")
         return (loss.mean(0).sum() / M) * N
 

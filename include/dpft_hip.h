@@ -474,6 +474,10 @@ int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, 
  * by HIP events on its launch stream.  Not thread-safe; do not use inside a graph capture.
  * ---------------------------------------------------------------------------------------- */
 int dpft_profile_start(void);
+/* on != 0: the ResNet plans keep weight gradients / weight transposes on the main stream (no side stream) WITHOUT event
+ * brackets, so that an external tracer (rocprofv3 --kernel-trace) sees every conv kernel running alone: the same
+ * serialized step bench.py brackets, reproducible from a profile.  Off by default. */
+int dpft_profile_serialize(int32_t on);
 int32_t dpft_profile_stop(void);                 /* -> number of recorded launches */
 float dpft_profile_overhead_ms(void);            /* elapsed time of an empty event bracket, calibrated by
                                                     dpft_profile_start and already subtracted by dpft_profile_get */

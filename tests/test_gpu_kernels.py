@@ -576,3 +576,149 @@ def test_fused_head_block_matches_eager(B, Q, V, ncls, flags):
     r0_ref = torch.stack([IMPFusion.get_reference_points(prev.detach(), projection[v][0], projection[v][1], shapes[v],
                                                         bool(flags[v])) for v in range(V)])
     assert torch.allclose(r0, r0_ref, rtol=1e-4, atol=1e-5)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Round 2: the fused TRAINING decoder blocks against the ORACLE (fp64 CPU restatement that
+# tests/test_oracle_golden.py pins to the reference's own modules), not against the package's eager path.
+# ---------------------------------------------------------------------------------------------------------
+def _sd64(module, prefix):
+    return {f"{prefix}.{k}": v.detach().double().cpu() for k, v in module.state_dict().items()}
+
+
+def _leaf64(t):
+    return t.detach().double().cpu().requires_grad_(True)
+
+
+def _check_grads(got, ref, names, tol):
+    for a, b, n in zip(got, ref, names):
+        a, b = a.detach().double().cpu(), b.detach().double()
+        err = float((a - b).norm() / b.norm().clamp_min(1e-12))
+        assert err < tol, (n, err, float(b.norm()))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,V", [(4, 400, 3), (2, 37, 2)])
+def test_fused_selfattn_block_vs_oracle(B, Q, V):
+    """sa_train_fwd / sa_train_bwd_q / sa_train_bwd_kv == oracle mha + residual + LayerNorm (mpfusion.py:122-148)."""
+    from dpft_amd.models.fusers import train_fused as tf
+    from oracle import dprt_oracle as O
+    dev = torch.device("cuda", 0)
+    layers = _sa_layers(V, 0.0, dev)
+    torch.manual_seed(11)
+    x = (torch.randn(B, Q, 16, device=dev) * 0.7).requires_grad_(True)
+    pos = (torch.randn(Q, 16, device=dev) * 0.5).requires_grad_(True)
+    gy = torch.randn(V, B, Q, 16, device=dev)
+    plist = [t for ml in layers for t in tf.sa_params(ml)]
+    out = tf.self_attn_blocks(layers, x, pos, torch.zeros(1, dtype=torch.int64, device=dev), 3, 0.0)
+    gout = torch.autograd.grad(out, [x, pos] + plist, gy)
+    # oracle, fp64
+    x64, pos64 = _leaf64(x), _leaf64(pos)
+    refs, leaves = [], []
+    for v, ml in enumerate(layers):
+        sd = {k: t.requires_grad_(True) for k, t in _sd64(ml, "ml").items()}
+        qk = x64 + pos64.unsqueeze(0)
+        refs.append(O._ln(x64 + O.mha(qk, qk, x64, sd, "ml.self_attn", 8), sd, "ml.norm1"))
+        leaves += [sd["ml.self_attn.in_proj_weight"], sd["ml.self_attn.in_proj_bias"], sd["ml.self_attn.out_proj.weight"],
+                   sd["ml.self_attn.out_proj.bias"], sd["ml.norm1.weight"], sd["ml.norm1.bias"]]
+    ref = torch.stack(refs)
+    gref = torch.autograd.grad(ref, [x64, pos64] + leaves, gy.double().cpu())
+    torch.testing.assert_close(out.detach().double().cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    _check_grads(gout, gref, ["x", "pos"] + [f"p{i}" for i in range(len(plist))], 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,V,L,P", [(2, 100, 3, 5, 4), (1, 37, 2, 3, 2)])
+def test_fused_xattn_ffn_block_vs_oracle(B, Q, V, L, P):
+    """xf_train_fwd / xf_train_bwd == oracle MSDeformAttn (value_proj on the flattened pyramid, grid_sample core,
+    output_proj) + residual + LN2 + Mish FFN + LN3 (mpfusion.py:150-229, layers/ms_deform_attn.py:138-217)."""
+    from dpft_amd.models.fusers import train_fused as tf
+    from oracle import dprt_oracle as O
+    import torch.nn.functional as F
+    dev = torch.device("cuda", 0)
+    layers, feats, y1, pos, refs, mk = _xf_setup(B, Q, V, 0.0, dev, L, P)
+    gy = torch.randn(V, B, Q, 16, device=dev)
+    flat_feats = [t for fv in feats for t in fv]
+    plist = [t for ml in layers for t in tf.view_params(ml)[6:]]
+    out = tf.xattn_ffn_blocks(layers, [mk(fv) for fv in feats], y1, pos, refs,
+                              torch.zeros(1, dtype=torch.int64, device=dev), 1, 0.0)
+    gout = torch.autograd.grad(out, [y1, pos, refs] + flat_feats + plist, gy)
+    y64, pos64, refs64 = _leaf64(y1), _leaf64(pos), _leaf64(refs)
+    feats64 = [[_leaf64(t) for t in fv] for fv in feats]
+    outs, leaves = [], []
+    names = ["ms_deform_attn.sampling_offsets.weight", "ms_deform_attn.sampling_offsets.bias",
+             "ms_deform_attn.attention_weights.weight", "ms_deform_attn.attention_weights.bias",
+             "ms_deform_attn.value_proj.weight", "ms_deform_attn.value_proj.bias",
+             "ms_deform_attn.output_proj.weight", "ms_deform_attn.output_proj.bias", "norm2.weight", "norm2.bias",
+             "ffn1.weight", "ffn1.bias", "ffn2.weight", "ffn2.bias", "norm3.weight", "norm3.bias"]
+    for v, ml in enumerate(layers):
+        sd = {k: t.requires_grad_(True) for k, t in _sd64(ml, "ml").items()}
+        # the same parameter order as view_params()[6:]
+        got_names = [n for n, p_ in ml.named_parameters() if any(p_ is q for q in tf.view_params(ml)[6:])]
+        assert sorted(got_names) == sorted(names)
+        ca = O.ms_deform_attn(y64[v] + pos64.unsqueeze(0), refs64[v], feats64[v], sd, "ml.ms_deform_attn", 8, P)
+        y2 = O._ln(y64[v] + ca, sd, "ml.norm2")
+        ff = F.linear(F.mish(F.linear(y2, sd["ml.ffn1.weight"], sd["ml.ffn1.bias"])), sd["ml.ffn2.weight"], sd["ml.ffn2.bias"])
+        outs.append(O._ln(y2 + ff, sd, "ml.norm3"))
+        by_id = {id(p_): n for n, p_ in ml.named_parameters()}
+        leaves += [sd["ml." + by_id[id(p_)]] for p_ in tf.view_params(ml)[6:]]
+    ref = torch.stack(outs)
+    gref = torch.autograd.grad(ref, [y64, pos64, refs64] + [t for fv in feats64 for t in fv] + leaves, gy.double().cpu())
+    torch.testing.assert_close(out.detach().double().cpu(), ref.detach(), rtol=1e-4, atol=5e-5)
+    gn = ["y1", "pos", "refs"] + [f"feat{i}" for i in range(len(flat_feats))] + [f"p{i}" for i in range(len(plist))]
+    _check_grads(gout, gref, gn, 5e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,V,ncls,flags", [(2, 100, 3, 2, (0, 1, 1)), (1, 33, 2, 5, (1, 0))])
+def test_fused_head_block_vs_oracle(B, Q, V, ncls, flags):
+    """hd_train_fwd / hd_train_bwd == oracle view reduction (channel-major / view-minor, mpfusion.py:434-438) +
+    detection head (heads/detection.py:252-275) + next reference points (mpfusion.py:617-696)."""
+    from dpft_amd.models.fusers import train_fused as tf
+    from dpft_amd.models.fusers.mpfusion import MPFusion
+    from dpft_amd.models.heads.detection import LinearDetectionHead
+    from oracle import dprt_oracle as O
+    import torch.nn.functional as F
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(19)
+    layer = MPFusion(V, d_model=16, d_ffn=32, n_levels=[2] * V, n_heads=[8] * V, n_points=[2] * V, activation="Mish",
+                     norm=True, reduction="linear").to(dev)
+    head = LinearDetectionHead(16, ncls, 3, 3).to(dev)
+    y3 = (torch.randn(V, B, Q, 16, device=dev) * 0.8).requires_grad_(True)
+    prev = (torch.randn(B, Q, 3, device=dev) * torch.tensor([20.0, 10.0, 2.0], device=dev)
+            + torch.tensor([30.0, 0.0, 0.0], device=dev)).requires_grad_(True)
+    projection, shapes = [], []
+    for v in range(V):
+        T = torch.eye(4, device=dev).repeat(B, 1, 1)
+        if flags[v]:
+            T[:, :3, :3] += torch.randn(B, 3, 3, device=dev) * 0.05
+            T[:, :3, 3] = torch.randn(B, 3, device=dev)
+        else:
+            T.zero_()
+        P = torch.zeros(B, 4, 4, device=dev)
+        P[:, 0, :] = torch.tensor([4.0, 1.5, 0.3, 60.0], device=dev)
+        P[:, 1, :] = torch.tensor([0.2, 0.4, 3.0, 40.0], device=dev)
+        P[:, 2, :] = torch.tensor([0.01, 0.0, 0.0, 1.0], device=dev) if v % 2 == 0 else torch.tensor([0.0, 0.0, 0.0, 1.0], device=dev)
+        P[:, 3, 3] = 1.0
+        projection.append((T, P))
+        shapes.append(torch.tensor([[128, 256, 3]] * B, device=dev))
+    weights = tf.head_params(layer, head)
+    x, out, refs = tf.head_block(layer, head, tf._Proj(projection, shapes, flags), y3, prev, True)
+    outs = [x, out["center"], out["size"], out["angle"], out["class"], refs]
+    gys = [torch.randn_like(t) for t in outs]
+    gout = torch.autograd.grad(outs, [y3, prev] + weights, gys)
+    # oracle, fp64
+    y64, prev64 = _leaf64(y3), _leaf64(prev)
+    sd = {k: t.requires_grad_(True) for k, t in {**_sd64(layer, "mp"), **_sd64(head, "hd")}.items()}
+    x_ref = F.linear(torch.stack(list(y64), dim=-1).reshape(B, Q, -1), sd["mp.reduction_layer.weight"])
+    o_ref = O.detection_head(x_ref, prev64, sd, "hd")
+    r_ref = torch.stack([O.reference_points(o_ref["center"], projection[v][0].double().cpu(), projection[v][1].double().cpu(),
+                                            shapes[v][:, :2].double().cpu()) for v in range(V)])
+    outs_ref = [x_ref, o_ref["center"], o_ref["size"], o_ref["angle"], o_ref["class"], r_ref]
+    by_id = {id(p_): "mp." + n for n, p_ in layer.named_parameters()}
+    by_id.update({id(p_): "hd." + n for n, p_ in head.named_parameters()})
+    gref = torch.autograd.grad(outs_ref, [y64, prev64] + [sd[by_id[id(w)]] for w in weights],
+                               [g.double().cpu() for g in gys])
+    for a, b_, n in zip(outs, outs_ref, ["x", "center", "size", "angle", "class", "refs"]):
+        torch.testing.assert_close(a.detach().double().cpu(), b_.detach(), rtol=1e-4, atol=1e-4, msg=lambda m: f"{n}: {m}")
+    _check_grads(gout, gref, ["y3", "prev"] + [f"w{i}" for i in range(len(weights))], 5e-4)

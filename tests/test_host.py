@@ -174,3 +174,99 @@ def test_synthetic_batch_contract():
     assert torch.equal(b["camera_mono"], b2["camera_mono"])
     lab = make_labels(4)
     assert len(lab) == 4 and all(1 <= l["gt_center"].shape[0] <= 8 for l in lab)
+
+
+def _foreign_tree(state_dict, module_path, cls_name):
+    """A module tree whose classes pickle as ``<module_path>.<cls_name>`` (a class path that will NOT be importable when
+    the file is read) holding exactly ``state_dict`` -- the shape of what torch.save(model) writes for the third-party
+    parts (torchvision ResNet / FPN) of a reference checkpoint."""
+    import sys
+    import types
+    mod = sys.modules.get(module_path) or types.ModuleType(module_path)
+    cls = getattr(mod, cls_name, None) or type(cls_name, (torch.nn.Module,), {"__module__": module_path})
+    setattr(mod, cls_name, cls)
+    sys.modules[module_path] = mod
+    root = cls()
+    for key, t in state_dict.items():
+        node, parts = root, key.split(".")
+        for part in parts[:-1]:
+            if part not in node._modules:
+                node.add_module(part, cls())
+            node = node._modules[part]
+        if parts[-1] in ("running_mean", "running_var", "num_batches_tracked"):
+            node.register_buffer(parts[-1], t.clone())
+        else:
+            node.register_parameter(parts[-1], torch.nn.Parameter(t.clone()))
+    return root
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout not present")
+def test_load_reads_reference_whole_module_checkpoint(tmp_path):
+    """f-3 remainder (VERDICT r1 missing #1): ``dpft_amd.models.load`` on a ``torch.save(model)`` file whose classes are
+    the REFERENCE's (dprt.models.dprt.DPRT, IMPFusion, MLFusion, MSDeformAttn, LinearDetectionHead, the querent, the
+    embeddings -- built here by the imported reference itself) and torchvision's (class paths that are not importable
+    when the file is read): the rebuilt dpft_amd model has the same hyper-parameters, parameters and buffers."""
+    import sys
+    from collections import OrderedDict
+    from oracle import ref_import
+    ref_import.install()
+    from dprt.models.dprt import DPRT as RefDPRT
+    from dprt.models.embeddings import build_embedding
+    from dprt.models.fusers import build_fuser
+    from dprt.models.heads import build_head
+    from dprt.models.queries import build_querent
+    from dpft_amd.configs import load_config
+    from dpft_amd.models import build, load
+    cfg = load_config("kradar")
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"         # keep the CPU test light
+    cfg["model"]["fuser"]["dropout"] = 0.05
+    comp, m = cfg["computing"], cfg["model"]
+    torch.manual_seed(12)
+    ours = build("dprt", cfg)                                               # source of the third-party tensors
+    with torch.no_grad():
+        for p in ours.parameters():
+            p.add_(torch.randn_like(p) * 0.01)
+    sd = ours.state_dict()
+    head = build_head(m["head"]["name"], dict(comp | m["head"]))
+    fuser = build_fuser(m["fuser"]["name"], dict(comp | m["fuser"]), head=head)
+    ref = RefDPRT(inputs=m["inputs"], skiplinks=m["skiplinks"],
+                  embeddings={v: build_embedding(e["name"], dict(comp | e)) for v, e in m["embeddings"].items()},
+                  querent=build_querent(m["querent"]["name"], dict(comp | m["querent"])), fuser=fuser, head=head)
+    ref.fuser.load_state_dict({k[len("fuser."):]: v for k, v in sd.items() if k.startswith("fuser.")})
+    ref.head.load_state_dict({k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")})
+    made = []
+    try:
+        for kind, path, cname in (("backbones", "torchvision.models.resnet", "ResNet"),
+                                  ("necks", "torchvision.ops.feature_pyramid_network", "FeaturePyramidNetwork")):
+            made.append(path)
+            holder = torch.nn.ModuleDict()
+            for v in m["inputs"]:
+                pre = f"{kind}.{v}."
+                holder[v] = _foreign_tree(OrderedDict((k[len(pre):], t) for k, t in sd.items() if k.startswith(pre)),
+                                          path, cname)
+            setattr(ref, kind, holder)
+        ref.eval()
+        ckpt = tmp_path / "20240101-120000_checkpoint_0042.pt"
+        torch.save(ref, str(ckpt))
+    finally:
+        for path in made:
+            if path not in ref_import.STUBS:
+                sys.modules.pop(path, None)
+    assert b"dprt.models.fusers.mpfusion" in ckpt.read_bytes() and b"torchvision.models.resnet" in ckpt.read_bytes()
+    model, epoch, stamp = load(str(ckpt))
+    assert (epoch, stamp) == (42, "20240101-120000")
+    assert type(model).__module__.startswith("dpft_amd.") and not model.training
+    got = model.state_dict()
+    assert list(got.keys()) == list(sd.keys())
+    for k in sd:
+        assert torch.equal(got[k], sd[k]), k
+    assert model.fuser.dropout == 0.05 and model.fuser.i_iter == 4 and model.inputs == m["inputs"]
+    from dpft_amd.models.checkpoint import infer_config, read_foreign
+    inferred = infer_config(read_foreign(str(ckpt)))["model"]
+    for section in ("inputs", "skiplinks", "backbones", "necks", "embeddings", "querent", "fuser", "head"):
+        assert inferred[section] == m[section], (section, inferred[section], m[section])
+    # this package's own whole-module checkpoints keep working
+    own = tmp_path / "20240101-130000_checkpoint_0001.pt"
+    torch.save(ours, str(own))
+    again, e2, _ = load(str(own))
+    assert e2 == 1 and type(again) is type(ours)

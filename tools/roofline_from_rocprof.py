@@ -1,0 +1,51 @@
+"""Conv-family roofline recomputed from a rocprofv3 --kernel-trace --stats summary (the bench line's
+`roofline.frac` must follow from what is committed under profiles/).
+
+    python tools/roofline_from_rocprof.py <kernel_stats.csv> <steps> [algorithmic_gflop_per_step]
+
+Kernel time of the conv family per step = sum of TotalDurationNs of every kernel a dpft_conv2d_nhwc_* call launches
+(main loops AND the split-K / slab reductions they need) / steps.  frac = algorithmic flops / that time / 157.3 TF."""
+import csv
+import json
+import re
+import sys
+
+MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
+        "conv16_", "wgrad16_", "thin_wgrad")
+AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel")
+GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", "pack_"),
+          "decoder_infer": ("decoder_selfattn", "decoder_xattn"), "loss": ("match_cost", "set_loss", "giou3d"),
+          "optimizer": ("adamw",), "weight_transpose": ("weight_transpose",), "fpn_misc": ("fpn_topdown", "add_pos", "add_inplace", "relu_bwd"),
+          "vendor_aten": ("at::native", "Cijk_", "__amd_rocclr", "rocclr")}
+
+
+def main():
+    path, steps = sys.argv[1], int(sys.argv[2])
+    gflop = float(sys.argv[3]) if len(sys.argv) > 3 else 1839.439164384       # kradar, B=4: 3 x 4 x 153.29 (bench.py log)
+    t = {"conv_main": 0.0, "conv_aux": 0.0, "other_dpft": 0.0}
+    t.update({k: 0.0 for k in GROUPS})
+    n = dict.fromkeys(t, 0)
+    for r in csv.DictReader(open(path)):
+        name = re.sub(r"\(.*", "", r["Name"])
+        ns, calls = float(r["TotalDurationNs"]), int(r["Calls"])
+        if any(m in name for m in MAIN):
+            key = "conv_main"
+        elif any(m in name for m in AUX):
+            key = "conv_aux"
+        else:
+            key = next((g for g, pats in GROUPS.items() if any(p in name for p in pats)), "other_dpft")
+        t[key] += ns
+        n[key] += calls
+    ms = {k: v / 1e6 / steps for k, v in t.items()}
+    conv = ms["conv_main"] + ms["conv_aux"]
+    out = {"source": path, "steps": steps, "kernel_ms_per_step": {k: round(v, 3) for k, v in ms.items()},
+           "launches_per_step": {k: round(v / steps, 1) for k, v in n.items()},
+           "algorithmic_gflop_per_step": gflop,
+           "conv_family_tflops_main_only": gflop / ms["conv_main"], "conv_family_tflops": gflop / conv,
+           "frac_main_only": gflop / ms["conv_main"] / 157.3, "frac": gflop / conv / 157.3,
+           "total_kernel_ms_per_step": round(sum(ms.values()), 3)}
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()

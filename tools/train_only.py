@@ -13,6 +13,10 @@ dev = torch.device("cuda", 0)
 tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
 data = make_batch(cfg["model"]["inputs"], 4, device=dev)
 labels = make_labels(4, device=dev)
+if os.environ.get("SERIAL") == "1":        # the serialized step bench.py brackets: one view stream, no wgrad side stream
+    from dpft_amd.hip.lib import lib
+    lib.call("dpft_profile_serialize", 1)
+    tr.model.concurrent_views = False
 if os.environ.get("GRAPHS", "1") == "1":
     tr.enable_graphs(data)
 for _ in range(3):
