@@ -1,5 +1,5 @@
 """Host side of the fused inference decoder (dpft_amd/csrc/decoder.hip): builds the C-ABI parameter
-structs from an ``IMPFusion`` module and runs 2*i_iter kernels instead of ~700 eager ops."""
+structs from an ``IMPFusion`` module and runs 3*i_iter kernels instead of ~700 eager ops."""
 from __future__ import annotations
 
 import ctypes as C
@@ -53,14 +53,14 @@ class FusedDecoder:
             return
         V, I = f.m_views, f.i_iter
         dev = f.query.device
-        nv, nh = int(lib.dpft_decoder_packed_view_floats()), int(lib.dpft_decoder_packed_head_floats())
+        nv, nh = int(lib.dpft_decoder_packed_infer_floats()), int(lib.dpft_decoder_packed_head_floats())
         self.packed_views = torch.empty(I * V * nv, dtype=torch.float32, device=dev)
         self.packed_heads = torch.empty(I * nh, dtype=torch.float32, device=dev)
         d = DecoderFwd()
         for it, layer in enumerate(f.mpfusion.values()):
             for v, ml in enumerate(layer.ml_fusion_layers.values()):
                 view, _keep = _view_struct(ml)
-                lib.call("dpft_decoder_pack_view_f32", C.byref(view), f.n_levels[v], f.n_points[v],
+                lib.call("dpft_decoder_pack_infer_f32", C.byref(view), f.n_levels[v], f.n_points[v],
                          self.packed_views.data_ptr() + (it * V + v) * nv * 4, stream())
             head = f.heads[it]
             hw = (C.c_void_p * 12)()
@@ -116,7 +116,7 @@ class FusedDecoder:
         self._res = res
 
     def launch(self):
-        """One C-ABI call: i_iter x (self attention | cross attention + FFN + view reduction + heads)."""
+        """One C-ABI call: i_iter x (attention scores | cross attention + FFN | view reduction + heads + next refs)."""
         lib.call("dpft_decoder_forward_f32", C.byref(self.desc), stream())
         res = self._res
         return OrderedDict([("center", res[0]), ("size", res[1]), ("angle", res[2]), ("class", res[3])])

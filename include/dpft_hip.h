@@ -263,11 +263,16 @@ typedef struct dpft_decoder_view {   /* parameters of one MLFusion, torch layout
     const float *ffn1_w, *ffn1_b, *ffn2_w, *ffn2_b, *norm3_w, *norm3_b;                       /* FFN */
 } dpft_decoder_view;
 
-int64_t dpft_decoder_packed_view_floats(void);   /* floats per packed MLFusion blob   */
+int64_t dpft_decoder_packed_view_floats(void);   /* floats per packed MLFusion blob (training cross-attention kernels) */
+int64_t dpft_decoder_packed_infer_floats(void);  /* floats per packed MLFusion blob of the inference decoder */
 int64_t dpft_decoder_packed_head_floats(void);   /* floats per packed reduction+head blob */
 /* packed <- one MLFusion's parameters (L levels, P points of its MSDeformAttn) */
 int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
                                dpft_stream_t stream);
+/* inference decoder's blob of one MLFusion (per-head in_proj rows with 1/sqrt(d)*log2(e) folded into q, the
+ * offsets / logits matrix in the lanes' sample-slot order, the LDS image of the cross-attention kernel) */
+int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
+                                dpft_stream_t stream);
 /* packed <- reduction_layer.weight (16, 16*V) and head_w[4][3] = center/size/angle/class x (layers .0,.3,.6)
  * weights, passed as a flat array of 12 pointers */
 int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, int32_t V, int32_t num_classes,
@@ -278,7 +283,7 @@ int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, i
 typedef struct dpft_decoder_fwd {
     int32_t B, Q, V, iters, num_classes;
     int32_t n_points[4];
-    const float* packed_views;           /* [iters][V] blobs of dpft_decoder_packed_view_floats()  */
+    const float* packed_views;           /* [iters][V] blobs of dpft_decoder_packed_infer_floats() */
     const float* packed_heads;           /* [iters] blobs of dpft_decoder_packed_head_floats()     */
     const dpft_pyramid* pyr;             /* [V]                                          */
     const float* query0;                 /* fuser.query (Q,16)                           */
