@@ -5,25 +5,33 @@
 //   (deformable cross attention), :210-229 (FFN), :416-470,:472-514 (view reduction), :617-696 (reference
 //   points), :698-745 (iteration), src/dprt/models/heads/detection.py:252-275 (head).
 // The eager decoder is ~700 launches of B*400x16-sized ops per forward (launch-bound: ~5 ms even when
-// replayed from a hipGraph); here one iteration is 3 kernels (round 2; the round-1 pair of kernels took 22 + 41 us
-// per iteration, bound by redundant per-lane work and by re-reading 30 KB of weights per query row):
-//   K1 decoder_scores_kernel  : block = (50-query chunk, head, view x batch).  A head's K/V are 2+2 of the 48 in_proj
-//                               rows, so every block projects only ITS head (no redundancy across the 8 heads);
-//                               thread = (query pair, key slice), exact two-pass softmax in the exp2 domain
-//                               (1/sqrt(d) * log2(e) folded into the q rows), slice partials merged through LDS.
-//                               Writes the pre-out_proj attention output (V,B,Q,16).  Iteration 0 runs it for ONE
-//                               batch element: its input (learned query + embedding) does not depend on b.
-//   K2 decoder_xattn_kernel   : block = R query rows of ONE view, one wave per row, the view's packed weights
-//                               (40 KB) staged once per block in LDS.  Per row: out_proj + LN1 (epilogue of K1),
-//                               offsets/logits GEMV whose packed column order delivers every lane exactly the
-//                               three (head, level, point) samples it will process, softmax across lanes, bilinear
-//                               weights / corner addresses computed ONCE per sample and handed to the 4-lane pixel
-//                               groups through a 1.75 KB per-wave LDS scratch, dwordx4 gathers (4 lanes = one 64-B
-//                               NHWC pixel), sample-then-project, output_proj + LN2, Mish FFN + LN3.
-//   K3 decoder_reduce_head_kernel : wave = (b, q): 48->16 view reduction, the 4 head MLPs, center += previous,
-//                               and the NEXT iteration's reference points of all views.
+// replayed from a hipGraph).  Round 1 ran 2 kernels per iteration (22 + 41 us: redundant per-lane work, 30 KB of
+// weights re-read per query row); round 2 runs 2 launches per iteration + 1 (9 for 4 iterations, ~130 us at B = 4):
+//   A decoder_scores_head_kernel, two kinds of blocks in ONE launch:
+//       score blocks  (50-query chunk, head, view x batch): a head's q/k/v are 2+2+2 of the 48 in_proj rows, so every
+//           block builds only ITS head's K/V (no redundancy across heads).  From iteration 1 on these rows are not
+//           projected at all: the previous cross-attention kernel already wrote each view's share of them (the next
+//           layer's in_proj composed with the 48->16 view reduction, "hand-over"), the block sums V 16-byte partials per
+//           key + a packed position table.  Thread = (query pair, key slice); one pass against the Cauchy-Schwarz
+//           bound |q| max|k| in the exp2 domain (1/sqrt(d) log2(e) folded into q; exact two-pass redo should a
+//           query underflow), two queries per packed-fp32 operation, slice partials merged through LDS.  Writes the
+//           pre-out_proj attention output.  Iteration 0 runs for ONE batch element (its input does not depend on b).
+//       head blocks   (wave = (b, q)) of the PREVIOUS iteration: 48->16 view reduction, the 4 head MLPs,
+//           center += previous, and the next reference points of all views.  Both kinds depend only on the previous
+//           cross-attention kernel, so the head MLPs' latency chain hides behind the scores.
+//   B decoder_xattn_kernel: block = 7 query rows of ONE view, one wave per row, the view's packed weights (40 KB)
+//       staged once per block in LDS (3 blocks per CU).  Per row: out_proj + LN1, offsets/logits GEMV whose packed
+//       column order delivers every lane exactly the three (head, level, point) samples it will produce, softmax
+//       across lanes (DPP / permlane swaps, no LDS round trips), bilinear weights + corner address computed ONCE per
+//       sample and handed to the 4-lane pixel groups through a 1.5 KB per-wave LDS scratch, dwordx4 gathers (4 lanes
+//       = one 64-byte NHWC pixel, 8 in flight per lane), sample-then-project, output_proj + LN2, Mish FFN + LN3,
+//       and the hand-over rows for the next layer's self-attention.
+// Measured phase structure (tools/decoder_stamps.py): every kernel pays ~2 us of launch + ~2-3 us until its first
+// loads return (data written by the previous kernel from other XCDs); inside B the gather phase runs at the L2's
+// line rate (197 MB of 64-byte line requests per launch) and, with all waves in lock step, does not overlap the GEMV.
 #include "common.h"
 #include "decoder_pack.h"
+#include <stdlib.h>
 
 #define RC(call)              \
     do {                      \
@@ -88,11 +96,33 @@ __global__ void pack_head_kernel(HeadSrc s, float* __restrict__ d) {
     }
 }
 
+// Cross-lane exchanges as DPP / permlane-swap VALU operations (a __shfl_xor is a ds_bpermute: an LDS-pipe round trip of
+// ~100 cycles, and the LayerNorms / softmax reductions chain 4-8 of them per row).
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, false));
+}
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_MIRROR = 0x140, DPP_ROR8 = 0x128;
+// value of lane ^ 16 / lane ^ 32 combined with the own value by `op` (all-reduce step)
+template <class Op>
+__device__ __forceinline__ float xor16_combine(float v, Op op) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), false, false);
+    return op(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+template <class Op>
+__device__ __forceinline__ float xor32_combine(float v, Op op) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(int, v), __builtin_bit_cast(int, v), false, false);
+    return op(__builtin_bit_cast(float, (int)r[0]), __builtin_bit_cast(float, (int)r[1]));
+}
+struct OpAdd { __device__ float operator()(float a, float b) const { return a + b; } };
+struct OpMax { __device__ float operator()(float a, float b) const { return fmaxf(a, b); } };
+
+// sum over the 16 lanes of a row, result in every lane (quad butterflies, then the mirrored half / row)
 __device__ __forceinline__ float group16_sum(float v) {
-    v += __shfl_xor(v, 1);
-    v += __shfl_xor(v, 2);
-    v += __shfl_xor(v, 4);
-    v += __shfl_xor(v, 8);
+    v += dpp_mov<DPP_XOR1>(v);
+    v += dpp_mov<DPP_XOR2>(v);
+    v += dpp_mov<DPP_HALF_MIRROR>(v);
+    v += dpp_mov<DPP_MIRROR>(v);
     return v;
 }
 
@@ -132,6 +162,17 @@ constexpr int K2_N1B = K2_N1W + 16;
 constexpr int K2_FLOATS = K2_N1B + 16;              // 10144 floats = 40 576 B
 constexpr int PI_FLOATS = PI_K2 + K2_FLOATS;
 static_assert(K2_FLOATS % 4 == 0 && PI_K2 % 4 == 0 && PI_FLOATS % 4 == 0, "float4 staging");
+// Hand-over to the NEXT layer's self-attention (appended to the blob).  The next layer's query is R y3cat (R = this
+// layer's 48->16 view reduction), and its q/k/v rows are linear in it, so every view's cross-attention wave can emit
+// its own share of them, NX[v'] y3_v with NX[v'] = W_in(next layer, target view v') R[:, view block v], right where
+// y3 is produced; the score kernel of the next iteration then sums V 16-byte partials per key instead of projecting
+// 192 bytes of y3, and no longer depends on the reduction / head kernel (they share a launch).
+//   PC_NX : [4 targets][16 k][64 outputs], output j = head * 8 + {0,1: q (pre-scaled) | 4,5: k | 6,7: v}, 2,3 unused
+//   PC_VB : v bias of THIS layer's heads;  PC_T : position part W (pos_k) + b of THIS layer's q and k rows
+constexpr int PC_NX = PI_FLOATS;
+constexpr int PC_VB = PC_NX + 4 * 16 * 64;          // [8][2] v bias (+ pad to 16)
+constexpr int PC_T = PC_VB + 16;                    // [8 heads][Q][4] = q0 q1 k0 k1: W pos_k + b (q rows pre-scaled)
+__host__ __device__ constexpr int64_t pi_floats(int Q) { return PC_T + (int64_t)Q * 32; }
 
 // slot (s, lane) -> head m, sample n of the head.  In gather round t = 4 s + (lane >> 4) the 4-lane pixel group
 // g = lane >> 2 ... of the CONSUMER reads the sample the PRODUCER lane (t & 3) * 16 + g computed, so that group g always
@@ -141,12 +182,33 @@ __device__ __forceinline__ void slot_decode(int s, int lane, int& m, int& n) {
     n = 2 * (4 * s + (lane >> 4)) + ((lane >> 3) & 1);
 }
 
-__global__ void pack_infer_kernel(dpft_decoder_view s, int L, int P, float* __restrict__ d) {
-    const int LP = L * P, n_off = DM * LP * 2;
+struct NextInProj {
+    const float* w[4];      // in_proj_weight (48,16) of the NEXT layer's views, all NULL for the last layer
+};
+__global__ void pack_infer_kernel(dpft_decoder_view s, int L, int P, const float* __restrict__ red_w, NextInProj nx,
+                                  int view, int V, const float* __restrict__ pos, int Q, float* __restrict__ d) {
+    const int LP = L * P;
     const float qscale = 0.70710678118654752f * 1.4426950408889634f;      // 1/sqrt(head_dim) * log2(e)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PI_FLOATS; i += gridDim.x * blockDim.x) {
+    const int total = (int)pi_floats(Q);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         float v = 0.f;
-        if (i < PI_SA_INB) {
+        if (i >= PC_T) {                          // position part of the q / k rows of (key, head)
+            const int j = i - PC_T, h = j / (Q * 4), k = (j >> 2) % Q, r = j & 3;
+            const int row = (r >> 1) * 16 + 2 * h + (r & 1);
+            v = s.in_proj_b[row];
+            for (int c = 0; c < 16; ++c) v = fmaf(s.in_proj_w[row * 16 + c], pos[k * 16 + c], v);
+            if (r < 2) v *= qscale;
+        } else if (i >= PC_VB) {
+            const int j = i - PC_VB;
+            if (j < 16) v = s.in_proj_b[32 + j];  // head h, d -> row 32 + 2h + d
+        } else if (i >= PC_NX) {
+            const int j = i - PC_NX, tv = j >> 10, k = (j >> 6) & 15, o = j & 63, h = o >> 3, e = o & 7;
+            if (tv < V && nx.w[tv] && (e < 2 || e >= 4)) {
+                const int row = (e < 2 ? 0 : (e < 6 ? 16 : 32)) + 2 * h + (e & 1);
+                for (int c = 0; c < 16; ++c) v = fmaf(nx.w[tv][row * 16 + c], red_w[c * 16 * V + k * V + view], v);
+                if (e < 2) v *= qscale;
+            }
+        } else if (i < PI_SA_INB) {
             const int h = i / 96, r = (i / 16) % 6, c = i & 15;
             const int row = (r >> 1) * 16 + 2 * h + (r & 1);
             v = s.in_proj_w[row * 16 + c] * (r < 2 ? qscale : 1.f);
@@ -188,87 +250,173 @@ __global__ void pack_infer_kernel(dpft_decoder_view s, int L, int P, float* __re
     }
 }
 
+// optional in-kernel phase stamps (tools/decoder_stamps.py; DPFT_DEC_DBG & 1024): 100 MHz wall clock per (block, slot)
+constexpr int STAMP_BLOCKS = 2048, STAMP_SLOTS = 8;
+__device__ unsigned long long g_stamps[2][STAMP_BLOCKS * STAMP_SLOTS];
+__device__ __forceinline__ void stamp(int on, int kernel, int block, int slot) {
+    if (on && block < STAMP_BLOCKS && (threadIdx.x & 63) == 0 && (threadIdx.x >> 6) == (slot == 0 ? 0 : (blockDim.x >> 6) - 1))
+        g_stamps[kernel][block * STAMP_SLOTS + slot] = __builtin_amdgcn_s_memrealtime();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // K1: attention scores of one head
 // ---------------------------------------------------------------------------------------------------------
 constexpr int QC = 50;      // queries per block (25 pairs); 2 * QC must be a multiple of 4 (LDS alignment of Pt)
 constexpr int NS = 10;      // key slices; 25 pairs x 10 slices = 250 of the 256 threads
+constexpr int SC_W = 120;   // LDS floats: the head's 6 in_proj rows + biases (first iteration) | 16 slice maxima
 
 struct ScoreArgs {
     const float* pi[4];   // packed inference blobs of this iteration
-    const float* query;   // (B,Q,16), or (Q,16) when qstride == 0
+    const float* query;   // first iteration: the learned (Q,16) table (same for every batch element)
+    const float* part;    // later iterations: partial q/k/v rows written by the previous xattn (layout: see scores_block)
     const float* pos;     // (Q,16)
     float* attn;          // (V,Bsa,Q,16) attention output before out_proj
-    int Bsa, Q, V;
-    long qstride;
+    int Bsa, B, Q, V, nchunk, stamps;
 };
 
-__global__ __launch_bounds__(256) void decoder_scores_kernel(ScoreArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// COMPOSED = false: q/k/v rows of the head applied to (query + pos | query + pos | query)  [first iteration]
+// COMPOSED = true : q/k/v = sum over the source views of the partials the previous xattn kernel wrote + position part
+template <bool COMPOSED>
+__device__ __forceinline__ void scores_block(const ScoreArgs& a, float* sm, int sid) {
     const int Q = a.Q, SL = (Q + NS - 1) / NS;
     f32x4* KV = reinterpret_cast<f32x4*>(sm);                     // [Q + NS] (k0,k1,v0,v1); one pad entry per slice
-    float* Ws = sm + 4 * (Q + NS);                                 // 96 weights + 6 biases (+2 pad)
-    f32x2* Qs = reinterpret_cast<f32x2*>(Ws + 104);                // [QC]
-    f32x4* Pt = reinterpret_cast<f32x4*>(Ws + 104 + 2 * QC);       // [QC][NS] (max, den, o0, o1); 16-byte aligned
+    float* Ws = sm + 4 * (Q + NS);                                 // SC_W floats
+    f32x2* Qs = reinterpret_cast<f32x2*>(Ws + SC_W);               // [QC]
+    f32x4* Pt = reinterpret_cast<f32x4*>(Ws + SC_W + 2 * QC);      // [QC][NS] (ref, den, o0, o1); 16-byte aligned
     const int tid = threadIdx.x;
-    const int h = blockIdx.y, view = blockIdx.z / a.Bsa, b = blockIdx.z - view * a.Bsa, q0 = blockIdx.x * QC;
+    const int chunk = sid % a.nchunk, h = (sid / a.nchunk) & 7, vb = sid / (a.nchunk * 8);
+    const int view = vb / a.Bsa, b = vb - view * a.Bsa, q0 = chunk * QC;
     const float* pi = a.pi[view];
-    const float* xb = a.query + (size_t)b * a.qstride;
-    if (tid < 96) Ws[tid] = pi[PI_SA_IN + h * 96 + tid];
-    else if (tid < 102) Ws[tid] = pi[PI_SA_INB + h * 6 + tid - 96];
+    stamp(a.stamps, 0, sid, 0);
+    unsigned* kmax = reinterpret_cast<unsigned*>(Ws + SC_W - 16);    // [NS] max |k|^2 of the slice's keys (float bits)
+    if (!COMPOSED) {
+        if (tid < 96) Ws[tid] = pi[PI_SA_IN + h * 96 + tid];
+        else if (tid < 102) Ws[tid] = pi[PI_SA_INB + h * 6 + tid - 96];
+    }
+    if (tid >= 128 && tid < 128 + NS) kmax[tid - 128] = 0u;
     __syncthreads();
-    for (int i = tid; i < Q + QC; i += 256) {
-        const bool isq = i >= Q;
-        const int k = isq ? min(q0 + i - Q, Q - 1) : i;
-        f32x4 x[4], xp[4];
+    stamp(a.stamps, 0, sid, 1);
+    if (COMPOSED) {
+        // q/k/v = position part + the V partial projections the previous cross-attention kernel wrote.  Those lines were
+        // written by other XCDs a moment ago (first touch = a fabric round trip of ~2 us): all loads of the thread's
+        // items are issued before the first one is consumed.
+        constexpr int NIT = 2;
+        static_assert(QC <= 112, "two items per thread cover Q + QC <= 512");
+        f32x4 t4[NIT], p4[NIT][4];
+        f32x2 vb2 = *reinterpret_cast<const f32x2*>(pi + PC_VB + 2 * h);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            x[c] = *reinterpret_cast<const f32x4*>(xb + (size_t)k * DC + 4 * c);
-            xp[c] = x[c] + *reinterpret_cast<const f32x4*>(a.pos + (size_t)k * DC + 4 * c);
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * 256;
+            const bool isq = i >= Q;
+            const int k = isq ? min(q0 + i - Q, Q - 1) : i;
+            // partials: kv (V targets,B,8 heads,V sources,Q,4) then q (same shape, q0 q1 - -): a block's reads
+            // (one target, batch element and head; lanes = consecutive keys) are contiguous
+            const size_t grp = (((size_t)view * a.B + b) * 8 + h) * a.V;
+            // (one load type for both item kinds: a select between a dwordx2 and a dwordx4 load serialises them)
+            const float* src = a.part + (isq ? (size_t)a.V * a.B * 8 * a.V * Q * 4 : 0) + (grp * Q + k) * 4;
+            if (i < Q + QC) {
+                t4[u] = *reinterpret_cast<const f32x4*>(pi + PC_T + ((size_t)h * Q + k) * 4);
+#pragma unroll
+                for (int v = 0; v < 4; ++v)
+                    if (v < a.V) p4[u][v] = *reinterpret_cast<const f32x4*>(src + (size_t)v * Q * 4);
+            }
         }
-        float r[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // query item: rows 0,1 of (x + pos); key item: rows 2,3 of (x + pos) and rows 4,5 of x
-            const int row = isq ? (j & 1) : 2 + j;
-            float acc = Ws[96 + row];
+        for (int u = 0; u < NIT; ++u) {
+            const int i = tid + u * 256;
+            if (i >= Q + QC) break;
+            const bool isq = i >= Q;
+            f32x4 r = isq ? f32x4{t4[u][0], t4[u][1], 0.f, 0.f} : f32x4{t4[u][2], t4[u][3], vb2[0], vb2[1]};      // (q items: lanes 2,3 unused)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (v < a.V) r += p4[u][v];
+            if (isq) Qs[i - Q] = f32x2{r[0], r[1]};
+            else {
+                KV[i + i / SL] = r;
+                atomicMax(kmax + i / SL, __float_as_uint(fmaf(r[0], r[0], r[1] * r[1])));      // >= 0: uint order = float order
+            }
+        }
+    } else {
+        for (int i = tid; i < Q + QC; i += 256) {
+            const bool isq = i >= Q;
+            const int k = isq ? min(q0 + i - Q, Q - 1) : i;
+            float r[4];
+            f32x4 x[4], xp[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 w = *reinterpret_cast<const f32x4*>(Ws + row * 16 + 4 * c);
-                const f32x4 v = (isq || j < 2) ? xp[c] : x[c];
-                acc = fmaf(w[0], v[0], acc); acc = fmaf(w[1], v[1], acc);
-                acc = fmaf(w[2], v[2], acc); acc = fmaf(w[3], v[3], acc);
+                x[c] = *reinterpret_cast<const f32x4*>(a.query + (size_t)k * DC + 4 * c);
+                xp[c] = x[c] + *reinterpret_cast<const f32x4*>(a.pos + (size_t)k * DC + 4 * c);
             }
-            r[j] = acc;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // query item: rows 0,1 of (x + pos); key item: rows 2,3 of (x + pos) and rows 4,5 of x
+                const int row = isq ? (j & 1) : 2 + j;
+                float acc = Ws[96 + row];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(Ws + row * 16 + 4 * c);
+                    const f32x4 v = (isq || j < 2) ? xp[c] : x[c];
+                    acc = fmaf(w[0], v[0], acc); acc = fmaf(w[1], v[1], acc);
+                    acc = fmaf(w[2], v[2], acc); acc = fmaf(w[3], v[3], acc);
+                }
+                r[j] = acc;
+            }
+            if (isq) Qs[i - Q] = f32x2{r[0], r[1]};
+            else {
+                KV[k + k / SL] = f32x4{r[0], r[1], r[2], r[3]};
+                atomicMax(kmax + k / SL, __float_as_uint(fmaf(r[0], r[0], r[1] * r[1])));
+            }
         }
-        if (isq) Qs[i - Q] = f32x2{r[0], r[1]};
-        else KV[k + k / SL] = f32x4{r[0], r[1], r[2], r[3]};
     }
     __syncthreads();
+    stamp(a.stamps, 0, sid, 2);
     if (tid < (QC / 2) * NS) {
         const int slice = tid / (QC / 2), pair = tid - slice * (QC / 2);
         const f32x2 qa = Qs[2 * pair], qb = Qs[2 * pair + 1];
         const int k0 = slice * SL, k1 = min(Q, k0 + SL);
         const f32x4* kv = KV + k0 + slice;
-        float ma = -INFINITY, mb = -INFINITY;
-        for (int k = 0; k < k1 - k0; ++k) {
-            const f32x2 kk = *reinterpret_cast<const f32x2*>(kv + k);
-            ma = fmaxf(ma, fmaf(qa[1], kk[1], qa[0] * kk[0]));
-            mb = fmaxf(mb, fmaf(qb[1], kk[1], qb[0] * kk[0]));
-        }
-        float da = 0.f, db = 0.f, a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
+        // One pass against an upper bound of the slice's scores, ref = |q| max|k| >= q.k (Cauchy-Schwarz; scores live in
+        // the exp2 domain): exp2(s - ref) <= 1 cannot overflow, and the partials (ref, den, o) merge exactly like
+        // (max, den, o) would.  Should every term of a query underflow (den below 2^-100: the bound is far above the
+        // true maximum) the slice is redone with the exact two-pass form.
+        const float kn = sqrtf(__uint_as_float(kmax[slice]));
+        float ma = sqrtf(fmaf(qa[0], qa[0], qa[1] * qa[1])) * kn, mb = sqrtf(fmaf(qb[0], qb[0], qb[1] * qb[1])) * kn;
+        // the two queries of the thread ride in the halves of packed fp32 operations (v_pk_mul / v_pk_fma / v_pk_add)
+        const f32x2 q0 = {qa[0], qb[0]}, q1 = {qa[1], qb[1]}, ref = {ma, mb};
+        f32x2 dd = {0.f, 0.f}, oo0 = {0.f, 0.f}, oo1 = {0.f, 0.f};
+#pragma unroll 4
         for (int k = 0; k < k1 - k0; ++k) {
             const f32x4 e = kv[k];
-            const float pa = __builtin_amdgcn_exp2f(fmaf(qa[1], e[1], qa[0] * e[0]) - ma);
-            const float pb = __builtin_amdgcn_exp2f(fmaf(qb[1], e[1], qb[0] * e[0]) - mb);
-            da += pa; db += pb;
-            a0 = fmaf(pa, e[2], a0); a1 = fmaf(pa, e[3], a1);
-            b0 = fmaf(pb, e[2], b0); b1 = fmaf(pb, e[3], b1);
+            const f32x2 sc = q0 * e[0] + q1 * e[1] - ref;
+            const f32x2 pp = {__builtin_amdgcn_exp2f(sc[0]), __builtin_amdgcn_exp2f(sc[1])};
+            dd += pp;
+            oo0 += pp * e[2];
+            oo1 += pp * e[3];
         }
+        float da = dd[0], db = dd[1], a0 = oo0[0], a1 = oo1[0], b0 = oo0[1], b1 = oo1[1];
+        if ((da < 0x1p-100f || db < 0x1p-100f) && k1 > k0) {
+            ma = mb = -INFINITY;
+            for (int k = 0; k < k1 - k0; ++k) {
+                const f32x2 kk = *reinterpret_cast<const f32x2*>(kv + k);
+                ma = fmaxf(ma, fmaf(qa[1], kk[1], qa[0] * kk[0]));
+                mb = fmaxf(mb, fmaf(qb[1], kk[1], qb[0] * kk[0]));
+            }
+            da = db = a0 = a1 = b0 = b1 = 0.f;
+            for (int k = 0; k < k1 - k0; ++k) {
+                const f32x4 e = kv[k];
+                const float pa = __builtin_amdgcn_exp2f(fmaf(qa[1], e[1], qa[0] * e[0]) - ma);
+                const float pb = __builtin_amdgcn_exp2f(fmaf(qb[1], e[1], qb[0] * e[0]) - mb);
+                da += pa; db += pb;
+                a0 = fmaf(pa, e[2], a0); a1 = fmaf(pa, e[3], a1);
+                b0 = fmaf(pb, e[2], b0); b1 = fmaf(pb, e[3], b1);
+            }
+        }
+        if (k1 <= k0) ma = mb = -INFINITY;                 // empty slice (fewer keys than slices)
         Pt[(2 * pair) * NS + slice] = f32x4{ma, da, a0, a1};
         Pt[(2 * pair + 1) * NS + slice] = f32x4{mb, db, b0, b1};
     }
     __syncthreads();
+    stamp(a.stamps, 0, sid, 3);
     if (tid < QC && q0 + tid < Q) {
         float mm = -INFINITY;
 #pragma unroll
@@ -285,6 +433,7 @@ __global__ __launch_bounds__(256) void decoder_scores_kernel(ScoreArgs a) {
         float* dst = a.attn + (((size_t)view * a.Bsa + b) * Q + q0 + tid) * DC + 2 * h;
         *reinterpret_cast<f32x2*>(dst) = f32x2{o0 / den, o1 / den};
     }
+    stamp(a.stamps, 0, sid, 4);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -308,8 +457,10 @@ struct XattnArgs {
     const int64_t* shape[4];    // (B,2) = H, W
     int prow[4], flag[4], P[4];
     float* y3;                  // (V,B,Q,16)
+    float* part;                // (V targets,B,Q,V sources,64) next layer's partial q/k/v rows, or NULL (last layer)
     int B, Q, V, Bsa;
     long qstride;
+    int dbg;
 };
 
 // reference point of one view: cartesian center -> (optional T + spherical) -> projection P -> normalised, clamped
@@ -341,7 +492,15 @@ __device__ __forceinline__ float rdlane(float v, int k) {     // k wave-uniform
 
 typedef __attribute__((address_space(1))) char gbytes;          // explicit global address space: addresses rebuilt from
 typedef __attribute__((address_space(1))) f32x4 gf32x4;        // integers would otherwise become flat loads
-constexpr int XW_FLOATS = 480;      // per-wave scratch: wq float4[64] | addr uint2[64] | pitch int[64] | vec float[32]
+// mish(x) = x tanh(softplus(x)) with tanh(log(1 + e^x)) = t / (t + 2), t = e^x (e^x + 2): one exp and one division
+// instead of log1p(exp) + tanh; for x > 20 the ratio is 1 in fp32 (torch switches softplus to x there as well).
+__device__ __forceinline__ float mish_fast(float x) {
+    const float n = __expf(fminf(x, 20.f));
+    const float t = n * (n + 2.f);
+    return x * (t / (t + 2.f));
+}
+
+constexpr int XW_FLOATS = 416;      // per-wave scratch: wq float4[64] | addr uint2[64] (low bits: dw, dh, level) | vec float[32]
 
 template <int R>
 __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
@@ -352,6 +511,8 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     const int view = blockIdx.y;
     const float* __restrict__ img = a.pi[view] + PI_K2;
     // stage the view's weights (the row's own loads are issued first so that their latency hides behind this)
+    const int sblk = blockIdx.y * gridDim.x + blockIdx.x, son = (a.dbg & 1024) && a.part;
+    stamp(son, 1, sblk, 0);
     const int bq = blockIdx.x * R + wave;
     const bool live = bq < a.B * a.Q;
     const int bqc = live ? bq : a.B * a.Q - 1;
@@ -389,11 +550,11 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     }
     __syncthreads();
     if (!live) return;
+    stamp(son, 1, sblk, 1);
     float* ws = sm + K2_FLOATS + wave * XW_FLOATS;
     f32x4* wq = reinterpret_cast<f32x4*>(ws);
     uint2* adr = reinterpret_cast<uint2*>(ws + 256);
-    int* pit = reinterpret_cast<int*>(ws + 384);
-    float* vec = ws + 448;
+    float* vec = ws + 384;
     // ---- self-attention epilogue: out_proj + residual + LayerNorm1 (mpfusion.py:142-148) ----
     float y1c = sm[K2_SAOB + c];
 #pragma unroll
@@ -410,7 +571,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         off[s] = *reinterpret_cast<const f32x2*>(sm + K2_OFF + (16 * NSLOT + idx[s]) * 2);
         lg[s] = sm[K2_LOG + 16 * NSLOT + idx[s]];
     }
-#pragma unroll 2
+#pragma unroll 4
     for (int k = 0; k < DC; ++k) {
         const float xk = rdlane(qpc, k);
 #pragma unroll
@@ -432,12 +593,13 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         ok[s] = ns[s] < LP && (s < 2 || lane < 32);
         if (ok[s]) mx = fmaxf(mx, lg[s]);
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 8)); mx = fmaxf(mx, __shfl_xor(mx, 16)); mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = fmaxf(mx, dpp_mov<DPP_ROR8>(mx)); mx = xor16_combine(mx, OpMax()); mx = xor32_combine(mx, OpMax());
     float aw[3], den = 0.f;
 #pragma unroll
     for (int s = 0; s < 3; ++s) { aw[s] = ok[s] ? __expf(lg[s] - mx) : 0.f; den += aw[s]; }
-    den += __shfl_xor(den, 8); den += __shfl_xor(den, 16); den += __shfl_xor(den, 32);
+    den += dpp_mov<DPP_ROR8>(den); den = xor16_combine(den, OpAdd()); den = xor32_combine(den, OpAdd());
     const float inv_den = 1.f / den;
+    stamp(son, 1, sblk, 2);
     // ---- sample-then-project: producer lanes write (weights, corner address), 4-lane pixel groups gather ----
     const int g = lane >> 2, j = lane & 3;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -449,7 +611,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
             const int4 lt = *reinterpret_cast<const int4*>(lvl_tab[l]);
             const int H = lt.z, W = lt.w;
             const float a_w = aw[s] * inv_den;
-            const float lx = rx + off[s][0] / (float)W, ly = ry + off[s][1] / (float)H;
+            const float lx = rx + off[s][0] * __builtin_amdgcn_rcpf((float)W), ly = ry + off[s][1] * __builtin_amdgcn_rcpf((float)H);
             const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
             const bool in = ok[s] && h_im > -1 && w_im > -1 && h_im < H && w_im < W;
             const float hf = floorf(h_im), wf = floorf(w_im);
@@ -462,9 +624,9 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
             wq[lane] = f32x4{k1 ? a_w * hh * hw : 0.f, k2 ? a_w * hh * lw : 0.f, k3 ? a_w * lh * hw : 0.f,
                              k4 ? a_w * lh * lw : 0.f};
             const uint64_t base = ((uint64_t)(uint32_t)lt.y << 32 | (uint32_t)lt.x)
-                                  + ((uint64_t)((int64_t)b * H + hl) * W + wl) * (DC * 4) + (wh_ - wl);   // bit 0: column step
+                                  + ((uint64_t)((int64_t)b * H + hl) * W + wl) * (DC * 4)
+                                  + ((wh_ - wl) | (hh_ - hl) << 1 | l << 2);      // 64-byte aligned: low bits carry dw, dh, level
             adr[lane] = uint2{(uint32_t)base, (uint32_t)(base >> 32)};
-            pit[lane] = (hh_ - hl) * W * (DC * 4);
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll 1
@@ -475,9 +637,9 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
                 const int src = (k + u) * 16 + g;
                 w4[u] = wq[src];
                 const uint2 ad = adr[src];
-                const int pitch = pit[src];
+                const int pitch = (ad.x & 2) ? lvl_tab[(ad.x >> 2) & 7][3] * (DC * 4) : 0;
                 const int cstep = (ad.x & 1) ? DC * 4 : 0;
-                const gbytes* A = reinterpret_cast<const gbytes*>(((uint64_t)ad.y << 32) | (ad.x & ~1u)) + j * 16;
+                const gbytes* A = reinterpret_cast<const gbytes*>(((uint64_t)ad.y << 32) | (ad.x & ~63u)) + j * 16;
                 v[u][0] = *reinterpret_cast<const gf32x4*>(A);          // global_load_dwordx4 (not flat)
                 v[u][1] = *reinterpret_cast<const gf32x4*>(A + cstep);
                 v[u][2] = *reinterpret_cast<const gf32x4*>(A + pitch);
@@ -491,6 +653,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         }
         __builtin_amdgcn_wave_barrier();
     }
+    stamp(son, 1, sblk, 3);
     // value_proj on the sampled features (+ bias * in-bounds mass), head m = g & 7 -> channels 2m, 2m+1
     {
         const int m = g & 7;
@@ -498,9 +661,9 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         const f32x4 w1 = *reinterpret_cast<const f32x4*>(sm + K2_VALW + (2 * m + 1) * DC + 4 * j);
         float o0 = w0[0] * acc[0] + w0[1] * acc[1] + w0[2] * acc[2] + w0[3] * acc[3];
         float o1 = w1[0] * acc[0] + w1[1] * acc[1] + w1[2] * acc[2] + w1[3] * acc[3];
-        o0 += __shfl_xor(o0, 1); o0 += __shfl_xor(o0, 2); o0 += __shfl_xor(o0, 32);
-        o1 += __shfl_xor(o1, 1); o1 += __shfl_xor(o1, 2); o1 += __shfl_xor(o1, 32);
-        ms += __shfl_xor(ms, 32);
+        o0 += dpp_mov<DPP_XOR1>(o0); o0 += dpp_mov<DPP_XOR2>(o0); o0 = xor32_combine(o0, OpAdd());
+        o1 += dpp_mov<DPP_XOR1>(o1); o1 += dpp_mov<DPP_XOR2>(o1); o1 = xor32_combine(o1, OpAdd());
+        ms = xor32_combine(ms, OpAdd());
         if (lane < 32 && j == 0) {
             vec[2 * m] = o0 + sm[K2_VALB + 2 * m] * ms;
             vec[2 * m + 1] = o1 + sm[K2_VALB + 2 * m + 1] * ms;
@@ -517,12 +680,26 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     float hsum = sm[K2_F1B + jf];
 #pragma unroll
     for (int k = 0; k < DC; ++k) hsum = fmaf(sm[K2_F1T + k * DFF + jf], rdlane(y2, k), hsum);
-    const float hval = mishf(hsum);
+    const float hval = mish_fast(hsum);
     float f = sm[K2_F2B + c];
 #pragma unroll
     for (int k = 0; k < DFF; ++k) f = fmaf(sm[K2_F2T + k * DC + c], rdlane(hval, k), f);
     const float y3 = layernorm16(f + y2, sm[K2_N3W + c], sm[K2_N3B + c]);
     if (lane < 16) a.y3[((size_t)view * a.B * a.Q + bq) * DC + lane] = y3;
+    stamp(son, 1, sblk, 4);
+    if (a.part) {       // this view's share of the next layer's q/k/v rows of every target view (lane = output)
+        const float* nx = a.pi[view] + PC_NX + lane;
+        for (int tv = 0; tv < a.V; ++tv) {
+            float o = 0.f;
+#pragma unroll
+            for (int k = 0; k < DC; ++k) o = fmaf(nx[(tv * 16 + k) * 64], rdlane(y3, k), o);
+            const int hh = lane >> 3, e = lane & 7;
+            const size_t grp = ((((size_t)tv * a.B + b) * 8 + hh) * a.V + view) * a.Q + q;
+            if (e >= 4) a.part[grp * 4 + (e - 4)] = o;
+            else if (e < 2) a.part[(size_t)a.V * a.B * 8 * a.V * a.Q * 4 + grp * 4 + e] = o;
+        }
+    }
+    stamp(son, 1, sblk, 5);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -539,15 +716,15 @@ struct HeadArgs {
     float* query_out;           // (B,Q,16)
     float *center, *size, *angle, *cls;
     float* refs_out;            // (V,B,Q,2) reference points of the NEW center, or NULL (last iteration)
-    int B, Q, V, ncls;
+    int B, Q, V, ncls, stamps;
 };
 
-__global__ __launch_bounds__(256) void decoder_reduce_head_kernel(HeadArgs a) {
-    __shared__ float hs[4][2][64];
+__device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)[2][64], int hid) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bq = blockIdx.x * 4 + wave;
+    const int bq = hid * 4 + wave;
     if (bq >= a.B * a.Q) return;
+    stamp(a.stamps, 0, 1024 + hid, 0);
     const int b = bq / a.Q;
     const int c = lane & 15, v2 = lane >> 4;
     const float* ph = a.ph;
@@ -558,6 +735,7 @@ __global__ __launch_bounds__(256) void decoder_reduce_head_kernel(HeadArgs a) {
 #pragma unroll
         for (int k = 0; k < DC; ++k) x = fmaf(ph[PH_RED_WT + (v * DC + k) * DC + c], rdlane(yv, v * 16 + k), x);
     if (lane < 16) a.query_out[(size_t)bq * DC + lane] = x;
+    stamp(a.stamps, 0, 1024 + hid, 1);
     // heads (heads/detection.py:252-275): branch g = lane / 16 (center, size, angle, class), row o = lane % 16
     const int g = lane >> 4, o = lane & 15;
     float t = 0.f;
@@ -581,6 +759,7 @@ __global__ __launch_bounds__(256) void decoder_reduce_head_kernel(HeadArgs a) {
         else if (g == 2) a.angle[bq * 2 + o] = tanhf(t);
         else a.cls[bq * a.ncls + o] = t;
     }
+    stamp(a.stamps, 0, 1024 + hid, 2);
     if (a.refs_out) {       // reference points of the new center for the next iteration: lane = view
         const float cx = rdlane(cen, 0), cy = rdlane(cen, 1), cz = rdlane(cen, 2);
         if (lane < a.V) {
@@ -590,6 +769,23 @@ __global__ __launch_bounds__(256) void decoder_reduce_head_kernel(HeadArgs a) {
                             (float)a.shape[lane][b * 2 + 1], u, vv);
             *reinterpret_cast<f32x2*>(a.refs_out + ((size_t)lane * a.B * a.Q + bq) * 2) = f32x2{u, vv};
         }
+    }
+    stamp(a.stamps, 0, 1024 + hid, 3);
+}
+
+
+// One launch = the score blocks of iteration it (blocks [0, n_score)) + the reduction / head blocks of iteration it-1
+// (blocks [n_score, ...)): both only depend on the previous cross-attention kernel, so the head MLPs' latency chain
+// hides behind the scores instead of sitting between two kernel boundaries.
+__global__ __launch_bounds__(256) void decoder_scores_head_kernel(ScoreArgs sa, HeadArgs ha, int n_score, int composed) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    __shared__ float hs[4][2][64];
+    const int bid = blockIdx.x;
+    if (bid < n_score) {
+        if (composed) scores_block<true>(sa, sm, bid);
+        else scores_block<false>(sa, sm, bid);
+    } else {
+        reduce_head_block(ha, hs, bid - n_score);
     }
 }
 
@@ -629,23 +825,30 @@ extern "C" int dpft_decoder_pack_head_f32(const float* red_w, const float* const
     return check_launch("decoder_pack_head");
 }
 
-extern "C" int64_t dpft_decoder_packed_infer_floats(void) { return PI_FLOATS; }
+extern "C" int64_t dpft_decoder_packed_infer_floats(int32_t Q) { return pi_floats(Q); }
 
-extern "C" int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
-                                           dpft_stream_t stream) {
-    DPFT_REQUIRE(view && packed, "decoder_pack_infer: null argument");
+extern "C" int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, const float* red_w,
+                                           const float* const* next_in_proj_w, int32_t view_index, int32_t V,
+                                           const float* pos, int32_t Q, float* packed, dpft_stream_t stream) {
+    DPFT_REQUIRE(view && packed && pos && red_w, "decoder_pack_infer: null argument");
+    DPFT_REQUIRE(view_index >= 0 && view_index < V, "decoder_pack_infer: view index out of range");
     DPFT_REQUIRE(L >= 1 && L <= DPFT_MAX_LEVELS && P >= 1 && P <= 4 && L * P <= 20,
                  "decoder_pack_infer: L=%d, P=%d exceed the fused kernel's budget (P <= 4, L*P <= 20)", L, P);
+    DPFT_REQUIRE(V >= 1 && V <= 4 && Q >= 1, "decoder_pack_infer: bad V / Q");
     const float* const* f = reinterpret_cast<const float* const*>(view);
     for (size_t i = 0; i < sizeof(dpft_decoder_view) / sizeof(float*); ++i)
         DPFT_REQUIRE(f[i], "decoder_pack_infer: parameter pointer %d is null", (int)i);
-    hipLaunchKernelGGL(pack_infer_kernel, dim3(cdiv(PI_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, *view, L, P, packed);
+    NextInProj nx;
+    for (int v = 0; v < 4; ++v) nx.w[v] = (next_in_proj_w && v < V) ? next_in_proj_w[v] : nullptr;
+    hipLaunchKernelGGL(pack_infer_kernel, dim3(cdiv(pi_floats(Q), 256)), dim3(256), 0, (hipStream_t)stream, *view, L, P,
+                       red_w, nx, view_index, V, pos, Q, packed);
     return check_launch("decoder_pack_infer");
 }
 
-constexpr int XR = 7;      // query rows (waves) per decoder_xattn_kernel block: 3 blocks of 54 KB LDS per CU
+constexpr int XR = 7;      // query rows (waves) per decoder_xattn_kernel block: 3 blocks of 51 KB LDS per CU
 
-// Whole IMPFusion forward from ONE call: 3 launches per iteration, nothing else on the host
+// Whole IMPFusion forward from ONE call: 2 launches per iteration + 1, nothing else on the host:
+//   [scores(0)] [xattn(0)] [scores(1) | heads(0)] [xattn(1)] ... [scores(I-1) | heads(I-2)] [xattn(I-1)] [heads(I-1)]
 extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t stream) {
     DPFT_REQUIRE(d && d->packed_views && d->packed_heads && d->pyr && d->query0 && d->pos && d->center0 && d->work,
                  "decoder_forward: null argument");
@@ -660,10 +863,14 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     float* y3 = attn + (size_t)V * nq * DC;
     float* cbuf[2] = {y3 + (size_t)V * nq * DC, y3 + (size_t)V * nq * DC + nq * 3};
     float* refs = cbuf[1] + nq * 3;
+    float* part = refs + (size_t)V * nq * 2;
     XattnArgs xa;
     HeadArgs ha;
+    ScoreArgs sa;
     memset(&xa, 0, sizeof(xa));
     memset(&ha, 0, sizeof(ha));
+    memset(&sa, 0, sizeof(sa));
+    { const char* e = getenv("DPFT_DEC_DBG"); xa.dbg = e ? atoi(e) : 0; sa.stamps = ha.stamps = xa.dbg & 1024; }
     for (int v = 0; v < V; ++v) {
         const dpft_pyramid* pyr = d->pyr + v;
         const int P = d->n_points[v];
@@ -685,41 +892,61 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     xa.attn = attn; xa.pos = d->pos; xa.y3 = y3; xa.B = B; xa.Q = Q; xa.V = V;
     ha.y3 = y3; ha.B = B; ha.Q = Q; ha.V = V; ha.ncls = d->num_classes;
     ha.size = d->size; ha.angle = d->angle; ha.cls = d->cls;
+    sa.query = d->query0; sa.part = part; sa.pos = d->pos; sa.attn = attn; sa.B = B; sa.Q = Q; sa.V = V;
+    sa.nchunk = cdiv(Q, QC);
+    const size_t lds1 = (4 * (size_t)(Q + NS) + SC_W + 2 * QC + 4 * QC * NS) * sizeof(float);
+    const size_t lds2 = ((size_t)K2_FLOATS + XR * XW_FLOATS) * sizeof(float);
+    DPFT_REQUIRE(lds1 <= 62 * 1024, "decoder_forward: %d queries do not fit the LDS of the score kernel", Q);
+    const int n_head = cdiv((int64_t)nq, 4);
     const float* query = d->query0;
     const float* center = d->center0;
-    const size_t lds1 = (4 * (size_t)(Q + NS) + 104 + 2 * QC + 4 * QC * NS) * sizeof(float);
-    const size_t lds2 = ((size_t)K2_FLOATS + XR * XW_FLOATS) * sizeof(float);
-    DPFT_REQUIRE(lds1 <= 64 * 1024, "decoder_forward: %d queries do not fit the LDS of the score kernel", Q);
-    for (int it = 0; it < d->iters; ++it) {
-        const bool first = it == 0, last = it == d->iters - 1;
-        ScoreArgs sa;
-        for (int v = 0; v < 4; ++v)
-            sa.pi[v] = xa.pi[v] = v < V ? d->packed_views + (size_t)(it * V + v) * PI_FLOATS : nullptr;
-        // iteration 0: query = the learned (Q,16) table for every batch element -> one batch element of scores
-        sa.query = query; sa.pos = d->pos; sa.attn = attn; sa.Q = Q; sa.V = V;
-        sa.Bsa = first ? 1 : B;
-        sa.qstride = first ? 0 : (long)Q * DC;
-        hipLaunchKernelGGL(decoder_scores_kernel, dim3(cdiv(Q, QC), DM, V * sa.Bsa), dim3(256), lds1, (hipStream_t)stream, sa);
-        RC(check_launch("decoder_scores"));
-        xa.query = query; xa.qstride = sa.qstride; xa.Bsa = sa.Bsa;
+    for (int it = 0; it <= d->iters; ++it) {
+        const bool first = it == 0, after_last = it == d->iters;
+        // ---- scores of iteration `it` + reduction / heads of iteration it-1 ----
+        int n_score = 0;
+        if (!after_last) {
+            for (int v = 0; v < 4; ++v)
+                sa.pi[v] = xa.pi[v] = v < V ? d->packed_views + (size_t)(it * V + v) * pi_floats(Q) : nullptr;
+            // iteration 0: query = the learned (Q,16) table for every batch element -> one batch element of scores
+            sa.Bsa = first ? 1 : B;
+            n_score = sa.nchunk * DM * V * sa.Bsa;
+        }
+        if (!first) {
+            const bool last = it == d->iters;
+            ha.ph = d->packed_heads + (size_t)(it - 1) * PH_FLOATS;
+            ha.prev_center = center;
+            ha.query_out = qbuf[(it - 1) & 1];
+            ha.center = last ? d->center : cbuf[(it - 1) & 1];
+            ha.refs_out = last ? nullptr : refs;
+        }
+        hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head)), dim3(256),
+                           after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? 0 : 1);
+        RC(check_launch("decoder_scores_head"));
+        if (!first) {
+            query = ha.query_out;
+            center = ha.center;
+        }
+        if (after_last) break;
+        // ---- cross attention + FFN of iteration `it` ----
+        xa.query = query; xa.qstride = first ? 0 : (long)Q * DC; xa.Bsa = sa.Bsa;
         xa.refs = first ? nullptr : refs;
         xa.prev_center = center;
+        xa.part = it + 1 < d->iters ? part : nullptr;
         hipLaunchKernelGGL(decoder_xattn_kernel<XR>, dim3(cdiv((int64_t)nq, XR), V), dim3(XR * 64), lds2, (hipStream_t)stream, xa);
         RC(check_launch("decoder_xattn"));
-        ha.ph = d->packed_heads + (size_t)it * PH_FLOATS;
-        ha.prev_center = center;
-        ha.query_out = qbuf[it & 1];
-        ha.center = last ? d->center : cbuf[it & 1];
-        ha.refs_out = last ? nullptr : refs;
-        hipLaunchKernelGGL(decoder_reduce_head_kernel, dim3(cdiv((int64_t)nq, 4)), dim3(256), 0, (hipStream_t)stream, ha);
-        RC(check_launch("decoder_reduce_head"));
-        query = qbuf[it & 1];
-        center = ha.center;
     }
     return DPFT_OK;
 }
 
 extern "C" int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V) {
     const int64_t nq = (int64_t)B * Q;
-    return 2 * nq * DC + 2 * (int64_t)V * nq * DC + 2 * nq * 3 + (int64_t)V * nq * 2 + 64;
+    return 2 * nq * DC + 2 * (int64_t)V * nq * DC + 2 * nq * 3 + (int64_t)V * nq * 2 + (int64_t)V * V * nq * 64 + 64;      // part: 2 x V*V*nq*8*4
+}
+
+// debug: copy the phase stamps of the last launches (2 kernels x 2048 blocks x 8 slots of uint64) to host memory
+extern "C" int dpft_debug_decoder_stamps(uint64_t* dst) {
+    DPFT_REQUIRE(dst, "debug_decoder_stamps: null");
+    DPFT_REQUIRE(hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * 2 * STAMP_BLOCKS * STAMP_SLOTS) == hipSuccess,
+                 "debug_decoder_stamps: copy failed");
+    return DPFT_OK;
 }

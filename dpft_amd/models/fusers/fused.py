@@ -1,5 +1,5 @@
 """Host side of the fused inference decoder (dpft_amd/csrc/decoder.hip): builds the C-ABI parameter
-structs from an ``IMPFusion`` module and runs 3*i_iter kernels instead of ~700 eager ops."""
+structs from an ``IMPFusion`` module and runs 2*i_iter + 1 kernels instead of ~700 eager ops."""
 from __future__ import annotations
 
 import ctypes as C
@@ -53,14 +53,25 @@ class FusedDecoder:
             return
         V, I = f.m_views, f.i_iter
         dev = f.query.device
-        nv, nh = int(lib.dpft_decoder_packed_infer_floats()), int(lib.dpft_decoder_packed_head_floats())
+        nv, nh = int(lib.dpft_decoder_packed_infer_floats(f.n_queries)), int(lib.dpft_decoder_packed_head_floats())
         self.packed_views = torch.empty(I * V * nv, dtype=torch.float32, device=dev)
         self.packed_heads = torch.empty(I * nh, dtype=torch.float32, device=dev)
         d = DecoderFwd()
-        for it, layer in enumerate(f.mpfusion.values()):
+        pos = f.query_embedding.weight
+        assert pos.is_contiguous() and pos.dtype == torch.float32
+        layers = list(f.mpfusion.values())
+        for it, layer in enumerate(layers):
+            # hand-over to the next layer's self-attention: its in_proj composed with this layer's view reduction
+            nxt = None
+            if it + 1 < len(layers):
+                nxt = (C.c_void_p * V)(*[ml.self_attn.in_proj_weight.data_ptr()
+                                         for ml in layers[it + 1].ml_fusion_layers.values()])
+            red = layer.reduction_layer.weight
+            assert red.is_contiguous() and red.dtype == torch.float32
             for v, ml in enumerate(layer.ml_fusion_layers.values()):
                 view, _keep = _view_struct(ml)
-                lib.call("dpft_decoder_pack_infer_f32", C.byref(view), f.n_levels[v], f.n_points[v],
+                lib.call("dpft_decoder_pack_infer_f32", C.byref(view), f.n_levels[v], f.n_points[v], red.data_ptr(),
+                         None if nxt is None else C.cast(nxt, C.c_void_p), v, V, pos.data_ptr(), f.n_queries,
                          self.packed_views.data_ptr() + (it * V + v) * nv * 4, stream())
             head = f.heads[it]
             hw = (C.c_void_p * 12)()

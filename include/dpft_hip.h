@@ -264,15 +264,19 @@ typedef struct dpft_decoder_view {   /* parameters of one MLFusion, torch layout
 } dpft_decoder_view;
 
 int64_t dpft_decoder_packed_view_floats(void);   /* floats per packed MLFusion blob (training cross-attention kernels) */
-int64_t dpft_decoder_packed_infer_floats(void);  /* floats per packed MLFusion blob of the inference decoder */
+int64_t dpft_decoder_packed_infer_floats(int32_t Q);  /* floats per packed MLFusion blob of the inference decoder */
 int64_t dpft_decoder_packed_head_floats(void);   /* floats per packed reduction+head blob */
 /* packed <- one MLFusion's parameters (L levels, P points of its MSDeformAttn) */
 int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
                                dpft_stream_t stream);
-/* inference decoder's blob of one MLFusion (per-head in_proj rows with 1/sqrt(d)*log2(e) folded into q, the
- * offsets / logits matrix in the lanes' sample-slot order, the LDS image of the cross-attention kernel) */
-int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
-                                dpft_stream_t stream);
+/* inference decoder's blob of one MLFusion = view `view_index` of one MPFusion layer: per-head in_proj rows with
+ * 1/sqrt(d)*log2(e) folded into q, the offsets / logits matrix in the lanes' sample-slot order, the LDS image of the
+ * cross-attention kernel, the position part W pos_k + b of the q / k rows over pos (Q,16) = query_embedding.weight,
+ * and the hand-over to the NEXT layer's self-attention: next_in_proj_w[V] = in_proj_weight (48,16) of the next layer's
+ * views (NULL for the last layer), composed with this layer's red_w = reduction_layer.weight (16, 16*V). */
+int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, const float* red_w,
+                                const float* const* next_in_proj_w, int32_t view_index, int32_t V,
+                                const float* pos, int32_t Q, float* packed, dpft_stream_t stream);
 /* packed <- reduction_layer.weight (16, 16*V) and head_w[4][3] = center/size/angle/class x (layers .0,.3,.6)
  * weights, passed as a flat array of 12 pointers */
 int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, int32_t V, int32_t num_classes,
@@ -283,7 +287,7 @@ int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, i
 typedef struct dpft_decoder_fwd {
     int32_t B, Q, V, iters, num_classes;
     int32_t n_points[4];
-    const float* packed_views;           /* [iters][V] blobs of dpft_decoder_packed_infer_floats() */
+    const float* packed_views;           /* [iters][V] blobs of dpft_decoder_packed_infer_floats(Q) */
     const float* packed_heads;           /* [iters] blobs of dpft_decoder_packed_head_floats()     */
     const dpft_pyramid* pyr;             /* [V]                                          */
     const float* query0;                 /* fuser.query (Q,16)                           */
@@ -297,6 +301,9 @@ typedef struct dpft_decoder_fwd {
     float *center, *size, *angle, *cls;
 } dpft_decoder_fwd;
 int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V);
+/* measurement aid: with DPFT_DEC_DBG=1024 in the environment the decoder kernels stamp a 100 MHz clock at their phase
+ * boundaries; copies 2 kernels x 2048 blocks x 8 slots of uint64 (last launches) to dst (tools/decoder_stamps.py) */
+int dpft_debug_decoder_stamps(uint64_t* dst);
 int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
