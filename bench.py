@@ -39,61 +39,104 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE: 4)")
     ap.add_argument("--config", default="kradar")
-    ap.add_argument("--latency-reps", type=int, default=30, help="event-timed eval forwards for fwd ms/frame")
+    ap.add_argument("--latency-reps", type=int, default=300,
+                    help="event-timed eval forwards for fwd ms/frame (reference protocol: 10 warm-up + 300)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="f32 = the reference's arithmetic (BASELINE metric, default); bf16 = mixed precision of "
                          "BASELINE.json configs[4]: bf16 operands / fp32 accumulation in the conv GEMMs")
     ap.add_argument("--no-graphs", action="store_true", help="do not replay the decoder from hipGraphs")
-    ap.add_argument("--cpu-batch", type=int, default=1)
-    ap.add_argument("--cpu-steps", type=int, default=1)
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = min(host cores, 32)")
-    ap.add_argument("--cpu-timeout", type=int, default=240)
+    ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size (default 25 MiB)")
+    ap.add_argument("--comm-dtype", default=None, choices=[None, "fp32", "bf16"], help="wire format of the gradient all-reduce")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (BASELINE.md section 3)")
+    ap.add_argument("--cpu-timeout", type=int, default=200, help="wall-clock budget of the CPU baseline leg in s")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args()
 
 
-def cpu_baseline(cfg, batch_size: int, steps: int, threads: int = 0):
-    """The oracle (CPU restatement of the reference path, torch fp32) timed on the host cores:
-    forward + set loss + backward of `steps` batches of `batch_size` (bounded sample).  Thread count is
-    capped at 32: torch's CPU kernels on this many small tensors get slower, not faster, beyond that."""
+def cpu_baseline(threads: int = 0, budget_s: float = 200.0):
+    """The oracle (CPU restatement of the reference path, torch fp32; pinned to the imported reference by
+    tests/test_oracle_golden.py) timed on the host cores with the protocol of BASELINE.md section 3: configs 1-3,
+    forward 2 warm-up + 5 timed, train step (forward + Hungarian set loss + backward + AdamW) 1 warm-up + 3 timed,
+    ``torch.set_num_threads(all host cores)``.  ``budget_s`` bounds the sample: a leg that would not fit is cut to
+    fewer timed repetitions (reported)."""
+    import platform
+    from dpft_amd.configs import load_config
     from dpft_amd.models import build
     from dpft_amd.synthetic import make_batch, make_labels
     from oracle import dprt_oracle as O
-    cores = threads if threads > 0 else min(os.cpu_count() or 1, 32)
+    cores = threads if threads > 0 else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
-    torch.manual_seed(0)
-    model = build("dprt", cfg)
-    sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach())
-          for k, v in model.state_dict().items()}
-    del model
-    inputs = cfg["model"]["inputs"]
-    w = cfg["train"]["loss_weights"]
-    t_total = 0.0
-    for s in range(steps):
-        batch = make_batch(inputs, batch_size, seed=100 + s)
-        labels = make_labels(batch_size, seed=100 + s)
-        t0 = time.perf_counter()
-        out = O.dprt_forward(sd, cfg, batch, train=True)
-        loss, _ = O.loss_forward(out, labels, w)
-        loss.backward()
-        t_total += time.perf_counter() - t0
-        for v in sd.values():
-            if v.is_floating_point() and v.grad is not None:
-                v.grad = None
-    return {"value": batch_size * steps / t_total, "unit": "samples/s", "cores": cores, "kind": "port",
-            "host_cores": os.cpu_count(),
-            "sample": f"{steps} train step(s) (fwd + Hungarian set loss + bwd, no optimizer) at batch {batch_size}, "
-                      f"torch-CPU fp32 oracle, {cores} threads"}
+    t_begin = time.perf_counter()
+    legs = {}
+
+    def state(cfg):
+        torch.manual_seed(0)
+        model = build("dprt", cfg)
+        sd = {k: (v.detach().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.detach())
+              for k, v in model.state_dict().items()}
+        return sd
+
+    def timed(fn, warm, reps):
+        for _ in range(warm):
+            fn()
+        ts = []
+        for _ in range(reps):
+            if ts and time.perf_counter() - t_begin + max(ts) > budget_s:
+                break
+            t0 = time.perf_counter()
+            fn()
+            ts.append(time.perf_counter() - t0)
+        return ts
+
+    for name, cfg_name, B, train in (("config1 kradar_camera_mono B=1 fwd (1280x720 frame)", "kradar_camera_mono", 1, False),
+                                     ("config2 kradar_radar_bev B=4 train", "kradar_radar_bev", 4, True),
+                                     ("config3 kradar B=4 fwd", "kradar", 4, False),
+                                     ("config3 kradar B=4 train", "kradar", 4, True)):
+        cfg = load_config(cfg_name)
+        inputs = cfg["model"]["inputs"]
+        sd = state(cfg)
+        shapes = {"camera_mono": (720, 1280, 3)} if cfg_name == "kradar_camera_mono" else None   # un-resized frame (SURVEY 8d)
+        batch = make_batch(inputs, B, seed=42, shapes=shapes) if shapes else make_batch(inputs, B, seed=42)
+        labels = make_labels(B, seed=42)
+        if train:
+            params = [v for v in sd.values() if v.is_floating_point() and v.requires_grad]
+            opt = torch.optim.AdamW(params, lr=cfg["train"]["optimizer"]["lr"])
+            w = cfg["train"]["loss_weights"]
+
+            def step():
+                opt.zero_grad(set_to_none=True)
+                out = O.dprt_forward(sd, cfg, batch, train=True)
+                loss, _ = O.loss_forward(out, labels, w)
+                loss.backward()
+                opt.step()
+            ts = timed(step, 1, 3)
+        else:
+            def fwd():
+                with torch.no_grad():
+                    O.dprt_forward(sd, cfg, batch, train=False)
+            ts = timed(fwd, 2, 5)
+        if ts:
+            mean = sum(ts) / len(ts)
+            legs[name] = {"ms": 1e3 * mean, "samples_per_s": B / mean, "timed_reps": len(ts)}
+        else:
+            legs[name] = {"ms": None, "samples_per_s": None, "timed_reps": 0}
+    head = legs["config3 kradar B=4 train"]
+    return {"value": head["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port",
+            "host_cores": os.cpu_count(), "cpu_model": platform.processor() or platform.machine(),
+            "sample": "BASELINE.md section 3 protocol on the torch-CPU fp32 oracle: configs 1-3, forward 2 warm-up + 5 timed, "
+                      "train step (fwd + Hungarian set loss + bwd + AdamW) 1 warm-up + 3 timed; value = config 3 "
+                      f"(kradar, batch 4) train samples/s; {cores} threads; wall {time.perf_counter() - t_begin:.0f} s",
+            "legs": legs}
 
 
 def cpu_baseline_subprocess(args):
     """Run the CPU leg in a child process with a wall-clock bound so that the default bench finishes in minutes."""
     import subprocess
-    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--config", args.config,
-           "--cpu-batch", str(args.cpu_batch), "--cpu-steps", str(args.cpu_steps), "--cpu-threads", str(args.cpu_threads)]
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-threads", str(args.cpu_threads),
+           "--cpu-timeout", str(args.cpu_timeout)]
     try:
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout,
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout + 60,
                            env=dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES=""))
         for ln in reversed(r.stdout.strip().splitlines()):
             if ln.startswith("{"):
@@ -101,7 +144,7 @@ def cpu_baseline_subprocess(args):
         return {"value": None, "unit": "samples/s", "cores": None, "kind": "port", "sample": "failed: " + r.stderr[-300:]}
     except subprocess.TimeoutExpired:
         return {"value": None, "unit": "samples/s", "cores": None, "kind": "port",
-                "sample": f"timed out after {args.cpu_timeout}s for {args.cpu_steps} step(s) at batch {args.cpu_batch}"}
+                "sample": f"timed out after {args.cpu_timeout}s"}
 
 
 def decoder_runner(m, data):
@@ -126,8 +169,7 @@ def decoder_runner(m, data):
 def main():
     args = parse()
     if args.cpu_baseline_only:
-        from dpft_amd.configs import load_config
-        print(json.dumps(cpu_baseline(load_config(args.config), args.cpu_batch, args.cpu_steps, args.cpu_threads)))
+        print(json.dumps(cpu_baseline(args.cpu_threads, float(args.cpu_timeout))))
         return
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -161,7 +203,7 @@ def main():
         cfg["computing"]["conv_compute"] = "bf16x3"
     torch.manual_seed(cfg["computing"]["seed"])
     model = build("dprt", cfg)
-    trainer = DataParallelTrainer(model, cfg, device)
+    trainer = DataParallelTrainer(model, cfg, device, bucket_mb=args.bucket_mb, comm_dtype=args.comm_dtype)
     inputs = cfg["model"]["inputs"]
     B = args.batch
     # weak scaling: every rank owns its own seeded shard of the global batch, resident in HBM
@@ -189,6 +231,7 @@ def main():
         loss, _ = trainer.train_step(data, labels)
     sync()
     elapsed = time.perf_counter() - t0
+    exposed_ms = trainer.reducer.exposed_ms() if world > 1 else 0.0      # last step: exchange time not hidden by backward
     if world > 1:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -230,27 +273,44 @@ def main():
         cam_w = {910, 455, 228, 114, 57, 29}          # widths of the camera feature maps (input of the conv)
         cam = [v for key, v in shapes.items() if key[3] in cam_w]
         cam_f, cam_t = sum(v[0] for v in cam), sum(v[1] for v in cam)
-        traffic = None      # HBM bytes per conv launch from the committed PMC passes (tools/pmc_traffic.sh)
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_conv_traffic_pmc.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                traffic = json.load(f).get("traffic_bytes_per_launch")
+        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/pmc_traffic.sh: FETCH_SIZE and
+        # WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  It is a
+        # constant read from profiles/, not a measurement of this run: the file is named in the line.
+        traffic, traffic_src = None, None
+        prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+        for name in ("r02_conv_traffic_pmc.json", "r01_conv_traffic_pmc.json"):
+            if os.path.exists(os.path.join(prof_dir, name)):
+                with open(os.path.join(prof_dir, name)) as f:
+                    traffic = json.load(f).get("traffic_bytes_per_launch")
+                traffic_src = "profiles/" + name
+                break
         # mixed precision: priced against the dense bf16 MFMA peak although the operands still arrive as fp32 (the
         # kernels are then bound by that fp32 operand path, not by the matrix pipe)
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        roof = {"bound": "mfma", "achieved": tot_f / tot_t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": tot_f / tot_t / 1e12 / peak, "traffic": traffic if args.dtype == "f32" else None,
-                "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family)",
-                "launches_per_step": n_launch, "avg_launch_us": 1e6 * tot_t / max(n_launch, 1),
-                "event_bracket_overhead_us_subtracted": 1e3 * float(ops.lib.dpft_profile_overhead_ms()),
-                "conv_ms_per_step": 1e3 * tot_t, "algorithmic_gflop_per_step": tot_f / 1e9,
-                "per_kind_tflops": {k: v[0] / v[1] / 1e12 for k, v in per_kind.items()},
+        # Accounting.  A bracket spans everything one dpft_conv2d_nhwc_* call launches: the implicit-GEMM
+        # main loop AND the split-K / slab reduction kernels it needs.  `frac` uses the RAW bracket time.  rocprofv3's
+        # kernel durations of the same serialized step (profiles/r02_serialized_step_kernel_stats.csv, recomputed by
+        # tools/roofline_from_rocprof.py) give the same number within a few %; `frac_main_kernels_only` removes the
+        # reduction kernels and the ~4.5 us an empty event bracket costs, i.e. what round 1 reported as `frac`.
+        ovh = float(ops.lib.dpft_profile_overhead_ms()) * 1e-3
+        raw_t = tot_t + ovh * n_launch
+        roof = {"bound": "mfma", "achieved": tot_f / raw_t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": tot_f / raw_t / 1e12 / peak,
+                "traffic": traffic if args.dtype == "f32" else None, "traffic_is": "HBM bytes per conv launch", "traffic_source": traffic_src,
+                "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family, incl. their split-K reductions)",
+                "launches_per_step": n_launch, "avg_launch_us": 1e6 * raw_t / max(n_launch, 1),
+                "conv_ms_per_step": 1e3 * raw_t, "algorithmic_gflop_per_step": tot_f / 1e9,
+                "timing": "HIP events around every conv call of one serialized step, on the launch stream (raw bracket time)",
+                "frac_main_kernels_only": tot_f / tot_t / 1e12 / peak,
+                "event_bracket_overhead_us": 1e6 * ovh,
+                "rocprof_summary": "profiles/r02_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py)",
+                "per_kind_tflops": {k: v[0] / (v[1] + ovh * v[2]) / 1e12 for k, v in per_kind.items()},
                 "frac_flop_weighted": flop_weighted / 1e12 / peak,
                 "frac_camera_encoder": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
                 "camera_encoder_share_of_conv_time": (cam_t / tot_t) if tot_t > 0 else None}
 
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
-    fwd_mean, fwd_std = trainer.inference_time(data, warmup=5, reps=args.latency_reps)
+    fwd_mean, fwd_std = trainer.inference_time(data, warmup=10, reps=args.latency_reps)
 
     # ---- HBM roofline of the deformable fusion decoder (SURVEY 8d "Roofline B") -------------------------
     # unit of work = one IMPFusion.forward (eval); algorithmic bytes = every cross-attention call streams its
@@ -275,10 +335,21 @@ def main():
         fcfg = cfg["model"]["fuser"]
         n_calls = fcfg["i_iter"] * len(m.inputs)
         dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
+        # counter traffic of the decoder kernels (tools/r02_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
+        dec_traffic, dec_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_decoder_traffic_pmc.json")
+        if os.path.exists(pmc):
+            with open(pmc) as f:
+                dec_traffic = json.load(f).get("traffic_bytes_per_forward")
+            dec_src = "profiles/r02_decoder_traffic_pmc.json"
         dec = {"bound": "hbm", "achieved": dec_bytes / t_dec / 1e9, "peak": 8000.0, "unit": "GB/s",
-               "frac": dec_bytes / t_dec / 8.0e12, "traffic": None, "decoder_fwd_us": t_dec * 1e6,
-               "algorithmic_mb": dec_bytes / 1e6, "kernel": "decoder_selfattn + decoder_xattn_head "
-               f"({2 * fcfg['i_iter']} launches per forward)"}
+               "frac": dec_bytes / t_dec / 8.0e12, "traffic": dec_traffic, "traffic_is": "HBM bytes per forward (counters)",
+               "traffic_source": dec_src, "decoder_fwd_us": t_dec * 1e6,
+               "algorithmic_mb": dec_bytes / 1e6, "kernel": "decoder_scores_head + decoder_xattn "
+               f"({2 * fcfg['i_iter'] + 1} launches per forward)",
+               "note": "frac prices the measured time against the time 8 TB/s needs for the ALGORITHMIC bytes of SURVEY 8d "
+                       "(every cross-attention call streaming its pyramid once); the sample-then-project kernels touch far "
+                       "fewer HBM bytes (traffic), they are bound by L2 line requests and kernel-boundary latency"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -299,6 +370,11 @@ def main():
                                      "f32x3": "experimental: fp32 conv operands as three bf16 terms, six term products "
                                               "on the bf16 matrix cores, fp32 accumulation"}[args.dtype]},
             "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,
+            "fwd_protocol": f"10 warm-up + {args.latency_reps} event-timed eval forwards of one batch (evaluator.py:109-125)",
+            "step_definition": "zero_grad, forward, Hungarian set loss, backward, bucketed all-reduce, AdamW; the per-step "
+                               "eval_fn of the reference's loop (trainer.py:134-136) is not part of the timed step",
+            "rccl_ranks": world, "exposed_allreduce_ms": exposed_ms, "dp_bucket_mb": trainer.bucket_mb,
+            "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
             "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,
         }
