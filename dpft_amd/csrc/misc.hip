@@ -474,3 +474,76 @@ extern "C" int dpft_detection_metrics_f32(const float* cls, const float* center,
     hipLaunchKernelGGL(detection_metric_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("detection_metrics");
 }
+
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradients of the fused training decoder from the per-row factor matrices its backward kernels write
+// (decoder_train_x.hip XR_*, decoder_train_h.hip HR_*):  out[a][b] = sum_r rows[r][col_a + a] * rows[r][col_b + b].
+// Replaces ~10 torch bmm / einsum / sum launches (Tensile kernels) per decoder layer by one launch; fixed summation
+// order (deterministic).  Block = one 16 x 16 output tile: thread = (row group of 16, column b), 16 accumulators (all a),
+// the 16 row groups are merged through LDS.
+// ---------------------------------------------------------------------------------------------------------
+namespace dpft {
+
+constexpr int OUTER_MAX_SPECS = 40;
+struct OuterSpecs {
+    dpft_outer_spec s[OUTER_MAX_SPECS];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void rows_outer_kernel(const float* __restrict__ rows, int R, int W, int64_t gstride_rows,
+                                                          OuterSpecs sp, float* __restrict__ out, int64_t gstride_out) {
+    const dpft_outer_spec s = sp.s[blockIdx.y];
+    const int tb = (s.n_b + 15) / 16, ta = (s.n_a + 15) / 16;
+    if ((int)blockIdx.x >= ta * tb) return;
+    const int a0 = ((int)blockIdx.x / tb) * 16, b0 = ((int)blockIdx.x % tb) * 16;
+    const int b = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const float* base = rows + (int64_t)blockIdx.z * gstride_rows;
+    const bool ones = s.col_b < 0;                       // column sums: the b operand is 1
+    const bool bok = ones ? b == 0 : (b0 + b < s.n_b);
+    const int na = min(16, s.n_a - a0);
+    float acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll 2
+    for (int r = rg; r < R; r += 16) {
+        const float* row = base + (int64_t)r * W;
+        const float bv = bok ? (ones ? 1.f : row[s.col_b + b0 + b]) : 0.f;
+        float av[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) av[i] = i < na ? row[s.col_a + a0 + i] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = fmaf(av[i], bv, acc[i]);
+    }
+    __shared__ float red[16][16][17];                   // [row group][a][b]
+#pragma unroll
+    for (int i = 0; i < 16; ++i) red[rg][i][b] = acc[i];
+    __syncthreads();
+    const int a = threadIdx.x >> 4;                      // thread -> output (a, b): sum the 16 row groups in order
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][a][b];
+    const int nb_out = ones ? 1 : s.n_b;
+    if (a < na && (ones ? b == 0 : b0 + b < s.n_b))
+        out[(int64_t)blockIdx.z * gstride_out + s.out_off + (int64_t)(a0 + a) * nb_out + (ones ? 0 : b0 + b)] = t;
+}
+
+}  // namespace dpft
+
+extern "C" int dpft_rows_outer_f32(const float* rows, int32_t G, int32_t R, int32_t W, const dpft_outer_spec* specs,
+                                   int32_t n_specs, float* out, int64_t out_gstride, dpft_stream_t stream) {
+    DPFT_REQUIRE(rows && specs && out && G > 0 && R > 0 && W > 0, "rows_outer: bad arguments");
+    DPFT_REQUIRE(n_specs >= 1 && n_specs <= dpft::OUTER_MAX_SPECS, "rows_outer: 1..%d specs per call", dpft::OUTER_MAX_SPECS);
+    dpft::OuterSpecs sp;
+    sp.n = n_specs;
+    int max_tiles = 1;
+    for (int i = 0; i < n_specs; ++i) {
+        const dpft_outer_spec& s = specs[i];
+        DPFT_REQUIRE(s.n_a >= 1 && s.col_a >= 0 && s.col_a + s.n_a <= W && s.out_off >= 0 &&
+                     (s.col_b < 0 ? s.n_b == 1 : (s.n_b >= 1 && s.col_b + s.n_b <= W)), "rows_outer: spec %d out of range", i);
+        sp.s[i] = s;
+        max_tiles = std::max(max_tiles, ((s.n_a + 15) / 16) * ((s.n_b + 15) / 16));
+    }
+    hipLaunchKernelGGL(dpft::rows_outer_kernel, dim3(max_tiles, n_specs, G), dim3(256), 0, (hipStream_t)stream, rows, R, W,
+                       (int64_t)R * W, sp, out, out_gstride);
+    return dpft::check_launch("rows_outer");
+}

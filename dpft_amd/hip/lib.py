@@ -71,6 +71,10 @@ class DecoderFwd(C.Structure):
                 ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p)]
 
 
+class OuterSpec(C.Structure):
+    _fields_ = [("col_a", C.c_int32), ("n_a", C.c_int32), ("col_b", C.c_int32), ("n_b", C.c_int32), ("out_off", C.c_int64)]
+
+
 _P, _I, _L, _F = C.c_void_p, C.c_int32, C.c_int64, C.c_float
 _DESC = C.POINTER(ConvDesc)
 _PYR = C.POINTER(Pyramid)
@@ -139,6 +143,7 @@ SIGNATURES = {
     "dpft_profile_serialize": (_I, [_I]),
     "dpft_profile_overhead_ms": (_F, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
+    "dpft_rows_outer_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _L, _P]),
     "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "dpft_resnet_plan_create": (_L, [C.POINTER(ResnetDesc)]),
     "dpft_resnet_plan_destroy": (None, [_L]),

@@ -102,6 +102,18 @@ def self_attn_blocks(layers, x, pos, seed, salt: int, p_drop: float):
     return SelfAttnBlocksFn.apply(x, pos, seed, salt, p_drop, *params)
 
 
+def _rows_outer(rows: torch.Tensor, specs, out_floats: int) -> torch.Tensor:
+    """out[g][off + a*n_b + b] = sum_r rows[g][r][col_a+a] * rows[g][r][col_b+b] for every (col_a, n_a, col_b, n_b, off)
+    of ``specs`` in ONE launch (dpft_rows_outer_f32; col_b < 0 = column sums).  rows (G,R,W) -> out (G,out_floats)."""
+    from dpft_amd.hip.lib import OuterSpec
+    G, R, W = rows.shape
+    arr = (OuterSpec * len(specs))(*[OuterSpec(*sp) for sp in specs])
+    out = torch.empty((G, out_floats), dtype=torch.float32, device=rows.device)
+    lib.call("dpft_rows_outer_f32", rows.data_ptr(), G, R, W, C.cast(arr, C.c_void_p), len(specs), out.data_ptr(),
+             out_floats, stream())
+    return out
+
+
 # ---------------------------------------------------------------------------------------------------------
 # deformable cross-attention + FFN block of all views (decoder_train_x.hip)
 # ---------------------------------------------------------------------------------------------------------
@@ -182,14 +194,26 @@ class XattnFfnBlocksFn(torch.autograd.Function):
                  V, C.cast(npts, C.c_void_p), y1.data_ptr(), pos.data_ptr(), refs.data_ptr(), p_drop, seed.data_ptr(),
                  salt, dy3.data_ptr(), dy1.data_ptr(), dqp.data_ptr(), dref.data_ptr(), rows.data_ptr(), B, Q, stream())
         X = _XR
-        col = rows[:, :, :X["QP"]].sum(1)                                                     # (V, 640) vector gradients
-        g_oa = torch.bmm(rows[:, :, X["DLIN"]:X["DF"]].transpose(1, 2), rows[:, :, X["QP"]:X["HD"]])      # (V,480,16)
-        g_f2 = torch.bmm(rows[:, :, X["DF"]:X["DPRE"]].transpose(1, 2), rows[:, :, X["HD"]:X["Y2"]])      # (V,16,32)
-        g_f1 = torch.bmm(rows[:, :, X["DPRE"]:X["DOUT"]].transpose(1, 2), rows[:, :, X["Y2"]:X["VEC"]])   # (V,32,16)
-        g_op = torch.bmm(rows[:, :, X["DOUT"]:X["G3"]].transpose(1, 2), rows[:, :, X["VEC"]:X["SAMP"]])   # (V,16,16)
-        dvec = rows[:, :, X["DVEC"]:X["QP"]].reshape(V, R, 8, 2)
-        samp = rows[:, :, X["SAMP"]:].reshape(V, R, 8, 16)
-        g_vw = torch.einsum("vrmd,vrmc->vmdc", dvec, samp).reshape(V, 16, 16)
+        # every weight gradient = a product of two column blocks of `rows`, summed over the rows: one launch
+        specs, off = [], 0
+        def add(ca, na, cb, nb):
+            nonlocal off
+            specs.append((ca, na, cb, nb, off))
+            off += na * (1 if cb < 0 else nb)
+            return off - na * (1 if cb < 0 else nb)
+        o_col = add(0, X["QP"], -1, 1)                                            # (640) vector gradients
+        o_oa = add(X["DLIN"], X["DF"] - X["DLIN"], X["QP"], 16)                   # (480,16)
+        o_f2 = add(X["DF"], X["DPRE"] - X["DF"], X["HD"], 32)                     # (16,32)
+        o_f1 = add(X["DPRE"], X["DOUT"] - X["DPRE"], X["Y2"], 16)                 # (32,16)
+        o_op = add(X["DOUT"], X["G3"] - X["DOUT"], X["VEC"], 16)                  # (16,16)
+        o_vw = [add(X["DVEC"] + 2 * m, 2, X["SAMP"] + 16 * m, 16) for m in range(8)][0]       # (8,2,16)
+        res = _rows_outer(rows, specs, off)
+        col = res[:, o_col:o_col + X["QP"]]
+        g_oa = res[:, o_oa:o_oa + 480 * 16].view(V, 480, 16)
+        g_f2 = res[:, o_f2:o_f2 + 512].view(V, 16, 32)
+        g_f1 = res[:, o_f1:o_f1 + 512].view(V, 32, 16)
+        g_op = res[:, o_op:o_op + 256].view(V, 16, 16)
+        g_vw = res[:, o_vw:o_vw + 256].view(V, 16, 16)
         grads = []
         for v in range(V):
             n_off = 8 * n_levels[v] * n_points[v] * 2
@@ -317,16 +341,18 @@ class HeadBlockFn(torch.autograd.Function):
         h.dy3, h.dcenter_prev, h.rows = dy3.data_ptr(), dcp.data_ptr(), rows.data_ptr()
         lib.call("dpft_head_train_bwd_f32", C.byref(h), B, Q, V, stream())
         X = _HR
-        g_red = rows[:, X["DX"]:X["Y3C"]].t() @ rows[:, X["Y3C"]:X["Y3C"] + 16 * V]                   # (16, 16V)
-        d1 = rows[:, X["D1"]:X["D2"]].reshape(R, 4, 16)
-        d2 = rows[:, X["D2"]:X["DO"]].reshape(R, 4, 16)
-        do = rows[:, X["DO"]:X["H1"]].reshape(R, 4, 16)
-        h1 = rows[:, X["H1"]:X["H2"]].reshape(R, 4, 16)
-        h2 = rows[:, X["H2"]:X["X"]].reshape(R, 4, 16)
-        xs = rows[:, X["X"]:]
-        g0 = torch.einsum("rgo,rk->gok", d1, xs)
-        g3 = torch.einsum("rgo,rgk->gok", d2, h1)
-        g6 = torch.einsum("rgo,rgk->gok", do, h2)
+        specs, off = [(X["DX"], 16, X["Y3C"], 16 * V, 0)], 16 * 16 * V                              # g_red (16, 16V)
+        o0 = off
+        specs.append((X["D1"], 64, X["X"], 16, off)); off += 64 * 16                              # "rgo,rk->gok"
+        o3 = off
+        for g in range(4):
+            specs.append((X["D2"] + 16 * g, 16, X["H1"] + 16 * g, 16, off)); off += 256           # "rgo,rgk->gok"
+        o6 = off
+        for g in range(4):
+            specs.append((X["DO"] + 16 * g, 16, X["H2"] + 16 * g, 16, off)); off += 256
+        res = _rows_outer(rows.view(1, R, W), specs, off)[0]
+        g_red = res[:16 * 16 * V].view(16, 16 * V)
+        g0, g3, g6 = res[o0:o3].view(4, 16, 16), res[o3:o6].view(4, 16, 16), res[o6:off].view(4, 16, 16)
         grads = [g_red]
         for g, nout in enumerate((3, 3, 2, ncls)):
             grads += [g0[g], g3[g], g6[g, :nout]]

@@ -388,6 +388,20 @@ int dpft_head_train_fwd_f32(const dpft_head_train* h, int32_t B, int32_t Q, int3
 int dpft_head_train_bwd_f32(const dpft_head_train* h, int32_t B, int32_t Q, int32_t V, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Weight gradients of the fused training decoder from the per-row factor matrices its backward kernels write:
+ *   out[g][out_off + a * n_b + b] = sum_r rows[g][r][col_a + a] * rows[g][r][col_b + b]     (a < n_a, b < n_b)
+ * col_b < 0 (with n_b == 1): column sums of the a-columns.  rows (G,R,W); specs is a HOST array of <= 40 entries;
+ * one launch for all specs and groups, fixed summation order.  Replaces the bmm / einsum / sum launches of
+ * dpft_amd/models/fusers/train_fused.py (torch -> Tensile kernels) on the training step.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct dpft_outer_spec {
+    int32_t col_a, n_a, col_b, n_b;
+    int64_t out_off;
+} dpft_outer_spec;
+int dpft_rows_outer_f32(const float* rows, int32_t G, int32_t R, int32_t W, const dpft_outer_spec* specs,
+                        int32_t n_specs, float* out, int64_t out_gstride, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Matcher cost helper: GIoU3D of yaw-only boxes, (B,N) predictions x (B,Mg) targets.
  * boxes are (x,y,z,l,w,h,yaw) rows of 7 floats; out (B,N,Mg).
  * ---------------------------------------------------------------------------------------- */
