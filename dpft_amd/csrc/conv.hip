@@ -1282,6 +1282,31 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// the same for up to 80 weight tensors in ONE launch (a ResNet stage's convs: 236 launches of ~5 us per step otherwise)
+__global__ void weight_transpose_batch_kernel(TransposeBatch tb) {
+    __shared__ float tile[32][33];
+    int i = 0;
+    while (i + 1 < tb.n && (int)blockIdx.x >= tb.blk_start[i + 1]) ++i;      // wave-uniform scan (n <= 80)
+    const int K = tb.K[i], taps = tb.taps[i], C = tb.C[i];
+    const float* __restrict__ w = tb.w[i];
+    float* __restrict__ wt = tb.wt[i];
+    int rel = blockIdx.x - tb.blk_start[i];
+    const int cb = (C + 31) / 32, kb = (K + 31) / 32;
+    const int tap = rel / (cb * kb);
+    rel -= tap * cb * kb;
+    const int k0 = (rel / cb) * 32, c0 = (rel % cb) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int k = k0 + j, c = c0 + tx;
+        tile[j][tx] = (k < K && c < C) ? w[((size_t)k * taps + tap) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, k = k0 + tx;
+        if (c < C && k < K) wt[((size_t)c * taps + tap) * K + k] = tile[tx][j];
+    }
+}
+
 // db[k] += sum_m dy[m][k]; db zeroed by the launcher; K <= 256
 __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict__ db, int64_t M, int K) {
     __shared__ float red[256];
@@ -1843,6 +1868,12 @@ extern "C" int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, 
     dim3 grid(cdiv(C, 32), cdiv(K, 32), taps);
     hipLaunchKernelGGL(weight_transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, w, w_t, K, taps, C);
     return check_launch("weight_transpose");
+}
+
+int dpft::weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream) {
+    DPFT_REQUIRE(tb.n >= 1 && tb.n <= TransposeBatch::MAX, "weight_transpose_batch: 1..%d tensors", TransposeBatch::MAX);
+    hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(tb.blk_start[tb.n]), dim3(256), 0, (hipStream_t)stream, tb);
+    return check_launch("weight_transpose_batch");
 }
 
 extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K,

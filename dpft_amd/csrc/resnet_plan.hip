@@ -380,12 +380,21 @@ struct SideCtx {
             DPFT_REQUIRE(hipEventRecord(p->ev_ready, main) == hipSuccess, "resnet_backward: record event");
             DPFT_REQUIRE(hipStreamWaitEvent(ts, p->ev_ready, 0) == hipSuccess, "resnet_backward: wait event");
         }
+        TransposeBatch tb;
+        tb.n = 0;
         for (auto& b : p->blocks) {
             if (b.layer != stage) continue;
             const ConvRef* cs[4] = {&b.c3, &b.c2, &b.c1, b.has_ds ? &b.cd : nullptr};
-            for (const ConvRef* c : cs)
-                if (c) RC(dpft_weight_transpose_f32(T.w(c->w), wt_base + c->wt, c->d.K, c->d.kh * c->d.kw, c->d.C, (dpft_stream_t)ts));
+            for (const ConvRef* c : cs) {
+                if (!c) continue;
+                tb.add(T.w(c->w), wt_base + c->wt, c->d.K, c->d.kh * c->d.kw, c->d.C);
+                if (tb.n == TransposeBatch::MAX) {
+                    RC(weight_transpose_batch(tb, (dpft_stream_t)ts));
+                    tb.n = 0;
+                }
+            }
         }
+        if (tb.n > 0) RC(weight_transpose_batch(tb, (dpft_stream_t)ts));
         if (ts != main) {
             DPFT_REQUIRE(hipEventRecord(p->ev_wt, ts) == hipSuccess, "resnet_backward: record event");
             DPFT_REQUIRE(hipStreamWaitEvent(main, p->ev_wt, 0) == hipSuccess, "resnet_backward: wait event");

@@ -412,7 +412,12 @@ def _train_parity(cfg, seed):
         assert p.grad is not None, n
         e, e32 = rel_l2(p.grad, gref), rel_l2(sd32[n].grad, gref)
         report.append((e / max(e32, 1e-7), e, e32, n))
-        if e > max(5e-3, 6 * e32):       # layer4 BN sees only 8-32 samples per channel at these sizes
+        # layer4 BN sees only 8-32 samples per channel at these sizes.  Decoder / head parameters: one ReLU of a head MLP
+        # (or of the size branch) whose pre-activation is ~1e-6 flips with ANY change of fp32 rounding upstream (a new
+        # summation order in a BatchNorm reduction is enough) and moves that layer's gradients by ~0.5 % in rel-L2; the
+        # fused decoder blocks themselves are held to 5e-4 against the oracle in tests/test_gpu_kernels.py (*_vs_oracle).
+        floor = 1e-2 if n.startswith(("fuser.", "head.")) else 5e-3
+        if e > max(floor, 6 * e32):
             bad.append((n, e, e32))
         checked += 1
     report.sort(reverse=True)
