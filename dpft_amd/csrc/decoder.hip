@@ -126,40 +126,49 @@ __device__ __forceinline__ float group16_sum(float v) {
     return v;
 }
 
+// sum over the 4 lanes c, c + 16, c + 32, c + 48 (k-slices of one output), result in all of them
+__device__ __forceinline__ float slices4_sum(float v) {
+    v = xor16_combine(v, OpAdd());
+    return xor32_combine(v, OpAdd());
+}
+
 // LayerNorm over 16 channels held by 16 consecutive lanes (torch: biased variance, eps inside the sqrt)
 __device__ __forceinline__ float layernorm16(float v, float g, float b) {
     const float mean = group16_sum(v) * (1.f / 16.f);
     const float d = v - mean;
     const float var = group16_sum(d * d) * (1.f / 16.f);
-    return d * (1.0f / sqrtf(var + 1e-5f)) * g + b;
+    return d * __builtin_amdgcn_rsqf(var + 1e-5f) * g + b;      // v_rsq_f32 (1 ulp) instead of an IEEE sqrt + division
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // packed INFERENCE blob of one MLFusion (per iteration, view), made by pack_infer_kernel
 // ---------------------------------------------------------------------------------------------------------
 constexpr int NSLOT = 160;                          // 8 heads x 20 (level, point) slots, in the lanes' slot order
-constexpr int PI_SA_IN = 0;                         // [8 heads][6 rows: q0 q1 k0 k1 v0 v1][16]; q rows pre-scaled
-constexpr int PI_SA_INB = PI_SA_IN + 768;           // [8][6]
-constexpr int PI_K2 = PI_SA_INB + 48;               // LDS image of decoder_xattn_kernel starts here (16-B aligned)
+constexpr int PI_K2 = 0;                            // LDS image of decoder_xattn_kernel (16-B aligned)
 constexpr int K2_OFF = 0;                           // [17][NSLOT][2] sampling_offsets^T (row 16 = bias), slot order
 constexpr int K2_LOG = K2_OFF + 17 * NSLOT * 2;     // [17][NSLOT]    attention_weights^T (row 16 = bias)
 constexpr int K2_VALW = K2_LOG + 17 * NSLOT;        // value_proj.weight (16,16) as is
 constexpr int K2_VALB = K2_VALW + 256;
-constexpr int K2_OUTPT = K2_VALB + 16;              // output_proj.weight^T [k][c]
-constexpr int K2_OUTPB = K2_OUTPT + 256;
+// small matrices in torch's own (out, in) layout, rows padded (+4) so that 16 lanes reading 16-byte pieces of 16
+// different rows hit 64 different LDS banks: every lane computes a k-SLICE of its output (the 64 lanes hold each of
+// the 16 / 32 outputs 4 / 2 times) and the slices are merged with permlane swaps -- 8 + 2 instead of 32 x 4 instructions
+constexpr int LD16 = 20, LD32 = 36;
+constexpr int K2_OUTP = K2_VALB + 16;               // output_proj.weight [c 16][k 16 (+4)]
+constexpr int K2_OUTPB = K2_OUTP + 16 * LD16;
 constexpr int K2_N2W = K2_OUTPB + 16;
 constexpr int K2_N2B = K2_N2W + 16;
-constexpr int K2_F1T = K2_N2B + 16;                 // ffn1.weight^T [k 16][j 32]
-constexpr int K2_F1B = K2_F1T + 512;
-constexpr int K2_F2T = K2_F1B + 32;                 // ffn2.weight^T [k 32][c 16]
-constexpr int K2_F2B = K2_F2T + 512;
+constexpr int K2_F1 = K2_N2B + 16;                  // ffn1.weight [j 32][k 16 (+4)]
+constexpr int K2_F1B = K2_F1 + 32 * LD16;
+constexpr int K2_F2 = K2_F1B + 32;                  // ffn2.weight [c 16][k 32 (+4)]
+constexpr int K2_F2B = K2_F2 + 16 * LD32;
 constexpr int K2_N3W = K2_F2B + 16;
 constexpr int K2_N3B = K2_N3W + 16;
-constexpr int K2_SAOT = K2_N3B + 16;                // self_attn.out_proj.weight^T [k][c]
-constexpr int K2_SAOB = K2_SAOT + 256;
+constexpr int K2_SAO = K2_N3B + 16;                 // self_attn.out_proj.weight [c 16][k 16 (+4)]
+constexpr int K2_SAOB = K2_SAO + 16 * LD16;
 constexpr int K2_N1W = K2_SAOB + 16;
 constexpr int K2_N1B = K2_N1W + 16;
-constexpr int K2_FLOATS = K2_N1B + 16;              // 10144 floats = 40 576 B
+constexpr int K2_SLOT = K2_N1B + 16;                // [NSLOT] int8: pyramid level of the slot, -1 = unused slot (n >= L*P)
+constexpr int K2_FLOATS = K2_SLOT + NSLOT / 4;      // 10504 floats = 42 016 B
 constexpr int PI_FLOATS = PI_K2 + K2_FLOATS;
 static_assert(K2_FLOATS % 4 == 0 && PI_K2 % 4 == 0 && PI_FLOATS % 4 == 0, "float4 staging");
 // Hand-over to the NEXT layer's self-attention (appended to the blob).  The next layer's query is R y3cat (R = this
@@ -168,11 +177,11 @@ static_assert(K2_FLOATS % 4 == 0 && PI_K2 % 4 == 0 && PI_FLOATS % 4 == 0, "float
 // y3 is produced; the score kernel of the next iteration then sums V 16-byte partials per key instead of projecting
 // 192 bytes of y3, and no longer depends on the reduction / head kernel (they share a launch).
 //   PC_NX : [4 targets][16 k][64 outputs], output j = head * 8 + {0,1: q (pre-scaled) | 4,5: k | 6,7: v}, 2,3 unused
-//   PC_VB : v bias of THIS layer's heads;  PC_T : position part W (pos_k) + b of THIS layer's q and k rows
+//   PC_T  : input-independent part of THIS layer's q / k / v rows
 constexpr int PC_NX = PI_FLOATS;
-constexpr int PC_VB = PC_NX + 4 * 16 * 64;          // [8][2] v bias (+ pad to 16)
-constexpr int PC_T = PC_VB + 16;                    // [8 heads][Q][4] = q0 q1 k0 k1: W pos_k + b (q rows pre-scaled)
-__host__ __device__ constexpr int64_t pi_floats(int Q) { return PC_T + (int64_t)Q * 32; }
+constexpr int PC_T = PC_NX + 4 * 16 * 64;                      // [8 heads][Q][8] = q0 q1 - - k0 k1 v0 v1: the part of the rows that does
+                                                    // not depend on the input: W (pos_k [+ query0_k in the first layer]) + b
+__host__ __device__ constexpr int64_t pi_floats(int Q) { return PC_T + (int64_t)Q * 64; }
 
 // slot (s, lane) -> head m, sample n of the head.  In gather round t = 4 s + (lane >> 4) the 4-lane pixel group
 // g = lane >> 2 ... of the CONSUMER reads the sample the PRODUCER lane (t & 3) * 16 + g computed, so that group g always
@@ -186,21 +195,24 @@ struct NextInProj {
     const float* w[4];      // in_proj_weight (48,16) of the NEXT layer's views, all NULL for the last layer
 };
 __global__ void pack_infer_kernel(dpft_decoder_view s, int L, int P, const float* __restrict__ red_w, NextInProj nx,
-                                  int view, int V, const float* __restrict__ pos, int Q, float* __restrict__ d) {
+                                  int view, int V, const float* __restrict__ pos, const float* __restrict__ query0, int Q,
+                                  float* __restrict__ d) {
     const int LP = L * P;
     const float qscale = 0.70710678118654752f * 1.4426950408889634f;      // 1/sqrt(head_dim) * log2(e)
     const int total = (int)pi_floats(Q);
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
         float v = 0.f;
-        if (i >= PC_T) {                          // position part of the q / k rows of (key, head)
-            const int j = i - PC_T, h = j / (Q * 4), k = (j >> 2) % Q, r = j & 3;
-            const int row = (r >> 1) * 16 + 2 * h + (r & 1);
-            v = s.in_proj_b[row];
-            for (int c = 0; c < 16; ++c) v = fmaf(s.in_proj_w[row * 16 + c], pos[k * 16 + c], v);
-            if (r < 2) v *= qscale;
-        } else if (i >= PC_VB) {
-            const int j = i - PC_VB;
-            if (j < 16) v = s.in_proj_b[32 + j];  // head h, d -> row 32 + 2h + d
+        if (i >= PC_T) {                          // input-independent part of the q / k / v rows of (head, key)
+            const int j = i - PC_T, h = j / (Q * 8), k = (j >> 3) % Q, e = j & 7;
+            if (e < 2 || e >= 4) {
+                const int row = (e < 2 ? 0 : (e < 6 ? 16 : 32)) + 2 * h + (e & 1);
+                v = s.in_proj_b[row];
+                for (int c = 0; c < 16; ++c) {
+                    const float x = (e < 6 ? pos[k * 16 + c] : 0.f) + (query0 ? query0[k * 16 + c] : 0.f);   // v rows see no pos
+                    v = fmaf(s.in_proj_w[row * 16 + c], x, v);
+                }
+                if (e < 2) v *= qscale;
+            }
         } else if (i >= PC_NX) {
             const int j = i - PC_NX, tv = j >> 10, k = (j >> 6) & 15, o = j & 63, h = o >> 3, e = o & 7;
             if (tv < V && nx.w[tv] && (e < 2 || e >= 4)) {
@@ -208,13 +220,6 @@ __global__ void pack_infer_kernel(dpft_decoder_view s, int L, int P, const float
                 for (int c = 0; c < 16; ++c) v = fmaf(nx.w[tv][row * 16 + c], red_w[c * 16 * V + k * V + view], v);
                 if (e < 2) v *= qscale;
             }
-        } else if (i < PI_SA_INB) {
-            const int h = i / 96, r = (i / 16) % 6, c = i & 15;
-            const int row = (r >> 1) * 16 + 2 * h + (r & 1);
-            v = s.in_proj_w[row * 16 + c] * (r < 2 ? qscale : 1.f);
-        } else if (i < PI_K2) {
-            const int j = i - PI_SA_INB, h = j / 6, r = j % 6;
-            v = s.in_proj_b[(r >> 1) * 16 + 2 * h + (r & 1)] * (r < 2 ? qscale : 1.f);
         } else {
             const int k = i - PI_K2;
             int r;
@@ -230,21 +235,31 @@ __global__ void pack_infer_kernel(dpft_decoder_view s, int L, int P, const float
                 slot_decode(slot >> 6, slot & 63, m, n);
                 if (n < LP) { const int o = m * LP + n; v = c < 16 ? s.att_w[o * 16 + c] : s.att_b[o]; }
             } else if (k < K2_VALB) v = s.val_w[k - K2_VALW];
-            else if (k < K2_OUTPT) v = s.val_b[k - K2_VALB];
-            else if (k < K2_OUTPB) { r = k - K2_OUTPT; v = s.outp_w[(r & 15) * 16 + (r >> 4)]; }
+            else if (k < K2_OUTP) v = s.val_b[k - K2_VALB];
+            else if (k < K2_OUTPB) { r = k - K2_OUTP; if (r % LD16 < 16) v = s.outp_w[(r / LD16) * 16 + r % LD16]; }
             else if (k < K2_N2W) v = s.outp_b[k - K2_OUTPB];
             else if (k < K2_N2B) v = s.norm2_w[k - K2_N2W];
-            else if (k < K2_F1T) v = s.norm2_b[k - K2_N2B];
-            else if (k < K2_F1B) { r = k - K2_F1T; v = s.ffn1_w[(r & 31) * 16 + (r >> 5)]; }
-            else if (k < K2_F2T) v = s.ffn1_b[k - K2_F1B];
-            else if (k < K2_F2B) { r = k - K2_F2T; v = s.ffn2_w[(r & 15) * 32 + (r >> 4)]; }
+            else if (k < K2_F1) v = s.norm2_b[k - K2_N2B];
+            else if (k < K2_F1B) { r = k - K2_F1; if (r % LD16 < 16) v = s.ffn1_w[(r / LD16) * 16 + r % LD16]; }
+            else if (k < K2_F2) v = s.ffn1_b[k - K2_F1B];
+            else if (k < K2_F2B) { r = k - K2_F2; if (r % LD32 < 32) v = s.ffn2_w[(r / LD32) * 32 + r % LD32]; }
             else if (k < K2_N3W) v = s.ffn2_b[k - K2_F2B];
             else if (k < K2_N3B) v = s.norm3_w[k - K2_N3W];
-            else if (k < K2_SAOT) v = s.norm3_b[k - K2_N3B];
-            else if (k < K2_SAOB) { r = k - K2_SAOT; v = s.out_proj_w[(r & 15) * 16 + (r >> 4)]; }
+            else if (k < K2_SAO) v = s.norm3_b[k - K2_N3B];
+            else if (k < K2_SAOB) { r = k - K2_SAO; if (r % LD16 < 16) v = s.out_proj_w[(r / LD16) * 16 + r % LD16]; }
             else if (k < K2_N1W) v = s.out_proj_b[k - K2_SAOB];
             else if (k < K2_N1B) v = s.norm1_w[k - K2_N1W];
-            else v = s.norm1_b[k - K2_N1B];
+            else if (k < K2_SLOT) v = s.norm1_b[k - K2_N1B];
+            else {      // four int8 slot levels per word
+                unsigned word = 0;
+                for (int e = 0; e < 4; ++e) {
+                    const int slot = (k - K2_SLOT) * 4 + e;
+                    int m, n;
+                    slot_decode(slot >> 6, slot & 63, m, n);
+                    word |= (unsigned)((n < LP ? n / P : -1) & 0xff) << (8 * e);
+                }
+                v = __uint_as_float(word);
+            }
         }
         d[i] = v;
     }
@@ -263,19 +278,18 @@ __device__ __forceinline__ void stamp(int on, int kernel, int block, int slot) {
 // ---------------------------------------------------------------------------------------------------------
 constexpr int QC = 50;      // queries per block (25 pairs); 2 * QC must be a multiple of 4 (LDS alignment of Pt)
 constexpr int NS = 10;      // key slices; 25 pairs x 10 slices = 250 of the 256 threads
-constexpr int SC_W = 120;   // LDS floats: the head's 6 in_proj rows + biases (first iteration) | 16 slice maxima
+constexpr int SC_W = 16;    // LDS floats: slice maxima
 
 struct ScoreArgs {
     const float* pi[4];   // packed inference blobs of this iteration
-    const float* query;   // first iteration: the learned (Q,16) table (same for every batch element)
     const float* part;    // later iterations: partial q/k/v rows written by the previous xattn (layout: see scores_block)
     const float* pos;     // (Q,16)
     float* attn;          // (V,Bsa,Q,16) attention output before out_proj
     int Bsa, B, Q, V, nchunk, stamps;
 };
 
-// COMPOSED = false: q/k/v rows of the head applied to (query + pos | query + pos | query)  [first iteration]
-// COMPOSED = true : q/k/v = sum over the source views of the partials the previous xattn kernel wrote + position part
+// COMPOSED = false: first layer -- the rows are constants of the weights (learned query table + embedding), read as packed
+// COMPOSED = true : rows = packed position part + sum over the source views of the partials the previous xattn wrote
 template <bool COMPOSED>
 __device__ __forceinline__ void scores_block(const ScoreArgs& a, float* sm, int sid) {
     const int Q = a.Q, SL = (Q + NS - 1) / NS;
@@ -288,34 +302,30 @@ __device__ __forceinline__ void scores_block(const ScoreArgs& a, float* sm, int 
     const int view = vb / a.Bsa, b = vb - view * a.Bsa, q0 = chunk * QC;
     const float* pi = a.pi[view];
     stamp(a.stamps, 0, sid, 0);
-    unsigned* kmax = reinterpret_cast<unsigned*>(Ws + SC_W - 16);    // [NS] max |k|^2 of the slice's keys (float bits)
-    if (!COMPOSED) {
-        if (tid < 96) Ws[tid] = pi[PI_SA_IN + h * 96 + tid];
-        else if (tid < 102) Ws[tid] = pi[PI_SA_INB + h * 6 + tid - 96];
-    }
-    if (tid >= 128 && tid < 128 + NS) kmax[tid - 128] = 0u;
+    unsigned* kmax = reinterpret_cast<unsigned*>(Ws);                // [NS] max |k|^2 of the slice's keys (float bits)
+    if (tid < NS) kmax[tid] = 0u;
     __syncthreads();
     stamp(a.stamps, 0, sid, 1);
-    if (COMPOSED) {
-        // q/k/v = position part + the V partial projections the previous cross-attention kernel wrote.  Those lines were
-        // written by other XCDs a moment ago (first touch = a fabric round trip of ~2 us): all loads of the thread's
-        // items are issued before the first one is consumed.
+    {
+        // q / k / v rows of the head = packed input-independent part (position embedding, biases; in the first layer the
+        // whole row: its input is the learned query table) [+ COMPOSED: the V partial projections the previous
+        // cross-attention kernel wrote].  Those lines were written by other XCDs a moment ago (first touch = a fabric
+        // round trip of ~2 us): all loads of the thread's items are issued before the first one is consumed.
         constexpr int NIT = 2;
         static_assert(QC <= 112, "two items per thread cover Q + QC <= 512");
         f32x4 t4[NIT], p4[NIT][4];
-        f32x2 vb2 = *reinterpret_cast<const f32x2*>(pi + PC_VB + 2 * h);
 #pragma unroll
         for (int u = 0; u < NIT; ++u) {
             const int i = tid + u * 256;
             const bool isq = i >= Q;
             const int k = isq ? min(q0 + i - Q, Q - 1) : i;
-            // partials: kv (V targets,B,8 heads,V sources,Q,4) then q (same shape, q0 q1 - -): a block's reads
-            // (one target, batch element and head; lanes = consecutive keys) are contiguous
-            const size_t grp = (((size_t)view * a.B + b) * 8 + h) * a.V;
-            // (one load type for both item kinds: a select between a dwordx2 and a dwordx4 load serialises them)
-            const float* src = a.part + (isq ? (size_t)a.V * a.B * 8 * a.V * Q * 4 : 0) + (grp * Q + k) * 4;
-            if (i < Q + QC) {
-                t4[u] = *reinterpret_cast<const f32x4*>(pi + PC_T + ((size_t)h * Q + k) * 4);
+            if (i < Q + QC) t4[u] = *reinterpret_cast<const f32x4*>(pi + PC_T + ((size_t)h * Q + k) * 8 + (isq ? 0 : 4));
+            if (COMPOSED && i < Q + QC) {
+                // partials: kv (V targets,B,8 heads,V sources,Q,4) then q (same shape, q0 q1 - -): a block's reads
+                // (one target, batch element and head; lanes = consecutive keys) are contiguous; one load type for both
+                // item kinds (a select between a dwordx2 and a dwordx4 load serialises them)
+                const size_t grp = (((size_t)view * a.B + b) * 8 + h) * a.V;
+                const float* src = a.part + (isq ? (size_t)a.V * a.B * 8 * a.V * Q * 4 : 0) + (grp * Q + k) * 4;
 #pragma unroll
                 for (int v = 0; v < 4; ++v)
                     if (v < a.V) p4[u][v] = *reinterpret_cast<const f32x4*>(src + (size_t)v * Q * 4);
@@ -326,45 +336,16 @@ __device__ __forceinline__ void scores_block(const ScoreArgs& a, float* sm, int 
             const int i = tid + u * 256;
             if (i >= Q + QC) break;
             const bool isq = i >= Q;
-            f32x4 r = isq ? f32x4{t4[u][0], t4[u][1], 0.f, 0.f} : f32x4{t4[u][2], t4[u][3], vb2[0], vb2[1]};      // (q items: lanes 2,3 unused)
+            f32x4 r = t4[u];                                       // q items: lanes 2,3 unused
+            if (COMPOSED) {
 #pragma unroll
-            for (int v = 0; v < 4; ++v)
-                if (v < a.V) r += p4[u][v];
+                for (int v = 0; v < 4; ++v)
+                    if (v < a.V) r += p4[u][v];
+            }
             if (isq) Qs[i - Q] = f32x2{r[0], r[1]};
             else {
                 KV[i + i / SL] = r;
                 atomicMax(kmax + i / SL, __float_as_uint(fmaf(r[0], r[0], r[1] * r[1])));      // >= 0: uint order = float order
-            }
-        }
-    } else {
-        for (int i = tid; i < Q + QC; i += 256) {
-            const bool isq = i >= Q;
-            const int k = isq ? min(q0 + i - Q, Q - 1) : i;
-            float r[4];
-            f32x4 x[4], xp[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                x[c] = *reinterpret_cast<const f32x4*>(a.query + (size_t)k * DC + 4 * c);
-                xp[c] = x[c] + *reinterpret_cast<const f32x4*>(a.pos + (size_t)k * DC + 4 * c);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // query item: rows 0,1 of (x + pos); key item: rows 2,3 of (x + pos) and rows 4,5 of x
-                const int row = isq ? (j & 1) : 2 + j;
-                float acc = Ws[96 + row];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(Ws + row * 16 + 4 * c);
-                    const f32x4 v = (isq || j < 2) ? xp[c] : x[c];
-                    acc = fmaf(w[0], v[0], acc); acc = fmaf(w[1], v[1], acc);
-                    acc = fmaf(w[2], v[2], acc); acc = fmaf(w[3], v[3], acc);
-                }
-                r[j] = acc;
-            }
-            if (isq) Qs[i - Q] = f32x2{r[0], r[1]};
-            else {
-                KV[k + k / SL] = f32x4{r[0], r[1], r[2], r[3]};
-                atomicMax(kmax + k / SL, __float_as_uint(fmaf(r[0], r[0], r[1] * r[1])));
             }
         }
     }
@@ -497,10 +478,10 @@ typedef __attribute__((address_space(1))) f32x4 gf32x4;        // integers would
 __device__ __forceinline__ float mish_fast(float x) {
     const float n = __expf(fminf(x, 20.f));
     const float t = n * (n + 2.f);
-    return x * (t / (t + 2.f));
+    return x * (t * __builtin_amdgcn_rcpf(t + 2.f));
 }
 
-constexpr int XW_FLOATS = 416;      // per-wave scratch: wq float4[64] | addr uint2[64] (low bits: dw, dh, level) | vec float[32]
+constexpr int XW_FLOATS = 384;      // per-wave scratch: wq float4[64] | addr uint2[64] (low bits: dw, dh, level); small vectors reuse wq
 
 template <int R>
 __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
@@ -554,13 +535,23 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     float* ws = sm + K2_FLOATS + wave * XW_FLOATS;
     f32x4* wq = reinterpret_cast<f32x4*>(ws);
     uint2* adr = reinterpret_cast<uint2*>(ws + 256);
-    float* vec = ws + 384;
+    float* vec = ws + 64;       // [16] head outputs (written after the last gather round: the gather scratch is dead)
     // ---- self-attention epilogue: out_proj + residual + LayerNorm1 (mpfusion.py:142-148) ----
-    float y1c = sm[K2_SAOB + c];
-#pragma unroll
-    for (int k = 0; k < DC; ++k) y1c = fmaf(sm[K2_SAOT + k * DC + c], rdlane(av, k), y1c);
+    // lane = (output c, k-slice kg): 4 of the 16 products per lane, slices merged with two permlane swaps
+    const int kg = lane >> 4;
+    float* xs = ws;                                   // 64 floats of wave scratch (the gather scratch is not live yet)
+    if (lane < 16) xs[lane] = av;
+    __builtin_amdgcn_wave_barrier();
+    float y1c;
+    {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + K2_SAO + c * LD16 + 4 * kg);
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + 4 * kg);
+        y1c = slices4_sum(w[0] * x4[0] + w[1] * x4[1] + w[2] * x4[2] + w[3] * x4[3]) + sm[K2_SAOB + c];
+    }
     y1c = layernorm16(y1c + xres, sm[K2_N1W + c], sm[K2_N1B + c]);
-    const float qpc = y1c + posc;
+    __builtin_amdgcn_wave_barrier();
+    if (lane < 16) xs[lane] = y1c + posc;             // qp = y1 + pos: the GEMV's input, read back as LDS broadcasts
+    __builtin_amdgcn_wave_barrier();
     // ---- sampling offsets + attention logits of this lane's 3 slots (ms_deform_attn.py:177-182) ----
     int idx[3];
     f32x2 off[3];
@@ -571,26 +562,28 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         off[s] = *reinterpret_cast<const f32x2*>(sm + K2_OFF + (16 * NSLOT + idx[s]) * 2);
         lg[s] = sm[K2_LOG + 16 * NSLOT + idx[s]];
     }
-#pragma unroll 4
-    for (int k = 0; k < DC; ++k) {
-        const float xk = rdlane(qpc, k);
+#pragma unroll 1
+    for (int k4 = 0; k4 < DC; k4 += 4) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xs + k4);      // same address in every lane: broadcast
 #pragma unroll
-        for (int s = 0; s < 3; ++s) {
-            const f32x2 w = *reinterpret_cast<const f32x2*>(sm + K2_OFF + (k * NSLOT + idx[s]) * 2);
-            off[s][0] = fmaf(w[0], xk, off[s][0]);
-            off[s][1] = fmaf(w[1], xk, off[s][1]);
-            lg[s] = fmaf(sm[K2_LOG + k * NSLOT + idx[s]], xk, lg[s]);
+        for (int e = 0; e < 4; ++e) {
+            const int k = k4 + e;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const f32x2 w = *reinterpret_cast<const f32x2*>(sm + K2_OFF + (k * NSLOT + idx[s]) * 2);
+                off[s] += w * x4[e];
+                lg[s] = fmaf(sm[K2_LOG + k * NSLOT + idx[s]], x4[e], lg[s]);
+            }
         }
     }
     // ---- softmax over the L*P slots of the head (lanes with equal lane & 7; bits 3..5 + the 3 slots) ----
-    int ns[3];
+    int lvl[3];                                        // pyramid level of the slot, -1 = unused
     bool ok[3];
     float mx = -INFINITY;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        int m_;
-        slot_decode(s, lane, m_, ns[s]);
-        ok[s] = ns[s] < LP && (s < 2 || lane < 32);
+        lvl[s] = reinterpret_cast<const signed char*>(sm + K2_SLOT)[idx[s]];
+        ok[s] = lvl[s] >= 0 && (s < 2 || lane < 32);
         if (ok[s]) mx = fmaxf(mx, lg[s]);
     }
     mx = fmaxf(mx, dpp_mov<DPP_ROR8>(mx)); mx = xor16_combine(mx, OpMax()); mx = xor32_combine(mx, OpMax());
@@ -598,7 +591,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) { aw[s] = ok[s] ? __expf(lg[s] - mx) : 0.f; den += aw[s]; }
     den += dpp_mov<DPP_ROR8>(den); den = xor16_combine(den, OpAdd()); den = xor32_combine(den, OpAdd());
-    const float inv_den = 1.f / den;
+    const float inv_den = __builtin_amdgcn_rcpf(den);
     stamp(son, 1, sblk, 2);
     // ---- sample-then-project: producer lanes write (weights, corner address), 4-lane pixel groups gather ----
     const int g = lane >> 2, j = lane & 3;
@@ -607,7 +600,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         {
-            const int l = ok[s] ? ns[s] / P : 0;
+            const int l = ok[s] ? lvl[s] : 0;
             const int4 lt = *reinterpret_cast<const int4*>(lvl_tab[l]);
             const int H = lt.z, W = lt.w;
             const float a_w = aw[s] * inv_den;
@@ -670,29 +663,54 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         }
     }
     __builtin_amdgcn_wave_barrier();
-    // ---- output_proj + residual + LayerNorm2 (lanes 0..15 = channels; other lanes mirror them) ----
-    float vo = sm[K2_OUTPB + c];
-#pragma unroll
-    for (int k = 0; k < DC; ++k) vo = fmaf(sm[K2_OUTPT + k * DC + c], vec[k], vo);
-    const float y2 = layernorm16(vo + y1c, sm[K2_N2W + c], sm[K2_N2B + c]);
+    // ---- output_proj + residual + LayerNorm2: lane = (output c, k-slice kg) ----
+    float y2;
+    {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(sm + K2_OUTP + c * LD16 + 4 * kg);
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(vec + 4 * kg);
+        const float vo = slices4_sum(w[0] * x4[0] + w[1] * x4[1] + w[2] * x4[2] + w[3] * x4[3]) + sm[K2_OUTPB + c];
+        y2 = layernorm16(vo + y1c, sm[K2_N2W + c], sm[K2_N2B + c]);
+    }
     // ---- FFN: 16 -> 32 (Mish) -> 16, residual, LayerNorm3 ----
-    const int jf = lane & 31;
-    float hsum = sm[K2_F1B + jf];
-#pragma unroll
-    for (int k = 0; k < DC; ++k) hsum = fmaf(sm[K2_F1T + k * DFF + jf], rdlane(y2, k), hsum);
-    const float hval = mish_fast(hsum);
-    float f = sm[K2_F2B + c];
-#pragma unroll
-    for (int k = 0; k < DFF; ++k) f = fmaf(sm[K2_F2T + k * DC + c], rdlane(hval, k), f);
-    const float y3 = layernorm16(f + y2, sm[K2_N3W + c], sm[K2_N3B + c]);
+    float* t16 = ws;            // [16] y2, later y3   (the gather scratch is dead now)
+    float* t32 = ws + 16;       // [32] hidden activations
+    if (lane < 16) t16[lane] = y2;
+    __builtin_amdgcn_wave_barrier();
+    {
+        const int jf = lane & 31, k2 = lane >> 5;       // hidden unit, k-slice of 8
+        const float* wr = sm + K2_F1 + jf * LD16 + 8 * k2;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(t16 + 8 * k2), x1 = *reinterpret_cast<const f32x4*>(t16 + 8 * k2 + 4);
+        float hsum = (w0[0] * x0[0] + w0[1] * x0[1] + w0[2] * x0[2] + w0[3] * x0[3])
+                   + (w1[0] * x1[0] + w1[1] * x1[1] + w1[2] * x1[2] + w1[3] * x1[3]);
+        hsum = xor32_combine(hsum, OpAdd()) + sm[K2_F1B + jf];
+        if (lane < 32) t32[lane] = mish_fast(hsum);
+    }
+    __builtin_amdgcn_wave_barrier();
+    float y3;
+    {
+        const float* wr = sm + K2_F2 + c * LD32 + 8 * kg;
+        const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr), w1 = *reinterpret_cast<const f32x4*>(wr + 4);
+        const f32x4 x0 = *reinterpret_cast<const f32x4*>(t32 + 8 * kg), x1 = *reinterpret_cast<const f32x4*>(t32 + 8 * kg + 4);
+        float f = (w0[0] * x0[0] + w0[1] * x0[1] + w0[2] * x0[2] + w0[3] * x0[3])
+                + (w1[0] * x1[0] + w1[1] * x1[1] + w1[2] * x1[2] + w1[3] * x1[3]);
+        f = slices4_sum(f) + sm[K2_F2B + c];
+        y3 = layernorm16(f + y2, sm[K2_N3W + c], sm[K2_N3B + c]);
+    }
     if (lane < 16) a.y3[((size_t)view * a.B * a.Q + bq) * DC + lane] = y3;
     stamp(son, 1, sblk, 4);
     if (a.part) {       // this view's share of the next layer's q/k/v rows of every target view (lane = output)
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 16) t16[lane] = y3;
+        __builtin_amdgcn_wave_barrier();
+        f32x4 y4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) y4[i] = *reinterpret_cast<const f32x4*>(t16 + 4 * i);      // broadcast reads
         const float* nx = a.pi[view] + PC_NX + lane;
         for (int tv = 0; tv < a.V; ++tv) {
             float o = 0.f;
 #pragma unroll
-            for (int k = 0; k < DC; ++k) o = fmaf(nx[(tv * 16 + k) * 64], rdlane(y3, k), o);
+            for (int k = 0; k < DC; ++k) o = fmaf(nx[(tv * 16 + k) * 64], y4[k >> 2][k & 3], o);
             const int hh = lane >> 3, e = lane & 7;
             const size_t grp = ((((size_t)tv * a.B + b) * 8 + hh) * a.V + view) * a.Q + q;
             if (e >= 4) a.part[grp * 4 + (e - 4)] = o;
@@ -829,7 +847,8 @@ extern "C" int64_t dpft_decoder_packed_infer_floats(int32_t Q) { return pi_float
 
 extern "C" int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, const float* red_w,
                                            const float* const* next_in_proj_w, int32_t view_index, int32_t V,
-                                           const float* pos, int32_t Q, float* packed, dpft_stream_t stream) {
+                                           const float* pos, const float* query0, int32_t Q, float* packed,
+                                           dpft_stream_t stream) {
     DPFT_REQUIRE(view && packed && pos && red_w, "decoder_pack_infer: null argument");
     DPFT_REQUIRE(view_index >= 0 && view_index < V, "decoder_pack_infer: view index out of range");
     DPFT_REQUIRE(L >= 1 && L <= DPFT_MAX_LEVELS && P >= 1 && P <= 4 && L * P <= 20,
@@ -841,7 +860,7 @@ extern "C" int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_
     NextInProj nx;
     for (int v = 0; v < 4; ++v) nx.w[v] = (next_in_proj_w && v < V) ? next_in_proj_w[v] : nullptr;
     hipLaunchKernelGGL(pack_infer_kernel, dim3(cdiv(pi_floats(Q), 256)), dim3(256), 0, (hipStream_t)stream, *view, L, P,
-                       red_w, nx, view_index, V, pos, Q, packed);
+                       red_w, nx, view_index, V, pos, query0, Q, packed);
     return check_launch("decoder_pack_infer");
 }
 
@@ -892,7 +911,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     xa.attn = attn; xa.pos = d->pos; xa.y3 = y3; xa.B = B; xa.Q = Q; xa.V = V;
     ha.y3 = y3; ha.B = B; ha.Q = Q; ha.V = V; ha.ncls = d->num_classes;
     ha.size = d->size; ha.angle = d->angle; ha.cls = d->cls;
-    sa.query = d->query0; sa.part = part; sa.pos = d->pos; sa.attn = attn; sa.B = B; sa.Q = Q; sa.V = V;
+    sa.part = part; sa.pos = d->pos; sa.attn = attn; sa.B = B; sa.Q = Q; sa.V = V;
     sa.nchunk = cdiv(Q, QC);
     const size_t lds1 = (4 * (size_t)(Q + NS) + SC_W + 2 * QC + 4 * QC * NS) * sizeof(float);
     const size_t lds2 = ((size_t)K2_FLOATS + XR * XW_FLOATS) * sizeof(float);

@@ -71,7 +71,8 @@ class FusedDecoder:
             for v, ml in enumerate(layer.ml_fusion_layers.values()):
                 view, _keep = _view_struct(ml)
                 lib.call("dpft_decoder_pack_infer_f32", C.byref(view), f.n_levels[v], f.n_points[v], red.data_ptr(),
-                         None if nxt is None else C.cast(nxt, C.c_void_p), v, V, pos.data_ptr(), f.n_queries,
+                         None if nxt is None else C.cast(nxt, C.c_void_p), v, V, pos.data_ptr(),
+                         f.query.data_ptr() if it == 0 else None, f.n_queries,
                          self.packed_views.data_ptr() + (it * V + v) * nv * 4, stream())
             head = f.heads[it]
             hw = (C.c_void_p * 12)()

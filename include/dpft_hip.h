@@ -271,12 +271,14 @@ int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t L, int32_t
                                dpft_stream_t stream);
 /* inference decoder's blob of one MLFusion = view `view_index` of one MPFusion layer: per-head in_proj rows with
  * 1/sqrt(d)*log2(e) folded into q, the offsets / logits matrix in the lanes' sample-slot order, the LDS image of the
- * cross-attention kernel, the position part W pos_k + b of the q / k rows over pos (Q,16) = query_embedding.weight,
+ * cross-attention kernel, the input-independent part of the self-attention's q / k / v rows over pos (Q,16) =
+ * query_embedding.weight (W pos_k + b; with query0 (Q,16) = the learned query table, non-NULL for the FIRST layer only,
+ * the whole rows W (query0_k + pos_k) + b: that layer's input is a parameter),
  * and the hand-over to the NEXT layer's self-attention: next_in_proj_w[V] = in_proj_weight (48,16) of the next layer's
  * views (NULL for the last layer), composed with this layer's red_w = reduction_layer.weight (16, 16*V). */
 int dpft_decoder_pack_infer_f32(const dpft_decoder_view* view, int32_t L, int32_t P, const float* red_w,
                                 const float* const* next_in_proj_w, int32_t view_index, int32_t V,
-                                const float* pos, int32_t Q, float* packed, dpft_stream_t stream);
+                                const float* pos, const float* query0, int32_t Q, float* packed, dpft_stream_t stream);
 /* packed <- reduction_layer.weight (16, 16*V) and head_w[4][3] = center/size/angle/class x (layers .0,.3,.6)
  * weights, passed as a flat array of 12 pointers */
 int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, int32_t V, int32_t num_classes,

@@ -37,3 +37,12 @@ def summarize(name, arr, nslot):
 summarize("scores blocks (kernel 0, ids < 1024)", st[0, :1024], 5)
 summarize("head blocks   (kernel 0, ids >= 1024)", st[0, 1024:], 4)
 summarize("xattn blocks  (kernel 1)", st[1], 6)
+nb = int((st[1][:, 0] > 0).sum())
+per = nb // 3
+t0 = st[1][:nb, 0].min()
+for v in range(3):
+    a = st[1][v * per:(v + 1) * per]
+    print(f"  view {v}: " + "  ".join(f"s{s}: med {np.median(a[:, s] - t0):6.2f} max {(a[:, s] - t0).max():6.2f}" for s in range(6)))
+# per-CU load: blocks are placed round-robin, so block b and b + 256 ... share a CU (approximately)
+end = st[1][:nb, 5] - t0
+print("  end-time histogram (us):", np.histogram(end, bins=8)[0].tolist(), [round(float(x), 1) for x in np.histogram(end, bins=8)[1]])
