@@ -277,7 +277,7 @@ __device__ __forceinline__ void stamp(int on, int kernel, int block, int slot) {
 // K1: attention scores of one head
 // ---------------------------------------------------------------------------------------------------------
 constexpr int QC = 50;      // queries per block (25 pairs); 2 * QC must be a multiple of 4 (LDS alignment of Pt)
-constexpr int NS = 10;      // key slices; 25 pairs x 10 slices = 250 of the 256 threads
+constexpr int NS = 10;      // key slices (<= SC_W); 25 pairs x 10 slices = 250 of the 256 threads
 constexpr int SC_W = 16;    // LDS floats: slice maxima
 
 struct ScoreArgs {
@@ -747,28 +747,40 @@ __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)
     const int c = lane & 15, v2 = lane >> 4;
     const float* ph = a.ph;
     const float yv = v2 < a.V ? a.y3[((size_t)v2 * a.B * a.Q + bq) * DC + c] : 0.f;
+    // all weights of the wave (input-independent, L2) are requested BEFORE the first use of y3, which was written by
+    // other XCDs a moment ago: one memory round trip for the whole block instead of one per MLP layer
+    float wr[4][DC], wh[3][DC];
+#pragma unroll
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int k = 0; k < DC; ++k) wr[v][k] = v < a.V ? ph[PH_RED_WT + (v * DC + k) * DC + c] : 0.f;
+#pragma unroll
+    for (int l = 0; l < 3; ++l)
+#pragma unroll
+        for (int k = 0; k < DC; ++k) wh[l][k] = ph[PH_W + (l * DC + k) * 64 + lane];
     // view reduction: queries.view(B,N,C*V) is channel-major / view-minor (mpfusion.py:436-438)
     float x = 0.f;
-    for (int v = 0; v < a.V; ++v)
 #pragma unroll
-        for (int k = 0; k < DC; ++k) x = fmaf(ph[PH_RED_WT + (v * DC + k) * DC + c], rdlane(yv, v * 16 + k), x);
+    for (int v = 0; v < 4; ++v)
+#pragma unroll
+        for (int k = 0; k < DC; ++k) x = fmaf(wr[v][k], rdlane(yv, v * 16 + k), x);
     if (lane < 16) a.query_out[(size_t)bq * DC + lane] = x;
     stamp(a.stamps, 0, 1024 + hid, 1);
     // heads (heads/detection.py:252-275): branch g = lane / 16 (center, size, angle, class), row o = lane % 16
     const int g = lane >> 4, o = lane & 15;
     float t = 0.f;
 #pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(ph[PH_W + (0 * DC + k) * 64 + lane], rdlane(x, k), t);
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[0][k], rdlane(x, k), t);
     hs[wave][0][lane] = fmaxf(t, 0.f);
     __builtin_amdgcn_wave_barrier();
     t = 0.f;
 #pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(ph[PH_W + (1 * DC + k) * 64 + lane], hs[wave][0][g * 16 + k], t);
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[1][k], hs[wave][0][g * 16 + k], t);
     hs[wave][1][lane] = fmaxf(t, 0.f);
     __builtin_amdgcn_wave_barrier();
     t = 0.f;
 #pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(ph[PH_W + (2 * DC + k) * 64 + lane], hs[wave][1][g * 16 + k], t);
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[2][k], hs[wave][1][g * 16 + k], t);
     const int nout = g == 0 ? 3 : (g == 1 ? 3 : (g == 2 ? 2 : a.ncls));
     float cen = 0.f;
     if (o < nout) {
@@ -795,7 +807,7 @@ __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)
 // One launch = the score blocks of iteration it (blocks [0, n_score)) + the reduction / head blocks of iteration it-1
 // (blocks [n_score, ...)): both only depend on the previous cross-attention kernel, so the head MLPs' latency chain
 // hides behind the scores instead of sitting between two kernel boundaries.
-__global__ __launch_bounds__(256) void decoder_scores_head_kernel(ScoreArgs sa, HeadArgs ha, int n_score, int composed) {
+__global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs sa, HeadArgs ha, int n_score, int composed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float hs[4][2][64];
     const int bid = blockIdx.x;
