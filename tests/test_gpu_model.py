@@ -350,6 +350,42 @@ def test_mixed_precision_mode_close_to_fp32():
     assert all(v == v and v < 10 for k, v in e_grp.items() if k != "head"), e_grp
 
 
+def test_config4_bf16_mixed_precision_batch8_trains_at_full_size():
+    """BASELINE.json configs[4] at ITS size on one GPU: kradar.json full C+R, bf16 mixed precision, batch 8 per GPU
+    (global batch 64 = 8 such ranks).  Graphed trainer steps on a fixed synthetic batch: finite, decreasing loss, every
+    step's loss within bf16 rounding of the fp32 trainer's first step, all gradients finite."""
+    from dpft_amd.configs import load_config
+    from dpft_amd.hip import ops
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    batch = make_batch(["camera_mono", "radar_bev", "radar_front"], 8, seed=15, device=DEV)
+    labels = make_labels(8, seed=15, device=DEV)
+    first = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            cfg = copy.deepcopy(load_config("kradar"))
+            cfg["model"]["fuser"]["dropout"] = 0.0
+            cfg["computing"]["conv_compute"] = mode
+            torch.manual_seed(0)
+            tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+            assert ops.conv_get_compute() == mode
+            tr.enable_graphs(batch)
+            losses = [float(tr.train_step(batch, labels)[0]) for _ in range(1 if mode == "fp32" else 6)]
+            assert all(l == l and l < 1e6 for l in losses), losses
+            first[mode] = losses[0]
+            if mode == "bf16":
+                assert losses[-1] < losses[0], losses
+                for n, p in tr.model.named_parameters():
+                    if p.grad is not None:
+                        assert bool(torch.isfinite(p.grad).all()), n
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        ops.conv_set_compute("fp32")
+    assert abs(first["bf16"] - first["fp32"]) < 2e-2 * abs(first["fp32"]), first
+
+
 def test_radar_bev_config_trains_at_full_size():
     """BASELINE.json configs[1] (kradar_radar_bev, batch 4, real 256x107 maps): graphed trainer steps run, reduce the
     loss on a fixed batch and equal the eager (ungraphed) step's loss."""
