@@ -6,6 +6,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <type_traits>
 
 namespace dpft {
 
@@ -129,6 +130,20 @@ __global__ void bn_eval_multi_kernel(BnEvalBatch a) {
     bnp[3 * K + c] = invstd;
 }
 
+// Activation storage: float (default) or __bf16 (mixed-precision storage, dpft_conv_desc.act16): a lane handles 4
+// consecutive channels = one 16-byte or one 8-byte access; all arithmetic is fp32 either way.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+template <typename T> __device__ __forceinline__ f32x4 ldv4(const void* base, int64_t i4);
+template <> __device__ __forceinline__ f32x4 ldv4<float>(const void* base, int64_t i4) { return reinterpret_cast<const f32x4*>(base)[i4]; }
+template <> __device__ __forceinline__ f32x4 ldv4<__bf16>(const void* base, int64_t i4) {
+    return __builtin_convertvector(reinterpret_cast<const bf16x4_t*>(base)[i4], f32x4);
+}
+template <typename T> __device__ __forceinline__ void stv4(void* base, int64_t i4, f32x4 v);
+template <> __device__ __forceinline__ void stv4<float>(void* base, int64_t i4, f32x4 v) { reinterpret_cast<f32x4*>(base)[i4] = v; }
+template <> __device__ __forceinline__ void stv4<__bf16>(void* base, int64_t i4, f32x4 v) {
+    reinterpret_cast<bf16x4_t*>(base)[i4] = __builtin_convertvector(v, bf16x4_t);
+}
+
 // BN block convention: bnp[4][K] = (mean, scale = gamma*invstd, beta, invstd); bn(y) = (y-mean)*scale+beta
 __device__ __forceinline__ f32x4 bn_apply4(f32x4 v, const float* __restrict__ bnp, int K, int c) {
     const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
@@ -140,27 +155,49 @@ __device__ __forceinline__ f32x4 bn_apply4(f32x4 v, const float* __restrict__ bn
 }
 
 // out = [relu](bn(y) [+ bn_r(res) | + res]); K % 4 == 0
+template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                       const float* __restrict__ res, const float* __restrict__ rbnp,
-                                                      int relu, float* __restrict__ out, int64_t n4, int K4) {
+                                                      int relu, float* __restrict__ out, float* __restrict__ out32,
+                                                      int64_t n4, int K4) {
     const int K = K4 * 4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % K4) * 4;
-        f32x4 v = bn_apply4(reinterpret_cast<const f32x4*>(y)[i], bnp, K, c);
-        if (res) {
-            f32x4 r = reinterpret_cast<const f32x4*>(res)[i];
-            if (rbnp) r = bn_apply4(r, rbnp, K, c);
-            v += r;
-        }
-        if (relu) {
+    // bf16 storage moves 8 bytes per lane and access: two independent groups per trip keep as many bytes in flight as
+    // the fp32 form (these passes are pure HBM streaming)
+    constexpr int U = std::is_same<T, float>::value ? 1 : 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
+        f32x4 yv[U], rv[U];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n4) {
+                yv[u] = ldv4<T>(y, i);
+                if (res) rv[u] = ldv4<T>(res, i);
+            }
         }
-        reinterpret_cast<f32x4*>(out)[i] = v;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n4) break;
+            const int c = (int)(i % K4) * 4;
+            f32x4 v = bn_apply4(yv[u], bnp, K, c);
+            if (res) {
+                f32x4 r = rv[u];
+                if (rbnp) r = bn_apply4(r, rbnp, K, c);
+                v += r;
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            stv4<T>(out, i, v);
+            if (out32) reinterpret_cast<f32x4*>(out32)[i] = v;      // fp32 copy of a stage output (consumers outside the plan)
+        }
     }
 }
 
 // stem: maxpool3x3/s2/p1 of relu(bn(y)); one thread per (b,ph,pw,4 channels)
+template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                                float* __restrict__ out,
                                                                int B, int H, int W, int K4, int PH, int PW) {
@@ -186,12 +223,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __res
                 for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
             }
         }
-        reinterpret_cast<f32x4*>(out)[i] = m;
+        stv4<T>(out, i, m);
     }
 }
 
 // backward of the above, gather form: dz[b,h,w,c] = (a>0) * sum_{windows containing (h,w) whose first
 // arg-max is (h,w)} dout.  a = relu(bn(y)) recomputed on the fly.
+template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                                    const float* __restrict__ dout,
                                                                    float* __restrict__ dz, int B, int H, int W, int K4, int PH, int PW) {
@@ -233,7 +271,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
                     }
                 }
                 const int me = (h - (ph * 2 - 1)) * 3 + (w - (pw * 2 - 1));
-                const f32x4 d = reinterpret_cast<const f32x4*>(dout)[(((int64_t)b * PH + ph) * PW + pw) * K4 + c4];
+                const f32x4 d = ldv4<T>(dout, (((int64_t)b * PH + ph) * PW + pw) * K4 + c4);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) g[e] += (bi[e] == me) ? d[e] : 0.f;
             }
@@ -245,6 +283,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
 }
 
 // BN backward pass 1: sums[0][k] += sum dz, sums[1][k] += sum dz*xhat
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                              const float* __restrict__ outp, const float* __restrict__ mbnp,
                                                              const float* __restrict__ bnp, float* __restrict__ sums,
@@ -264,21 +303,23 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     if (g < groups) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c4 * 4);
         const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c4 * 4);
-        // 4 rows per trip: 8-12 independent 16-byte loads in flight per lane (this kernel is pure HBM streaming)
-        for (int64_t rb = r0 + g; rb < r1; rb += 4 * groups) {
-            f32x4 dv[4], yv4[4], ov[4];
-            bool ok[4];
+        // RT rows per trip: 8-12 independent 16-byte (bf16 storage: 16-24 8-byte) loads in flight per lane (this kernel is
+        // pure HBM streaming)
+        constexpr int RT = std::is_same<T, float>::value ? 4 : 8;
+        for (int64_t rb = r0 + g; rb < r1; rb += RT * groups) {
+            f32x4 dv[RT], yv4[RT], ov[RT];
+            bool ok[RT];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RT; ++u) {
                 const int64_t r = rb + (int64_t)u * groups;
                 ok[u] = r < r1;
                 const int64_t idx = (ok[u] ? r : r0) * K4 + c4;
-                dv[u] = reinterpret_cast<const f32x4*>(dout)[idx];
-                yv4[u] = reinterpret_cast<const f32x4*>(y)[idx];
-                if (outp) ov[u] = reinterpret_cast<const f32x4*>(outp)[idx];
+                dv[u] = ldv4<T>(dout, idx);
+                yv4[u] = ldv4<T>(y, idx);
+                if (outp) ov[u] = ldv4<T>(outp, idx);
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < RT; ++u) {
                 if (!ok[u]) continue;
                 f32x4 d = dv[u];
                 const f32x4 yv = yv4[u];
@@ -319,6 +360,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 }
 
 // BN backward pass 2
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                             const float* __restrict__ outp, const float* __restrict__ mbnp,
                                                             const float* __restrict__ bnp, const float* __restrict__ gamma,
@@ -335,12 +377,28 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         // ping-pong accumulators of the launch plan: clear the buffer the NEXT reduction will add into
         for (int c = threadIdx.x; c < zero_n; c += blockDim.x) zero_buf[c] = 0.f;
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    constexpr int U = std::is_same<T, float>::value ? 1 : 2;      // see bn_act_kernel
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
+      f32x4 dq[U], yq[U], oq[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+          const int64_t i = i0 + u * stride;
+          if (i < n4) {
+              dq[u] = ldv4<T>(dout, i);
+              yq[u] = ldv4<T>(y, i);
+              if (outp) oq[u] = ldv4<T>(outp, i);
+          }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int64_t i = i0 + u * stride;
+        if (i >= n4) break;
         const int c = (int)(i % K4) * 4;
-        f32x4 d = reinterpret_cast<const f32x4*>(dout)[i];
-        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+        f32x4 d = dq[u];
+        const f32x4 yv = yq[u];
         if (outp) {
-            const f32x4 o = reinterpret_cast<const f32x4*>(outp)[i];
+            const f32x4 o = oq[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
         } else if (mbnp) {
@@ -359,7 +417,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
             const float xh = (yv[e] - mu[e]) * is[e];
             r[e] = ga[e] * is[e] * (d[e] - s0[e] * invM - xh * s1[e] * invM);
         }
-        reinterpret_cast<f32x4*>(dy)[i] = r;
+        stv4<T>(dy, i, r);
+      }
     }
 }
 
@@ -379,13 +438,15 @@ __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a, const float* __restrict__ b, int64_t n) {
     const int64_t n4 = n / 4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 v = reinterpret_cast<f32x4*>(a)[i];
+        f32x4 v = ldv4<T>(a, i);
         v += reinterpret_cast<const f32x4*>(b)[i];
-        reinterpret_cast<f32x4*>(a)[i] = v;
+        stv4<T>(a, i, v);
     }
+    if (!std::is_same<T, float>::value) return;      // bf16 storage: n % 4 == 0 (host side)
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = n4 * 4 + threadIdx.x;
         a[i] += b[i];
@@ -394,6 +455,12 @@ __global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ a,
 
 __device__ __forceinline__ int nearest_src(int dst, float scale, int n_in) {
     return min((int)floorf((float)dst * scale), n_in - 1);
+}
+
+// dst (bf16) = src (fp32): the external gradient of a stage output entering a bf16-storage plan
+__global__ __launch_bounds__(256) void cvt_f32_bf16_kernel(const float* __restrict__ src, float* __restrict__ dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        stv4<__bf16>(dst, i, reinterpret_cast<const f32x4*>(src)[i]);
 }
 
 // lat += nearest_upsample(top)
@@ -509,35 +576,62 @@ int dpft::bn_eval_params_batch(const BnEvalBatch& batch, dpft_stream_t stream) {
     return check_launch("bn_eval_params_batch");
 }
 
-extern "C" int dpft_bn_act_f32(const float* y, const float* bnp, const float* res, const float* res_bnp,
-                               int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream) {
+int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const float* res_bnp, int32_t relu, float* out,
+                     float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream) {
     DPFT_REQUIRE(y && bnp && out && M > 0 && K > 0 && K % 4 == 0, "bn_act: bad arguments (K=%d)", K);
     DPFT_REQUIRE(res || !res_bnp, "bn_act: res_bnp without res");
     const int64_t n4 = M * K / 4;
-    hipLaunchKernelGGL(bn_act_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
-                       res_bnp, relu, out, n4, K / 4);
+    if (act16)
+        hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
+                           res_bnp, relu, out, out32, n4, K / 4);
+    else
+        hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
+                           res_bnp, relu, out, out32, n4, K / 4);
     return check_launch("bn_act");
+}
+
+extern "C" int dpft_bn_act_f32(const float* y, const float* bnp, const float* res, const float* res_bnp,
+                               int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream) {
+    return dpft::bn_act_any(y, bnp, res, res_bnp, relu, out, nullptr, M, K, false, stream);
+}
+
+int dpft::bn_relu_maxpool_any(const float* y, const float* bnp, float* out, int32_t B, int32_t H, int32_t W, int32_t K,
+                              int32_t PH, int32_t PW, bool out16, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && bnp && out && K % 4 == 0, "bn_relu_maxpool: bad arguments");
+    DPFT_REQUIRE(PH == (H + 2 - 3) / 2 + 1 && PW == (W + 2 - 3) / 2 + 1, "bn_relu_maxpool: PH/PW inconsistent");
+    const int64_t total = (int64_t)B * PH * PW * (K / 4);
+    if (out16)
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, bnp,
+                           out, B, H, W, K / 4, PH, PW);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, bnp,
+                           out, B, H, W, K / 4, PH, PW);
+    return check_launch("bn_relu_maxpool");
 }
 
 extern "C" int dpft_bn_relu_maxpool_f32(const float* y, const float* bnp, float* out,
                                         int32_t B, int32_t H, int32_t W, int32_t K, int32_t PH, int32_t PW,
                                         dpft_stream_t stream) {
-    DPFT_REQUIRE(y && bnp && out && K % 4 == 0, "bn_relu_maxpool: bad arguments");
-    DPFT_REQUIRE(PH == (H + 2 - 3) / 2 + 1 && PW == (W + 2 - 3) / 2 + 1, "bn_relu_maxpool: PH/PW inconsistent");
-    const int64_t total = (int64_t)B * PH * PW * (K / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y, bnp,
-                       out, B, H, W, K / 4, PH, PW);
-    return check_launch("bn_relu_maxpool");
+    return dpft::bn_relu_maxpool_any(y, bnp, out, B, H, W, K, PH, PW, false, stream);
+}
+
+int dpft::bn_relu_maxpool_bwd_any(const float* y, const float* bnp, const float* dout, float* dact, int32_t B, int32_t H,
+                                  int32_t W, int32_t K, int32_t PH, int32_t PW, bool dout16, dpft_stream_t stream) {
+    DPFT_REQUIRE(y && bnp && dout && dact && K % 4 == 0, "bn_relu_maxpool_bwd: bad arguments");
+    const int64_t total = (int64_t)B * H * W * (K / 4);
+    if (dout16)
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y,
+                           bnp, dout, dact, B, H, W, K / 4, PH, PW);
+    else
+        hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<float>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y,
+                           bnp, dout, dact, B, H, W, K / 4, PH, PW);
+    return check_launch("bn_relu_maxpool_bwd");
 }
 
 extern "C" int dpft_bn_relu_maxpool_bwd_f32(const float* y, const float* bnp,
                                             const float* dout, float* dact, int32_t B, int32_t H, int32_t W,
                                             int32_t K, int32_t PH, int32_t PW, dpft_stream_t stream) {
-    DPFT_REQUIRE(y && bnp && dout && dact && K % 4 == 0, "bn_relu_maxpool_bwd: bad arguments");
-    const int64_t total = (int64_t)B * H * W * (K / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y,
-                       bnp, dout, dact, B, H, W, K / 4, PH, PW);
-    return check_launch("bn_relu_maxpool_bwd");
+    return dpft::bn_relu_maxpool_bwd_any(y, bnp, dout, dact, B, H, W, K, PH, PW, false, stream);
 }
 
 extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const float* out,
@@ -545,12 +639,12 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
                                       int32_t K, dpft_stream_t stream) {
     DPFT_REQUIRE(sums && K > 0, "bn_bwd_reduce: bad arguments");
     DPFT_REQUIRE(hipMemsetAsync(sums, 0, sizeof(float) * 2 * K, (hipStream_t)stream) == hipSuccess, "bn_bwd_reduce: memset failed");
-    return dpft::bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, stream);
+    return dpft::bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, false, stream);
 }
 
 // `sums` (2K floats) must already be zero (the launch plan keeps two buffers and lets each apply pass clear the other)
 int dpft::bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out, const float* mask_bnp,
-                                  const float* bnp, float* sums, int64_t M, int32_t K, dpft_stream_t stream) {
+                                  const float* bnp, float* sums, int64_t M, int32_t K, bool act16, dpft_stream_t stream) {
     DPFT_REQUIRE(y && dout && bnp && sums && M > 0 && K > 0 && K % 4 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int K4 = K / 4;
@@ -563,8 +657,12 @@ int dpft::bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float
     const int want_blocks = std::min(64, std::max(1, (kNumCU * 4) / slabs));
     int64_t rows_per_block = std::max<int64_t>((int64_t)groups * 4, (M + want_blocks - 1) / want_blocks);
     dim3 grid(cdiv(M, rows_per_block), slabs);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
-                       (int)rows_per_block, slab);
+    if (act16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
+                           (int)rows_per_block, slab);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
+                           (int)rows_per_block, slab);
     return check_launch("bn_bwd_reduce");
 }
 
@@ -572,16 +670,21 @@ extern "C" int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const fl
                                      const float* mask_bnp, const float* bnp, const float* gamma,
                                      const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
                                      int32_t K, dpft_stream_t stream) {
-    return dpft::bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, nullptr, 0, stream);
+    return dpft::bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, nullptr, 0, false, stream);
 }
 
 int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp,
                                const float* bnp, const float* gamma, const float* sums, float* dy, float* dgamma,
-                               float* dbeta, int64_t M, int32_t K, float* zero_buf, int32_t zero_n, dpft_stream_t stream) {
+                               float* dbeta, int64_t M, int32_t K, float* zero_buf, int32_t zero_n, bool act16,
+                               dpft_stream_t stream) {
     DPFT_REQUIRE(y && dout && bnp && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = M * K / 4;
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                       mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n);
+    if (act16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
+                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
+                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n);
     return check_launch("bn_bwd_apply");
 }
 
@@ -591,10 +694,21 @@ extern "C" int dpft_relu_bwd_f32(const float* dout, const float* out, float* dz,
     return check_launch("relu_bwd");
 }
 
-extern "C" int dpft_add_inplace_f32(float* a, const float* b, int64_t n, dpft_stream_t stream) {
-    DPFT_REQUIRE(a && b && n > 0, "add_inplace: bad arguments");
-    hipLaunchKernelGGL(add_inplace_kernel, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, n);
+int dpft::add_inplace_any(float* a, const float* b, int64_t n, bool a16, dpft_stream_t stream) {
+    DPFT_REQUIRE(a && b && n > 0 && (!a16 || n % 4 == 0), "add_inplace: bad arguments");
+    if (a16) hipLaunchKernelGGL(add_inplace_kernel<__bf16>, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, n);
+    else hipLaunchKernelGGL(add_inplace_kernel<float>, dim3(ew_blocks(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, a, b, n);
     return check_launch("add_inplace");
+}
+
+extern "C" int dpft_add_inplace_f32(float* a, const float* b, int64_t n, dpft_stream_t stream) {
+    return dpft::add_inplace_any(a, b, n, false, stream);
+}
+
+int dpft::cvt_f32_to_bf16(const float* src, float* dst_bf16, int64_t n, dpft_stream_t stream) {
+    DPFT_REQUIRE(src && dst_bf16 && n > 0 && n % 4 == 0, "cvt_f32_to_bf16: bad arguments");
+    hipLaunchKernelGGL(cvt_f32_bf16_kernel, dim3(ew_blocks(n / 4)), dim3(256), 0, (hipStream_t)stream, src, dst_bf16, n / 4);
+    return check_launch("cvt_f32_to_bf16");
 }
 
 extern "C" int dpft_fpn_topdown_add_f32(float* lat, const float* top, int32_t B, int32_t H, int32_t W,

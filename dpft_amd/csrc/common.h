@@ -15,11 +15,21 @@ namespace dpft {
 void set_error(const char* fmt, ...);
 int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
                         const float* res_mask, void* workspace, dpft_stream_t stream);      // conv.hip
+// bn.hip -- `act16`: the activation / gradient tensors (y, dout, out, dy, res) are bf16 in memory (the pointers keep
+// their float* type); BN blocks, sums and parameter gradients are fp32
 int bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
-                            float* sums, int64_t M, int32_t K, dpft_stream_t stream);                       // bn.hip
+                            float* sums, int64_t M, int32_t K, bool act16, dpft_stream_t stream);
 int bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                          const float* gamma, const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
-                         int32_t K, float* zero_buf, int32_t zero_n, dpft_stream_t stream);                // bn.hip
+                         int32_t K, float* zero_buf, int32_t zero_n, bool act16, dpft_stream_t stream);
+int bn_act_any(const float* y, const float* bnp, const float* res, const float* res_bnp, int32_t relu, float* out,
+               float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream);
+int bn_relu_maxpool_any(const float* y, const float* bnp, float* out, int32_t B, int32_t H, int32_t W, int32_t K,
+                        int32_t PH, int32_t PW, bool out16, dpft_stream_t stream);
+int bn_relu_maxpool_bwd_any(const float* y, const float* bnp, const float* dout, float* dact, int32_t B, int32_t H,
+                            int32_t W, int32_t K, int32_t PH, int32_t PW, bool dout16, dpft_stream_t stream);
+int add_inplace_any(float* a, const float* b, int64_t n, bool a16, dpft_stream_t stream);
+int cvt_f32_to_bf16(const float* src, float* dst_bf16, int64_t n, dpft_stream_t stream);
 struct BnEvalBatch {      // eval-mode BN blocks of up to 16 layers (bn.hip)
     const float *gamma[16], *beta[16], *rm[16], *rv[16];
     float* out[16];

@@ -41,6 +41,39 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 constexpr int LDG = BK + 1;   // generic path: odd pad, ds_read_b32 fragments
 constexpr int BKP = 64;       // wgrad vector path: pixels per step
 
+// Activation tensors may live in HBM as bf16 (dpft_conv_desc.act16: mixed-precision storage of BASELINE.json configs[4]).
+// A loader lane still owns 4 consecutive channels: 8 bytes instead of 16.  Offsets keep their fp32 (x 4 bytes) form and
+// are halved at the load (the out-of-range marker 0x80000000 >> 1 still lies beyond any tensor), the 4 values are
+// widened to fp32 registers -- everything downstream (BN + ReLU prologue, LDS formats, MFMA) is unchanged.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 widen_bf16x4(u32x2 v) {
+    return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                 __uint_as_float(v[1] & 0xffff0000u)};
+}
+__device__ __forceinline__ f32x4 ld4(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff, bool half16) {
+    if (half16)
+        return widen_bf16x4(__builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff >> 1), soff >> 1, 0)));
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, soff, 0));
+}
+// the same 4 channels as their raw bf16 bits: written into lanes 0,1 of an existing register quad, lanes 2,3 are left
+// alone (building a fresh {lo, hi, 0, 0} quad is a USE of the load and makes the compiler wait for it on the spot).
+// Operands that need no arithmetic on the way into a bf16 LDS tile (data gradients, un-normalised inputs) are copied
+// as they are, the others are widened when their register set is consumed.
+__device__ __forceinline__ void ld4_raw16(f32x4& dst, __amdgpu_buffer_rsrc_t rsrc, unsigned voff, int soff) {
+    const u32x2 v = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(voff >> 1), soff >> 1, 0));
+    dst[0] = __uint_as_float(v[0]);
+    dst[1] = __uint_as_float(v[1]);
+}
+typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4 load4_act(const float* base, size_t off, bool half16) {      // off in elements
+    if (half16) return __builtin_convertvector(*reinterpret_cast<const bf16x4s*>(reinterpret_cast<const __bf16*>(base) + off), f32x4);
+    return *reinterpret_cast<const f32x4*>(base + off);
+}
+__device__ __forceinline__ void store4_act(float* base, size_t off, f32x4 v, bool half16) {
+    if (half16) *reinterpret_cast<bf16x4s*>(reinterpret_cast<__bf16*>(base) + off) = __builtin_convertvector(v, bf16x4s);
+    else *reinterpret_cast<f32x4*>(base + off) = v;
+}
+
 struct IgemmArgs {
     const float* x;
     const float* w;
@@ -65,6 +98,7 @@ struct IgemmArgs {
     // r = sub_r0 + sub_step*k, s = sub_s0 + sub_step*l can hit them (all others fall between the dy samples).
     // A plain launch over all pixels and taps would spend stride^2 = 4x the MFMA work on structural zeros.
     int sub_step, sub_ph, sub_pw, sub_oh, sub_ow, sub_r0, sub_s0, sub_nr, sub_ns;
+    int x16, y16;     // the A-source tensor / the output tensor (and res_src, res_mask, accumulate source) are bf16
 };
 
 // output row (GEMM row m) -> pixel index of the output tensor
@@ -156,6 +190,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.M * a.N : a.y;
     const bool add_bias = (a.bias != nullptr) && (a.partial == nullptr);
     const bool accum = a.accumulate && (a.partial == nullptr);
+    const bool y16 = a.y16 && (a.partial == nullptr);      // split-K partials stay fp32
     if ((a.N & 3) == 0) {
         constexpr int C4 = BN / 4;
         constexpr int ITER = BM * C4 / 256;
@@ -170,27 +205,31 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
                     const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c4 * 4;
                     if (resid) {
-                        const f32x4 g = *reinterpret_cast<const f32x4*>(a.res_src + off);
-                        const f32x4 o = *reinterpret_cast<const f32x4*>(a.res_mask + off);
+                        const f32x4 g = load4_act(a.res_src, off, y16);
+                        const f32x4 o = load4_act(a.res_mask, off, y16);
 #pragma unroll
                         for (int e = 0; e < 4; ++e) old[it][e] = o[e] > 0.f ? g[e] : 0.f;
                     } else {
-                        old[it] = *reinterpret_cast<const f32x4*>(out + off);
+                        old[it] = load4_act(out, off, y16);
                     }
                 }
             }
         }
+        auto store_all = [&](auto H16) {
 #pragma unroll
-        for (int it = 0; it < ITER; ++it) {
-            const int idx = tid + it * 256;
-            const int row = idx / C4, c4 = idx - row * C4;
-            if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
-                if (add_bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + c4 * 4);
-                if (accum || resid) v += old[it];
-                *reinterpret_cast<f32x4*>(out + out_pixel(a, m0 + row) * a.N + n0 + c4 * 4) = v;
+            for (int it = 0; it < ITER; ++it) {
+                const int idx = tid + it * 256;
+                const int row = idx / C4, c4 = idx - row * C4;
+                if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
+                    if (add_bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + c4 * 4);
+                    if (accum || resid) v += old[it];
+                    store4_act(out, out_pixel(a, m0 + row) * a.N + n0 + c4 * 4, v, decltype(H16)::value);
+                }
             }
-        }
+        };
+        if (y16) store_all(std::true_type{});
+        else store_all(std::false_type{});
     } else {
         for (int idx = tid; idx < BM * BN; idx += 256) {
             const int row = idx / BN, c = idx - row * BN;
@@ -326,7 +365,9 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         b_off[i] = n < a.N ? (unsigned)(n * a.Ktot + chunk * 4) * 4u : OOB;
     }
     const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * (a.x16 ? 2 : 4), 0x00020000);
+    const bool x16 = a.x16 != 0;
+    const bool raw_a = BF16 && !X3 && !PRO && x16;      // bf16 tensor -> bf16 LDS tile without arithmetic: copy the bits
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.N * a.Ktot * 4, 0x00020000);
     const int cpt = a.C / BKV;  // K-steps per filter tap
@@ -393,10 +434,20 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
             p_mu[sidx] = *reinterpret_cast<const f32x4*>(a.pro + c0 + chunk * 4);
             p_sc[sidx] = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + chunk * 4);
             p_sh[sidx] = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + chunk * 4);
+            // bf16 operands: one fma per element, bn(v) = v * scale + (beta - mean * scale).  (The fp32 path subtracts the
+            // mean first: that form keeps digits when |mean| >> sigma; with an 8-bit mantissa downstream it buys nothing.)
+            if (BF16) p_sh[sidx] -= p_mu[sidx] * p_sc[sidx];
         }
+        // one uniform branch around the whole batch of loads (a select per load would put every load in its own basic
+        // block and serialise them).  bf16 tensors arrive as raw bits (lanes 0,1 of the quad) and are widened only when
+        // the register set is consumed in store_tile: touching a load here would put its latency in front of the MFMAs.
+        if (x16) {
 #pragma unroll
-        for (int i = 0; i < AP; ++i)
-            ra[sidx][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_off[i], c0 * 4, 0));
+            for (int i = 0; i < AP; ++i) ld4_raw16(ra[sidx][i], rsrc_a, a_off[i], c0 * 4);
+        } else {
+#pragma unroll
+            for (int i = 0; i < AP; ++i) ra[sidx][i] = ld4(rsrc_a, a_off[i], c0 * 4, false);
+        }
         a_valid[sidx] = a_valid_tap;
 #pragma unroll
         for (int i = 0; i < BP; ++i)
@@ -416,19 +467,34 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     const bool pro_mask = a.kh * a.kw > 1 || a.pad > 0;      // padding exists: BN(0) != 0 must be forced back to 0
     auto store_tile = [&](auto S) {
         constexpr int sidx = decltype(S)::value;
+        // (storage-format branches stay OUTSIDE the unrolled loops: a branch per register quad puts every store in its
+        // own basic block with its own wait)
+        if (BF16 && raw_a) {
 #pragma unroll
-        for (int i = 0; i < AP; ++i) {
-            f32x4 val = ra[sidx][i];
-            if (PRO) {
+            for (int i = 0; i < AP; ++i)
+                *reinterpret_cast<u32x2*>(&Ah[(rowl + 16 * i) * LDKH + chunk * 4]) =
+                    u32x2{__float_as_uint(ra[sidx][i][0]), __float_as_uint(ra[sidx][i][1])};
+        } else {
+            if (x16) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    float t = fmaf(val[e] - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
-                    val[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
-                }
-                if (pro_mask && !((a_valid[sidx] >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int i = 0; i < AP; ++i)
+                    ra[sidx][i] = widen_bf16x4(u32x2{__float_as_uint(ra[sidx][i][0]), __float_as_uint(ra[sidx][i][1])});
             }
-            if (BF16) store_bf16(&Ah[(rowl + 16 * i) * LDKH + chunk * 4], val);
-            else *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
+#pragma unroll
+            for (int i = 0; i < AP; ++i) {
+                f32x4 val = ra[sidx][i];
+                if (PRO) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float t = BF16 ? fmaf(val[e], p_sc[sidx][e], p_sh[sidx][e])
+                                       : fmaf(val[e] - p_mu[sidx][e], p_sc[sidx][e], p_sh[sidx][e]);
+                        val[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
+                    }
+                    if (pro_mask && !((a_valid[sidx] >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                if (BF16) store_bf16(&Ah[(rowl + 16 * i) * LDKH + chunk * 4], val);
+                else *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
+            }
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
@@ -852,6 +918,7 @@ struct WgradArgs {
     int ktiles, ctiles, taps, splits, psteps, psteps_per_split;
     int pro_relu;
     int J;            // generic path: taps*C
+    int x16, dy16;    // x / dy stored as bf16 (vector path only)
 };
 
 // BF16 = true (mixed-precision mode, square tiles): both operands are rounded to bf16 and TRANSPOSED on their
@@ -892,6 +959,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + xch * 4);
         sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + xch * 4);
         sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + xch * 4);
+        if (BF16) sh -= mu * sc;      // one fma per element (see igemm_vec_kernel)
     }
     const int ohw = a.OH * a.OW;
 
@@ -901,9 +969,11 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     // buffer loads, dy rows at fixed per-lane offsets + a scalar pixel offset, and for x a (b, oh, ow) triple per loader
     // row that is decomposed once and then ADVANCED by the 64 pixels of a step with two carries.
     constexpr unsigned OOB = 0x80000000u;
-    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * 4, 0x00020000);
+    const bool x16 = a.x16 != 0, dy16 = a.dy16 != 0;
+    const __amdgpu_buffer_rsrc_t rsrc_y =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * (dy16 ? 2 : 4), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_x =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * (x16 ? 2 : 4), 0x00020000);
     // pixel (within the step) of loader pass i: fp32 -- row + i * rows-per-pass; bf16 -- passes 2k, 2k+1 are ADJACENT pixels
     // (they share one 32-bit LDS word of the transposed tile)
     auto ypix = [&](int i) { return BF16 ? 2 * YRP * (i >> 1) + 2 * yrow + (i & 1) : yrow + i * YRP; };
@@ -928,22 +998,34 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     const int x_lane = (c0 + xch * 4);
     auto load_tile = [&](int ps) {      // called once per step, in step order
         const int soff_y = ps * BKP * a.K * 4;
+        if (dy16) {      // bf16 tensors: raw bits now, widened when the registers are consumed (see igemm_vec_kernel)
 #pragma unroll
-        for (int i = 0; i < YP; ++i)
-            ry[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, (int)y_voff[i], soff_y, 0));
+            for (int i = 0; i < YP; ++i) ld4_raw16(ry[i], rsrc_y, y_voff[i], soff_y);
+        } else {
+#pragma unroll
+            for (int i = 0; i < YP; ++i) ry[i] = ld4(rsrc_y, y_voff[i], soff_y, false);
+        }
         unsigned valid = 0;
+        unsigned xoffs[XP];
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int hi = xoh[i] * a.stride - a.pad + r, wi = xow[i] * a.stride - a.pad + s;
             const bool v = x_ok && xb[i] < a.B && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
             const unsigned e = ((((unsigned)xb[i] * a.H + hi) * a.W + wi) * a.C + x_lane) * 4u;      // garbage where !v
-            rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)(v ? e : OOB), 0, 0));
+            xoffs[i] = v ? e : OOB;
             valid |= v ? (1u << i) : 0u;
             // advance to the next step's pixel
             int ow = xow[i] + adv_ow, oh = xoh[i] + adv_oh, b = xb[i] + adv_b;
             if (ow >= a.OW) { ow -= a.OW; ++oh; }
             if (oh >= a.OH) { oh -= a.OH; ++b; }
             xow[i] = ow; xoh[i] = oh; xb[i] = b;
+        }
+        if (x16) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) ld4_raw16(rx[i], rsrc_x, xoffs[i], 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) rx[i] = ld4(rsrc_x, xoffs[i], 0, false);
         }
         x_valid = valid;
     };
@@ -984,14 +1066,23 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
         if (PRO) {      // producer BN+ReLU applied after the MFMAs of the current step (see igemm_vec_kernel)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const float t = fmaf(v[e] - mu[e], sc[e], sh[e]);
+                const float t = BF16 ? fmaf(v[e], sc[e], sh[e]) : fmaf(v[e] - mu[e], sc[e], sh[e]);
                 v[e] = a.pro_relu ? fmaxf(t, 0.f) : t;
             }
             if (!((x_valid >> i) & 1u)) v = f32x4{0.f, 0.f, 0.f, 0.f};      // padding / pixel tail: BN(0) != 0
         }
         return v;
     };
+    auto unraw = [](f32x4 v) { return widen_bf16x4(u32x2{__float_as_uint(v[0]), __float_as_uint(v[1])}); };
     auto store_tile = [&]() {
+        if (dy16) {
+#pragma unroll
+            for (int i = 0; i < YP; ++i) ry[i] = unraw(ry[i]);
+        }
+        if (x16) {
+#pragma unroll
+            for (int i = 0; i < XP; ++i) rx[i] = unraw(rx[i]);
+        }
         if constexpr (BF16) {
 #pragma unroll
             for (int i = 0; i < YP; i += 2) store_pair(Yh, ych, ypix(i), ry[i], ry[i + 1]);
@@ -1553,6 +1644,10 @@ static int check_desc(const dpft_conv_desc* d) {
                  d->OH, d->OW, oh, ow);
     DPFT_REQUIRE((int64_t)d->B * d->H * d->W * d->C < (1ll << 31) &&
                  (int64_t)d->B * d->OH * d->OW * d->K < (1ll << 31), "conv: tensor too large for 32-bit row indices");
+    DPFT_REQUIRE(d->act16 == 0 || d->act16 == 1, "conv: act16 must be 0 or 1 (is the descriptor zero-initialised?)");
+    // bf16 activation storage rides on the vector loaders / the staged epilogue only
+    DPFT_REQUIRE(!d->act16 || (d->C % BKV == 0 && d->K % BKV == 0 && d->kh <= 8 && d->kw <= 8),
+                 "conv: act16 (bf16 activation storage) needs C %% 64 == 0 and K %% 64 == 0 (C=%d, K=%d)", d->C, d->K);
     return DPFT_OK;
 }
 
@@ -1613,8 +1708,10 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
     a.pro = pro_bn; a.pro_relu = pro_relu;
+    a.x16 = a.y16 = d->act16;
     const bool pro = pro_bn != nullptr;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (d->act16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors
     DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 64 == 0 (C=%d)", d->C);
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
@@ -1666,11 +1763,12 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     }
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
+    a.x16 = a.y16 = d->act16;
     // Parity classes pay when each class fills the chip on its own (4x fewer MFMAs); on small maps (radar encoders) the
     // stride^2 classes are stride^2 dependent launches of a few workgroups with the whole tap x channel loop inside
     // (170 us for a 4x16x7 map) -- there one split-K launch over all taps is ~6x faster despite the wasted taps.
     const int64_t class_wgs = (int64_t)cdiv((int64_t)a.B * cdiv(a.OH, d->stride) * cdiv(a.OW, d->stride), 64) * cdiv(a.N, 64);
-    if (d->stride > 1 && (a.C % BKV) == 0 && (class_wgs >= kNumCU / 2 || !workspace)) {
+    if (d->stride > 1 && (a.C % BKV) == 0 && (class_wgs >= kNumCU / 2 || !workspace || d->act16)) {
         // one launch per output-pixel parity class, each over the taps that can reach it (see IgemmArgs::sub_*)
         const int sp = d->stride, cpt = a.C / BKV;
         bool empty_class = false;
@@ -1680,7 +1778,7 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
                 if (r0 >= d->kh || s0 >= d->kw) empty_class = true;
             }
         if (empty_class && !accumulate)      // pixels no tap reaches (1x1 stride-2: three of four) are plain zeros
-            DPFT_REQUIRE(hipMemsetAsync(dx, 0, sizeof(float) * (size_t)a.B * a.OH * a.OW * a.N, st) == hipSuccess,
+            DPFT_REQUIRE(hipMemsetAsync(dx, 0, (d->act16 ? 2 : sizeof(float)) * (size_t)a.B * a.OH * a.OW * a.N, st) == hipSuccess,
                          "conv dgrad: memset failed");
         for (int ph = 0; ph < sp; ++ph)
             for (int pw = 0; pw < sp; ++pw) {
@@ -1701,6 +1799,7 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
         return DPFT_OK;
     }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (d->act16) t.splits = 1;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
         a.partial = (float*)workspace;
@@ -1727,7 +1826,9 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     ProfScope prof(1, d, st);
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.res_src = res_src; a.res_mask = res_mask;
+    a.x16 = a.y16 = d->act16;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (d->act16) t.splits = 1;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
         a.partial = (float*)workspace;
@@ -1758,6 +1859,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     }
     WgradArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy; a.dw = dw; a.pro = pro_bn; a.pro_relu = pro_relu;
+    a.x16 = a.dy16 = d->act16;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.OH = d->OH; a.OW = d->OW; a.K = d->K;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.M = d->B * d->OH * d->OW;

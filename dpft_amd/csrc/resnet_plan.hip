@@ -43,6 +43,7 @@ struct ResnetPlan {
     int PH, PW;
     int n_conv, n_bn;
     size_t out_off[4];
+    size_t out32_off[4];      // act16: fp32 copies of the stage outputs (what the neck reads)
     int out_shape[4][4];
     size_t fwd_floats;      // activations kept for backward
     size_t bwd_floats;      // backward temporaries (placed after fwd_floats)
@@ -73,6 +74,7 @@ static size_t align64(size_t f) { return (f + 63) & ~(size_t)63; }
 
 static dpft_conv_desc mk(int B, int H, int W, int C, int K, int k, int s, int p) {
     dpft_conv_desc d;
+    d.act16 = 0;
     d.B = B; d.H = H; d.W = W; d.C = C; d.K = K; d.kh = k; d.kw = k; d.stride = s; d.pad = p;
     d.OH = (H + 2 * p - k) / s + 1;
     d.OW = (W + 2 * p - k) / s + 1;
@@ -155,6 +157,8 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
             } else {
                 bp.cd.w = -1; bp.bnd = -1;
             }
+            bp.c1.d.act16 = bp.c2.d.act16 = bp.c3.d.act16 = desc->act16 ? 1 : 0;      // bf16 activation storage inside the body
+            if (bp.has_ds) bp.cd.d.act16 = desc->act16 ? 1 : 0;
             bp.y1 = take(nelem_out(bp.c1.d));  bp.p1 = take(4 * planes);  bp.s1 = take(stats_of(bp.c1.d, bp.t1, bp.r1));
             bp.y2 = take(nelem_out(bp.c2.d));  bp.p2 = take(4 * planes);  bp.s2 = take(stats_of(bp.c2.d, bp.t2, bp.r2));
             bp.y3 = take(nelem_out(bp.c3.d));  bp.p3 = take(4 * planes * 4);  bp.s3 = take(stats_of(bp.c3.d, bp.t3, bp.r3));
@@ -172,6 +176,7 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
             curH = oh; curW = ow; inC = planes * 4;
         }
         p->out_off[li] = cur;
+        p->out32_off[li] = desc->act16 ? take(nelem_out(p->blocks.back().c3.d)) : cur;
         p->out_shape[li][0] = B; p->out_shape[li][1] = curH; p->out_shape[li][2] = curW; p->out_shape[li][3] = inC;
     }
     p->n_conv = nconv;
@@ -219,7 +224,7 @@ extern "C" int64_t dpft_resnet_plan_query(int64_t h, int32_t what, int32_t idx) 
         case 0: return (int64_t)p->arena_bytes;
         case 1: return p->n_conv;
         case 2: return p->n_bn;
-        case 3: return (int64_t)p->out_off[idx];          // float offset of stage output idx
+        case 3: return (int64_t)p->out32_off[idx];        // float offset of (the fp32 form of) stage output idx
         case 4: return p->out_shape[idx / 4][idx % 4];    // shape entries
         case 5: return (int64_t)p->fwd_floats;
         default: return -1;
@@ -245,6 +250,12 @@ struct Tables {
         int rc_ = (call);     \
         if (rc_) return rc_;  \
     } while (0)
+
+// act16: the last block of a stage also writes the fp32 copy of its output that the neck reads
+static float* stage_out32(const ResnetPlan* p, const BlockPlan& b, float* A) {
+    if (!p->desc.act16 || b.out != p->out_off[b.layer]) return nullptr;
+    return A + p->out32_off[b.layer];
+}
 
 static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* stats, int tiles, int rows, int64_t M,
                      int K, float* bnp, bool train, dpft_stream_t st) {
@@ -298,7 +309,8 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
     }
     RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr ? A + p->s0 : nullptr, ws, st));
     RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr, st));
-    RC(dpft_bn_relu_maxpool_f32(A + p->y0, A + p->p0, A + p->pool, p->c0.d.B, p->c0.d.OH, p->c0.d.OW, 64, p->PH, p->PW, st));
+    const bool a16 = p->desc.act16 != 0;
+    RC(bn_relu_maxpool_any(A + p->y0, A + p->p0, A + p->pool, p->c0.d.B, p->c0.d.OH, p->c0.d.OW, 64, p->PH, p->PW, a16, st));
     for (const BlockPlan& b : p->blocks) {
         const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
         RC(dpft_conv2d_nhwc_fwd_f32(&b.c1.d, A + b.x, T.w(b.c1.w), nullptr, nullptr, 0, A + b.y1, tr ? A + b.s1 : nullptr, ws, st));
@@ -310,9 +322,9 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
         if (b.has_ds) {
             RC(dpft_conv2d_nhwc_fwd_f32(&b.cd.d, A + b.x, T.w(b.cd.w), nullptr, nullptr, 0, A + b.yd, tr ? A + b.sd : nullptr, ws, st));
             RC(bn_params(p, T, b.bnd, A + b.sd, b.td, b.rd, M2, b.cd.d.K, A + b.pd, tr, st));
-            RC(dpft_bn_act_f32(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, M2, b.c3.d.K, st));
+            RC(bn_act_any(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st));
         } else {
-            RC(dpft_bn_act_f32(A + b.y3, A + b.p3, A + b.x, nullptr, 1, A + b.out, M2, b.c3.d.K, st));
+            RC(bn_act_any(A + b.y3, A + b.p3, A + b.x, nullptr, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st));
         }
     }
     p->g_valid = false;
@@ -330,12 +342,12 @@ struct BnSums {
 };
 static int bn_backward(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                        const float* gamma, BnSums& bs, float* dy, float* dgamma, float* dbeta, int64_t M, int K,
-                       dpft_stream_t st) {
+                       dpft_stream_t st, bool act16 = false) {
     float* sums = bs.buf[bs.cur];
     float* other = bs.buf[bs.cur ^ 1];
     bs.cur ^= 1;
-    RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, st));
-    return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, st);
+    RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st));
+    return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, act16, st);
 }
 
 // Weight gradients do not feed the rest of the backward, so they run on the plan's side stream while the main
@@ -416,27 +428,28 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     float* dyd = A + p->o_dd;
     float* wt = A + p->o_wt;
     const int planes = b.c1.d.K, K3 = b.c3.d.K;
+    const bool a16 = p->desc.act16 != 0;
     const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
     int& cur = p->dyi;
     // bn3 (+ the residual ReLU mask taken from the block output)
     RC(sc.acquire(cur));
-    RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st));
+    RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16));
     RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
     RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyv[cur], wt + b.c3.wt, dab, 0, ws, st));
     cur ^= 1;
     // bn2 (fused-ReLU mask recomputed from its BN block)
     RC(sc.acquire(cur));
-    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st));
+    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st, a16));
     RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
     RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyv[cur], wt + b.c2.wt, dab, 0, ws, st));
     cur ^= 1;
     // bn1
     RC(sc.acquire(cur));
-    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyv[cur], T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st));
+    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyv[cur], T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st, a16));
     RC(sc.wgrad(cur, &b.c1.d, A + b.x, dyv[cur], nullptr, 0, T.dw(b.c1.w)));
     if (b.has_ds) {
         RC(sc.acquire(2));
-        RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st));
+        RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st, a16));
         RC(sc.wgrad(2, &b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w)));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt + b.cd.wt, dx, 0, ws, st));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st));
@@ -467,14 +480,17 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
     const float* gp;
     if (!p->g_valid) {
         DPFT_REQUIRE(stage == p->desc.n_layers - 1, "resnet_backward: stages must start at the last one");
-        if (dout) {
+        if (dout && p->desc.act16) {      // external gradient arrives in fp32: the body's running gradient is bf16
+            RC(cvt_f32_to_bf16(dout, A + p->g_off[p->g_cur], (int64_t)out_n, st));
+            gp = A + p->g_off[p->g_cur];
+        } else if (dout) {
             gp = dout;
         } else {
             RC((int)hipMemsetAsync(A + p->g_off[p->g_cur], 0, out_n * sizeof(float), (hipStream_t)st));
             gp = A + p->g_off[p->g_cur];
         }
     } else {
-        if (dout) RC(dpft_add_inplace_f32(A + p->g_off[p->g_cur], dout, (int64_t)out_n, st));
+        if (dout) RC(add_inplace_any(A + p->g_off[p->g_cur], dout, (int64_t)out_n, p->desc.act16 != 0, st));
         gp = A + p->g_off[p->g_cur];
     }
     BnSums sums{{A + p->o_sums, A + p->o_sums + 2 * 2048}, 0};
@@ -497,7 +513,7 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         const int64_t M0 = (int64_t)d0.B * d0.OH * d0.OW;
         const int slot = p->dyi;
         float* dyb = A + (slot ? p->o_dy2 : p->o_dy);
-        RC(dpft_bn_relu_maxpool_bwd_f32(A + p->y0, A + p->p0, gp, dab, d0.B, d0.OH, d0.OW, 64, p->PH, p->PW, st));
+        RC(bn_relu_maxpool_bwd_any(A + p->y0, A + p->p0, gp, dab, d0.B, d0.OH, d0.OW, 64, p->PH, p->PW, p->desc.act16 != 0, st));
         RC(sc.acquire(slot));
         RC(bn_backward(A + p->y0, dab, nullptr, nullptr, A + p->p0, T.gamma(p->bn0), sums, dyb, T.dgamma(p->bn0), T.dbeta(p->bn0), M0, 64, st));
         const float* xa = p->adj.w >= 0 ? A + p->xa : x;

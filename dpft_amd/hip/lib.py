@@ -21,7 +21,7 @@ class HipLibraryError(RuntimeError):
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "K", "kh", "kw", "stride", "pad", "OH", "OW")]
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "K", "kh", "kw", "stride", "pad", "OH", "OW", "act16")]
 
 
 class Pyramid(C.Structure):
@@ -32,7 +32,8 @@ class Pyramid(C.Structure):
 
 class ResnetDesc(C.Structure):
     _fields_ = [("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("in_channels", C.c_int32),
-                ("depths", C.c_int32 * 4), ("n_layers", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float)]
+                ("depths", C.c_int32 * 4), ("n_layers", C.c_int32), ("eps", C.c_float), ("momentum", C.c_float),
+                ("act16", C.c_int32)]
 
 
 class ResnetTables(C.Structure):

@@ -87,10 +87,11 @@ class ResNetBody(nn.Module):
 class _Plan:
     """Cached per (input shape): the C plan handle + arena geometry."""
 
-    def __init__(self, owner: "BackboneBase", B: int, H: int, W: int):
+    def __init__(self, owner: "BackboneBase", B: int, H: int, W: int, act16: bool = False):
         body = owner.body
         d = ResnetDesc()
         d.B, d.H, d.W, d.in_channels = B, H, W, owner.in_channels
+        d.act16 = int(act16)
         for i, n in enumerate(owner.depths):
             d.depths[i] = n
         d.n_layers = body.n_layers
@@ -249,11 +250,20 @@ class BackboneBase(nn.Module):
         if weights:
             self.load_state_dict(weights)
 
+    # bf16 activation storage inside the body (mixed precision, BASELINE.json configs[4]): taken when the conv GEMMs run
+    # in bf16 mode AND the maps are large (the camera encoder: >= 500k input pixels per batch) -- the small radar maps
+    # live on split-K launches whose reduction kernels write fp32
+    ACT16_MIN_PIXELS = 500_000
+
     def _plan(self, B: int, H: int, W: int) -> "_Plan":
-        key = (B, H, W)
+        from dpft_amd.hip import ops as _ops
+        import os as _os
+        act16 = _ops.conv_get_compute() == "bf16" and B * H * W >= self.ACT16_MIN_PIXELS \
+            and _os.environ.get("DPFT_ACT16", "1") != "0"           # DPFT_ACT16=0: keep fp32 storage (A/B measurements)
+        key = (B, H, W, act16)
         p = self._plans.get(key)
         if p is None:
-            p = self._plans[key] = _Plan(self, B, H, W)
+            p = self._plans[key] = _Plan(self, B, H, W, act16)
         return p
 
     def __getstate__(self):          # plans hold native handles: rebuild lazily after unpickling / deepcopy

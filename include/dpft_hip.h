@@ -54,6 +54,11 @@ typedef struct dpft_conv_desc {
     int32_t K;               /* output channels                       */
     int32_t kh, kw, stride, pad;
     int32_t OH, OW;          /* output spatial size                   */
+    int32_t act16;           /* 0: activations (x, y, dy, dx, residual sources) are fp32 tensors;
+                              * 1: they are bf16 tensors ("bf16 mixed precision" storage of BASELINE.json configs[4]:
+                              *    4 channels = 8 bytes per loader lane, BatchNorm statistics still from the fp32
+                              *    accumulators); weights, weight gradients, BN blocks and statistics stay fp32.
+                              *    Needs C % 64 == 0 and K % 64 == 0; the pointers are still declared const float*.  */
 } dpft_conv_desc;
 
 /* bytes of workspace dpft_conv2d_* may need for this problem (split-K partials); may be 0 */
@@ -159,6 +164,10 @@ typedef struct dpft_resnet_desc {
     int32_t depths[4];              /* bottlenecks per stage, e.g. {3,4,23,3}                       */
     int32_t n_layers;               /* stages to run (multi_scale), 1..4                            */
     float eps, momentum;            /* BatchNorm2d hyper-parameters (1e-5, 0.1)                     */
+    int32_t act16;                  /* 1: bf16 activation / gradient storage inside the body (dpft_conv_desc.act16;
+                                     * with dpft_conv_set_compute(1) = the mixed precision of BASELINE.json configs[4]);
+                                     * input image, stem conv output, stage outputs handed to the caller, all
+                                     * parameters, BatchNorm statistics and parameter gradients stay fp32          */
 } dpft_resnet_desc;
 
 /* Pointer tables in plan order.  conv: [adjustment], stem conv1, then per bottleneck conv1, conv2,

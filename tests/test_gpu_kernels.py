@@ -722,3 +722,69 @@ def test_fused_head_block_vs_oracle(B, Q, V, ncls, flags):
     for a, b_, n in zip(outs, outs_ref, ["x", "center", "size", "angle", "class", "refs"]):
         torch.testing.assert_close(a.detach().double().cpu(), b_.detach(), rtol=1e-4, atol=1e-4, msg=lambda m: f"{n}: {m}")
     _check_grads(gout, gref, ["y3", "prev"] + [f"w{i}" for i in range(len(weights))], 5e-4)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# bf16 activation storage (dpft_conv_desc.act16): the conv kernels read / write bf16 tensors, fp32 accumulation
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,K,k,stride", [(2, 24, 40, 64, 128, 3, 1), (2, 24, 40, 128, 64, 1, 1), (1, 33, 29, 64, 64, 3, 2),
+                                                    (2, 16, 24, 256, 256, 3, 1)])
+def test_conv_bf16_activation_storage(B, H, W, Cin, K, k, stride):
+    """Forward (with fused BN+ReLU prologue and BN-statistics epilogue), data gradient (plain, accumulate) and weight
+    gradient on bf16 activation tensors vs fp64 references evaluated on the SAME bf16-rounded inputs: what is left is
+    the bf16 rounding of the operands inside the GEMM and of the stored output (2^-9 relative each)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from dpft_amd.hip import ops
+    from dpft_amd.hip.lib import lib, make_desc, ptr, stream
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(13)
+    pad = k // 2
+    d = make_desc(B, H, W, Cin, K, k, k, stride, pad)
+    d.act16 = 1
+    x = torch.randn(B, H, W, Cin, generator=g).bfloat16().to(dev)
+    w = (torch.randn(K, k, k, Cin, generator=g) * 0.05).to(dev)
+    mean, scale, beta = torch.randn(Cin, generator=g) * 0.2, torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.2
+    bnp = torch.stack((mean, scale, beta, torch.ones(Cin))).to(dev)
+    dy = torch.randn(B, d.OH, d.OW, K, generator=g).bfloat16().to(dev)
+    tr = C.c_int32(0)
+    tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(d), C.byref(tr)))
+    ws = torch.empty(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (64 << 20), dtype=torch.uint8, device=dev)
+    ops.conv_set_compute("bf16")
+    try:
+        y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device=dev)
+        stats = torch.empty(tiles, 2, K, dtype=torch.float32, device=dev)
+        lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(d), ptr(x), ptr(w), None, ptr(bnp), 1, ptr(y), ptr(stats), ptr(ws), stream())
+        wt = ops.weight_transpose(w)
+        dx = torch.empty(B, H, W, Cin, dtype=torch.bfloat16, device=dev)
+        lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, ptr(ws), stream())
+        dx2 = dx.clone()
+        lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(d), ptr(dy), ptr(wt), ptr(dx2), 1, ptr(ws), stream())
+        dw = torch.empty(K, k, k, Cin, dtype=torch.float32, device=dev)
+        lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(d), ptr(x), ptr(dy), ptr(bnp), 1, ptr(dw), ptr(ws), stream())
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_set_compute("fp32")
+    # fp64 references on the same (bf16-valued) inputs
+    x64 = x.double().cpu().requires_grad_(True)
+    w64 = w.double().cpu().requires_grad_(True)
+    act = torch.relu((x64 - mean.double()) * scale.double() + beta.double())
+    y_ref = F.conv2d(act.permute(0, 3, 1, 2), w64.permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    (y_ref * dy.double().cpu()).sum().backward()
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(y, y_ref.detach()) < 8e-3, rel(y, y_ref.detach())
+    assert rel(dw, w64.grad) < 8e-3, rel(dw, w64.grad)
+    # statistics come from the fp32 accumulators (not from the rounded output): merged mean per channel
+    cnt = torch.full((tiles,), float(tr.value)); cnt[-1] = B * d.OH * d.OW - tr.value * (tiles - 1)
+    m = (stats[:, 0].double().cpu() * cnt[:, None]).sum(0) / cnt.sum()
+    assert float((m - y_ref.detach().reshape(-1, K).mean(0)).abs().max()) < 6e-3 * float(y_ref.detach().abs().mean()) + 1e-3
+    # data gradient of the plain conv (no prologue): linear in dy
+    dy64 = dy.double().cpu()
+    dx_ref = torch.autograd.grad(F.conv2d(x64.detach().requires_grad_(True).permute(0, 3, 1, 2), w64.detach().permute(0, 3, 1, 2),
+                                          stride=stride, padding=pad), [], allow_unused=True) if False else None
+    xin = x64.detach().clone().requires_grad_(True)
+    out = F.conv2d(xin.permute(0, 3, 1, 2), w64.detach().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    (out * dy64).sum().backward()
+    assert rel(dx, xin.grad) < 8e-3, rel(dx, xin.grad)
+    assert rel(dx2, 2 * xin.grad) < 1.2e-2, rel(dx2, 2 * xin.grad)      # accumulate: dx (bf16) + dgrad, rounded again
