@@ -111,9 +111,10 @@ def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
     return out
 
 
-def conv_wgrad(cv: Conv, x, dy, pro=None):
-    """dw physical [K][kh][kw][C] (returned as a (K,kh,kw,C) tensor)."""
-    dw = torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
+def conv_wgrad(cv: Conv, x, dy, pro=None, out=None):
+    """dw physical [K][kh][kw][C] (returned as a (K,kh,kw,C) tensor).  ``out``: write into this buffer (same physical
+    layout, e.g. a DP bucket view) instead of a fresh tensor."""
+    dw = out if out is not None else torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
     lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(pb), prelu, ptr(dw),
@@ -129,9 +130,9 @@ def weight_transpose(w_khwc: torch.Tensor) -> torch.Tensor:
     return wt
 
 
-def bias_grad(dy: torch.Tensor) -> torch.Tensor:
+def bias_grad(dy: torch.Tensor, out=None) -> torch.Tensor:
     K = dy.shape[-1]
-    db = torch.empty((K,), dtype=torch.float32, device=dy.device)
+    db = out if out is not None else torch.empty((K,), dtype=torch.float32, device=dy.device)
     lib.call("dpft_bias_grad_f32", ptr(dy), ptr(db), dy.numel() // K, K, stream())
     return db
 

@@ -36,7 +36,7 @@ class FeaturePyramidNetwork(nn.Module):
 
 class _FPNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, fpn: FeaturePyramidNetwork, n: int, *tensors: torch.Tensor):
+    def forward(ctx, owner, fpn: FeaturePyramidNetwork, n: int, *tensors: torch.Tensor):
         xs = [t.contiguous() for t in tensors[:n]]
         K = fpn.out_channels
         lasts, outs, ci, cl = [None] * n, [None] * n, [None] * n, [None] * n
@@ -54,12 +54,27 @@ class _FPNFn(torch.autograd.Function):
         ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl = fpn, n, xs, lasts, ci, cl
         ctx.params = tensors[n:]
         ctx.x_needs = [t.requires_grad for t in tensors[:n]]
+        # DP reducer attached by the trainer: weight / bias gradients are written straight into its bucket views
+        # (each FPN parameter receives exactly one gradient per step) instead of going through AccumulateGrad
+        direct = owner.grad_direct if owner is not None else None
+        if direct is not None and any(direct.grad_buffer(p) is None for p in fpn.parameters()):
+            direct = None
+        ctx.direct = direct
         return tuple(outs)
 
     @staticmethod
     def backward(ctx, *douts):
-        fpn, n, xs, lasts, ci, cl = ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl
+        fpn, n, xs, lasts, ci, cl, direct = ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl, ctx.direct
         grads: Dict[nn.Parameter, torch.Tensor] = {}
+
+        def wgrad(cv, x, dy, conv):
+            if direct is not None:          # bucket view of a conv weight: physically [K][kh][kw][C]
+                ops.conv_wgrad(cv, x, dy, out=direct.grad_buffer(conv.weight).permute(0, 2, 3, 1))
+                ops.bias_grad(dy, out=direct.grad_buffer(conv.bias))
+            else:
+                grads[conv.weight] = ops.conv_wgrad(cv, x, dy).permute(0, 3, 1, 2)
+                grads[conv.bias] = ops.bias_grad(dy)
+
         dxs: List[Optional[torch.Tensor]] = [None] * n
         g_prev = None
         for i in range(n):
@@ -68,18 +83,18 @@ class _FPNFn(torch.autograd.Function):
                 g = torch.zeros_like(lasts[i])
             else:
                 do = douts[i].contiguous()
-                grads[conv.weight] = ops.conv_wgrad(cl[i], lasts[i], do).permute(0, 3, 1, 2)
-                grads[conv.bias] = ops.bias_grad(do)
+                wgrad(cl[i], lasts[i], do, conv)
                 g = ops.conv_dgrad(cl[i], do, ops.weight_transpose(khwc(conv.weight)))
             if g_prev is not None:
                 ops.fpn_topdown_add_bwd_(g_prev, g)       # grad(last_i) += upsample_bwd(grad(last_{i-1}))
             conv = fpn.inner_blocks[i][0]
-            grads[conv.weight] = ops.conv_wgrad(ci[i], xs[i], g).permute(0, 3, 1, 2)
-            grads[conv.bias] = ops.bias_grad(g)
+            wgrad(ci[i], xs[i], g, conv)
             if ctx.x_needs[i]:
                 dxs[i] = ops.conv_dgrad(ci[i], g, ops.weight_transpose(khwc(conv.weight)))
             g_prev = g
-        return (None, None, *dxs, *[grads.get(p) for p in ctx.params])
+        if direct is not None:
+            direct.mark_ready_many(list(fpn.parameters()))
+        return (None, None, None, *dxs, *[grads.get(p) for p in ctx.params])
 
 
 class FPN(nn.Module):
@@ -92,6 +107,12 @@ class FPN(nn.Module):
         self.out_channels = out_channels
         self.channel_last = channel_last
         self.fpn = FeaturePyramidNetwork(in_channels_list, out_channels)
+        self.grad_direct = None     # optional DP reducer (grad_buffer / mark_ready_many), installed by the trainer
+
+    def __getstate__(self):          # the reducer belongs to a trainer, not to the module (torch.save(model), deepcopy)
+        st = self.__dict__.copy()
+        st["grad_direct"] = None
+        return st
 
     @classmethod
     def from_config(cls, config: Dict[str, Any]):
@@ -102,7 +123,7 @@ class FPN(nn.Module):
         xs = list(batch.values())
         if not self.channel_last:
             xs = [x.movedim(1, -1) for x in xs]
-        outs = _FPNFn.apply(self.fpn, len(xs), *xs, *self.fpn.parameters())
+        outs = _FPNFn.apply(self, self.fpn, len(xs), *xs, *self.fpn.parameters())
         if not self.channel_last:
             outs = [o.movedim(-1, 1) for o in outs]
         return OrderedDict(zip(keys, outs))
