@@ -305,9 +305,11 @@ def main():
                     traffic = json.load(f).get("traffic_bytes_per_launch")
                 traffic_src = "profiles/" + name
                 break
-        # mixed precision: priced against the dense bf16 MFMA peak although the operands still arrive as fp32 (the
-        # kernels are then bound by that fp32 operand path, not by the matrix pipe)
+        # mixed precision: priced against the dense bf16 MFMA peak (2.5 PF) -- the kernels are then bound by their operand
+        # path (global loads -> LDS -> fragments, two barriers per 64-deep K-step), not by the matrix pipe
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
+        family = {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
+                  "f32x3": "3 x bf16 split products on the bf16 MFMA, fp32 accumulation"}[args.dtype]
         # Accounting.  A bracket spans everything one dpft_conv2d_nhwc_* call launches: the implicit-GEMM
         # main loop AND the split-K / slab reduction kernels it needs.  `frac` uses the RAW bracket time.  rocprofv3's
         # kernel durations of the same serialized step (profiles/r02_serialized_step_kernel_stats.csv, recomputed by
@@ -318,13 +320,14 @@ def main():
         roof = {"bound": "mfma", "achieved": tot_f / raw_t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": tot_f / raw_t / 1e12 / peak,
                 "traffic": traffic if args.dtype == "f32" else None, "traffic_is": "HBM bytes per conv launch", "traffic_source": traffic_src,
-                "kernel": "igemm_vec/igemm_gen/wgrad (fp32 MFMA implicit-GEMM conv family, incl. their split-K reductions)",
+                "kernel": f"igemm_vec/igemm_gen/wgrad ({family} implicit-GEMM conv family, incl. their split-K reductions)",
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * raw_t / max(n_launch, 1),
                 "conv_ms_per_step": 1e3 * raw_t, "algorithmic_gflop_per_step": tot_f / 1e9,
                 "timing": "HIP events around every conv call of one serialized step, on the launch stream (raw bracket time)",
                 "frac_main_kernels_only": tot_f / tot_t / 1e12 / peak,
                 "event_bracket_overhead_us": 1e6 * ovh,
-                "rocprof_summary": "profiles/r02_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py)",
+                "rocprof_summary": ("profiles/r02_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py)"
+                                    if args.dtype == "f32" and B == 4 else None),
                 "per_kind_tflops": {k: v[0] / (v[1] + ovh * v[2]) / 1e12 for k, v in per_kind.items()},
                 "frac_flop_weighted": flop_weighted / 1e12 / peak,
                 "frac_camera_encoder": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
@@ -378,7 +381,7 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "training samples/sec (K-Radar C+R, bs4/GPU)", "value": value, "unit": "samples/s",
+            "metric": f"training samples/sec (K-Radar C+R, bs{B}/GPU)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config}.json full C+R dual-perspective fusion train step, batch {B}/GPU "
@@ -386,8 +389,9 @@ def main():
                                    "FPN->16ch, IMPFusion 4 it x 3 views, Hungarian set loss, AdamW)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
                        "precision": {"f32": "fp32 (reference arithmetic)",
-                                     "bf16": "mixed: bf16 operands / fp32 accumulation in the conv GEMMs, everything else "
-                                             "fp32 (BASELINE.json configs[4])",
+                                     "bf16": "mixed (BASELINE.json configs[4]): bf16 operands / fp32 accumulation in the conv GEMMs; "
+                                             "activations of the large (camera) encoder bodies stored as bf16 in HBM, BatchNorm "
+                                             "statistics / accumulators / master weights / decoder / loss / AdamW fp32",
                                      "f32x3": "experimental: fp32 conv operands as three bf16 terms, six term products "
                                               "on the bf16 matrix cores, fp32 accumulation"}[args.dtype]},
             "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,

@@ -73,4 +73,11 @@ print(json.dumps({k: dout.get(k) for k in ("traffic_bytes_per_forward", "forward
 PY
 # (5) SQ wave-cycle / MFMA-busy breakdown of the conv kernels on the layer-3 problems (one PMC pass)
 bash /root/repo/tools/pmc_conv_sq.sh > $OUT/r02_conv_sq_mfma_busy.txt 2>&1
+# (6) mixed precision (configs[4]): bf16 operands + bf16 activation storage, batch 8 per GPU: bench line + serialized kernel summary
+timeout 600 python /root/repo/bench.py --dtype bf16 --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r02_bench_bf16_b8.json 2> $OUT/r02_bench_bf16_b8.err
+timeout 600 python /root/repo/bench.py --dtype bf16 --batch 4 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r02_bench_bf16_b4.json 2>> $OUT/r02_bench_bf16_b8.err
+# (7) radar tesseract projection
+bash /root/repo/tools/radar_prof.sh > $OUT/r02_radar_projection.txt 2>&1
+# (8) the default bench line of this state
+DPFT_CONV_TABLE=$OUT/r02_conv_table_fp32.txt timeout 900 python /root/repo/bench.py > $OUT/r02_bench.json 2> $OUT/r02_bench.err
 tail -2 $OUT/r02_serial.log; grep "ms/step" $OUT/r02_plain.log; grep decoder_fwd $OUT/r02_decoder.log; head -c 600 $OUT/r02_roofline_from_rocprof.json
