@@ -294,12 +294,12 @@ def main():
         cam_w = {910, 455, 228, 114, 57, 29}          # widths of the camera feature maps (input of the conv)
         cam = [v for key, v in shapes.items() if key[3] in cam_w]
         cam_f, cam_t = sum(v[0] for v in cam), sum(v[1] for v in cam)
-        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/pmc_traffic.sh: FETCH_SIZE and
+        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/r02_profile.sh: FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  It is a
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for name in ("r02_conv_traffic_pmc.json", "r01_conv_traffic_pmc.json"):
+        for name in ("r02_conv_traffic_pmc.json",):
             if os.path.exists(os.path.join(prof_dir, name)):
                 with open(os.path.join(prof_dir, name)) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
