@@ -179,3 +179,32 @@ def test_gpu_radar_projection_full_size_matches_oracle():
     for ch in (0, 1, 2, 4, 5):
         np.testing.assert_allclose(ra_p[..., ch].cpu().numpy(), ra[..., ch].cpu().numpy(), rtol=1e-5, atol=1e-4)
         np.testing.assert_allclose(ea_p[..., ch].cpu().numpy(), ea[..., ch].cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("D,R,E,A,crop", [
+    (64, 40, 16, 13, (0, 40)),        # elevation fold n = 16 (exact register count), range fold n = 40
+    (33, 70, 5, 107, (3, 68)),        # odd doppler count (finish kernel padding), range fold n = 65 -> 128 registers
+    (64, 255, 37, 21, (4, 253)),      # range fold n = 249: odd length on the two-lane (SEG = 2) path
+    (16, 200, 64, 9, (10, 139)),      # elevation fold n = 64, range fold n = 129: smallest two-lane case, odd
+    (64, 6, 3, 70, (1, 3)),           # tiny folds (n = 3 and n = 2: even-length median of two)
+])
+def test_gpu_radar_projection_register_paths_vs_oracle(D, R, E, A, crop):
+    """Every register-count / lane-count variant of the fold kernel (radar.hip: 16 | 40 | 64 | 128 registers, one or two
+    lanes per column, odd and even column lengths, padded doppler counts) against the numpy oracle's per-map features."""
+    import numpy as np
+    from dpft_amd.data import radar_projection
+    from oracle import radar_oracle as RO
+    rs = np.random.RandomState(D * 1000 + R)
+    t = (10.0 ** (rs.rand(D, R, E, A) * 12.0 + 4.0)).astype(np.float32)
+    t[:, :, :, 0] = t[:, :1, :1, 0]           # an azimuth column of identical values: ties everywhere in the bisection
+    raster = np.linspace(-1.9, 1.9, D)
+    db = 10 * np.log10(t)
+    ra_ref = RO._features(db, 2, raster, "median")
+    ea_ref = RO._features(db[:, crop[0]:crop[1]], 1, raster, "mean")
+    ra, ea = radar_projection(torch.from_numpy(t).cuda(), torch.from_numpy(raster).float(), crop=crop)
+    ra, ea = ra.cpu().numpy(), ea.cpu().numpy()
+    assert ra.shape == (R, A, 6) and ea.shape == (E, A, 6)
+    # the constant column: every statistic is exact (variance 0 up to rounding of the mean), argmax = first doppler bin
+    np.testing.assert_allclose(ra[:, 0, [0, 1, 4]], ra_ref[:, 0, [0, 1, 4]], rtol=2e-6)
+    _check_projection(ra[:, 1:], ea[:, 1:], ra_ref[:, 1:], ea_ref[:, 1:])
