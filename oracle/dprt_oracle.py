@@ -290,9 +290,11 @@ def ms_deform_attn(query, ref_points_2d, levels_nhwc: List[torch.Tensor], sd, p:
 # --------------------------------------------------------------------------- #
 # MLFusion / MPFusion / IMPFusion (src/dprt/models/fusers/mpfusion.py)
 # --------------------------------------------------------------------------- #
-def mha(q_in, k_in, v_in, sd, p: str, n_heads: int):
+def mha(q_in, k_in, v_in, sd, p: str, n_heads: int, att_scale=None):
     """nn.MultiheadAttention(batch_first) explicit form: rows of
-    in_proj_weight packed [q;k;v]; softmax(q k^T / sqrt(hd)) v; out_proj."""
+    in_proj_weight packed [q;k;v]; softmax(q k^T / sqrt(hd)) v; out_proj.
+    ``att_scale`` (B,heads,Q,Q): explicit dropout on the attention probabilities (0 or 1/(1-p) per entry; torch applies
+    ``dropout(softmax(...))`` there, functional.py multi_head_attention_forward) for tests that replay given masks."""
     C = q_in.shape[-1]
     Wi, bi = sd[p + ".in_proj_weight"], sd[p + ".in_proj_bias"]
     q = F.linear(q_in, Wi[:C], bi[:C]); k = F.linear(k_in, Wi[C:2 * C], bi[C:2 * C])
@@ -302,6 +304,8 @@ def mha(q_in, k_in, v_in, sd, p: str, n_heads: int):
     q = q.view(B, Q, n_heads, hd).transpose(1, 2); k = k.view(B, Q, n_heads, hd).transpose(1, 2)
     v = v.view(B, Q, n_heads, hd).transpose(1, 2)
     att = torch.softmax((q @ k.transpose(-1, -2)) / math.sqrt(hd), dim=-1)
+    if att_scale is not None:
+        att = att * att_scale
     out = (att @ v).transpose(1, 2).reshape(B, Q, C)
     return F.linear(out, sd[p + ".out_proj.weight"], sd[p + ".out_proj.bias"])
 

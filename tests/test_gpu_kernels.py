@@ -628,6 +628,80 @@ def test_fused_selfattn_block_vs_oracle(B, Q, V):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,V,p_drop,seed,salt", [(2, 100, 3, 0.1, 12345678901234, 7), (1, 37, 2, 0.3, -5, 1)])
+def test_fused_selfattn_block_dropout_vs_oracle_with_replayed_masks(B, Q, V, p_drop, seed, salt):
+    """dropout > 0, element by element: the kernels' keep decisions are replayed in numpy (tests/dropout_masks.py) and
+    handed to the oracle as explicit masks -- attention-probability dropout inside nn.MultiheadAttention and dropout1
+    (mpfusion.py:122-148) -- so forward and every gradient are compared exactly like the p = 0 case."""
+    from dpft_amd.models.fusers import train_fused as tf
+    from oracle import dprt_oracle as O
+    from tests.dropout_masks import self_attn_masks
+    dev = torch.device("cuda", 0)
+    layers = _sa_layers(V, p_drop, dev)
+    torch.manual_seed(13)
+    x = (torch.randn(B, Q, 16, device=dev) * 0.7).requires_grad_(True)
+    pos = (torch.randn(Q, 16, device=dev) * 0.5).requires_grad_(True)
+    gy = torch.randn(V, B, Q, 16, device=dev)
+    plist = [t for ml in layers for t in tf.sa_params(ml)]
+    out = tf.self_attn_blocks(layers, x, pos, torch.full((1,), seed, dtype=torch.int64, device=dev), salt, p_drop)
+    gout = torch.autograd.grad(out, [x, pos] + plist, gy)
+    att, d1 = self_attn_masks(seed, salt, p_drop, V, B, Q)
+    keep = float((att > 0).mean())
+    assert abs(keep - (1 - p_drop)) < 0.01, keep
+    att, d1 = torch.from_numpy(att), torch.from_numpy(d1)
+    x64, pos64 = _leaf64(x), _leaf64(pos)
+    refs, leaves = [], []
+    for v, ml in enumerate(layers):
+        sd = {k: t.requires_grad_(True) for k, t in _sd64(ml, "ml").items()}
+        qk = x64 + pos64.unsqueeze(0)
+        sa = O.mha(qk, qk, x64, sd, "ml.self_attn", 8, att_scale=att[v])
+        refs.append(O._ln(x64 + sa * d1[v], sd, "ml.norm1"))
+        leaves += [sd["ml.self_attn.in_proj_weight"], sd["ml.self_attn.in_proj_bias"], sd["ml.self_attn.out_proj.weight"],
+                   sd["ml.self_attn.out_proj.bias"], sd["ml.norm1.weight"], sd["ml.norm1.bias"]]
+    ref = torch.stack(refs)
+    gref = torch.autograd.grad(ref, [x64, pos64] + leaves, gy.double().cpu())
+    torch.testing.assert_close(out.detach().double().cpu(), ref.detach(), rtol=1e-4, atol=2e-5)
+    _check_grads(gout, gref, ["x", "pos"] + [f"p{i}" for i in range(len(plist))], 2e-4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,V,L,P,p_drop,seed,salt", [(2, 100, 3, 5, 4, 0.1, 987654321987, 2), (1, 37, 2, 3, 2, 0.25, 3, 9)])
+def test_fused_xattn_ffn_block_dropout_vs_oracle_with_replayed_masks(B, Q, V, L, P, p_drop, seed, salt):
+    """dropout2 (after the cross attention), dropout3 (inside the FFN), dropout4 (after the FFN) of mpfusion.py:150-229
+    with the kernel's own keep decisions replayed in the oracle."""
+    from dpft_amd.models.fusers import train_fused as tf
+    from oracle import dprt_oracle as O
+    from tests.dropout_masks import xattn_ffn_masks
+    import torch.nn.functional as F
+    dev = torch.device("cuda", 0)
+    layers, feats, y1, pos, refs, mk = _xf_setup(B, Q, V, p_drop, dev, L, P)
+    gy = torch.randn(V, B, Q, 16, device=dev)
+    flat_feats = [t for fv in feats for t in fv]
+    plist = [t for ml in layers for t in tf.view_params(ml)[6:]]
+    out = tf.xattn_ffn_blocks(layers, [mk(fv) for fv in feats], y1, pos, refs,
+                              torch.full((1,), seed, dtype=torch.int64, device=dev), salt, p_drop)
+    gout = torch.autograd.grad(out, [y1, pos, refs] + flat_feats + plist, gy)
+    d2, d3, d4 = [torch.from_numpy(m) for m in xattn_ffn_masks(seed, salt, p_drop, V, B, Q)]
+    y64, pos64, refs64 = _leaf64(y1), _leaf64(pos), _leaf64(refs)
+    feats64 = [[_leaf64(t) for t in fv] for fv in feats]
+    outs, leaves = [], []
+    for v, ml in enumerate(layers):
+        sd = {k: t.requires_grad_(True) for k, t in _sd64(ml, "ml").items()}
+        ca = O.ms_deform_attn(y64[v] + pos64.unsqueeze(0), refs64[v], feats64[v], sd, "ml.ms_deform_attn", 8, P)
+        y2 = O._ln(y64[v] + ca * d2[v], sd, "ml.norm2")
+        hid = F.mish(F.linear(y2, sd["ml.ffn1.weight"], sd["ml.ffn1.bias"])) * d3[v]
+        ff = F.linear(hid, sd["ml.ffn2.weight"], sd["ml.ffn2.bias"])
+        outs.append(O._ln(y2 + ff * d4[v], sd, "ml.norm3"))
+        by_id = {id(p_): n for n, p_ in ml.named_parameters()}
+        leaves += [sd["ml." + by_id[id(p_)]] for p_ in tf.view_params(ml)[6:]]
+    ref = torch.stack(outs)
+    gref = torch.autograd.grad(ref, [y64, pos64, refs64] + [t for fv in feats64 for t in fv] + leaves, gy.double().cpu())
+    torch.testing.assert_close(out.detach().double().cpu(), ref.detach(), rtol=1e-4, atol=5e-5)
+    gn = ["y1", "pos", "refs"] + [f"feat{i}" for i in range(len(flat_feats))] + [f"p{i}" for i in range(len(plist))]
+    _check_grads(gout, gref, gn, 5e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,Q,V,L,P", [(2, 100, 3, 5, 4), (1, 37, 2, 3, 2)])
 def test_fused_xattn_ffn_block_vs_oracle(B, Q, V, L, P):
     """xf_train_fwd / xf_train_bwd == oracle MSDeformAttn (value_proj on the flattened pyramid, grid_sample core,
