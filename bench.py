@@ -176,7 +176,7 @@ def decoder_runner(m, data):
         feats = m._encode_views(data)
         proj = m._get_projetions(m.inputs, data)
         shp = [data[f"{i}_shape"][:, :2] for i in m.inputs]
-        flags = m.fuser.transformation_flags(proj)
+        flags = None                                   # transformation.any() evaluated on the device, as in DPRT.forward
         c0 = m.querent(data)
         vb = [feats[i] for i in m.inputs]
         m.fuser(batch=vb, shape=shp, projection=proj, out=c0, has_transformation=flags)   # builds the fused decoder

@@ -286,6 +286,10 @@ struct ScoreArgs {
     const float* pos;     // (Q,16)
     float* attn;          // (V,Bsa,Q,16) attention output before out_proj
     int Bsa, B, Q, V, nchunk, stamps;
+    // first launch only, when the caller left `transformation.any()` (mpfusion.py:647) to the device (has_t < 0): block 0
+    // evaluates it per view and leaves the flags for the kernels that follow -- no host read-back of the matrices
+    const float* flag_T[4];
+    int* flag_out;
 };
 
 // COMPOSED = false: first layer -- the rows are constants of the weights (learned query table + embedding), read as packed
@@ -437,6 +441,7 @@ struct XattnArgs {
     const float* Pm[4];         // (B,prow,4)
     const int64_t* shape[4];    // (B,2) = H, W
     int prow[4], flag[4], P[4];
+    const int* flag_dev;        // device-side transformation.any() per view (overrides flag[] when set)
     float* y3;                  // (V,B,Q,16)
     float* part;                // (V targets,B,Q,V sources,64) next layer's partial q/k/v rows, or NULL (last layer)
     int B, Q, V, Bsa;
@@ -525,7 +530,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         rx = r2[0]; ry = r2[1];
     } else {
         const float* pc = a.prev_center + (size_t)bqc * 3;
-        reference_point(pc[0], pc[1], pc[2], a.flag[view], a.T[view] ? a.T[view] + (size_t)b * 16 : nullptr,
+        reference_point(pc[0], pc[1], pc[2], a.flag_dev ? a.flag_dev[view] : a.flag[view], a.T[view] ? a.T[view] + (size_t)b * 16 : nullptr,
                         a.Pm[view] + (size_t)b * a.prow[view] * 4, (float)a.shape[view][b * 2 + 0],
                         (float)a.shape[view][b * 2 + 1], rx, ry);
     }
@@ -731,6 +736,7 @@ struct HeadArgs {
     const float* Pm[4];
     const int64_t* shape[4];
     int prow[4], flag[4];
+    const int* flag_dev;
     float* query_out;           // (B,Q,16)
     float *center, *size, *angle, *cls;
     float* refs_out;            // (V,B,Q,2) reference points of the NEW center, or NULL (last iteration)
@@ -794,7 +800,7 @@ __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)
         const float cx = rdlane(cen, 0), cy = rdlane(cen, 1), cz = rdlane(cen, 2);
         if (lane < a.V) {
             float u, vv;
-            reference_point(cx, cy, cz, a.flag[lane], a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
+            reference_point(cx, cy, cz, a.flag_dev ? a.flag_dev[lane] : a.flag[lane], a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
                             a.Pm[lane] + (size_t)b * a.prow[lane] * 4, (float)a.shape[lane][b * 2 + 0],
                             (float)a.shape[lane][b * 2 + 1], u, vv);
             *reinterpret_cast<f32x2*>(a.refs_out + ((size_t)lane * a.B * a.Q + bq) * 2) = f32x2{u, vv};
@@ -811,6 +817,15 @@ __global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs s
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float hs[4][2][64];
     const int bid = blockIdx.x;
+    if (sa.flag_out && bid == 0) {
+        for (int v = 0; v < sa.V; ++v) {
+            int nz = 0;
+            if (sa.flag_T[v])
+                for (int i = threadIdx.x; i < sa.B * 16; i += 256) nz |= sa.flag_T[v][i] != 0.f;
+            nz = __syncthreads_or(nz);
+            if (threadIdx.x == 0) sa.flag_out[v] = nz ? 1 : 0;
+        }
+    }
     if (bid < n_score) {
         if (composed) scores_block<true>(sa, sm, bid);
         else scores_block<false>(sa, sm, bid);
@@ -902,6 +917,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     memset(&ha, 0, sizeof(ha));
     memset(&sa, 0, sizeof(sa));
     { const char* e = getenv("DPFT_DEC_DBG"); xa.dbg = e ? atoi(e) : 0; sa.stamps = ha.stamps = xa.dbg & 1024; }
+    bool device_flags = false;
     for (int v = 0; v < V; ++v) {
         const dpft_pyramid* pyr = d->pyr + v;
         const int P = d->n_points[v];
@@ -917,8 +933,15 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
         xa.P[v] = P;
         xa.T[v] = ha.T[v] = d->T[v]; xa.Pm[v] = ha.Pm[v] = d->P[v]; xa.shape[v] = ha.shape[v] = d->shape[v];
         xa.prow[v] = ha.prow[v] = d->p_rows[v]; xa.flag[v] = ha.flag[v] = d->has_t[v];
-        DPFT_REQUIRE(xa.Pm[v] && xa.shape[v] && (xa.T[v] || !xa.flag[v]) && xa.prow[v] >= 3,
+        DPFT_REQUIRE(xa.Pm[v] && xa.shape[v] && (xa.T[v] || d->has_t[v] <= 0) && xa.prow[v] >= 3,
                      "decoder_forward: projection inputs of view %d missing", v);
+        if (d->has_t[v] < 0) device_flags = true;
+    }
+    if (device_flags) {      // has_t < 0: `transformation.any()` is evaluated on the device by the first launch
+        int* fd = reinterpret_cast<int*>(part + (size_t)V * V * nq * 64);      // the 64 spare floats of the work buffer
+        for (int v = 0; v < V; ++v) sa.flag_T[v] = d->T[v];
+        sa.flag_out = fd;
+        xa.flag_dev = ha.flag_dev = fd;
     }
     xa.attn = attn; xa.pos = d->pos; xa.y3 = y3; xa.B = B; xa.Q = Q; xa.V = V;
     ha.y3 = y3; ha.B = B; ha.Q = Q; ha.V = V; ha.ncls = d->num_classes;
@@ -953,6 +976,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
         hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head)), dim3(256),
                            after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? 0 : 1);
         RC(check_launch("decoder_scores_head"));
+        sa.flag_out = nullptr;      // only the first launch evaluates the flags
         if (!first) {
             query = ha.query_out;
             center = ha.center;

@@ -111,7 +111,11 @@ class _Plan:
 
 
 def _ordered_modules(owner: "BackboneBase"):
-    """conv / bn modules in the plan's table order (include/dpft_hip.h dpft_resnet_tables)."""
+    """conv / bn modules in the plan's table order (include/dpft_hip.h dpft_resnet_tables); the module tree of a backbone
+    is fixed after construction, so the lists are built once."""
+    cached = owner.__dict__.get("_ordered")
+    if cached is not None:
+        return cached
     body = owner.body
     convs, bns = [], []
     if owner.adjustment_layer is not None:
@@ -125,6 +129,7 @@ def _ordered_modules(owner: "BackboneBase"):
             if blk.downsample is not None:
                 convs.append(blk.downsample[0])
                 bns.append(blk.downsample[1])
+    owner.__dict__["_ordered"] = (convs, bns)
     return convs, bns
 
 
@@ -152,35 +157,46 @@ class _BodyFn(torch.autograd.Function):
         convs, bns = _ordered_modules(owner)
         assert len(convs) == plan.n_conv and len(bns) == plan.n_bn
         arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
-        weights = [khwc(c.weight) for c in convs]                       # physical [K][kh][kw][C]
-        # gradient buffers: straight into the DP buckets when a reducer is attached, else one flat buffer
-        direct = owner.grad_direct if need_grad else None
-        conv_g, bn_g, bn_b, flat = [None] * len(convs), [None] * len(bns), [None] * len(bns), None
-        if need_grad:
-            if direct is not None:
-                conv_g = [direct.grad_buffer(c.weight) for c in convs]
-                bn_g = [direct.grad_buffer(m.weight) for m in bns]
-                bn_b = [direct.grad_buffer(m.bias) for m in bns]
-            if direct is None or any(g is None for g in conv_g + bn_g + bn_b):
-                direct = None
-                total = sum(c.weight.numel() for c in convs) + 2 * sum(m.weight.numel() for m in bns)
-                flat = torch.empty(total, dtype=torch.float32, device=x.device)
-                off = 0
-                conv_g, bn_g, bn_b = [], [], []
-                for c in convs:
-                    K, Ci, kh, kw = c.weight.shape
-                    conv_g.append(flat[off:off + c.weight.numel()].view(K, kh, kw, Ci).permute(0, 3, 1, 2))
-                    off += c.weight.numel()
-                for m in bns:
-                    n = m.weight.numel()
-                    bn_g.append(flat[off:off + n]); bn_b.append(flat[off + n:off + 2 * n])
-                    off += 2 * n
-        t = ResnetTables()
-        keep = [_ptr_array(weights), _ptr_array(conv_g), _ptr_array([m.weight for m in bns]),
-                _ptr_array([m.bias for m in bns]), _ptr_array([m.running_mean for m in bns]),
-                _ptr_array([m.running_var for m in bns]), _ptr_array(bn_g), _ptr_array(bn_b)]
-        (t.conv_w, t.conv_dw, t.bn_gamma, t.bn_beta, t.bn_rm, t.bn_rv, t.bn_dgamma, t.bn_dbeta) = \
-            [C.cast(k, C.POINTER(C.c_void_p)) for k in keep]
+        # inference: the pointer tables only depend on where the parameters live -- rebuilt when a tensor moved
+        # (building them costs ~0.4 ms of host time per backbone, in front of the forward's first kernel)
+        sig = None if need_grad else (sum(c.weight.data_ptr() for c in convs), sum(m.running_var.data_ptr() for m in bns),
+                                      bns[0].weight.data_ptr(), bns[-1].bias.data_ptr())
+        cached = owner.__dict__.get("_infer_tables") if sig is not None else None
+        if cached is not None and cached[0] == sig:
+            _, t, keep, weights = cached
+            conv_g = bn_g = bn_b = flat = direct = None
+        else:
+            weights = [khwc(c.weight) for c in convs]                       # physical [K][kh][kw][C]
+            # gradient buffers: straight into the DP buckets when a reducer is attached, else one flat buffer
+            direct = owner.grad_direct if need_grad else None
+            conv_g, bn_g, bn_b, flat = [None] * len(convs), [None] * len(bns), [None] * len(bns), None
+            if need_grad:
+                if direct is not None:
+                    conv_g = [direct.grad_buffer(c.weight) for c in convs]
+                    bn_g = [direct.grad_buffer(m.weight) for m in bns]
+                    bn_b = [direct.grad_buffer(m.bias) for m in bns]
+                if direct is None or any(g is None for g in conv_g + bn_g + bn_b):
+                    direct = None
+                    total = sum(c.weight.numel() for c in convs) + 2 * sum(m.weight.numel() for m in bns)
+                    flat = torch.empty(total, dtype=torch.float32, device=x.device)
+                    off = 0
+                    conv_g, bn_g, bn_b = [], [], []
+                    for c in convs:
+                        K, Ci, kh, kw = c.weight.shape
+                        conv_g.append(flat[off:off + c.weight.numel()].view(K, kh, kw, Ci).permute(0, 3, 1, 2))
+                        off += c.weight.numel()
+                    for m in bns:
+                        n = m.weight.numel()
+                        bn_g.append(flat[off:off + n]); bn_b.append(flat[off + n:off + 2 * n])
+                        off += 2 * n
+            t = ResnetTables()
+            keep = [_ptr_array(weights), _ptr_array(conv_g), _ptr_array([m.weight for m in bns]),
+                    _ptr_array([m.bias for m in bns]), _ptr_array([m.running_mean for m in bns]),
+                    _ptr_array([m.running_var for m in bns]), _ptr_array(bn_g), _ptr_array(bn_b)]
+            (t.conv_w, t.conv_dw, t.bn_gamma, t.bn_beta, t.bn_rm, t.bn_rv, t.bn_dgamma, t.bn_dbeta) = \
+                [C.cast(k, C.POINTER(C.c_void_p)) for k in keep]
+            if sig is not None:
+                owner.__dict__["_infer_tables"] = (sig, t, keep, weights)
         lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), int(train), stream())
         if train:
             torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
@@ -270,13 +286,17 @@ class BackboneBase(nn.Module):
         st = self.__dict__.copy()
         st["_plans"] = {}
         st["grad_direct"] = None
+        for k in ("_ordered", "_infer_tables", "_plist"):
+            st.pop(k, None)
         return st
 
     def forward(self, batch: torch.Tensor) -> "OrderedDict[str, torch.Tensor]":
         """(B,H,W,C) [channel_last] or (B,C,H,W) -> {'1': layer1, ...} in the input's channel format."""
         if not self.channel_last:
             batch = batch.movedim(1, -1)
-        params = [p for p in self.parameters()]
+        params = self.__dict__.get("_plist")
+        if params is None:              # the Parameter objects of a backbone are fixed after construction
+            params = self.__dict__["_plist"] = list(self.parameters())
         # grad mode is off inside Function.forward, so the decision is taken here
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         outs = _BodyFn.apply(self, need_grad, batch, *params)

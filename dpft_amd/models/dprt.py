@@ -110,11 +110,26 @@ class DPRT(nn.Module):
         if self.__dict__.get("_view_streams") is None or len(self._view_streams) != len(self.inputs) - 1:
             self.__dict__["_view_streams"] = [torch.cuda.Stream(first.device) for _ in self.inputs[1:]]
         features = {}
-        for i, s in zip(self.inputs[1:], self._view_streams):      # small views first, on side streams
-            s.wait_stream(main)
-            with torch.cuda.stream(s):
-                features[i] = self._encode_view(i, batch)
-        features[self.inputs[0]] = self._encode_view(self.inputs[0], batch)
+        if torch.is_grad_enabled():
+            # training: the small views first.  The host runs ahead of the GPU here (the previous step's backward is still
+            # executing), so the issue order of the forward costs nothing, and autograd replays the LAST-created branch
+            # first: the camera's backward chain -- the critical path of the step -- is queued before the radar ones.
+            for i, s in zip(self.inputs[1:], self._view_streams):
+                s.wait_stream(main)
+                with torch.cuda.stream(s):
+                    features[i] = self._encode_view(i, batch)
+            features[self.inputs[0]] = self._encode_view(self.inputs[0], batch)
+        else:
+            # inference (fwd ms/frame, evaluator.py:109-125): the GPU is idle when the forward starts, so the longest
+            # chain must be queued first -- with the radar views first the camera's first kernel waited 3.7 ms for the
+            # host to issue their ~260 launches (tools/eval_trace.sh).  The side streams wait for what preceded the
+            # forward on the main stream (an event), not for the camera.
+            ev = main.record_event()
+            features[self.inputs[0]] = self._encode_view(self.inputs[0], batch)
+            for i, s in zip(self.inputs[1:], self._view_streams):
+                s.wait_event(ev)
+                with torch.cuda.stream(s):
+                    features[i] = self._encode_view(i, batch)
         for i, s in zip(self.inputs[1:], self._view_streams):
             main.wait_stream(s)
             for t in features[i].values():

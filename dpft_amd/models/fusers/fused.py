@@ -4,7 +4,7 @@ from __future__ import annotations
 
 import ctypes as C
 from collections import OrderedDict
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 from torch import nn
@@ -48,7 +48,10 @@ class FusedDecoder:
     def _build(self):
         """(Re)pack the parameters into the kernels' transposed blobs whenever a weight changed."""
         f = self.fuser
-        key = (weights_generation(),) + tuple((p.data_ptr(), p._version) for p in f.parameters())
+        plist = self.__dict__.get("_plist")
+        if plist is None:               # walking the module tree costs ~1 ms per forward; the Parameter objects are fixed
+            plist = self._plist = list(f.parameters())
+        key = (weights_generation(),) + tuple((p.data_ptr(), p._version) for p in plist)
         if key == self._key:
             return
         V, I = f.m_views, f.i_iter
@@ -97,7 +100,7 @@ class FusedDecoder:
     @torch.no_grad()
     def prepare(self, batch: List[Dict[str, torch.Tensor]], shape: List[torch.Tensor],
                 projection: List[Tuple[torch.Tensor, torch.Tensor]], out: Dict[str, torch.Tensor],
-                flags: List[bool]):
+                flags: Optional[List[bool]] = None):
         """Fill the C-ABI descriptor for these inputs (allocates outputs + scratch); `launch()` then runs it."""
         f = self.fuser
         self._build()
@@ -117,7 +120,7 @@ class FusedDecoder:
         d.center0 = center0.data_ptr()
         for v in range(V):
             d.T[v], d.P[v], d.shape[v] = Ts[v].data_ptr(), Ps[v].data_ptr(), shapes[v].data_ptr()
-            d.p_rows[v], d.has_t[v] = Ps[v].shape[1], int(flags[v])
+            d.p_rows[v], d.has_t[v] = Ps[v].shape[1], (-1 if flags is None else int(flags[v]))      # -1: decided on the device
         work = torch.empty(int(lib.dpft_decoder_work_floats(B, Q, V)), dtype=torch.float32, device=dev)
         ncls = d.num_classes
         res = (torch.empty((B, Q, 3), dtype=torch.float32, device=dev), torch.empty((B, Q, 3), dtype=torch.float32, device=dev),

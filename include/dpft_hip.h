@@ -307,7 +307,8 @@ typedef struct dpft_decoder_fwd {
     const float* T[4];                   /* label_to_X_t (B,4,4)                         */
     const float* P[4];                   /* label_to_X_p (B,p_rows,4)                    */
     const int64_t* shape[4];             /* X_shape[:, :2] contiguous (B,2) = (H, W)     */
-    int32_t p_rows[4], has_t[4];         /* rows of P (3 or 4); transformation.any()     */
+    int32_t p_rows[4], has_t[4];         /* rows of P (3 or 4); transformation.any(): 1 / 0, or -1 = evaluated on the
+                                            device (no host read-back of the matrices) */
     float* work;
     float *center, *size, *angle, *cls;
 } dpft_decoder_fwd;
