@@ -99,6 +99,12 @@ struct IgemmArgs {
     // A plain launch over all pixels and taps would spend stride^2 = 4x the MFMA work on structural zeros.
     int sub_step, sub_ph, sub_pw, sub_oh, sub_ow, sub_r0, sub_s0, sub_nr, sub_ns;
     int x16, y16;     // the A-source tensor / the output tensor (and res_src, res_mask, accumulate source) are bf16
+    // inference epilogue (dpft_conv2d_nhwc_fwd_bnact_f32): y = [relu](bn(result) [+ oadd]) with a BN block [4][N] of the OUTPUT
+    // channels -- BatchNorm + ReLU + residual add without a separate elementwise pass and without an operand prologue
+    // in the consumer (which applies them once per tap and column tile instead of once per element)
+    const float* obn;
+    const float* oadd;
+    int orelu;
 };
 
 // output row (GEMM row m) -> pixel index of the output tensor
@@ -196,7 +202,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         constexpr int ITER = BM * C4 / 256;
         f32x4 old[ITER];
         const bool resid = (a.res_src != nullptr) && (a.partial == nullptr);
-        if (accum || resid) {
+        const bool obn = (a.obn != nullptr) && (a.partial == nullptr);
+        const bool oadd = obn && a.oadd != nullptr;
+        if (accum || resid || oadd) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + it * 256;
@@ -204,7 +212,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
                     const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c4 * 4;
-                    if (resid) {
+                    if (oadd) {
+                        old[it] = load4_act(a.oadd, off, y16);
+                    } else if (resid) {
                         const f32x4 g = load4_act(a.res_src, off, y16);
                         const f32x4 o = load4_act(a.res_mask, off, y16);
 #pragma unroll
@@ -223,7 +233,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
                     if (add_bias) v += *reinterpret_cast<const f32x4*>(a.bias + n0 + c4 * 4);
-                    if (accum || resid) v += old[it];
+                    if (obn) {      // the expression of bn_apply4 (bn.hip): (v - mean) * scale + beta
+                        const int n = n0 + c4 * 4;
+                        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.obn + n);
+                        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.obn + a.N + n);
+                        const f32x4 be = *reinterpret_cast<const f32x4*>(a.obn + 2 * a.N + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e] - mu[e], sc[e], be[e]);
+                    }
+                    if (accum || resid || oadd) v += old[it];
+                    if (obn && a.orelu) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
                     store4_act(out, out_pixel(a, m0 + row) * a.N + n0 + c4 * 4, v, decltype(H16)::value);
                 }
             }
@@ -1509,6 +1531,7 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps) {
 }
 
 static void fill_igemm(IgemmArgs& a, const dpft_conv_desc* d, bool dgrad) {
+    a.obn = nullptr; a.oadd = nullptr; a.orelu = 0;
     memset(&a, 0, sizeof(a));
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     if (!dgrad) {
@@ -1735,6 +1758,32 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
         }
     }
     return rc;
+}
+
+// Inference form of conv + BatchNorm (+ residual) (+ ReLU): y = [relu](bn(conv(x, w)) [+ residual]) with the BN block of the
+// OUTPUT channels.  One launch when the problem takes the vector path without split-K (the epilogue does it); otherwise
+// the plain convolution followed by the elementwise pass -- same arithmetic, same result.
+extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const float* x, const float* w, const float* out_bn,
+                                              int32_t relu, const float* residual, float* y, void* workspace,
+                                              dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(x && w && y && out_bn, "conv fwd_bnact: null tensor");
+    hipStream_t st = (hipStream_t)stream;
+    IgemmArgs a; fill_igemm(a, d, false);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    if (d->act16) t.splits = 1;
+    const int64_t M = (int64_t)d->B * d->OH * d->OW;
+    if (!t.vec || t.splits > 1 || (a.N & 3) != 0 || conv16_matches(d)) {
+        rc = dpft_conv2d_nhwc_fwd_f32(d, x, w, nullptr, nullptr, 0, y, nullptr, workspace, stream);
+        if (rc) return rc;
+        return bn_act_any(y, out_bn, residual, nullptr, relu, y, nullptr, M, d->K, d->act16 != 0, stream);
+    }
+    ProfScope prof(0, d, st);
+    a.x = x; a.w = w; a.y = y; a.bias = nullptr; a.stats = nullptr; a.pro = nullptr; a.pro_relu = 0;
+    a.x16 = a.y16 = d->act16;
+    a.obn = out_bn; a.oadd = residual; a.orelu = relu;
+    return launch_igemm<false>(a, t, false, st);
 }
 
 extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,

@@ -311,6 +311,31 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
     RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr, st));
     const bool a16 = p->desc.act16 != 0;
     RC(bn_relu_maxpool_any(A + p->y0, A + p->p0, A + p->pool, p->c0.d.B, p->c0.d.OH, p->c0.d.OW, 64, p->PH, p->PW, a16, st));
+    if (!tr) {
+        // Inference: BatchNorm, ReLU and the residual add ride in the epilogue of the conv that produces the tensor
+        // (dpft_conv2d_nhwc_fwd_bnact_f32), so no conv carries an operand prologue (applied once per tap and column tile)
+        // and no block needs the elementwise pass: 3 launches per bottleneck instead of 4.  y1 / y2 / yd hold ACTIVATED
+        // tensors in this mode.
+        for (const BlockPlan& b : p->blocks) {
+            const int64_t M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
+            RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.c1.d, A + b.x, T.w(b.c1.w), A + b.p1, 1, nullptr, A + b.y1, ws, st));
+            RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.c2.d, A + b.y1, T.w(b.c2.w), A + b.p2, 1, nullptr, A + b.y2, ws, st));
+            const float* identity = A + b.x;
+            if (b.has_ds) {
+                RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.cd.d, A + b.x, T.w(b.cd.w), A + b.pd, 0, nullptr, A + b.yd, ws, st));
+                identity = A + b.yd;
+            }
+            float* o32 = stage_out32(p, b, A);
+            if (o32) {      // bf16 storage: the stage output also needs its fp32 copy -- the elementwise pass writes both
+                RC(dpft_conv2d_nhwc_fwd_f32(&b.c3.d, A + b.y2, T.w(b.c3.w), nullptr, nullptr, 0, A + b.y3, nullptr, ws, st));
+                RC(bn_act_any(A + b.y3, A + b.p3, identity, nullptr, 1, A + b.out, o32, M2, b.c3.d.K, a16, st));
+            } else {
+                RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.c3.d, A + b.y2, T.w(b.c3.w), A + b.p3, 1, identity, A + b.out, ws, st));
+            }
+        }
+        p->g_valid = false;
+        return DPFT_OK;
+    }
     for (const BlockPlan& b : p->blocks) {
         const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
         RC(dpft_conv2d_nhwc_fwd_f32(&b.c1.d, A + b.x, T.w(b.c1.w), nullptr, nullptr, 0, A + b.y1, tr ? A + b.s1 : nullptr, ws, st));

@@ -100,6 +100,16 @@ def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False):
     return y, stats
 
 
+def conv_fwd_bnact(cv: Conv, x, w, out_bn, relu=True, residual=None):
+    """Inference conv + BatchNorm (+ residual) (+ ReLU): [relu](bn(conv(x, w)) [+ residual]); out_bn = BN block (4,K) of
+    the output channels (bn_eval_params)."""
+    y = torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
+    ws = workspace(cv.ws_bytes, x.device)
+    lib.call("dpft_conv2d_nhwc_fwd_bnact_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(out_bn), int(relu), ptr(residual),
+             ptr(y), ptr(ws), stream())
+    return y
+
+
 def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
     """dx (B,H,W,C); w_t physical [C][kh][kw][K]."""
     if out is None:

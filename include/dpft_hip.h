@@ -91,6 +91,14 @@ int32_t dpft_conv_get_compute(void);
 int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x, const float* w,
                              const float* bias, const float* pro_bn, int32_t pro_relu, float* y,
                              float* stats, void* workspace, dpft_stream_t stream);
+/* Inference form of conv + BatchNorm (+ residual add) (+ ReLU) -- what torchvision's Bottleneck.forward computes in eval
+ * mode per conv (resnet.py Bottleneck: conv -> bn -> relu, and conv3 -> bn3 -> += identity -> relu; reached through
+ * src/dprt/models/backbones/resnet.py:80-107):  y = [relu](bn(conv(x, w)) [+ residual]),  out_bn = BN block [4][K] of the
+ * output channels (dpft_bn_eval_params_f32).  One launch where the problem takes the C % 64 == 0 path without split-K
+ * (applied in the GEMM epilogue), otherwise the convolution followed by dpft_bn_act_f32 in place: same arithmetic. */
+int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* desc, const float* x, const float* w, const float* out_bn,
+                                   int32_t relu, const float* residual, float* y, void* workspace, dpft_stream_t stream);
+
 /* dx[B,H,W,C] (+)= conv_transpose(dy, w).  w_t is the transposed weight [C][kh][kw][K]
  * (see dpft_weight_transpose_f32); accumulate != 0 adds into dx instead of overwriting it. */
 int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,

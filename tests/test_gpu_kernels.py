@@ -862,3 +862,36 @@ def test_conv_bf16_activation_storage(B, H, W, Cin, K, k, stride):
     (out * dy64).sum().backward()
     assert rel(dx, xin.grad) < 8e-3, rel(dx, xin.grad)
     assert rel(dx2, 2 * xin.grad) < 1.2e-2, rel(dx2, 2 * xin.grad)      # accumulate: dx (bf16) + dgrad, rounded again
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,K,k,stride,res,relu", [
+    (2, 32, 57, 256, 256, 3, 1, False, True),      # vector path, epilogue form
+    (2, 32, 57, 256, 1024, 1, 1, True, True),      # conv3 + identity + ReLU
+    (2, 64, 114, 256, 512, 1, 2, False, False),    # downsample branch: BN only
+    (1, 8, 4, 256, 256, 3, 1, True, True),         # small map: split-K -> convolution + elementwise pass
+    (2, 16, 29, 6, 16, 1, 1, False, True),         # thin channels: generic path -> convolution + elementwise pass
+])
+def test_conv_fwd_bnact_inference_epilogue(B, H, W, Cin, K, k, stride, res, relu):
+    """dpft_conv2d_nhwc_fwd_bnact_f32 == relu(bn_eval(conv(x)) + residual) in fp64 (torchvision Bottleneck.forward in eval
+    mode), on both of its forms."""
+    from dpft_amd.hip import ops
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(B * 100 + K)
+    pad = k // 2
+    cv = ops.conv_problem(B, H, W, Cin, K, k, k, stride, pad)
+    x = torch.randn(B, H, W, Cin, device=dev)
+    w = torch.randn(K, k, k, Cin, device=dev) / (Cin * k * k) ** 0.5
+    gamma, beta = torch.rand(K, device=dev) + 0.5, torch.randn(K, device=dev) * 0.3
+    rm, rv = torch.randn(K, device=dev) * 0.2, torch.rand(K, device=dev) + 0.3
+    bnp = ops.bn_eval_params(gamma, beta, rm, rv, 1e-5)
+    r = torch.randn(B, cv.OH, cv.OW, K, device=dev) if res else None
+    y = ops.conv_fwd_bnact(cv, x, w, bnp, relu=relu, residual=r)
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), stride=stride, padding=pad)
+    ref = F.batch_norm(ref, rm.double().cpu(), rv.double().cpu(), gamma.double().cpu(), beta.double().cpu(), False, 0.0, 1e-5)
+    ref = ref.permute(0, 2, 3, 1)
+    if res:
+        ref = ref + r.double().cpu()
+    if relu:
+        ref = ref.relu()
+    torch.testing.assert_close(y.double().cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()) + 1e-6)
