@@ -303,6 +303,38 @@ def test_view_subset_configs_match_oracle(name):
 
 
 @pytest.mark.parametrize("storage", ["fp32", "bf16"])
+def test_mixed_precision_eval_forward_close_to_fp32(storage, monkeypatch):
+    """Inference in the mixed-precision mode (bf16 operands; with storage = "bf16" also bf16 activations inside the
+    bodies, where the stage outputs take the conv + elementwise form that also writes the fp32 copy for the neck): the
+    four outputs stay within bf16 rounding of the fp32 forward, the class decision is the same for all but a few queries."""
+    from dpft_amd.hip import ops
+    from dpft_amd.models.backbones.resnet import BackboneBase
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch
+    monkeypatch.setattr(BackboneBase, "ACT16_MIN_PIXELS", 0 if storage == "bf16" else 1 << 60)
+    batch = make_batch(["camera_mono", "radar_bev", "radar_front"], 2, seed=11, shapes=SHAPES, device=DEV)
+    cfg = small_config(dropout=0.0)
+    torch.manual_seed(0)
+    model = build("dprt", cfg).to(DEV).eval()
+    outs = {}
+    try:
+        for mode in ("fp32", "bf16"):
+            ops.conv_set_compute(mode)
+            with torch.no_grad():
+                outs[mode] = {k: v.double().cpu() for k, v in model(batch).items()}
+    finally:
+        ops.conv_set_compute("fp32")
+    errs = {k: float((outs["fp32"][k] - outs["bf16"][k]).norm() / outs["fp32"][k].norm().clamp_min(1e-12))
+            for k in ("center", "size", "angle", "class")}
+    print("mixed-precision eval forward vs fp32:", {k: f"{v:.1e}" for k, v in errs.items()})
+    # centre / class carry O(1) values; size and angle are small residual heads whose relative error is larger
+    assert 0 < errs["center"] < 3e-2 and 0 < errs["class"] < 3e-2, errs
+    assert errs["size"] < 0.15 and errs["angle"] < 0.15, errs
+    same = float((outs["fp32"]["class"].argmax(-1) == outs["bf16"]["class"].argmax(-1)).double().mean())
+    assert same > 0.95, same
+
+
+@pytest.mark.parametrize("storage", ["fp32", "bf16"])
 def test_mixed_precision_mode_close_to_fp32(storage, monkeypatch):
     """BASELINE.json configs[4] (bf16 mixed precision): with config["computing"]["conv_compute"] = "bf16" the trainer runs
     the conv GEMMs with bf16 operands / fp32 accumulation.  Same model, same batch: outputs, loss and the gradient of the

@@ -14,12 +14,12 @@ def short(n):
     n = re.sub(r"<.*", "", n)
     return n[:44]
 dec = [i for i, r in enumerate(step) if any(p in r["Kernel_Name"] for p in ("sa_train", "xf_train", "hd_train"))]
-lo, hi = dec[0] - 12, dec[-1] + 12
+lo, hi = (0, len(step)) if __import__("os").environ.get("WHOLE") else (dec[0] - 12, dec[-1] + 12)
 seq = []
 for r in step[max(lo, 0):hi]:
     n = short(r["Kernel_Name"])
     if any(p in n for p in ("igemm", "wgrad", "bn_", "splitk", "slab", "conv16", "transpose", "thin_", "fpn_", "add_inplace", "bias_grad")):
-        n = "(encoder kernel)"
+        n = "(conv/bn kernel)" if __import__("os").environ.get("WHOLE") is None else n
     if seq and seq[-1][0] == n: seq[-1][1] += 1
     else: seq.append([n, 1])
 for n, c in seq: print(f"{c:4d} x {n}")
