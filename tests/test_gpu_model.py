@@ -328,7 +328,7 @@ def test_mixed_precision_eval_forward_close_to_fp32(storage, monkeypatch):
             for k in ("center", "size", "angle", "class")}
     print("mixed-precision eval forward vs fp32:", {k: f"{v:.1e}" for k, v in errs.items()})
     # centre / class carry O(1) values; size and angle are small residual heads whose relative error is larger
-    assert 0 < errs["center"] < 3e-2 and 0 < errs["class"] < 3e-2, errs
+    assert 0 < errs["center"] < 3e-2 and 0 < errs["class"] < 6e-2, errs
     assert errs["size"] < 0.15 and errs["angle"] < 0.15, errs
     same = float((outs["fp32"]["class"].argmax(-1) == outs["bf16"]["class"].argmax(-1)).double().mean())
     assert same > 0.95, same
