@@ -120,10 +120,14 @@ __device__ __forceinline__ size_t out_pixel(const IgemmArgs& a, int m) {
 // ---------------------------------------------------------------------------------------------
 // shared epilogue: store accumulators (+bias), optional split-K partial, optional BN tile stats
 // ---------------------------------------------------------------------------------------------
-template <int BM, int BN, int WGM, int WGN, int RB, int CB>
+// NT = threads of the workgroup: 256, or 512 for the K-split form of the vector kernel whose waves 4..7 have already
+// handed their accumulators to waves 0..3 -- they own no results here (`own`) but take part in the barriers and in the
+// LDS -> global store loops.
+template <int BM, int BN, int WGM, int WGN, int RB, int CB, int NT = 256>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[RB][CB], int m0,
                                                int n0, int mt, int split, float* smem) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const bool own = NT == 256 || tid < 256;
     const int wm = wave / WGN, wn = wave % WGN;
     const int rbase = m0 + wm * RB * 32 + 4 * (lane >> 5);
     __syncthreads();  // LDS operand tiles are dead now
@@ -143,7 +147,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                     s += (row < a.M) ? acc[rb][cb][r] : 0.f;
                 }
             s += __shfl_xor(s, 32);
-            if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;
+            if (own && lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;
         }
         __syncthreads();
         if (tid < BN) {
@@ -168,7 +172,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                     s += (row < a.M) ? d * d : 0.f;
                 }
             s += __shfl_xor(s, 32);
-            if (lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;  // red is free: barrier above
+            if (own && lane < 32) red[wm * BN + wn * CB * 32 + cb * 32 + lane] = s;  // red is free: barrier above
         }
         __syncthreads();
         if (tid < BN && n0 + tid < a.N) {
@@ -183,6 +187,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     // (per-register scalar stores are store-issue bound and, with vmcnt counting stores, serialise)
     constexpr int LDC = BN + 4;
     float* Cs = smem;  // [BM][LDC]
+    if (own)
 #pragma unroll
     for (int cb = 0; cb < CB; ++cb)
 #pragma unroll
@@ -199,7 +204,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     const bool y16 = a.y16 && (a.partial == nullptr);      // split-K partials stay fp32
     if ((a.N & 3) == 0) {
         constexpr int C4 = BN / 4;
-        constexpr int ITER = BM * C4 / 256;
+        constexpr int ITER = BM * C4 / NT;
+        static_assert(BM * C4 % NT == 0, "tile / thread count");
         f32x4 old[ITER];
         const bool resid = (a.res_src != nullptr) && (a.partial == nullptr);
         const bool obn = (a.obn != nullptr) && (a.partial == nullptr);
@@ -207,7 +213,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         if (accum || resid || oadd) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * NT;
                 const int row = idx / C4, c4 = idx - row * C4;
                 old[it] = f32x4{0.f, 0.f, 0.f, 0.f};
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
@@ -228,7 +234,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         auto store_all = [&](auto H16) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid + it * NT;
                 const int row = idx / C4, c4 = idx - row * C4;
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
                     f32x4 v = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
@@ -253,7 +259,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         if (y16) store_all(std::true_type{});
         else store_all(std::false_type{});
     } else {
-        for (int idx = tid; idx < BM * BN; idx += 256) {
+        for (int idx = tid; idx < BM * BN; idx += NT) {
             const int row = idx / BN, c = idx - row * BN;
             if (m0 + row < a.M && n0 + c < a.N) {
                 float v = Cs[row * LDC + c];
@@ -291,12 +297,19 @@ __device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt
 // product sum uses the six term products of weight >= 2^-16: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, all exact in the
 // bf16 MFMA, accumulated in fp32 -- fp32-grade results from the matrix cores, which (unlike the fp32 MFMA) do not share
 // the vector ALUs (tools/probes/mfma_valu_overlap.hip): 6 x 32 instead of 8 x 64 cycles per 16 reduction indices.
-template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false, bool X3 = false>
-__global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
+// KS = 2: 512 threads per tile -- waves 4..7 mirror waves 0..3 on the ODD K-groups of every step and hand their
+// accumulators over through LDS at the end.  Same tile, same loads, same MFMA count, twice the waves per SIMD: the mid / late
+// layers launch < 2 workgroups per CU (456 tiles at layer 3) and run latency-bound -- two of these kernels side by side
+// finish in 1.55-1.68x the time of one (tools/occupancy_probe.py).
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false, bool X3 = false,
+          int KS = 1>
+__global__ __launch_bounds__(256 * KS) void igemm_vec_kernel(IgemmArgs a) {
     static_assert(!X3 || BF16, "the split mode builds on the bf16 path");
+    static_assert(KS == 1 || (KS == 2 && !X3), "K-split form: two wave sets");
+    constexpr int NT = 256 * KS, ROWS = NT / 16;      // loader: 16 lanes x 16 bytes per row, ROWS rows per pass
     constexpr int PLANE = (BM + BN) * LDKH;      // halfs per bf16 plane (split mode: 3 planes)
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
-    constexpr int AP = BM / 16, BP = BN / 16;      // 16 rows x 16 chunks (of 16 B) per loader pass
+    constexpr int AP = BM / ROWS, BP = BN / ROWS;      // ROWS rows x 16 chunks (of 16 B) per loader pass
     static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1, "bad tile");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // (BM + BN) * LDK floats
     float* As = smem;
@@ -305,7 +318,8 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     __bf16* Ah = reinterpret_cast<__bf16*>(smem);
     __bf16* Bh = Ah + BM * LDKH;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
+    const int kh = KS == 1 ? 0 : tid >> 8;            // which K-groups of a step this wave multiplies
     const int wm = wave / WGN, wn = wave % WGN;
     int mt, nt, split;
     decode_tile(a, mt, nt, split);
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     unsigned a_mask[AP];                    // which filter rows / columns read a real pixel (see below)
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-        const int m = m0 + rowl + 16 * i;
+        const int m = m0 + rowl + ROWS * i;
         const bool ok = m < a.M;
         const int mm = ok ? m : 0;
         const int b = mm / ohw;
@@ -383,7 +397,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
     unsigned b_off[BP];      // byte offset of weight row n (+ this lane's 16-byte chunk); OOB for rows >= N
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
-        const int n = n0 + rowl + 16 * i;
+        const int n = n0 + rowl + ROWS * i;
         b_off[i] = n < a.N ? (unsigned)(n * a.Ktot + chunk * 4) * 4u : OOB;
     }
     const __amdgpu_buffer_rsrc_t rsrc_a =
@@ -494,7 +508,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
         if (BF16 && raw_a) {
 #pragma unroll
             for (int i = 0; i < AP; ++i)
-                *reinterpret_cast<u32x2*>(&Ah[(rowl + 16 * i) * LDKH + chunk * 4]) =
+                *reinterpret_cast<u32x2*>(&Ah[(rowl + ROWS * i) * LDKH + chunk * 4]) =
                     u32x2{__float_as_uint(ra[sidx][i][0]), __float_as_uint(ra[sidx][i][1])};
         } else {
             if (x16) {
@@ -514,14 +528,14 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                     }
                     if (pro_mask && !((a_valid[sidx] >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
                 }
-                if (BF16) store_bf16(&Ah[(rowl + 16 * i) * LDKH + chunk * 4], val);
-                else *reinterpret_cast<f32x4*>(&As[(rowl + 16 * i) * LDK + chunk * 4]) = val;
+                if (BF16) store_bf16(&Ah[(rowl + ROWS * i) * LDKH + chunk * 4], val);
+                else *reinterpret_cast<f32x4*>(&As[(rowl + ROWS * i) * LDK + chunk * 4]) = val;
             }
         }
 #pragma unroll
         for (int i = 0; i < BP; ++i) {
-            if (BF16) store_bf16(&Bh[(rowl + 16 * i) * LDKH + chunk * 4], rbv[sidx][i]);
-            else *reinterpret_cast<f32x4*>(&Bs[(rowl + 16 * i) * LDK + chunk * 4]) = rbv[sidx][i];
+            if (BF16) store_bf16(&Bh[(rowl + ROWS * i) * LDKH + chunk * 4], rbv[sidx][i]);
+            else *reinterpret_cast<f32x4*>(&Bs[(rowl + ROWS * i) * LDK + chunk * 4]) = rbv[sidx][i];
         }
     };
 
@@ -559,16 +573,17 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < CB; ++j) bf[set][j] = *reinterpret_cast<const bf16x8*>(b_fragh + j * 32 * LDKH + kg * 16);
         };
-        frags(0, 0);
+        constexpr int NG = BKV / 16 / KS;      // K-groups of this wave: kg = KS * g + kh
+        frags(0, kh);
 #pragma unroll
-        for (int kg = 0; kg < BKV / 16; ++kg) {
-            if (kg + 1 < BKV / 16) frags((kg + 1) & 1, kg + 1);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) frags((g + 1) & 1, KS * (g + 1) + kh);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < RB; ++i)
 #pragma unroll
                 for (int j = 0; j < CB; ++j)
-                    accp[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[kg & 1][i], bf[kg & 1][j], accp[0][i][j], 0, 0, 0);
+                    accp[0][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g & 1][i], bf[g & 1][j], accp[0][i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
     };
@@ -621,10 +636,11 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
             for (int j = 0; j < CB; ++j)
                 bf[set][j] = *reinterpret_cast<const f32x4*>(b_frag + j * 32 * LDK + kg * 8);
         };
-        frags(0, 0);
+        constexpr int NG = BKV / 8 / KS;      // K-groups of this wave: kg = KS * g + kh
+        frags(0, kh);
 #pragma unroll
-        for (int kg = 0; kg < BKV / 8; ++kg) {
-            if (kg + 1 < BKV / 8) frags((kg + 1) & 1, kg + 1);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) frags((g + 1) & 1, KS * (g + 1) + kh);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -632,7 +648,7 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
                 for (int i = 0; i < RB; ++i)
 #pragma unroll
                     for (int j = 0; j < CB; ++j)
-                        accp[e % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kg & 1][i][e], bf[kg & 1][j][e],
+                        accp[e % NACC][i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e],
                                                                                     accp[e % NACC][i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -686,7 +702,29 @@ __global__ __launch_bounds__(256) void igemm_vec_kernel(IgemmArgs a) {
 #pragma unroll
             for (int j = 0; j < CB; ++j) acc[i][j] += accp[NACC - 1][i][j];
     }
-    igemm_epilogue<BM, BN, WGM, WGN, RB, CB>(a, acc, m0, n0, mt, split, smem);
+    if constexpr (KS == 2) {      // waves 4..7 hand their partial sums to waves 0..3: [wave][block][register][lane] in LDS
+        static_assert((size_t)4 * RB * CB * 16 * 64 <= (size_t)(BM + BN) * LDK, "hand-over buffer exceeds the operand tiles");
+        __syncthreads();          // the operand tiles are dead
+        float* hand = smem + ((size_t)wave * RB * CB * 16) * 64 + lane;
+        if (kh == 1) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hand[((i * CB + j) * 16 + r) * 64] = acc[i][j][r];
+        }
+        __syncthreads();
+        if (kh == 0) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i)
+#pragma unroll
+                for (int j = 0; j < CB; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] += hand[((i * CB + j) * 16 + r) * 64];
+        }
+    }
+    igemm_epilogue<BM, BN, WGM, WGN, RB, CB, NT>(a, acc, m0, n0, mt, split, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1588,6 +1626,15 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
         }
         return check_launch("conv igemm (strided dgrad, all taps)");
     }
+    // K-split form (512 threads per tile) where the grid leaves the chip latency-bound: fewer than 3 workgroups per CU and
+    // a reduction deep enough to amortise the hand-over.  Measured (tools/ksplit_ab.sh): -8...-10 % on the data gradients
+    // of the 64 x 64-tile problems (layer-3 3x3: 102 -> 93.5 us), nothing or a loss on the forward kernels (prologue,
+    // statistics epilogue) and on the 128-row tiles (one workgroup per CU either way) -- waves of ONE workgroup march in
+    // step between barriers, so they do not fill each other's stalls the way a second resident workgroup does.
+    static const int ks_env = getenv("DPFT_KSPLIT") ? atoi(getenv("DPFT_KSPLIT")) : -1;      // tuning aid: 0 / 1 force
+    const bool ks2 = DGRAD && !pro && bm == 64 && bn == 64 &&
+                     (ks_env >= 0 ? ks_env != 0 : (nwg < kNumCU * 3 && a.ksteps_per_split >= 8));
+    const dim3 block2(512);
 #define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
     do {                                                                                      \
         constexpr size_t lds = (size_t)(BM_ + BN_) * LDK * sizeof(float);                     \
@@ -1595,9 +1642,15 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
             constexpr size_t lds3 = std::max(lds, (size_t)3 * (BM_ + BN_) * LDKH * 2);        \
             if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true, true>, grid, block, lds3, st, a); \
             else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true, true>, grid, block, lds3, st, a);      \
+        } else if (g_conv_bf16 && ks2) {                                                      \
+            if constexpr (DGRAD && BM_ == 64 && BN_ == 64)                                    \
+                launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, true, false, true, true, false, 2>, grid, block2, lds, st, a); \
         } else if (g_conv_bf16) {                                                             \
             if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true>, grid, block, lds, st, a); \
             else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true>, grid, block, lds, st, a);      \
+        } else if (ks2) {                                                                     \
+            if constexpr (DGRAD && BM_ == 64 && BN_ == 64)                                    \
+                launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, true, false, true, false, false, 2>, grid, block2, lds, st, a); \
         } else if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>, grid, block, lds, st, a); \
         else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false>, grid, block, lds, st, a);      \
     } while (0)
