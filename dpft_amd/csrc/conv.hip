@@ -303,10 +303,10 @@ __device__ __forceinline__ void decode_tile(const IgemmArgs& a, int& mt, int& nt
 // finish in 1.55-1.68x the time of one (tools/occupancy_probe.py).
 template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false, bool X3 = false,
           int KS = 1>
-__global__ __launch_bounds__(256 * KS) void igemm_vec_kernel(IgemmArgs a) {
+__global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArgs a) {
     static_assert(!X3 || BF16, "the split mode builds on the bf16 path");
     static_assert(KS == 1 || (KS == 2 && !X3), "K-split form: two wave sets");
-    constexpr int NT = 256 * KS, ROWS = NT / 16;      // loader: 16 lanes x 16 bytes per row, ROWS rows per pass
+    constexpr int NT = 64 * WGM * WGN * KS, ROWS = NT / 16;      // loader: 16 lanes x 16 bytes per row, ROWS rows per pass
     constexpr int PLANE = (BM + BN) * LDKH;      // halfs per bf16 plane (split mode: 3 planes)
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
     constexpr int AP = BM / ROWS, BP = BN / ROWS;      // ROWS rows x 16 chunks (of 16 B) per loader pass
@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256 * KS) void igemm_vec_kernel(IgemmArgs a) {
     __bf16* Bh = Ah + BM * LDKH;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
-    const int kh = KS == 1 ? 0 : tid >> 8;            // which K-groups of a step this wave multiplies
+    const int kh = KS == 1 ? 0 : tid >> 8;            // which K-groups of a step this wave multiplies (4-wave tiles)
     const int wm = wave / WGN, wn = wave % WGN;
     int mt, nt, split;
     decode_tile(a, mt, nt, split);
@@ -1630,7 +1630,8 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     // a reduction deep enough to amortise the hand-over.  Measured (tools/ksplit_ab.sh): -8...-10 % on the data gradients
     // of the 64 x 64-tile problems (layer-3 3x3: 102 -> 93.5 us), nothing or a loss on the forward kernels (prologue,
     // statistics epilogue) and on the 128-row tiles (one workgroup per CU either way) -- waves of ONE workgroup march in
-    // step between barriers, so they do not fill each other's stalls the way a second resident workgroup does.
+    // step between barriers, so they do not fill each other's stalls the way a second resident workgroup does.  (A two-wave
+    // 64 x 32 tile -- twice the workgroups -- was 15-90 % slower on the same problems: tools/tile6432.sh, removed.)
     static const int ks_env = getenv("DPFT_KSPLIT") ? atoi(getenv("DPFT_KSPLIT")) : -1;      // tuning aid: 0 / 1 force
     const bool ks2 = DGRAD && !pro && bm == 64 && bn == 64 &&
                      (ks_env >= 0 ? ks_env != 0 : (nwg < kNumCU * 3 && a.ksteps_per_split >= 8));
