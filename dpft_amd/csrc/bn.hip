@@ -159,7 +159,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                       const float* __restrict__ res, const float* __restrict__ rbnp,
                                                       int relu, float* __restrict__ out, float* __restrict__ out32,
-                                                      int64_t n4, int K4) {
+                                                      int64_t n4, int K4, unsigned char* __restrict__ mask8) {
     const int K = K4 * 4;
     // bf16 storage moves 8 bytes per lane and access: two independent groups per trip keep as many bytes in flight as
     // the fp32 form (these passes are pure HBM streaming)
@@ -192,6 +192,8 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
             }
             stv4<T>(out, i, v);
             if (out32) reinterpret_cast<f32x4*>(out32)[i] = v;      // fp32 copy of a stage output (consumers outside the plan)
+            if (mask8)                                               // which elements passed the ReLU: all the backward needs of `out`
+                mask8[i] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
         }
     }
 }
@@ -287,7 +289,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                              const float* __restrict__ outp, const float* __restrict__ mbnp,
                                                              const float* __restrict__ bnp, float* __restrict__ sums,
-                                                             int64_t M, int K, int rows_per_block, int slab) {
+                                                             int64_t M, int K, int rows_per_block, int slab,
+                                                             const unsigned char* __restrict__ mask8) {
     __shared__ float red0[256 * 4];
     __shared__ float red1[256 * 4];
     const int K4 = K / 4;
@@ -308,6 +311,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
         constexpr int RT = std::is_same<T, float>::value ? 4 : 8;
         for (int64_t rb = r0 + g; rb < r1; rb += RT * groups) {
             f32x4 dv[RT], yv4[RT], ov[RT];
+            unsigned mk[RT];
             bool ok[RT];
 #pragma unroll
             for (int u = 0; u < RT; ++u) {
@@ -316,14 +320,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                 const int64_t idx = (ok[u] ? r : r0) * K4 + c4;
                 dv[u] = ldv4<T>(dout, idx);
                 yv4[u] = ldv4<T>(y, idx);
-                if (outp) ov[u] = ldv4<T>(outp, idx);
+                if (mask8) mk[u] = mask8[idx];
+                else if (outp) ov[u] = ldv4<T>(outp, idx);
             }
 #pragma unroll
             for (int u = 0; u < RT; ++u) {
                 if (!ok[u]) continue;
                 f32x4 d = dv[u];
                 const f32x4 yv = yv4[u];
-                if (outp) {
+                if (mask8) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[e] = ((mk[u] >> e) & 1u) ? d[e] : 0.f;
+                } else if (outp) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[e] = ov[u][e] > 0.f ? d[e] : 0.f;
                 } else if (mbnp) {
@@ -367,7 +375,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             const float* __restrict__ sums, float* __restrict__ dy,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int64_t n4, int K, float invM, float* __restrict__ zero_buf,
-                                                            int zero_n) {
+                                                            int zero_n, const unsigned char* __restrict__ mask8) {
     const int K4 = K / 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < K; c += blockDim.x) {
@@ -381,13 +389,15 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n4; i0 += U * stride) {
       f32x4 dq[U], yq[U], oq[U];
+      unsigned mq[U];
 #pragma unroll
       for (int u = 0; u < U; ++u) {
           const int64_t i = i0 + u * stride;
           if (i < n4) {
               dq[u] = ldv4<T>(dout, i);
               yq[u] = ldv4<T>(y, i);
-              if (outp) oq[u] = ldv4<T>(outp, i);
+              if (mask8) mq[u] = mask8[i];
+              else if (outp) oq[u] = ldv4<T>(outp, i);
           }
       }
 #pragma unroll
@@ -397,7 +407,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
         const int c = (int)(i % K4) * 4;
         f32x4 d = dq[u];
         const f32x4 yv = yq[u];
-        if (outp) {
+        if (mask8) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = ((mq[u] >> e) & 1u) ? d[e] : 0.f;
+        } else if (outp) {
             const f32x4 o = oq[u];
 #pragma unroll
             for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
@@ -577,16 +590,16 @@ int dpft::bn_eval_params_batch(const BnEvalBatch& batch, dpft_stream_t stream) {
 }
 
 int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const float* res_bnp, int32_t relu, float* out,
-                     float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream) {
+                     float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream, unsigned char* mask8) {
     DPFT_REQUIRE(y && bnp && out && M > 0 && K > 0 && K % 4 == 0, "bn_act: bad arguments (K=%d)", K);
     DPFT_REQUIRE(res || !res_bnp, "bn_act: res_bnp without res");
     const int64_t n4 = M * K / 4;
     if (act16)
         hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
-                           res_bnp, relu, out, out32, n4, K / 4);
+                           res_bnp, relu, out, out32, n4, K / 4, mask8);
     else
         hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
-                           res_bnp, relu, out, out32, n4, K / 4);
+                           res_bnp, relu, out, out32, n4, K / 4, mask8);
     return check_launch("bn_act");
 }
 
@@ -644,7 +657,8 @@ extern "C" int dpft_bn_bwd_reduce_f32(const float* y, const float* dout, const f
 
 // `sums` (2K floats) must already be zero (the launch plan keeps two buffers and lets each apply pass clear the other)
 int dpft::bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out, const float* mask_bnp,
-                                  const float* bnp, float* sums, int64_t M, int32_t K, bool act16, dpft_stream_t stream) {
+                                  const float* bnp, float* sums, int64_t M, int32_t K, bool act16, dpft_stream_t stream,
+                                  const unsigned char* mask8) {
     DPFT_REQUIRE(y && dout && bnp && sums && M > 0 && K > 0 && K % 4 == 0, "bn_bwd_reduce: bad arguments");
     hipStream_t st = (hipStream_t)stream;
     const int K4 = K / 4;
@@ -659,10 +673,10 @@ int dpft::bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float
     dim3 grid(cdiv(M, rows_per_block), slabs);
     if (act16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<__bf16>, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
-                           (int)rows_per_block, slab);
+                           (int)rows_per_block, slab, mask8);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, y, dout, out, mask_bnp, bnp, sums, M, K,
-                           (int)rows_per_block, slab);
+                           (int)rows_per_block, slab, mask8);
     return check_launch("bn_bwd_reduce");
 }
 
@@ -676,15 +690,15 @@ extern "C" int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const fl
 int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp,
                                const float* bnp, const float* gamma, const float* sums, float* dy, float* dgamma,
                                float* dbeta, int64_t M, int32_t K, float* zero_buf, int32_t zero_n, bool act16,
-                               dpft_stream_t stream) {
+                               dpft_stream_t stream, const unsigned char* mask8) {
     DPFT_REQUIRE(y && dout && bnp && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = M * K / 4;
     if (act16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n);
+                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n, mask8);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n);
+                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n, mask8);
     return check_launch("bn_bwd_apply");
 }
 

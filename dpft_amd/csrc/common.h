@@ -17,13 +17,17 @@ int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w
                         const float* res_mask, void* workspace, dpft_stream_t stream);      // conv.hip
 // bn.hip -- `act16`: the activation / gradient tensors (y, dout, out, dy, res) are bf16 in memory (the pointers keep
 // their float* type); BN blocks, sums and parameter gradients are fp32
+// `mask8` (one byte per 4 channels: bit e = element e of the group passed the ReLU): written by bn_act_any next to the
+// activation, read by the backward passes INSTEAD of the block output `out` -- 1 byte where the mask test read 16
 int bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
-                            float* sums, int64_t M, int32_t K, bool act16, dpft_stream_t stream);
+                            float* sums, int64_t M, int32_t K, bool act16, dpft_stream_t stream,
+                            const unsigned char* mask8 = nullptr);
 int bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                          const float* gamma, const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
-                         int32_t K, float* zero_buf, int32_t zero_n, bool act16, dpft_stream_t stream);
+                         int32_t K, float* zero_buf, int32_t zero_n, bool act16, dpft_stream_t stream,
+                         const unsigned char* mask8 = nullptr);
 int bn_act_any(const float* y, const float* bnp, const float* res, const float* res_bnp, int32_t relu, float* out,
-               float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream);
+               float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream, unsigned char* mask8 = nullptr);
 int bn_relu_maxpool_any(const float* y, const float* bnp, float* out, int32_t B, int32_t H, int32_t W, int32_t K,
                         int32_t PH, int32_t PW, bool out16, dpft_stream_t stream);
 int bn_relu_maxpool_bwd_any(const float* y, const float* bnp, const float* dout, float* dact, int32_t B, int32_t H,

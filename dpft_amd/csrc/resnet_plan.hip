@@ -26,7 +26,7 @@ struct BlockPlan {
     int bn1, bn2, bn3, bnd;
     int layer;
     // arena offsets (floats)
-    size_t x, y1, y2, y3, yd, out;
+    size_t x, y1, y2, y3, yd, out, mask;   // mask: ReLU byte mask of `out` (1 byte per 4 channels)
     size_t p1, p2, p3, pd;      // BN blocks [4][K]
     size_t s1, s2, s3, sd;      // stats [tiles][2][K]
     int t1, t2, t3, td, r1, r2, r3, rd;   // stats tiles / tile rows
@@ -169,6 +169,7 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
                 bp.yd = bp.pd = bp.sd = (size_t)-1; bp.td = bp.rd = 0;
             }
             bp.out = take(nelem_out(bp.c3.d));
+            bp.mask = take((nelem_out(bp.c3.d) / 4 + 3) / 4);      // ReLU byte mask of the block output: 1 byte per 4 channels
             track_ws(bp.c1.d); track_ws(bp.c2.d); track_ws(bp.c3.d);
             track_g(nelem_in(bp.c1.d)); track_g(nelem_out(bp.c1.d)); track_g(nelem_out(bp.c2.d)); track_g(nelem_out(bp.c3.d));
             p->blocks.push_back(bp);
@@ -347,9 +348,11 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
         if (b.has_ds) {
             RC(dpft_conv2d_nhwc_fwd_f32(&b.cd.d, A + b.x, T.w(b.cd.w), nullptr, nullptr, 0, A + b.yd, tr ? A + b.sd : nullptr, ws, st));
             RC(bn_params(p, T, b.bnd, A + b.sd, b.td, b.rd, M2, b.cd.d.K, A + b.pd, tr, st));
-            RC(bn_act_any(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st));
+            RC(bn_act_any(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st,
+                          tr ? (unsigned char*)(A + b.mask) : nullptr));
         } else {
-            RC(bn_act_any(A + b.y3, A + b.p3, A + b.x, nullptr, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st));
+            RC(bn_act_any(A + b.y3, A + b.p3, A + b.x, nullptr, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st,
+                          tr ? (unsigned char*)(A + b.mask) : nullptr));
         }
     }
     p->g_valid = false;
@@ -367,12 +370,13 @@ struct BnSums {
 };
 static int bn_backward(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                        const float* gamma, BnSums& bs, float* dy, float* dgamma, float* dbeta, int64_t M, int K,
-                       dpft_stream_t st, bool act16 = false) {
+                       dpft_stream_t st, bool act16 = false, const unsigned char* mask8 = nullptr) {
     float* sums = bs.buf[bs.cur];
     float* other = bs.buf[bs.cur ^ 1];
     bs.cur ^= 1;
-    RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st));
-    return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, act16, st);
+    RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st, mask8));
+    return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, act16, st,
+                                mask8);
 }
 
 // Weight gradients do not feed the rest of the backward, so they run on the plan's side stream while the main
@@ -458,7 +462,8 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     int& cur = p->dyi;
     // bn3 (+ the residual ReLU mask taken from the block output)
     RC(sc.acquire(cur));
-    RC(bn_backward(A + b.y3, gp, A + b.out, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16));
+    const unsigned char* m8 = (const unsigned char*)(A + b.mask);      // ReLU mask of the block output (written by the forward)
+    RC(bn_backward(A + b.y3, gp, nullptr, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16, m8));
     RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
     RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyv[cur], wt + b.c3.wt, dab, 0, ws, st));
     cur ^= 1;
@@ -474,7 +479,7 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     RC(sc.wgrad(cur, &b.c1.d, A + b.x, dyv[cur], nullptr, 0, T.dw(b.c1.w)));
     if (b.has_ds) {
         RC(sc.acquire(2));
-        RC(bn_backward(A + b.yd, gp, A + b.out, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st, a16));
+        RC(bn_backward(A + b.yd, gp, nullptr, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st, a16, m8));
         RC(sc.wgrad(2, &b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w)));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt + b.cd.wt, dx, 0, ws, st));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st));
