@@ -495,6 +495,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int view = blockIdx.y;
+    const int t_flag = a.flag_dev ? a.flag_dev[view] : a.flag[view];      // requested first: its round trip hides behind the staging
     const float* __restrict__ img = a.pi[view] + PI_K2;
     // stage the view's weights (the row's own loads are issued first so that their latency hides behind this)
     const int sblk = blockIdx.y * gridDim.x + blockIdx.x, son = (a.dbg & 1024) && a.part;
@@ -530,7 +531,7 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         rx = r2[0]; ry = r2[1];
     } else {
         const float* pc = a.prev_center + (size_t)bqc * 3;
-        reference_point(pc[0], pc[1], pc[2], a.flag_dev ? a.flag_dev[view] : a.flag[view], a.T[view] ? a.T[view] + (size_t)b * 16 : nullptr,
+        reference_point(pc[0], pc[1], pc[2], t_flag, a.T[view] ? a.T[view] + (size_t)b * 16 : nullptr,
                         a.Pm[view] + (size_t)b * a.prow[view] * 4, (float)a.shape[view][b * 2 + 0],
                         (float)a.shape[view][b * 2 + 1], rx, ry);
     }
@@ -751,6 +752,8 @@ __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)
     stamp(a.stamps, 0, 1024 + hid, 0);
     const int b = bq / a.Q;
     const int c = lane & 15, v2 = lane >> 4;
+    // transformation.any() of view `lane` (device-side form): requested now, used at the very end of the block
+    const int t_flag = (a.refs_out && lane < a.V) ? (a.flag_dev ? a.flag_dev[lane] : a.flag[lane]) : 0;
     const float* ph = a.ph;
     const float yv = v2 < a.V ? a.y3[((size_t)v2 * a.B * a.Q + bq) * DC + c] : 0.f;
     // all weights of the wave (input-independent, L2) are requested BEFORE the first use of y3, which was written by
@@ -800,7 +803,7 @@ __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)
         const float cx = rdlane(cen, 0), cy = rdlane(cen, 1), cz = rdlane(cen, 2);
         if (lane < a.V) {
             float u, vv;
-            reference_point(cx, cy, cz, a.flag_dev ? a.flag_dev[lane] : a.flag[lane], a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
+            reference_point(cx, cy, cz, t_flag, a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
                             a.Pm[lane] + (size_t)b * a.prow[lane] * 4, (float)a.shape[lane][b * 2 + 0],
                             (float)a.shape[lane][b * 2 + 1], u, vv);
             *reinterpret_cast<f32x2*>(a.refs_out + ((size_t)lane * a.B * a.Q + bq) * 2) = f32x2{u, vv};
@@ -817,7 +820,7 @@ __global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs s
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float hs[4][2][64];
     const int bid = blockIdx.x;
-    if (sa.flag_out && bid == 0) {
+    if (sa.flag_out && bid == (int)gridDim.x - 1) {      // one extra block of the first launch: nobody waits for it
         for (int v = 0; v < sa.V; ++v) {
             int nz = 0;
             if (sa.flag_T[v])
@@ -825,6 +828,7 @@ __global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs s
             nz = __syncthreads_or(nz);
             if (threadIdx.x == 0) sa.flag_out[v] = nz ? 1 : 0;
         }
+        return;
     }
     if (bid < n_score) {
         if (composed) scores_block<true>(sa, sm, bid);
@@ -973,7 +977,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
             ha.center = last ? d->center : cbuf[(it - 1) & 1];
             ha.refs_out = last ? nullptr : refs;
         }
-        hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head)), dim3(256),
+        hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head) + (sa.flag_out ? 1 : 0)), dim3(256),
                            after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? 0 : 1);
         RC(check_launch("decoder_scores_head"));
         sa.flag_out = nullptr;      // only the first launch evaluates the flags
