@@ -286,10 +286,6 @@ struct ScoreArgs {
     const float* pos;     // (Q,16)
     float* attn;          // (V,Bsa,Q,16) attention output before out_proj
     int Bsa, B, Q, V, nchunk, stamps;
-    // first launch only, when the caller left `transformation.any()` (mpfusion.py:647) to the device (has_t < 0): block 0
-    // evaluates it per view and leaves the flags for the kernels that follow -- no host read-back of the matrices
-    const float* flag_T[4];
-    int* flag_out;
 };
 
 // COMPOSED = false: first layer -- the rows are constants of the weights (learned query table + embedding), read as packed
@@ -424,11 +420,18 @@ __device__ __forceinline__ void scores_block(const ScoreArgs& a, float* sm, int 
 // ---------------------------------------------------------------------------------------------------------
 // K2: deformable cross attention + FFN of R query rows of one view
 // ---------------------------------------------------------------------------------------------------------
+constexpr int PYR_L = 5;      // levels the fused inference kernels carry in their arguments (every config: 5)
 struct Pyr5 {
-    const float* level[DPFT_MAX_LEVELS];
-    int H[DPFT_MAX_LEVELS], W[DPFT_MAX_LEVELS];
+    const float* level[PYR_L];
+    int H[PYR_L], W[PYR_L];
     int L;
 };
+// `transformation.any()` per view (mpfusion.py:647) left to the device (dpft_decoder_fwd.has_t < 0 -> flag[v] < 0): an
+// extra block of the first launch evaluates it and leaves the result in the 16 ints in FRONT of y3 (a gap of the work
+// buffer), where the kernels that need it find it through a pointer they already carry -- the argument structs do not
+// grow (three more pointers cost every kernel of the forward 0.3-0.5 us).
+__device__ __forceinline__ int* dev_flags(const float* y3) { return reinterpret_cast<int*>(const_cast<float*>(y3)) - 16; }
+
 struct XattnArgs {
     Pyr5 pyr[4];
     const float* pi[4];         // packed inference blobs
@@ -441,7 +444,6 @@ struct XattnArgs {
     const float* Pm[4];         // (B,prow,4)
     const int64_t* shape[4];    // (B,2) = H, W
     int prow[4], flag[4], P[4];
-    const int* flag_dev;        // device-side transformation.any() per view (overrides flag[] when set)
     float* y3;                  // (V,B,Q,16)
     float* part;                // (V targets,B,Q,V sources,64) next layer's partial q/k/v rows, or NULL (last layer)
     int B, Q, V, Bsa;
@@ -495,7 +497,14 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int view = blockIdx.y;
-    const int t_flag = a.flag_dev ? a.flag_dev[view] : a.flag[view];      // requested first: its round trip hides behind the staging
+    // transformation.any() of this view (first iteration only: later ones read the reference points the heads wrote).
+    // Requested first -- its round trip hides behind the staging; selects instead of a runtime index into the kernel
+    // arguments (which would move them to scratch).
+    int t_flag = 0;
+    if (!a.refs) {
+        const int hf = view == 0 ? a.flag[0] : view == 1 ? a.flag[1] : view == 2 ? a.flag[2] : a.flag[3];
+        t_flag = hf < 0 ? dev_flags(a.y3)[view] : hf;
+    }
     const float* __restrict__ img = a.pi[view] + PI_K2;
     // stage the view's weights (the row's own loads are issued first so that their latency hides behind this)
     const int sblk = blockIdx.y * gridDim.x + blockIdx.x, son = (a.dbg & 1024) && a.part;
@@ -737,7 +746,6 @@ struct HeadArgs {
     const float* Pm[4];
     const int64_t* shape[4];
     int prow[4], flag[4];
-    const int* flag_dev;
     float* query_out;           // (B,Q,16)
     float *center, *size, *angle, *cls;
     float* refs_out;            // (V,B,Q,2) reference points of the NEW center, or NULL (last iteration)
@@ -753,7 +761,11 @@ __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)
     const int b = bq / a.Q;
     const int c = lane & 15, v2 = lane >> 4;
     // transformation.any() of view `lane` (device-side form): requested now, used at the very end of the block
-    const int t_flag = (a.refs_out && lane < a.V) ? (a.flag_dev ? a.flag_dev[lane] : a.flag[lane]) : 0;
+    int t_flag = 0;
+    if (a.refs_out && lane < a.V) {
+        const int hf = lane == 0 ? a.flag[0] : lane == 1 ? a.flag[1] : lane == 2 ? a.flag[2] : a.flag[3];
+        t_flag = hf < 0 ? dev_flags(a.y3)[lane] : hf;
+    }
     const float* ph = a.ph;
     const float yv = v2 < a.V ? a.y3[((size_t)v2 * a.B * a.Q + bq) * DC + c] : 0.f;
     // all weights of the wave (input-independent, L2) are requested BEFORE the first use of y3, which was written by
@@ -820,18 +832,23 @@ __global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs s
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float hs[4][2][64];
     const int bid = blockIdx.x;
-    if (sa.flag_out && bid == (int)gridDim.x - 1) {      // one extra block of the first launch: nobody waits for it
-        for (int v = 0; v < sa.V; ++v) {
-            int nz = 0;
-            if (sa.flag_T[v])
-                for (int i = threadIdx.x; i < sa.B * 16; i += 256) nz |= sa.flag_T[v][i] != 0.f;
-            nz = __syncthreads_or(nz);
-            if (threadIdx.x == 0) sa.flag_out[v] = nz ? 1 : 0;
+    if (composed == 2 && bid == (int)gridDim.x - 1) {      // first launch, flags left to the device: one extra block
+        if (threadIdx.x < 64) {                            // one wave, one ballot per view: no LDS, no barrier
+            const float* const Ts[4] = {ha.T[0], ha.T[1], ha.T[2], ha.T[3]};
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                if (v >= ha.V) break;
+                bool nz = false;
+                if (Ts[v])
+                    for (int i = threadIdx.x; i < ha.B * 16; i += 64) nz |= Ts[v][i] != 0.f;
+                const bool any = __ballot(nz) != 0ull;
+                if (threadIdx.x == 0) dev_flags(ha.y3)[v] = any ? 1 : 0;
+            }
         }
         return;
     }
     if (bid < n_score) {
-        if (composed) scores_block<true>(sa, sm, bid);
+        if (composed == 1) scores_block<true>(sa, sm, bid);
         else scores_block<false>(sa, sm, bid);
     } else {
         reduce_head_block(ha, hs, bid - n_score);
@@ -910,7 +927,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     float* w = d->work;
     float* qbuf[2] = {w, w + nq * DC};
     float* attn = w + 2 * nq * DC;
-    float* y3 = attn + (size_t)V * nq * DC;
+    float* y3 = attn + (size_t)V * nq * DC + 64;      // 64-float gap: the device-side transformation flags sit in front of y3
     float* cbuf[2] = {y3 + (size_t)V * nq * DC, y3 + (size_t)V * nq * DC + nq * 3};
     float* refs = cbuf[1] + nq * 3;
     float* part = refs + (size_t)V * nq * 2;
@@ -925,8 +942,8 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     for (int v = 0; v < V; ++v) {
         const dpft_pyramid* pyr = d->pyr + v;
         const int P = d->n_points[v];
-        DPFT_REQUIRE(pyr->L >= 1 && pyr->L <= DPFT_MAX_LEVELS && P >= 1 && P <= 4 && pyr->L * P <= 20,
-                     "decoder_forward: L=%d, P=%d exceed the fused kernel's budget (P <= 4, L*P <= 20)", pyr->L, P);
+        DPFT_REQUIRE(pyr->L >= 1 && pyr->L <= PYR_L && P >= 1 && P <= 4 && pyr->L * P <= 20,
+                     "decoder_forward: L=%d, P=%d exceed the fused kernel's budget (L <= 5, P <= 4, L*P <= 20)", pyr->L, P);
         xa.pyr[v].L = pyr->L;
         for (int l = 0; l < pyr->L; ++l) {
             DPFT_REQUIRE(pyr->level[l], "decoder_forward: view %d level %d is null", v, l);
@@ -941,12 +958,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
                      "decoder_forward: projection inputs of view %d missing", v);
         if (d->has_t[v] < 0) device_flags = true;
     }
-    if (device_flags) {      // has_t < 0: `transformation.any()` is evaluated on the device by the first launch
-        int* fd = reinterpret_cast<int*>(part + (size_t)V * V * nq * 64);      // the 64 spare floats of the work buffer
-        for (int v = 0; v < V; ++v) sa.flag_T[v] = d->T[v];
-        sa.flag_out = fd;
-        xa.flag_dev = ha.flag_dev = fd;
-    }
+    // has_t < 0: `transformation.any()` is evaluated on the device by an extra block of the first launch (dev_flags)
     xa.attn = attn; xa.pos = d->pos; xa.y3 = y3; xa.B = B; xa.Q = Q; xa.V = V;
     ha.y3 = y3; ha.B = B; ha.Q = Q; ha.V = V; ha.ncls = d->num_classes;
     ha.size = d->size; ha.angle = d->angle; ha.cls = d->cls;
@@ -977,10 +989,10 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
             ha.center = last ? d->center : cbuf[(it - 1) & 1];
             ha.refs_out = last ? nullptr : refs;
         }
-        hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head) + (sa.flag_out ? 1 : 0)), dim3(256),
-                           after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? 0 : 1);
+        const bool eval_flags = first && device_flags;
+        hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head) + (eval_flags ? 1 : 0)), dim3(256),
+                           after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? (eval_flags ? 2 : 0) : 1);
         RC(check_launch("decoder_scores_head"));
-        sa.flag_out = nullptr;      // only the first launch evaluates the flags
         if (!first) {
             query = ha.query_out;
             center = ha.center;

@@ -18,7 +18,7 @@ def supported(fuser: nn.Module) -> bool:
         ok = (fuser.d_model == 16 and fuser.d_ffn == 32 and fuser.norm and fuser.reduction == "linear"
               and fuser.activation == "Mish" and 1 <= fuser.m_views <= 4
               and all(h == 8 for h in fuser.n_heads)
-              and all(l * p <= 20 and l <= 8 for l, p in zip(fuser.n_levels, fuser.n_points)))
+              and all(l * p <= 20 and l <= 5 for l, p in zip(fuser.n_levels, fuser.n_points)))
         for h in fuser.heads:
             ok = ok and isinstance(h, LinearDetectionHead) and h.num_reg_layers == 3 and h.num_cls_layers == 3 \
                 and not h.bias and h.num_classes <= 16
