@@ -490,13 +490,13 @@ struct OuterSpecs {
     int n;
 };
 
-__global__ __launch_bounds__(256) void rows_outer_kernel(const float* __restrict__ rows, int R, int W, int64_t gstride_rows,
+__global__ __launch_bounds__(1024) void rows_outer_kernel(const float* __restrict__ rows, int R, int W, int64_t gstride_rows,
                                                           OuterSpecs sp, float* __restrict__ out, int64_t gstride_out) {
     const dpft_outer_spec s = sp.s[blockIdx.y];
     const int tb = (s.n_b + 15) / 16, ta = (s.n_a + 15) / 16;
     if ((int)blockIdx.x >= ta * tb) return;
     const int a0 = ((int)blockIdx.x / tb) * 16, b0 = ((int)blockIdx.x % tb) * 16;
-    const int b = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int b = threadIdx.x & 15, rg = threadIdx.x >> 4;      // 64 row groups: the loop is a latency chain over R / 64 rows
     const float* base = rows + (int64_t)blockIdx.z * gstride_rows;
     const bool ones = s.col_b < 0;                       // column sums: the b operand is 1
     const bool bok = ones ? b == 0 : (b0 + b < s.n_b);
@@ -504,21 +504,52 @@ __global__ __launch_bounds__(256) void rows_outer_kernel(const float* __restrict
     float acc[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    // the 16 a-values of a row are one 64-byte segment (column offsets and tiles are multiples of 16 floats when the row
+    // pitch is a multiple of 4): four 16-byte loads instead of sixteen scalar ones, four rows in flight per thread --
+    // the loop is a latency chain over R / 16 rows, not a bandwidth problem
+    const bool vec = ((s.col_a & 3) == 0) && ((W & 3) == 0) && na == 16 && ((reinterpret_cast<uintptr_t>(base) & 15) == 0);
+    if (vec) {
+#pragma unroll 4
+        for (int r = rg; r < R; r += 64) {
+            const float* row = base + (int64_t)r * W;
+            const float bv = bok ? (ones ? 1.f : row[s.col_b + b0 + b]) : 0.f;
+            const f32x4* ap = reinterpret_cast<const f32x4*>(row + s.col_a + a0);
+            const f32x4 a0v = ap[0], a1v = ap[1], a2v = ap[2], a3v = ap[3];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                acc[i] = fmaf(a0v[i], bv, acc[i]);
+                acc[4 + i] = fmaf(a1v[i], bv, acc[4 + i]);
+                acc[8 + i] = fmaf(a2v[i], bv, acc[8 + i]);
+                acc[12 + i] = fmaf(a3v[i], bv, acc[12 + i]);
+            }
+        }
+    } else {
 #pragma unroll 2
-    for (int r = rg; r < R; r += 16) {
-        const float* row = base + (int64_t)r * W;
-        const float bv = bok ? (ones ? 1.f : row[s.col_b + b0 + b]) : 0.f;
-        float av[16];
+        for (int r = rg; r < R; r += 64) {
+            const float* row = base + (int64_t)r * W;
+            const float bv = bok ? (ones ? 1.f : row[s.col_b + b0 + b]) : 0.f;
+            float av[16];
 #pragma unroll
-        for (int i = 0; i < 16; ++i) av[i] = i < na ? row[s.col_a + a0 + i] : 0.f;
+            for (int i = 0; i < 16; ++i) av[i] = i < na ? row[s.col_a + a0 + i] : 0.f;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = fmaf(av[i], bv, acc[i]);
+            for (int i = 0; i < 16; ++i) acc[i] = fmaf(av[i], bv, acc[i]);
+        }
     }
-    __shared__ float red[16][16][17];                   // [row group][a][b]
+    // the 4 row groups of a wave first (lanes b, b + 16, b + 32, b + 48), then the 16 waves through LDS, in a fixed order
 #pragma unroll
-    for (int i = 0; i < 16; ++i) red[rg][i][b] = acc[i];
+    for (int i = 0; i < 16; ++i) {
+        acc[i] += __shfl_xor(acc[i], 16);
+        acc[i] += __shfl_xor(acc[i], 32);
+    }
+    __shared__ float red[16][16][17];                   // [wave][a][b]
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < 16) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[wave][i][b] = acc[i];
+    }
     __syncthreads();
-    const int a = threadIdx.x >> 4;                      // thread -> output (a, b): sum the 16 row groups in order
+    if (threadIdx.x >= 256) return;
+    const int a = threadIdx.x >> 4;                      // thread -> output (a, b): sum the 16 waves in order
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += red[g][a][b];
@@ -543,7 +574,7 @@ extern "C" int dpft_rows_outer_f32(const float* rows, int32_t G, int32_t R, int3
         sp.s[i] = s;
         max_tiles = std::max(max_tiles, ((s.n_a + 15) / 16) * ((s.n_b + 15) / 16));
     }
-    hipLaunchKernelGGL(dpft::rows_outer_kernel, dim3(max_tiles, n_specs, G), dim3(256), 0, (hipStream_t)stream, rows, R, W,
+    hipLaunchKernelGGL(dpft::rows_outer_kernel, dim3(max_tiles, n_specs, G), dim3(1024), 0, (hipStream_t)stream, rows, R, W,
                        (int64_t)R * W, sp, out, out_gstride);
     return dpft::check_launch("rows_outer");
 }
