@@ -247,7 +247,7 @@ __global__ __launch_bounds__(256) void xf_train_fwd_kernel(XfArgs a) {
 }
 
 __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
-    __shared__ float sm[4][16 + NOA + 32 + NOA + 32 + 32];
+    __shared__ float sm[4][16 + NOA + 32 + NOA + 32 + 32 + 128 + 32 + 32];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bq = blockIdx.x * 4 + wv, view = blockIdx.y;
     if (bq >= a.B * a.Q) return;
@@ -258,6 +258,9 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
     float* dlin = vec + 32;      // [NOA]
     float* va = dlin + NOA;      // [32] scratch vector A
     float* vb2 = va + 32;        // [32] scratch vector B
+    float* ds16 = vb2 + 32;      // [8 heads][16 channels] d(sampled features): the scatter's payload
+    float* sc_w = ds16 + 128;    // [8 heads][4 corners] attention x bilinear weight (0 = corner not written)
+    int* sc_o = reinterpret_cast<int*>(sc_w + 32);      // [8 heads][4 corners] pixel offset (floats) inside the level
     XfFwd f;
     xf_forward_row(a, view, bq, b, q, lane, qp, lin, vec, f);      // qp = y2, vec = hd, lin = offsets | logits
     const float* pv = a.pv[view];
@@ -339,6 +342,7 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
     const f32x2 w1v = *reinterpret_cast<const f32x2*>(pv + PV_VAL_W + (m * DD + 1) * DC + j * 2);
     const f32x2 dS = {w0[0] * g0 + w1v[0] * g1, w0[1] * g0 + w1v[1] * g1};
     const float dM = pv[PV_VAL_B + m * DD + 0] * g0 + pv[PV_VAL_B + m * DD + 1] * g1;
+    *reinterpret_cast<f32x2*>(ds16 + m * DC + j * 2) = dS;
     // ---- bilinear gather backward (as dpft_xattn_bwd_f32): pyramid gradients, d attention prob, d offsets, d ref ----
     const float* lg = lin + n_off + m * LP;
     const float* offp = lin + m * LP * 2;
@@ -351,7 +355,12 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
         const float* base = pyr.level[l] + lb;
         // tiny levels: replica (row % R) of the gradient buffer, so that the fp32 atomics of 1600 rows x 8 heads do
         // not serialise on a few hundred addresses
-        float* gbase = pyr.grad[l] + (int64_t)(bq % pyr.rep[l]) * a.B * H * W * DC + lb;
+        // The scatter is issued by a DIFFERENT lane layout than the gather: its cost is the number of distinct 64-byte lines an
+        // atomic instruction touches (measured: 8x fewer active lanes or a narrower scope change nothing, half the lines
+        // halve it).  With lane = (head, channel pair) an instruction covers 8 pixels -- one per head -- and a pixel needs two
+        // instructions (channels 2j, 2j+1); with lane = (head % 4, channel) it covers 4 pixels and a pixel needs ONE:
+        // half the line requests.  Heads hand their corner weights / offsets over through LDS (sc_w, sc_o).
+        float* gl = pyr.grad[l] + (int64_t)(bq % pyr.rep[l]) * a.B * H * W * DC + (int64_t)b * H * W * DC;
         for (int p = 0; p < P; ++p) {
             const int lp = l * P + p;
             const float ox = offp[lp * 2 + 0], oy = offp[lp * 2 + 1];
@@ -359,7 +368,9 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
             const float lx = f.rx + ox / (float)W, ly = f.ry + oy / (float)H;
             const float h_im = ly * H - 0.5f, w_im = lx * W - 0.5f;
             float ga = 0.f, gw = 0.f, gh = 0.f;
-            if (h_im > -1 && w_im > -1 && h_im < H && w_im < W) {
+            const bool inb = h_im > -1 && w_im > -1 && h_im < H && w_im < W;
+            if (!inb && j == 0) *reinterpret_cast<f32x4*>(sc_w + m * 4) = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (inb) {
                 const int h_lo = (int)floorf(h_im), w_lo = (int)floorf(w_im);
                 const int h_hi = h_lo + 1, w_hi = w_lo + 1;
                 const float lh = h_im - h_lo, lw = w_im - w_lo, hh = 1 - lh, hw = 1 - lw;
@@ -373,10 +384,10 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
                 if (k3) v3 = *reinterpret_cast<const f32x2*>(base + o3);
                 if (k4) v4 = *reinterpret_cast<const f32x2*>(base + o4);
                 const float w1 = hh * hw, w2 = hh * lw, w3 = lh * hw, w4 = lh * lw;
-                if (k1) { atomicAdd(gbase + o1, aw * w1 * dS[0]); atomicAdd(gbase + o1 + 1, aw * w1 * dS[1]); }
-                if (k2) { atomicAdd(gbase + o2, aw * w2 * dS[0]); atomicAdd(gbase + o2 + 1, aw * w2 * dS[1]); }
-                if (k3) { atomicAdd(gbase + o3, aw * w3 * dS[0]); atomicAdd(gbase + o3 + 1, aw * w3 * dS[1]); }
-                if (k4) { atomicAdd(gbase + o4, aw * w4 * dS[0]); atomicAdd(gbase + o4 + 1, aw * w4 * dS[1]); }
+                if (j == 0) {
+                    *reinterpret_cast<f32x4*>(sc_w + m * 4) = f32x4{k1 ? aw * w1 : 0.f, k2 ? aw * w2 : 0.f, k3 ? aw * w3 : 0.f, k4 ? aw * w4 : 0.f};
+                    sc_o[m * 4 + 0] = (int)o1; sc_o[m * 4 + 1] = (int)o2; sc_o[m * 4 + 2] = (int)o3; sc_o[m * 4 + 3] = (int)o4;
+                }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     ga += dS[e] * (w1 * v1[e] + w2 * v2[e] + w3 * v3[e] + w4 * v4[e]);
@@ -390,6 +401,20 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
                     gw += dM * aw * (-hh * i1 + hh * i2 - lh * i3 + lh * i4);
                 }
             }
+            __builtin_amdgcn_wave_barrier();
+            {      // scatter: lane = (head % 4, channel); two head halves x four corners, one 64-byte line per 16 lanes
+                const int h4 = lane >> 4, ch = lane & 15;
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const int m2 = h4 + 4 * half;
+                    const f32x4 cw = *reinterpret_cast<const f32x4*>(sc_w + m2 * 4);
+                    const float val = ds16[m2 * DC + ch];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (cw[k] != 0.f) atomicAdd(gl + sc_o[m2 * 4 + k] + ch, cw[k] * val);
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
             ga = xg8_sum(ga);
             gw = xg8_sum(gw);
             gh = xg8_sum(gh);
