@@ -162,7 +162,7 @@ class _SetLossFn(torch.autograd.Function):
     """dpft_set_loss_fwd/bwd_f32: the five batch-reduced, weighted criterion terms for fixed assignments."""
 
     @staticmethod
-    def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha):
+    def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel):
         import ctypes as C
         from dpft_amd.hip.lib import lib, stream
         B, N, ncls = cls.shape
@@ -172,26 +172,30 @@ class _SetLossFn(torch.autograd.Function):
         lib.call("dpft_set_loss_fwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                  gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
                  losses.data_ptr(), B, N, Mmax, ncls, stream())
-        ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts)
+        # the total of the configured terms is taken here (one op) instead of select x5 / stack / sum in autograd, whose
+        # backward alone is a dozen tiny launches between the step's two host syncs
+        total = torch.dot(losses, sel)
+        ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts, sel)
         ctx.meta = (weights5, float(alpha))
-        return losses
+        ctx.mark_non_differentiable(losses)
+        return losses, total
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, _glosses, gtotal):
         import ctypes as C
         from dpft_amd.hip.lib import lib, stream
-        cls, center, size, angle, gt_box, gt_onehot, match, counts = ctx.saved_tensors
+        cls, center, size, angle, gt_box, gt_onehot, match, counts, sel = ctx.saved_tensors
         weights5, alpha = ctx.meta
         B, N, ncls = cls.shape
         Mmax = gt_box.shape[1]
-        gout = gout.contiguous().float()
+        gout = (sel * gtotal).contiguous().float()          # d total / d term = 1 for the configured terms
         dcls, dcenter, dsize, dangle = (torch.empty_like(t) for t in (cls, center, size, angle))
         w = (C.c_float * 5)(*weights5)
         lib.call("dpft_set_loss_bwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                  gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), alpha,
                  gout.data_ptr(), dcls.data_ptr(), dcenter.data_ptr(), dsize.data_ptr(), dangle.data_ptr(), B, N, Mmax,
                  ncls, stream())
-        return dcls, dcenter, dsize, dangle, None, None, None, None, None, None
+        return dcls, dcenter, dsize, dangle, None, None, None, None, None, None, None
 
 
 class Loss(nn.modules.loss._Loss):
@@ -242,18 +246,23 @@ class Loss(nn.modules.loss._Loss):
                      gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
                      ncls, stream())
         host = cost.cpu().numpy()                                                             # the one sync of the step
-        match = np.full((B, Mmax, 2), -1, dtype=np.int32)
+        packed = np.full(B * Mmax * 2 + B, -1, dtype=np.int32)      # assignments | pair counts: ONE upload
+        match = packed[:B * Mmax * 2].reshape(B, Mmax, 2)
         for b, m in enumerate(counts):
             if m:
                 i, j = linear_sum_assignment(host[b, :, :m])
                 match[b, :len(i), 0], match[b, :len(i), 1] = i, j
                 counts[b] = len(i)           # min(N, m) assigned pairs
-        match_t = torch.from_numpy(match).to(dev, non_blocking=True)
-        counts_m = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
+        packed[B * Mmax * 2:] = counts
+        packed_t = torch.from_numpy(packed).to(dev, non_blocking=True)
+        match_t, counts_m = packed_t[:B * Mmax * 2].view(B, Mmax, 2), packed_t[B * Mmax * 2:]
         weights5 = tuple(float(self.loss_weights.get(k, 0.0)) for k in self._TERMS)
-        losses5 = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75)
-        batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}
-        total = torch.stack(tuple(batch_losses.values())).sum(dim=-1)
+        sel = self.__dict__.get("_sel")
+        if sel is None or sel.device != dev:
+            sel = self.__dict__["_sel"] = torch.tensor([1.0 if k in self.loss_weights else 0.0 for k in self._TERMS],
+                                                       dtype=torch.float32, device=dev)
+        losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel)
+        batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}       # views, for logging
         return total, batch_losses
 
     def forward(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
