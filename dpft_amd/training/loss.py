@@ -262,7 +262,8 @@ class Loss(nn.modules.loss._Loss):
             sel = self.__dict__["_sel"] = torch.tensor([1.0 if k in self.loss_weights else 0.0 for k in self._TERMS],
                                                        dtype=torch.float32, device=dev)
         losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel)
-        batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}       # views, for logging
+        terms = losses5.unbind(0)                                                            # views, for logging
+        batch_losses = {k: terms[self._TERMS.index(k)] for k in self.loss_weights}
         return total, batch_losses
 
     def forward(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):

@@ -1,0 +1,57 @@
+"""Host time inside the window that the GPU spends waiting for the host: from the matcher's D2H sync to the launch of
+the backward graph (monkeypatched timestamps, no extra syncs)."""
+import os, sys, time, torch, numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from dpft_amd.configs import load_config
+from dpft_amd.models import build
+from dpft_amd.synthetic import make_batch, make_labels
+from dpft_amd.training.trainer import DataParallelTrainer
+from dpft_amd.training import loss as L
+from dpft_amd.models.fusers import graphed as G
+cfg = load_config("kradar"); torch.manual_seed(0); dev = torch.device("cuda", 0)
+tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
+data = make_batch(cfg["model"]["inputs"], 4, device=dev); labels = make_labels(4, device=dev)
+tr.enable_graphs(data)
+marks = {}
+orig_lsa = L.linear_sum_assignment
+def lsa(c):
+    marks.setdefault("sync_done", time.perf_counter())
+    t0 = time.perf_counter(); r = orig_lsa(c); marks["lsa"] = marks.get("lsa", 0.0) + time.perf_counter() - t0
+    return r
+L.linear_sum_assignment = lsa
+orig_fwd = L._SetLossFn.forward
+orig_bwd = G._Replay.backward
+def rb(ctx, *g):
+    marks["replay_bwd_enter"] = time.perf_counter()
+    r = orig_bwd(ctx, *g)
+    marks["replay_bwd_done"] = time.perf_counter()
+    return r
+G._Replay.backward = staticmethod(rb)
+orig_sl_bwd = L._SetLossFn.backward
+def slb(ctx, *g):
+    marks["setloss_bwd_enter"] = time.perf_counter()
+    return orig_sl_bwd(ctx, *g)
+L._SetLossFn.backward = staticmethod(slb)
+acc = {}
+for it in range(25):
+    marks.clear()
+    t_a = time.perf_counter()
+    tr.model.train(); tr.reducer.reset()
+    out = tr.model(data)
+    loss, losses = tr.loss_fn(out, labels)
+    marks["loss_fn_done"] = time.perf_counter()
+    ok = bool(loss > 0)
+    marks["gt_sync_done"] = time.perf_counter()
+    loss.backward()
+    tr.reducer.finish(); tr.optimizer.set_active(tr.reducer.seen_ids()); tr.optimizer.step()
+    if it >= 5:
+        s = marks["sync_done"]
+        for k in ("lsa",): acc[k] = acc.get(k, 0) + marks[k]
+        for k in ("loss_fn_done", "gt_sync_done", "setloss_bwd_enter", "replay_bwd_enter", "replay_bwd_done"):
+            acc[k] = acc.get(k, 0) + marks[k] - s
+torch.cuda.synchronize()
+n = 20
+print("per step, host time from the matcher's sync (us):")
+print(f"  scipy assignments (4 samples)      {acc['lsa'] / n * 1e6:7.0f}")
+for k in ("loss_fn_done", "gt_sync_done", "setloss_bwd_enter", "replay_bwd_enter", "replay_bwd_done"):
+    print(f"  -> {k:22s} {acc[k] / n * 1e6:7.0f}")
