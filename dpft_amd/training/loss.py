@@ -262,11 +262,32 @@ class Loss(nn.modules.loss._Loss):
             sel = self.__dict__["_sel"] = torch.tensor([1.0 if k in self.loss_weights else 0.0 for k in self._TERMS],
                                                        dtype=torch.float32, device=dev)
         losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel)
+        self.__dict__["_last"] = (cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel, total)
         terms = losses5.unbind(0)                                                            # views, for logging
         batch_losses = {k: terms[self._TERMS.index(k)] for k in self.loss_weights}
         return total, batch_losses
 
+    def backward_into(self, total: torch.Tensor, dcenter, dsize, dangle, dcls) -> bool:
+        """d total / d (center, size, angle, class) of the LAST fused forward, written into the given buffers by the one
+        backward launch (what ``total.backward()`` would hand to the producers of the outputs, without autograd)."""
+        import ctypes as C
+        from dpft_amd.hip.lib import lib, stream
+        last = self.__dict__.pop("_last", None)
+        if last is None or last[-1] is not total:
+            return False
+        cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel, _ = last
+        B, N, ncls = cls.shape
+        w = (C.c_float * 5)(*weights5)
+        for t, ref in ((dcenter, center), (dsize, size), (dangle, angle), (dcls, cls)):
+            assert t.shape == ref.shape and t.is_contiguous() and t.dtype == torch.float32
+        lib.call("dpft_set_loss_bwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), alpha,
+                 sel.data_ptr(), dcls.data_ptr(), dcenter.data_ptr(), dsize.data_ptr(), dangle.data_ptr(), B, N,
+                 gt_box.shape[1], ncls, stream())
+        return True
+
     def forward(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
+        self.__dict__.pop("_last", None)
         if self._fused_ok(inputs):
             return self.forward_fused(inputs, targets)
         return self.forward_eager(inputs, targets)

@@ -7,6 +7,8 @@ forward -> loss -> if loss > 0: backward, optimizer.step) and of
 """
 from __future__ import annotations
 
+import os
+
 from typing import Any, Dict, List, Optional
 
 import torch
@@ -85,7 +87,8 @@ class DataParallelTrainer:
         if stepped:
             if not local:
                 loss = sum(v.sum() for v in output.values()) * 0.0
-            loss.backward()
+            if not (local and self._backward_without_engine(loss)):
+                loss.backward()
             self.reducer.finish()
             if isinstance(self.optimizer, FusedAdamW):
                 self.optimizer.set_active(self.reducer.seen_ids())
@@ -93,6 +96,23 @@ class DataParallelTrainer:
         if with_metrics and self.eval_fn is not None:
             return loss.detach(), {k: v.detach() for k, v in losses.items()}, self.eval_fn(output, labels)
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
+
+    def _backward_without_engine(self, loss: torch.Tensor) -> bool:
+        """Replayed decoder + fused loss: their two backward steps are launched directly (GraphedFuser.backward_from),
+        autograd starts behind them.  False = the plain ``loss.backward()`` has to run."""
+        g = self.model.__dict__.get("_graphed_fuser")
+        if g is None or g.last_inputs is None or os.environ.get("DPFT_MANUAL_CHAIN", "1") == "0":
+            return False
+        if not hasattr(self.loss_fn, "backward_into") or self.loss_fn.__dict__.get("_last") is None:
+            return False
+        done = []
+
+        def write(go):          # static_grad_outputs = (center, size, angle, class)
+            done.append(self.loss_fn.backward_into(loss, go[0], go[1], go[2], go[3]))
+        if self.loss_fn.__dict__["_last"][-1] is not loss:
+            return False
+        g.backward_from(write)
+        return bool(done and done[0])
 
     @torch.no_grad()
     def inference_time(self, data: Dict[str, torch.Tensor], warmup: int = 10, reps: int = 300):

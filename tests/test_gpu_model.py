@@ -762,6 +762,47 @@ def test_graphed_decoder_step_equals_eager_step():
     assert errs[0][0] < 5e-3, errs[:6]
 
 
+def test_engine_free_decoder_backward_equals_autograd_backward():
+    """DataParallelTrainer._backward_without_engine (set-loss backward written into the graph's static buffers, backward graph
+    launched directly, autograd started on the pyramid tensors afterwards) == ``loss.backward()`` through the same graphs:
+    same gradients for every parameter of the model."""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=9, shapes=SHAPES, device=DEV)
+    labels = make_labels(2, seed=9, device=DEV)
+    torch.manual_seed(0)
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+    tr.enable_graphs(batch)
+    tr.model.train()
+    res = []
+    for manual in (False, True, False):
+        tr.reducer.reset()
+        out = tr.model(batch)
+        loss, _ = tr.loss_fn(out, labels)
+        if manual:
+            assert tr._backward_without_engine(loss), "the engine-free path must be taken with graphs + fused loss"
+        else:
+            loss.backward()
+        tr.reducer.finish()
+        res.append({n: p.grad.detach().clone() for n, p in tr.model.named_parameters() if p.grad is not None})
+    ref, got, again = res
+    assert set(ref) == set(got)
+    typical = torch.stack([g.abs().mean() for g in ref.values() if float(g.norm()) > 0]).median()
+    worst = []
+    for k in ref:
+        den = max(float(ref[k].norm()), 1e-4 * float(typical) * ref[k].numel() ** 0.5)
+        # yardstick: two autograd passes of the same state (the pyramid gradients use fp32 atomics, batch statistics move
+        # the running buffers only) differ by `noise`; the engine-free pass must sit in the same band
+        noise = float((again[k] - ref[k]).norm()) / den
+        err = float((got[k] - ref[k]).norm()) / den
+        worst.append((err - 3 * noise, err, noise, k))
+    worst.sort(reverse=True)
+    print("engine-free vs autograd backward, worst (excess, err, run-to-run noise, name):", worst[:3])
+    assert worst[0][1] < max(2e-3, 3 * worst[0][2] + 1e-5), worst[:5]
+
+
 def test_eval_after_fused_optimizer_steps_uses_updated_weights():
     """The fused AdamW kernel writes parameters through raw pointers (no torch version bump): the inference decoder's
     packed weight blobs must still be rebuilt, i.e. eval after training == the eager decoder on the current weights."""
