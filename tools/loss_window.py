@@ -19,19 +19,20 @@ def lsa(c):
     t0 = time.perf_counter(); r = orig_lsa(c); marks["lsa"] = marks.get("lsa", 0.0) + time.perf_counter() - t0
     return r
 L.linear_sum_assignment = lsa
-orig_fwd = L._SetLossFn.forward
-orig_bwd = G._Replay.backward
-def rb(ctx, *g):
-    marks["replay_bwd_enter"] = time.perf_counter()
-    r = orig_bwd(ctx, *g)
-    marks["replay_bwd_done"] = time.perf_counter()
-    return r
-G._Replay.backward = staticmethod(rb)
-orig_sl_bwd = L._SetLossFn.backward
-def slb(ctx, *g):
-    marks["setloss_bwd_enter"] = time.perf_counter()
-    return orig_sl_bwd(ctx, *g)
-L._SetLossFn.backward = staticmethod(slb)
+orig_bf = G.GraphedFuser.backward_from
+def bf(self, write):
+    marks["backward_from_enter"] = time.perf_counter()
+    orig_replay = self.bwd_graph.replay
+    def rp():
+        marks["bwd_graph_replay_call"] = time.perf_counter()
+        orig_replay()
+        marks["bwd_graph_replay_returned"] = time.perf_counter()
+    self.bwd_graph.replay = rp
+    try:
+        return orig_bf(self, write)
+    finally:
+        self.bwd_graph.replay = orig_replay
+G.GraphedFuser.backward_from = bf
 acc = {}
 for it in range(25):
     marks.clear()
@@ -42,16 +43,18 @@ for it in range(25):
     marks["loss_fn_done"] = time.perf_counter()
     ok = bool(loss > 0)
     marks["gt_sync_done"] = time.perf_counter()
-    loss.backward()
+    if not tr._backward_without_engine(loss):
+        loss.backward()
+    marks["backward_returned"] = time.perf_counter()
     tr.reducer.finish(); tr.optimizer.set_active(tr.reducer.seen_ids()); tr.optimizer.step()
     if it >= 5:
         s = marks["sync_done"]
         for k in ("lsa",): acc[k] = acc.get(k, 0) + marks[k]
-        for k in ("loss_fn_done", "gt_sync_done", "setloss_bwd_enter", "replay_bwd_enter", "replay_bwd_done"):
+        for k in ("loss_fn_done", "gt_sync_done", "backward_from_enter", "bwd_graph_replay_call", "bwd_graph_replay_returned", "backward_returned"):
             acc[k] = acc.get(k, 0) + marks[k] - s
 torch.cuda.synchronize()
 n = 20
 print("per step, host time from the matcher's sync (us):")
 print(f"  scipy assignments (4 samples)      {acc['lsa'] / n * 1e6:7.0f}")
-for k in ("loss_fn_done", "gt_sync_done", "setloss_bwd_enter", "replay_bwd_enter", "replay_bwd_done"):
+for k in ("loss_fn_done", "gt_sync_done", "backward_from_enter", "bwd_graph_replay_call", "bwd_graph_replay_returned", "backward_returned"):
     print(f"  -> {k:22s} {acc[k] / n * 1e6:7.0f}")
