@@ -224,7 +224,7 @@ class XattnFfnBlocksFn(torch.autograd.Function):
                       col[v, X["G2"]:X["B2"]], col[v, X["B2"]:X["DBV"]],
                       g_f1[v], col[v, X["DPRE"]:X["DOUT"]], g_f2[v], col[v, X["DF"]:X["DPRE"]],
                       col[v, X["G3"]:X["B3"]], col[v, X["B3"]:X["G2"]]]
-        gtok = [torch.zeros((), dtype=dy3.dtype, device=dev) for _ in range(V)]
+        gtok = [None] * V                       # tokens carry ordering only (_PyramidHub ignores their gradient)
         return (None, None, None, None, None, dy1, dqp.sum((0, 1)), dref, *gtok, *grads)
 
 

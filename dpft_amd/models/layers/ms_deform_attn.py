@@ -58,18 +58,36 @@ class PyramidState:
         self.grads = None
         self.rep = None
 
+    def _alloc(self, with_replicas: bool):
+        """All gradient buffers of the view from ONE zero-filled allocation (one fill launch instead of one per level and
+        replica stack); chunks start on 64-element boundaries."""
+        shapes = [tuple(l.shape) for l in self.levels]
+        reps = [(self.REPLICAS,) + sh if with_replicas and sh[1] * sh[2] <= self.TINY_PIXELS else None for sh in shapes]
+        sizes = [int(torch.Size(sh).numel()) for sh in shapes] + [int(torch.Size(r).numel()) if r else 0 for r in reps]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += (n + 63) // 64 * 64
+        l0 = self.levels[0]
+        flat = torch.zeros(total, dtype=l0.dtype, device=l0.device)
+        n = len(shapes)
+        self.grads = [flat[offs[i]:offs[i] + sizes[i]].view(shapes[i]) for i in range(n)]
+        if with_replicas:
+            self.rep = [flat[offs[n + i]:offs[n + i] + sizes[n + i]].view(reps[i]) if reps[i] else None for i in range(n)]
+
     def grad_buffers(self) -> List[torch.Tensor]:
         if self.grads is None:
-            self.grads = [torch.zeros_like(l) for l in self.levels]
+            self._alloc(False)
         return self.grads
 
     def replicated_grad_buffers(self) -> List[torch.Tensor]:
         """Like grad_buffers(), but tiny levels come as (R,B,H,W,C) replica stacks that `finish()` folds back."""
-        g = self.grad_buffers()
-        if self.rep is None:
+        if self.grads is None:
+            self._alloc(True)
+        elif self.rep is None:           # plain buffers exist already (mixed use): add the replica stacks
             self.rep = [torch.zeros((self.REPLICAS,) + tuple(l.shape), dtype=l.dtype, device=l.device)
                         if l.shape[1] * l.shape[2] <= self.TINY_PIXELS else None for l in self.levels]
-        return [r if r is not None else t for r, t in zip(self.rep, g)]
+        return [r if r is not None else t for r, t in zip(self.rep, self.grads)]
 
     def finish(self):
         if self.rep is not None and self.grads is not None:
@@ -84,6 +102,7 @@ class _PyramidHub(Function):
     def forward(ctx, state: PyramidState, *levels):
         ctx.state = state
         ctx.n = len(levels)
+        ctx.set_materialize_grads(False)      # the token carries ordering only: its consumers return no gradient for it
         return levels[0].new_zeros(())
 
     @staticmethod
@@ -125,8 +144,7 @@ class _XAttnFn(Function):
         g4 = gout.view(B, Q, M, C // M)
         gWv = torch.einsum("bqmd,bqmc->mdc", g4, samp).reshape(C, C)
         gbv = torch.einsum("bqmd,bqm->md", g4, mass).reshape(C)
-        gtoken = torch.zeros((), dtype=gout.dtype, device=gout.device)
-        return None, gtoken, gref, goff, gattn, gWv, gbv, None, None
+        return None, None, gref, goff, gattn, gWv, gbv, None, None      # token: ordering only (_PyramidHub)
 
 
 def _is_power_of_2(n):
