@@ -176,6 +176,8 @@ class _BodyFn(torch.autograd.Function):
                     bn_g = [direct.grad_buffer(m.weight) for m in bns]
                     bn_b = [direct.grad_buffer(m.bias) for m in bns]
                 if direct is None or any(g is None for g in conv_g + bn_g + bn_b):
+                    if owner.grad_direct is not None:      # gradients will be ACCUMULATED by autograd this step: the
+                        owner.grad_direct.clear(params)     # reducer no longer clears these (set_overwritten)
                     direct = None
                     total = sum(c.weight.numel() for c in convs) + 2 * sum(m.weight.numel() for m in bns)
                     flat = torch.empty(total, dtype=torch.float32, device=x.device)

@@ -58,6 +58,7 @@ class _FPNFn(torch.autograd.Function):
         # (each FPN parameter receives exactly one gradient per step) instead of going through AccumulateGrad
         direct = owner.grad_direct if owner is not None else None
         if direct is not None and any(direct.grad_buffer(p) is None for p in fpn.parameters()):
+            direct.clear(list(fpn.parameters()))      # accumulated by autograd this step (see GradBucketReducer.set_overwritten)
             direct = None
         ctx.direct = direct
         return tuple(outs)
@@ -81,6 +82,9 @@ class _FPNFn(torch.autograd.Function):
             conv = fpn.layer_blocks[i][0]
             if douts[i] is None:
                 g = torch.zeros_like(lasts[i])
+                if direct is not None:      # this output was not used: its conv receives no gradient -- the bucket is not
+                    direct.grad_buffer(conv.weight).zero_()      # cleared per step for overwritten parameters
+                    direct.grad_buffer(conv.bias).zero_()
             else:
                 do = douts[i].contiguous()
                 wgrad(cl[i], lasts[i], do, conv)

@@ -56,9 +56,13 @@ class DataParallelTrainer:
         self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=int(bucket_mb * (1 << 20)),
                                          group_of=group_of, comm_dtype=wire)
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
+        overwritten = []
         for m in self.model.modules():
             if hasattr(m, "grad_direct"):
                 m.grad_direct = self.reducer
+                overwritten += list(m.parameters())      # their gradients are written (not added) into the buckets
+        if self.device.type == "cuda" and os.environ.get("DPFT_ZERO_ALL_GRADS", "0") != "1":
+            self.reducer.set_overwritten(overwritten)
 
     def enable_graphs(self, sample_data: Dict[str, torch.Tensor]):
         """Replay the launch-bound decoder from hipGraphs (static shapes of ``sample_data``)."""
