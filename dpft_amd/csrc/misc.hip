@@ -403,6 +403,67 @@ extern "C" int dpft_giou3d_yaw_f32(const float* pred, const float* gt, float* ou
     return check_launch("giou3d_yaw");
 }
 
+// Per-sample label tensors -> the padded batch tensors of the loss / matcher / metric kernels in ONE launch (the torch
+// form -- cat x B, pad_sequence x 2, zeros, argmax, casts -- is ~17 launches that sit between the decoder and the matcher):
+// gt_box (B,Mmax,8) = center | size | angle, gt_onehot (B,Mmax,C), gt_id (B,Mmax) = argmax of the class row (first
+// maximum, like torch.argmax), counts (B).  Rows >= count are zero.
+namespace dpft {
+constexpr int PACK_MAX_B = 32;
+struct PackTargetsArgs {
+    const float* center[PACK_MAX_B];
+    const float* size[PACK_MAX_B];
+    const float* angle[PACK_MAX_B];
+    const float* cls[PACK_MAX_B];
+    int count[PACK_MAX_B];
+    float* gt_box;
+    float* gt_onehot;
+    int* gt_id;
+    int* counts;
+    int B, Mmax, C;
+};
+__global__ __launch_bounds__(64) void pack_targets_kernel(PackTargetsArgs a) {
+    const int b = blockIdx.x, n = a.count[b];
+    if (threadIdx.x == 0) a.counts[b] = n;
+    for (int m = threadIdx.x; m < a.Mmax; m += 64) {
+        float* box = a.gt_box + ((size_t)b * a.Mmax + m) * 8;
+        float* oh = a.gt_onehot + ((size_t)b * a.Mmax + m) * a.C;
+        int id = 0;
+        if (m < n) {
+            for (int k = 0; k < 3; ++k) box[k] = a.center[b][m * 3 + k];
+            for (int k = 0; k < 3; ++k) box[3 + k] = a.size[b][m * 3 + k];
+            for (int k = 0; k < 2; ++k) box[6 + k] = a.angle[b][m * 2 + k];
+            float best = -INFINITY;
+            for (int c = 0; c < a.C; ++c) {
+                const float v = a.cls[b][m * a.C + c];
+                oh[c] = v;
+                if (v > best) { best = v; id = c; }
+            }
+        } else {
+            for (int k = 0; k < 8; ++k) box[k] = 0.f;
+            for (int c = 0; c < a.C; ++c) oh[c] = 0.f;
+        }
+        a.gt_id[(size_t)b * a.Mmax + m] = id;
+    }
+}
+}  // namespace dpft
+
+extern "C" int dpft_pack_targets_f32(const float* const* center, const float* const* size, const float* const* angle,
+                                     const float* const* cls, const int32_t* counts_host, int32_t B, int32_t Mmax, int32_t C,
+                                     float* gt_box, float* gt_onehot, int32_t* gt_id, int32_t* counts, dpft_stream_t stream) {
+    DPFT_REQUIRE(center && size && angle && cls && counts_host && gt_box && gt_onehot && gt_id && counts, "pack_targets: null argument");
+    DPFT_REQUIRE(B >= 1 && B <= dpft::PACK_MAX_B && Mmax >= 1 && C >= 1, "pack_targets: 1..%d samples per call", dpft::PACK_MAX_B);
+    dpft::PackTargetsArgs a;
+    memset(&a, 0, sizeof(a));
+    for (int b = 0; b < B; ++b) {
+        DPFT_REQUIRE(counts_host[b] >= 0 && counts_host[b] <= Mmax, "pack_targets: sample %d has %d targets (Mmax %d)", b, counts_host[b], Mmax);
+        DPFT_REQUIRE(counts_host[b] == 0 || (center[b] && size[b] && angle[b] && cls[b]), "pack_targets: sample %d has null labels", b);
+        a.center[b] = center[b]; a.size[b] = size[b]; a.angle[b] = angle[b]; a.cls[b] = cls[b]; a.count[b] = counts_host[b];
+    }
+    a.gt_box = gt_box; a.gt_onehot = gt_onehot; a.gt_id = gt_id; a.counts = counts; a.B = B; a.Mmax = Mmax; a.C = C;
+    hipLaunchKernelGGL(dpft::pack_targets_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, a);
+    return dpft::check_launch("pack_targets");
+}
+
 extern "C" int dpft_match_cost_f32(const float* cls, const float* center, const float* size, const float* angle,
                                    const float* gt_box, const int32_t* gt_id, const int32_t* counts, const float* weights5,
                                    float* cost, int32_t B, int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream) {

@@ -130,6 +130,7 @@ SIGNATURES = {
     "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _I, _I, _P]),
     "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
+    "dpft_pack_targets_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dpft_match_cost_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),

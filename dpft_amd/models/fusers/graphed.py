@@ -53,6 +53,8 @@ class _Replay(torch.autograd.Function):
         g.fwd_graph.replay()
         ctx.g = g
         g.last_inputs = inputs[1:1 + g.n_levels]            # this step's pyramid tensors (see backward_from)
+        if not g.clone_outputs:                             # the caller consumes the outputs before the next replay
+            return tuple(o.detach() for o in g.static_outputs)
         return tuple(o.detach().clone() for o in g.static_outputs)
 
     @staticmethod
@@ -73,6 +75,7 @@ class _Replay(torch.autograd.Function):
 
 class GraphedFuser:
     last_inputs = None
+    clone_outputs = True        # False: hand out the graph's static output buffers (DataParallelTrainer.train_step)
 
     def backward_from(self, write_output_grads) -> None:
         """The backward of the replayed decoder WITHOUT the autograd engine in front of it: ``write_output_grads`` fills

@@ -143,6 +143,10 @@ def pack_targets(targets: List[Dict[str, torch.Tensor]], counts: List[int], ncls
     gt_box (B,Mmax,8) = center | size | angle, gt_onehot (B,Mmax,C), gt_id (B,Mmax) int32, counts (B) int32."""
     from torch.nn.utils.rnn import pad_sequence
     Mmax = max(max(counts), 1)
+    if dev.type == "cuda" and len(targets) <= 32:
+        fused = _pack_targets_hip(targets, counts, ncls, dev, Mmax)
+        if fused is not None:
+            return fused
     empty8 = torch.zeros((0, 8), dtype=torch.float32, device=dev)
     emptyc = torch.zeros((0, ncls), dtype=torch.float32, device=dev)
     boxes = [torch.cat((t["gt_center"], t["gt_size"], t["gt_angle"]), -1).float() if m else empty8
@@ -155,6 +159,33 @@ def pack_targets(targets: List[Dict[str, torch.Tensor]], counts: List[int], ncls
         gt_onehot = torch.zeros((len(targets), Mmax, ncls), dtype=torch.float32, device=dev)
     gt_id = gt_onehot.argmax(-1).to(torch.int32).contiguous()
     counts_t = torch.tensor(counts, dtype=torch.int32).to(dev, non_blocking=True)
+    return gt_box, gt_onehot, gt_id, counts_t, Mmax
+
+
+def _pack_targets_hip(targets, counts, ncls, dev, Mmax):
+    """One launch (dpft_pack_targets_f32) when every label tensor is fp32, contiguous and on the device; else None."""
+    import ctypes as C
+    from dpft_amd.hip.lib import lib, stream
+    B = len(targets)
+    keys = ("gt_center", "gt_size", "gt_angle", "gt_class")
+    widths = (3, 3, 2, ncls)
+    ptrs = [(C.c_void_p * B)() for _ in keys]
+    for b, (t, m) in enumerate(zip(targets, counts)):
+        for arr, k, w in zip(ptrs, keys, widths):
+            v = t[k]
+            if m == 0:
+                arr[b] = None
+                continue
+            if not (v.is_cuda and v.dtype == torch.float32 and v.is_contiguous() and tuple(v.shape) == (m, w)):
+                return None
+            arr[b] = v.data_ptr()
+    gt_box = torch.empty((B, Mmax, 8), dtype=torch.float32, device=dev)
+    gt_onehot = torch.empty((B, Mmax, ncls), dtype=torch.float32, device=dev)
+    gt_id = torch.empty((B, Mmax), dtype=torch.int32, device=dev)
+    counts_t = torch.empty((B,), dtype=torch.int32, device=dev)
+    ch = (C.c_int32 * B)(*counts)
+    lib.call("dpft_pack_targets_f32", ptrs[0], ptrs[1], ptrs[2], ptrs[3], ch, B, Mmax, ncls, gt_box.data_ptr(),
+             gt_onehot.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), stream())
     return gt_box, gt_onehot, gt_id, counts_t, Mmax
 
 

@@ -78,7 +78,14 @@ class DataParallelTrainer:
         configured detection metrics on the step's outputs (two more launches) and returns them as a third value."""
         self.model.train()
         self.reducer.reset()                               # zero_grad (grads live in the buckets)
-        output = self.model(data)
+        g = self.model.__dict__.get("_graphed_fuser")
+        if g is not None:
+            g.clone_outputs = False                        # loss, metrics and the backward below are done with them in time
+        try:
+            output = self.model(data)
+        finally:
+            if g is not None:
+                g.clone_outputs = True
         loss, losses = self.loss_fn(output, labels)
         stepped = local = bool(loss > 0)                   # trainer.py:131 (host sync, as in the reference)
         if self.world > 1:

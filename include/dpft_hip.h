@@ -428,6 +428,14 @@ int dpft_rows_outer_f32(const float* rows, int32_t G, int32_t R, int32_t W, cons
 int dpft_giou3d_yaw_f32(const float* pred, const float* gt, float* out, int32_t B, int32_t N,
                         int32_t Mg, dpft_stream_t stream);
 
+/* Per-sample label tensors (host arrays of B device pointers: gt_center (m,3), gt_size (m,3), gt_angle (m,2), gt_class (m,C)
+ * one-hot, fp32 contiguous; counts_host[b] = m) -> the padded batch tensors the matcher / loss / metric kernels read:
+ * gt_box (B,Mmax,8) = center | size | angle, gt_onehot (B,Mmax,C), gt_id (B,Mmax) = argmax(gt_class), counts (B).
+ * Replaces the per-sample decollate of src/dprt/training/assigner.py:92-111 / loss.py:524-541 (B <= 32 per call). */
+int dpft_pack_targets_f32(const float* const* center, const float* const* size, const float* const* angle,
+                          const float* const* cls, const int32_t* counts_host, int32_t B, int32_t Mmax, int32_t C,
+                          float* gt_box, float* gt_onehot, int32_t* gt_id, int32_t* counts, dpft_stream_t stream);
+
 /* Whole matcher cost (src/dprt/training/assigner.py:113-132) in one launch:
  * cost[b,n,j] = w0*(-cls[b,n,gt_id[b,j]]) + w1*L1(center) + w2*L1(size) + w3*L1(angle) - w4*GIoU3D, 0 for j >= counts[b].
  * gt_box (B,Mmax,8) = center | size | angle(2); weights5 is a HOST array. */

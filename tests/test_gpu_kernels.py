@@ -895,3 +895,26 @@ def test_conv_fwd_bnact_inference_epilogue(B, H, W, Cin, K, k, stride, res, relu
     if relu:
         ref = ref.relu()
     torch.testing.assert_close(y.double().cpu(), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_pack_targets_kernel_matches_torch_packing(monkeypatch):
+    """dpft_pack_targets_f32 == the torch packing (cat / pad_sequence / argmax) on ragged label batches incl. an empty sample."""
+    from dpft_amd.training import loss as L
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    ncls = 4
+    counts = [3, 0, 7, 1]
+    targets = []
+    for m in counts:
+        cls = torch.zeros(m, ncls, device=dev)
+        if m:
+            cls[torch.arange(m), torch.randint(0, ncls, (m,))] = 1.0
+        targets.append({"gt_center": torch.randn(m, 3, device=dev), "gt_size": torch.rand(m, 3, device=dev),
+                        "gt_angle": torch.randn(m, 2, device=dev), "gt_class": cls})
+    got = L.pack_targets(targets, list(counts), ncls, dev)
+    monkeypatch.setattr(L, "_pack_targets_hip", lambda *a, **k: None)
+    ref = L.pack_targets(targets, list(counts), ncls, dev)
+    assert got[4] == ref[4] == 7
+    for g, r in zip(got[:4], ref[:4]):
+        assert g.dtype == r.dtype and torch.equal(g, r)
