@@ -256,6 +256,18 @@ class Loss(nn.modules.loss._Loss):
                 and isinstance(self.anassigner, HungarianAnassigner) and isinstance(self.criterion, SetCriterion)
                 and set(self.loss_weights) <= set(self._TERMS) and inputs["class"].dtype == torch.float32)
 
+    def _to_host(self, t: torch.Tensor) -> "np.ndarray":
+        """Device tensor -> numpy through a reused pinned buffer (one async copy + one stream sync instead of a pageable
+        allocation and a staged copy: this read-back is the step's host sync, the GPU idles until the host moves on)."""
+        n = t.numel()
+        pin = self.__dict__.get("_pin_f32")
+        if pin is None or pin.numel() < n:
+            pin = self.__dict__["_pin_f32"] = torch.empty(max(n, 1 << 16), dtype=torch.float32).pin_memory()
+        view = pin[:n].view(t.shape)
+        view.copy_(t, non_blocking=True)
+        torch.cuda.current_stream(t.device).synchronize()
+        return view.numpy()
+
     def forward_fused(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
         """Same values as ``forward_eager`` from three launches + the host assignment (one D2H, one H2D copy)."""
         import ctypes as C
@@ -276,8 +288,13 @@ class Loss(nn.modules.loss._Loss):
             lib.call("dpft_match_cost_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                      gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
                      ncls, stream())
-        host = cost.cpu().numpy()                                                             # the one sync of the step
-        packed = np.full(B * Mmax * 2 + B, -1, dtype=np.int32)      # assignments | pair counts: ONE upload
+        host = self._to_host(cost)                                                            # the one sync of the step
+        n_pack = B * Mmax * 2 + B
+        pin = self.__dict__.get("_pin_i32")
+        if pin is None or pin.numel() < n_pack:
+            pin = self.__dict__["_pin_i32"] = torch.empty(max(n_pack, 4096), dtype=torch.int32).pin_memory()
+        packed = pin.numpy()[:n_pack]                                # assignments | pair counts: ONE upload, from pinned memory
+        packed[:] = -1
         match = packed[:B * Mmax * 2].reshape(B, Mmax, 2)
         for b, m in enumerate(counts):
             if m:
@@ -285,7 +302,8 @@ class Loss(nn.modules.loss._Loss):
                 match[b, :len(i), 0], match[b, :len(i), 1] = i, j
                 counts[b] = len(i)           # min(N, m) assigned pairs
         packed[B * Mmax * 2:] = counts
-        packed_t = torch.from_numpy(packed).to(dev, non_blocking=True)
+        packed_t = torch.empty(n_pack, dtype=torch.int32, device=dev)
+        packed_t.copy_(pin[:n_pack], non_blocking=True)      # (the pinned buffer is rewritten only after the next step's sync)
         match_t, counts_m = packed_t[:B * Mmax * 2].view(B, Mmax, 2), packed_t[B * Mmax * 2:]
         weights5 = tuple(float(self.loss_weights.get(k, 0.0)) for k in self._TERMS)
         sel = self.__dict__.get("_sel")
