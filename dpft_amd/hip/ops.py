@@ -88,10 +88,12 @@ def conv_problem(B, H, W, Cin, K, kh, kw, stride, pad) -> Conv:
     return c
 
 
-def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False):
+def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False, out=None):
     """x (B,H,W,C) contiguous; w physical [K][kh][kw][C]. pro = (bn_block[4][C], relu) or None.
-    Returns y (B,OH,OW,K) and the per-tile stats tensor (or None)."""
-    y = torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
+    Returns y (B,OH,OW,K) and the per-tile stats tensor (or None).  ``out``: write y into this buffer."""
+    y = out if out is not None else torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
+    if out is not None and (tuple(out.shape) != (cv.B, cv.OH, cv.OW, cv.K) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise ValueError("conv_fwd: the output buffer does not match the problem")
     stats = torch.empty((cv.tiles, 2, cv.K), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)

@@ -97,6 +97,12 @@ class DPRT(nn.Module):
         f = self.backbones[i](batch[i])                                         # dprt.py:219
         if self.skiplinks[i]:
             f = self._add_raw_data(f, batch[i])                                 # :222-225
+        bufs = None
+        graphed = self.__dict__.get("_graphed_fuser")
+        if graphed is not None and self.training and torch.is_grad_enabled():
+            bufs = graphed.level_buffers(i, f)           # the decoder graph's static inputs: the neck writes them directly
+        if bufs is not None:
+            return self.embeddings[i](self.necks[i](f, out_buffers=bufs))
         return self.embeddings[i](self.necks[i](f))                             # :228, :231
 
     def _encode_views(self, batch: Dict[str, torch.Tensor]) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:

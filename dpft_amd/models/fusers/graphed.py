@@ -13,7 +13,7 @@ forward temporaries of the same pool.
 from __future__ import annotations
 
 from collections import OrderedDict
-from typing import Dict, List
+from typing import Dict, List, Optional
 
 import torch
 from torch import nn
@@ -76,6 +76,22 @@ class _Replay(torch.autograd.Function):
 class GraphedFuser:
     last_inputs = None
     clone_outputs = True        # False: hand out the graph's static output buffers (DataParallelTrainer.train_step)
+
+    def level_buffers(self, view: str, feats) -> "Optional[List[torch.Tensor]]":
+        """The static pyramid inputs of ``view`` (in the neck's level order) as plain tensors sharing their storage, or None
+        when this step's shapes differ from the captured ones."""
+        try:
+            vi = self.inputs.index(view)
+        except ValueError:
+            return None
+        start = 1 + sum(len(k) for k in self.level_keys[:vi])
+        bufs = self.static_inputs[start:start + len(self.level_keys[vi])]
+        if list(feats.keys()) != self.level_keys[vi] or getattr(self, "_neck_direct", True) is False:
+            return None
+        for b, x in zip(bufs, feats.values()):
+            if b.shape[0] != x.shape[0] or tuple(b.shape[1:3]) != tuple(x.shape[1:3]):
+                return None
+        return [b.detach() for b in bufs]
 
     def backward_from(self, write_output_grads) -> None:
         """The backward of the replayed decoder WITHOUT the autograd engine in front of it: ``write_output_grads`` fills

@@ -36,7 +36,7 @@ class FeaturePyramidNetwork(nn.Module):
 
 class _FPNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, owner, fpn: FeaturePyramidNetwork, n: int, *tensors: torch.Tensor):
+    def forward(ctx, owner, fpn: FeaturePyramidNetwork, n: int, out_buffers, *tensors: torch.Tensor):
         xs = [t.contiguous() for t in tensors[:n]]
         K = fpn.out_channels
         lasts, outs, ci, cl = [None] * n, [None] * n, [None] * n, [None] * n
@@ -50,7 +50,8 @@ class _FPNFn(torch.autograd.Function):
             lasts[i] = lat
             cl[i] = ops.conv_problem(B, H, W, K, K, 3, 3, 1, 1)
             conv = fpn.layer_blocks[i][0]
-            outs[i], _ = ops.conv_fwd(cl[i], lat, khwc(conv.weight), bias=conv.bias)
+            outs[i], _ = ops.conv_fwd(cl[i], lat, khwc(conv.weight), bias=conv.bias,
+                                      out=None if out_buffers is None else out_buffers[i])
         ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl = fpn, n, xs, lasts, ci, cl
         ctx.params = tensors[n:]
         ctx.x_needs = [t.requires_grad for t in tensors[:n]]
@@ -98,7 +99,7 @@ class _FPNFn(torch.autograd.Function):
             g_prev = g
         if direct is not None:
             direct.mark_ready_many(list(fpn.parameters()))
-        return (None, None, None, *dxs, *[grads.get(p) for p in ctx.params])
+        return (None, None, None, None, *dxs, *[grads.get(p) for p in ctx.params])
 
 
 class FPN(nn.Module):
@@ -122,12 +123,15 @@ class FPN(nn.Module):
     def from_config(cls, config: Dict[str, Any]):
         return cls(config["in_channels_list"], config["out_channels"], config.get("norm_layer"))
 
-    def forward(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    def forward(self, batch: Dict[str, torch.Tensor], out_buffers: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+        """``out_buffers`` (NHWC, one per level): the pyramid is written there (e.g. the static input buffers of a captured
+        decoder graph: no copy between the neck and the graph)."""
         keys = list(batch.keys())
         xs = list(batch.values())
         if not self.channel_last:
             xs = [x.movedim(1, -1) for x in xs]
-        outs = _FPNFn.apply(self, self.fpn, len(xs), *xs, *self.fpn.parameters())
+            out_buffers = None
+        outs = _FPNFn.apply(self, self.fpn, len(xs), out_buffers, *xs, *self.fpn.parameters())
         if not self.channel_last:
             outs = [o.movedim(-1, 1) for o in outs]
         return OrderedDict(zip(keys, outs))

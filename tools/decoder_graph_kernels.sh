@@ -14,7 +14,7 @@ def short(n):
     n = re.sub(r"<.*", "", n)
     return n[:44]
 dec = [i for i, r in enumerate(step) if any(p in r["Kernel_Name"] for p in ("sa_train", "xf_train", "hd_train"))]
-lo, hi = (0, len(step)) if __import__("os").environ.get("WHOLE") else (dec[0] - 12, dec[-1] + 12)
+lo, hi = (0, len(step)) if __import__("os").environ.get("WHOLE") else (dec[0] - int(__import__("os").environ.get("BEFORE", "12")), dec[-1] + 12)
 seq = []
 for r in step[max(lo, 0):hi]:
     n = short(r["Kernel_Name"])
