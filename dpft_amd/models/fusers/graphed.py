@@ -126,7 +126,7 @@ class GraphedFuser:
         self.flags = model.fuser.transformation_flags(proj)
         self.level_keys = [list(feats[i].keys()) for i in self.inputs]
         center0 = model.querent(sample_batch)["center"]
-        static = [center0.detach().clone()]
+        static = [center0.detach()]          # the querent's cached constant: the same storage every step, never copied
         for i in self.inputs:
             static += [v.detach().clone().requires_grad_(True) for v in feats[i].values()]
         self.n_levels = len(static) - 1

@@ -72,10 +72,22 @@ class DataAgnosticStaticQueries(nn.Module):
             self._cache[key] = g
         return g
 
+    def __getstate__(self):          # caches are rebuilt on demand (torch.save(model), deepcopy)
+        st = self.__dict__.copy()
+        st.pop("_batched", None)
+        return st
+
     def forward(self, batch: Union[torch.Tensor, Sequence[torch.Tensor], Dict[str, torch.Tensor]]):
         first = self._first(batch)
         g = self._grid(first.dtype, first.device)
-        return OrderedDict({"center": g.unsqueeze(0).repeat(first.shape[0], 1, 1)})
+        # the batch of query centres is a constant of (B, dtype, device): built once, handed out read-only (the heads write
+        # their refined centres into new tensors) -- a captured decoder graph can then take it as a static input as it is
+        key = (first.shape[0], first.dtype, str(first.device))
+        cache = self.__dict__.setdefault("_batched", {})
+        c = cache.get(key)
+        if c is None or c.data_ptr() == 0:
+            c = cache[key] = g.unsqueeze(0).repeat(first.shape[0], 1, 1)
+        return OrderedDict({"center": c})
 
 
 def build_data_agnostic_query(name: str, *args, **kwargs):
