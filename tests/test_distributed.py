@@ -102,3 +102,29 @@ def test_reducer_sink_and_single_process():
     red.finish()
     assert torch.equal(w.grad, g) and w.grad.permute(0, 2, 3, 1).is_contiguous()
     assert not red.grad_sink(torch.nn.Parameter(torch.zeros(1)), torch.zeros(1))
+
+
+def test_reducer_clears_only_parameters_that_accumulate():
+    """GradBucketReducer.set_overwritten: reset() leaves the bucket views of producers that overwrite their gradients
+    alone (or clears them too where a small one sits between cleared spans) and zeroes everything else; clear() zeroes
+    the views of given parameters on demand."""
+    import torch
+    from dpft_amd.training.distributed import GradBucketReducer
+    torch.manual_seed(0)
+    ps = [torch.nn.Parameter(torch.randn(n)) for n in (10, 20000, 64, 7, 30000, 5)]
+    r = GradBucketReducer(ps, bucket_bytes=1 << 20)
+    r.set_overwritten([ps[1], ps[4]])
+    r.arena.fill_(1.0)
+    r.reset()
+    view = lambda p: r.buckets[r._index[id(p)]]["views"][id(p)]
+    for i in (0, 2, 3, 5):
+        assert float(view(ps[i]).abs().sum()) == 0.0, i           # accumulating parameters: cleared
+    for i in (1, 4):
+        assert float(view(ps[i]).sum()) == ps[i].numel(), i        # overwritten parameters: untouched
+    assert all(p.grad is view(p) for p in ps)
+    r.clear([ps[1]])
+    assert float(view(ps[1]).abs().sum()) == 0.0 and float(view(ps[4]).sum()) == ps[4].numel()
+    r.set_overwritten([])                                          # back to the full clear
+    r.arena.fill_(1.0)
+    r.reset()
+    assert float(r.arena.abs().sum()) == 0.0
