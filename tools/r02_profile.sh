@@ -74,7 +74,7 @@ PY
 # (5) SQ wave-cycle / MFMA-busy breakdown of the conv kernels on the layer-3 problems (one PMC pass)
 bash /root/repo/tools/pmc_conv_sq.sh > $OUT/r02_conv_sq_mfma_busy.txt 2>&1
 # (6) mixed precision (configs[4]): bf16 operands + bf16 activation storage, batch 8 per GPU: bench line + serialized kernel summary
-timeout 600 python /root/repo/bench.py --dtype bf16 --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r02_bench_bf16_b8.json 2> $OUT/r02_bench_bf16_b8.err
+DPFT_CONV_TABLE=$OUT/r02_conv_table_bf16_b8.txt timeout 600 python /root/repo/bench.py --dtype bf16 --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r02_bench_bf16_b8.json 2> $OUT/r02_bench_bf16_b8.err
 timeout 600 python /root/repo/bench.py --dtype bf16 --batch 4 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r02_bench_bf16_b4.json 2>> $OUT/r02_bench_bf16_b8.err
 # (7) radar tesseract projection
 bash /root/repo/tools/radar_prof.sh > $OUT/r02_radar_projection.txt 2>&1
