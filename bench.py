@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--no-graphs", action="store_true", help="do not replay the decoder from hipGraphs")
     ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size (default 25 MiB)")
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp32", "bf16"], help="wire format of the gradient all-reduce")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="N=1 only: run the N>1 exchange path (RCCL communicator of one rank, every bucket through "
+                         "dist.all_reduce on RCCL's stream, all-ranks step decision) on the single GPU")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (BASELINE.md section 3)")
     ap.add_argument("--cpu-timeout", type=int, default=120, help="wall-clock budget of the CPU baseline leg in s")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
@@ -209,7 +212,15 @@ def main():
             dist.init_process_group(backend="gloo")
         else:
             dist.init_process_group(backend="nccl", device_id=device)
+    elif args.force_collectives:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(backend="nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=device)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    collective = world > 1 or args.force_collectives
 
     from dpft_amd.configs import load_config
     from dpft_amd.hip import ops
@@ -224,7 +235,8 @@ def main():
         cfg["computing"]["conv_compute"] = "bf16x3"
     torch.manual_seed(cfg["computing"]["seed"])
     model = build("dprt", cfg)
-    trainer = DataParallelTrainer(model, cfg, device, bucket_mb=args.bucket_mb, comm_dtype=args.comm_dtype)
+    trainer = DataParallelTrainer(model, cfg, device, bucket_mb=args.bucket_mb, comm_dtype=args.comm_dtype,
+                                  force_collectives=args.force_collectives)
     inputs = cfg["model"]["inputs"]
     B = args.batch
     # weak scaling: every rank owns its own seeded shard of the global batch, resident in HBM
@@ -232,7 +244,7 @@ def main():
     labels = make_labels(B, seed=cfg["computing"]["seed"] + rank, device=device)
 
     def sync():
-        if world > 1:
+        if collective:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -252,8 +264,8 @@ def main():
         loss, _ = trainer.train_step(data, labels)
     sync()
     elapsed = time.perf_counter() - t0
-    exposed_ms = trainer.reducer.exposed_ms() if world > 1 else 0.0      # last step: exchange time not hidden by backward
-    if world > 1:
+    exposed_ms = trainer.reducer.exposed_ms() if collective else 0.0     # last step: exchange time not hidden by backward
+    if collective:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -398,13 +410,18 @@ def main():
             "fwd_protocol": f"10 warm-up + {args.latency_reps} event-timed eval forwards of one batch (evaluator.py:109-125)",
             "step_definition": "zero_grad, forward, Hungarian set loss, backward, bucketed all-reduce, AdamW; the per-step "
                                "eval_fn of the reference's loop (trainer.py:134-136) is not part of the timed step",
-            "rccl_ranks": world, "exposed_allreduce_ms": exposed_ms, "dp_bucket_mb": trainer.bucket_mb,
+            "rccl_ranks": world, "collectives_forced": bool(args.force_collectives and world == 1),
+            "exposed_allreduce_ms": exposed_ms,
+            "exposed_allreduce_is": "last timed step: from the point the rank's CURRENT (main) stream has finished its own "
+                                    "backward work to the completion of the last bucket's collective, bracketed by events on "
+                                    "that stream; collectives of view-stream buckets that finish earlier are not in it",
+            "dp_bucket_mb": trainer.bucket_mb,
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
             "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if collective:
         dist.barrier()                    # rank 0 is still measuring (decoder roofline) when the others get here
         dist.destroy_process_group()
 

@@ -58,10 +58,11 @@ struct ResnetPlan {
     bool g_valid;
     // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
     hipStream_t side = nullptr;
+    bool side_owned = true;
     hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr, ev_wt = nullptr;
     int dyi = 0;
     ~ResnetPlan() {
-        if (side) (void)hipStreamDestroy(side);
+        if (side && side_owned) (void)hipStreamDestroy(side);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_wt) (void)hipEventDestroy(ev_wt);
@@ -383,13 +384,33 @@ static int bn_backward(const float* y, const float* dout, const float* out, cons
 // stream continues with the data-gradient chain (mid/late layers launch < 2 workgroups per CU: two kernels in
 // flight share the chip).  dy buffers alternate (dy / dy2 / dyd) and each has an event "last wgrad that read it
 // is done" which the main stream waits on before overwriting the buffer.
+// DPFT_SHARED_WGRAD_STREAM=1: the plans of a process share ONE weight-gradient side stream instead of owning one each
+// (the runtime multiplexes HIP streams onto 4 hardware queues; with RCCL's stream next to main + view streams + one side
+// stream per plan, streams start to share queues and serialise -- DESIGN.md section 6).  Ordering is by events, so which
+// stream carries the work does not change results.
+static hipStream_t shared_side_stream() {
+    static hipStream_t s = nullptr;
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("DPFT_SHARED_WGRAD_STREAM");
+        mode = (e && e[0] == '1') ? 1 : 0;
+    }
+    if (mode == 1 && !s && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    return mode == 1 ? s : nullptr;
+}
+
 struct SideCtx {
     ResnetPlan* p;
     hipStream_t main;
     void* ws2;
     int init() {
         if (!p->side) {
-            DPFT_REQUIRE(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess, "resnet_backward: side stream");
+            if (hipStream_t sh = shared_side_stream()) {
+                p->side = sh;
+                p->side_owned = false;
+            } else {
+                DPFT_REQUIRE(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess, "resnet_backward: side stream");
+            }
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_wt, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");

@@ -25,7 +25,7 @@ from torch import nn
 import ctypes as C
 
 from dpft_amd.hip import ops
-from dpft_amd.hip.lib import HipLibraryError, ResnetDesc, ResnetTables, lib, ptr, stream
+from dpft_amd.hip.lib import HipLibraryError, ResnetDesc, ResnetTables, lib, ptr, stream, weights_generation
 
 DEPTHS = {"resnet50": (3, 4, 6, 3), "resnet101": (3, 4, 23, 3), "resnet152": (3, 8, 36, 3)}
 
@@ -159,8 +159,9 @@ class _BodyFn(torch.autograd.Function):
         arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
         # inference: the pointer tables only depend on where the parameters live -- rebuilt when a tensor moved
         # (building them costs ~0.4 ms of host time per backbone, in front of the forward's first kernel)
-        sig = None if need_grad else (sum(c.weight.data_ptr() for c in convs), sum(m.running_var.data_ptr() for m in bns),
-                                      bns[0].weight.data_ptr(), bns[-1].bias.data_ptr())
+        sig = None if need_grad else (weights_generation(), tuple(c.weight.data_ptr() for c in convs),
+                                      tuple(m.running_var.data_ptr() for m in bns),
+                                      tuple(m.weight.data_ptr() for m in bns), tuple(m.bias.data_ptr() for m in bns))
         cached = owner.__dict__.get("_infer_tables") if sig is not None else None
         if cached is not None and cached[0] == sig:
             _, t, keep, weights = cached
@@ -197,7 +198,9 @@ class _BodyFn(torch.autograd.Function):
                     _ptr_array([m.running_var for m in bns]), _ptr_array(bn_g), _ptr_array(bn_b)]
             (t.conv_w, t.conv_dw, t.bn_gamma, t.bn_beta, t.bn_rm, t.bn_rv, t.bn_dgamma, t.bn_dbeta) = \
                 [C.cast(k, C.POINTER(C.c_void_p)) for k in keep]
-            if sig is not None:
+            # cached only if every table entry aliases its parameter: khwc() COPIES a weight that is not physically
+            # [K][kh][kw][C] (p.data reassigned, load_state_dict(assign=True)), and a cached copy would go stale
+            if sig is not None and all(wk.data_ptr() == c.weight.data_ptr() for wk, c in zip(weights, convs)):
                 owner.__dict__["_infer_tables"] = (sig, t, keep, weights)
         lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), int(train), stream())
         if train:
@@ -283,6 +286,12 @@ class BackboneBase(nn.Module):
         if p is None:
             p = self._plans[key] = _Plan(self, B, H, W, act16)
         return p
+
+    def overwritten_parameters(self):
+        """Parameters whose gradients the native backward plan writes (not adds) into an attached reducer's bucket views:
+        the conv weights and BatchNorm affine parameters of the plan's tables (``_ordered_modules``)."""
+        convs, bns = _ordered_modules(self)
+        return [c.weight for c in convs] + [m.weight for m in bns] + [m.bias for m in bns]
 
     def __getstate__(self):          # plans hold native handles: rebuild lazily after unpickling / deepcopy
         st = self.__dict__.copy()

@@ -66,10 +66,10 @@ class _Unpickler(pickle.Unpickler):
         root = module.split(".")[0]
         if root in _FOREIGN:
             return _stand_in(module, name)
-        try:
-            return super().find_class(module, name)        # also applies pickle's py2 -> py3 name fixes (__builtin__ ...)
-        except (ImportError, AttributeError):
-            return _stand_in(module, name)
+        # everything else (torch, collections, this package, builtins, ...) must resolve: a renamed or missing class of
+        # dpft_amd / torch is an error of the checkpoint, not something an inert stand-in may paper over.  super() also
+        # applies pickle's py2 -> py3 name fixes (__builtin__ ...).
+        return super().find_class(module, name)
 
 
 class _PickleModule:
@@ -96,9 +96,24 @@ def _child(mod: nn.Module, name: str):
     return mod._modules.get(name) if isinstance(mod, nn.Module) else None
 
 
+_TRANSFORMATIONS = {"Spher2Cart": "spher2cart", "Cart2Spher": "cart2spher", "Polar2Cart": "polar2cart",
+                    "Cart2Polar": "cart2polar"}
+
+
+def _hyper(obj, name, default, what):
+    """Constructor argument the reference keeps as an attribute of ``obj``; a module without it is not one this loader
+    understands (the value is NOT a tensor, so a silently assumed default would compute something different)."""
+    if obj is None or not hasattr(obj, "__dict__") or name not in obj.__dict__:
+        raise ValueError(f"checkpoint: {what} has no attribute {name!r}; cannot infer it (default would be {default!r})")
+    return obj.__dict__[name]
+
+
 def infer_config(model: nn.Module) -> Dict[str, Any]:
     """Config (reference schema, sections computing / model) of a DPRT module tree -- from the constructor arguments the
-    reference's modules keep as attributes and, for the third-party parts, from tensor shapes."""
+    reference's modules keep as attributes and, for the third-party parts, from tensor shapes.  Every hyper-parameter that
+    is not visible in a tensor shape (temperature / scale / offset of the embedding, the querent's distribution and
+    transformation, head dropout / bias, the fuser's ffn_layer, the backbone's multi_scale and norm layer) is READ from
+    the pickled modules; one that cannot be read or mapped raises instead of falling back to a default."""
     sd = model.state_dict()
     inputs = list(_attr(model, "inputs") or [])
     if not inputs:
@@ -107,12 +122,26 @@ def infer_config(model: nn.Module) -> Dict[str, Any]:
     for v in inputs:
         p = f"backbones.{v}.body."
         if any(k.startswith(p) for k in sd):
-            blocks = [len({k.split(".")[4] for k in sd if k.startswith(f"{p}layer{i}.")}) for i in (1, 2, 3, 4)]
-            name = {(3, 4, 6, 3): "ResNet50", (3, 4, 23, 3): "ResNet101"}.get(tuple(blocks))
+            bmod = _child(_child(model, "backbones"), v)
+            layers = [i for i in (1, 2, 3, 4) if any(k.startswith(f"{p}layer{i}.") for k in sd)]
+            blocks = [len({k.split(".")[4] for k in sd if k.startswith(f"{p}layer{i}.")}) for i in layers]
+            full = {(3, 4, 6, 3): "ResNet50", (3, 4, 23, 3): "ResNet101", (3, 8, 36, 3): "ResNet152"}
+            name = next((n for d, n in full.items() if tuple(blocks) == d[:len(blocks)]), None) if blocks else None
+            if len(blocks) < 3 and name is not None:      # (3,) / (3, 4) prefixes are ambiguous between the depths
+                name = None
             if name is None or f"{p}layer1.0.conv3.weight" not in sd:
                 raise ValueError(f"checkpoint: backbone of {v!r} has block counts {blocks}; dpft_amd supports the "
-                                 "ResNet-50 / ResNet-101 bottleneck bodies")
-            bb = {"name": name, "weights": "", "multi_scale": 4, "norm_layer": "BatchNorm2d"}
+                                 "ResNet-50 / -101 / -152 bottleneck bodies with at least three stages")
+            # IntermediateLayerGetter drops every stage behind the last returned one: multi_scale is visible in the tensors
+            multi_scale = len(layers)
+            ms_attr = _attr(bmod, "multi_scale")
+            if ms_attr is not None and max(1, min(4, int(ms_attr))) != len(layers):
+                raise ValueError(f"checkpoint: backbone {v!r} has multi_scale={ms_attr} but {len(layers)} stages")
+            # norm layer: torchvision's BatchNorm2d keeps running statistics AND counts batches; anything else
+            # (FrozenBatchNorm2d, GroupNorm, ...) is not what the HIP plan computes
+            if f"{p}bn1.num_batches_tracked" not in sd or f"{p}bn1.running_var" not in sd:
+                raise ValueError(f"checkpoint: backbone {v!r} does not use BatchNorm2d")
+            bb = {"name": name, "weights": "", "multi_scale": multi_scale, "norm_layer": "BatchNorm2d"}
             adj = f"backbones.{v}.adjustment_layer.weight"
             if adj in sd:
                 bb["in_channels"] = int(sd[adj].shape[1])
@@ -120,30 +149,50 @@ def infer_config(model: nn.Module) -> Dict[str, Any]:
         p = f"necks.{v}.fpn.inner_blocks."
         n_in = len({k.split(".")[4] for k in sd if k.startswith(p)})
         if n_in:
+            nmod = _child(_child(model, "necks"), v)
+            if _attr(nmod, "norm_layer") is not None or any(k.split(".")[5] != "0" for k in sd if k.startswith(f"necks.{v}.fpn.")):
+                raise ValueError(f"checkpoint: neck {v!r} uses a norm layer; dpft_amd's FPN has none (no reference config does)")
             necks[v] = {"name": "FPN", "in_channels_list": [int(sd[f"{p}{i}.0.weight"].shape[1]) for i in range(n_in)],
                         "out_channels": int(sd[f"{p}0.0.weight"].shape[0])}
         emb = _child(_child(model, "embeddings"), v) if _child(model, "embeddings") is not None else None
         if emb is not None and _attr(emb, "n_levels") is not None:
-            layer0 = next(iter(emb._modules.get("embedding_layers", nn.ModuleDict())._modules.values()), None)
+            layers_ = list(emb._modules.get("embedding_layers", nn.ModuleDict())._modules.values())
+            if not layers_:
+                raise ValueError(f"checkpoint: embedding {v!r} has no embedding layers")
+            what = f"embedding {v!r}"
+            keys = ("num_feats", "temperature", "normalize", "scale", "eps", "offset")
+            per_level = [tuple(_hyper(l, k, None, what) for k in keys) for l in layers_]
+            if any(t != per_level[0] for t in per_level):
+                raise ValueError(f"checkpoint: {what} has per-level hyper-parameters {per_level}; one set is supported")
             embeddings[v] = {"name": "sinusoidal_embedding", "n_levels": int(_attr(emb, "n_levels")),
-                             "num_feats": int(_attr(layer0, "num_feats", 16)) if layer0 is not None else 16,
-                             "normalize": bool(_attr(layer0, "normalize", True)) if layer0 is not None else True}
+                             **dict(zip(keys, per_level[0]))}
     fuser, head, querent = _child(model, "fuser"), _child(model, "head"), _child(model, "querent")
     cfg_model: Dict[str, Any] = {"name": "dprt", "inputs": inputs,
                                  "skiplinks": dict(_attr(model, "skiplinks") or {v: True for v in inputs}),
                                  "backbones": backbones, "necks": necks, "embeddings": embeddings}
     if querent is not None and _attr(querent, "resolution") is not None:
-        cfg_model["querent"] = {"name": "data_agnostic_static_querent", "transformation": "spher2cart",
+        tr = _hyper(querent, "transformation", None, "querent") if "transformation" in querent.__dict__ \
+            else querent._modules.get("transformation")
+        tname = type(tr).__name__
+        if tr is None or tname == "Identity":
+            transformation = None
+        elif tname in _TRANSFORMATIONS:
+            transformation = _TRANSFORMATIONS[tname]
+        else:
+            raise ValueError(f"checkpoint: querent transformation {tname!r} cannot be mapped")
+        cfg_model["querent"] = {"name": "data_agnostic_static_querent", "transformation": transformation,
                                 "resolution": list(_attr(querent, "resolution")),
-                                "minimum": list(_attr(querent, "minimum")), "maximum": list(_attr(querent, "maximum"))}
+                                "minimum": list(_attr(querent, "minimum")), "maximum": list(_attr(querent, "maximum")),
+                                "distribution": list(_hyper(querent, "distribution", "linear", "querent"))}
     if fuser is not None and _attr(fuser, "i_iter") is not None:
         keys = ("i_iter", "m_views", "d_model", "d_ffn", "n_queries", "n_levels", "n_heads", "n_points", "norm", "dropout",
-                "reduction", "activation")
-        cfg_model["fuser"] = {"name": "IMPFusion", **{k: _attr(fuser, k) for k in keys}}
+                "reduction", "activation", "ffn_layer")
+        cfg_model["fuser"] = {"name": "IMPFusion", **{k: _hyper(fuser, k, None, "fuser") for k in keys}}
     if head is not None and _attr(head, "num_classes") is not None:
-        cfg_model["head"] = {"name": "linear_detection_head", **{k: _attr(head, k) for k in
-                                                                ("in_channels", "num_classes", "num_reg_layers",
-                                                                 "num_cls_layers")}}
+        keys = ("in_channels", "num_classes", "num_reg_layers", "num_cls_layers", "bias", "dropout")
+        cfg_model["head"] = {"name": "linear_detection_head", **{k: _hyper(head, k, None, "head") for k in keys}}
+        if type(head).__name__ not in ("LinearDetectionHead",):
+            raise ValueError(f"checkpoint: head class {type(head).__name__!r}; dpft_amd builds the linear detection head")
     return {"computing": {"dtype": "float32", "device": "cuda" if torch.cuda.is_available() else "cpu"},
             "model": cfg_model}
 

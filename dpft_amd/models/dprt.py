@@ -6,6 +6,7 @@ contract (``X``, ``X_shape``, ``label_to_X_t``, ``label_to_X_p`` per input) and 
 """
 from __future__ import annotations
 
+import os
 from collections import OrderedDict
 from typing import Any, Callable, Dict, List, Tuple
 
@@ -114,7 +115,11 @@ class DPRT(nn.Module):
             return {i: self._encode_view(i, batch) for i in self.inputs}
         main = torch.cuda.current_stream(first.device)
         if self.__dict__.get("_view_streams") is None or len(self._view_streams) != len(self.inputs) - 1:
-            self.__dict__["_view_streams"] = [torch.cuda.Stream(first.device) for _ in self.inputs[1:]]
+            if os.environ.get("DPFT_SHARED_VIEW_STREAM", "0") == "1":      # the small views queue behind each other on ONE stream
+                one = torch.cuda.Stream(first.device)
+                self.__dict__["_view_streams"] = [one for _ in self.inputs[1:]]
+            else:
+                self.__dict__["_view_streams"] = [torch.cuda.Stream(first.device) for _ in self.inputs[1:]]
         features = {}
         if torch.is_grad_enabled():
             # training: the small views first.  The host runs ahead of the GPU here (the previous step's backward is still

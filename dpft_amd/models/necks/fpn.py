@@ -114,6 +114,10 @@ class FPN(nn.Module):
         self.fpn = FeaturePyramidNetwork(in_channels_list, out_channels)
         self.grad_direct = None     # optional DP reducer (grad_buffer / mark_ready_many), installed by the trainer
 
+    def overwritten_parameters(self):
+        """Parameters whose gradients ``_FPNFn.backward`` writes (not adds) into an attached reducer's bucket views."""
+        return list(self.fpn.parameters())
+
     def __getstate__(self):          # the reducer belongs to a trainer, not to the module (torch.save(model), deepcopy)
         st = self.__dict__.copy()
         st["grad_direct"] = None

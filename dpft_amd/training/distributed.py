@@ -30,12 +30,18 @@ import torch.distributed as dist
 
 class GradBucketReducer:
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 25 << 20, process_group=None,
-                 average: bool = True, group_of: Dict[int, str] = None, comm_dtype: Optional[torch.dtype] = None):
+                 average: bool = True, group_of: Dict[int, str] = None, comm_dtype: Optional[torch.dtype] = None,
+                 force_collectives: bool = False):
         """``group_of`` (id(param) -> group key) keeps buckets from spanning groups: the three view encoders run
         (forward and backward) on their own HIP streams, and a bucket whose gradients all come from one stream
-        can be reduced from that stream without joining the others."""
+        can be reduced from that stream without joining the others.  ``force_collectives``: issue every bucket's
+        all-reduce even in a one-rank group (the N>1 code path -- stream joins, RCCL's own stream, wire staging --
+        exercised on a single GPU; the reduction over one rank is the identity)."""
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
+        # RCCL averages inside the collective (ncclAvg): no separate division pass over the 360 MB of buckets
+        self._avg_op = average and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.average = average
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.params = [p for p in params if p.requires_grad]
@@ -63,6 +69,7 @@ class GradBucketReducer:
         for ps, st in zip(plan, starts):
             self._add_bucket(ps, self.arena[st:st + sum(p.numel() for p in ps)])
         self._exposed = None
+        self._overwritten = set()                # ids of parameters reset() does not clear (set_overwritten)
         self._zero_spans = [(0, total)]          # arena spans reset() clears (see set_overwritten)
         self._spans = {id(p): (st + off, st + off + p.numel())
                        for ps, st in zip(plan, starts)
@@ -96,6 +103,8 @@ class GradBucketReducer:
         """Parameters whose gradient producer OVERWRITES the bucket view every step (the native backbone plans, the FPN's
         direct hand-over) need no clearing: reset() then zeroes only the spans of the others (the decoder's gradients are
         added into the buckets, parameters without a gradient must read as zero) -- ~5 MB instead of 360 MB per step."""
+        params = list(params)
+        self._overwritten = {id(p) for p in params if id(p) in self._spans}
         skip = sorted(self._spans[id(p)] for p in params if id(p) in self._spans)
         spans, cur = [], 0
         for a, b in skip:
@@ -202,19 +211,22 @@ class GradBucketReducer:
 
     def _fire(self, b):
         b["fired"] = True
-        if b["flat"].is_cuda and self.world > 1:      # single process: backward() itself joins the streams
+        if b["flat"].is_cuda and self.collective:     # single process: backward() itself joins the streams
             cur = torch.cuda.current_stream(b["flat"].device)
             for sid, st in b["streams"].items():
                 if sid != cur.cuda_stream:          # tail of that stream is after its last contribution
                     cur.wait_stream(st)
-        if self.world > 1:
-            if self.average:
+        if self.collective:
+            op = dist.ReduceOp.SUM
+            if self._avg_op:
+                op = dist.ReduceOp.AVG
+            elif self.average and self.world > 1:
                 b["flat"].div_(self.world)
             wire = b["flat"]
             if b["stage"] is not None:
                 wire = b["stage"]
                 wire.copy_(b["flat"])                                 # round to the wire dtype (RNE)
-            self._pending.append((dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True), b))
+            self._pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), b))
 
     def seen_ids(self):
         """ids of the parameters that received a gradient since the last reset()."""
@@ -227,6 +239,11 @@ class GradBucketReducer:
         """Flush buckets whose parameters did not all receive gradients, then wait for every collective."""
         for b in self.buckets:
             if not b["fired"]:
+                # a parameter announced as overwritten whose producer did not run this step (a backward that was not
+                # reached, a partially used view) still holds the PREVIOUS step's gradient: reset() skipped it
+                for p in b["params"]:
+                    if id(p) in self._overwritten and id(p) not in b["seen"]:
+                        b["views"][id(p)].zero_()
                 self._fire(b)
         if not self._pending:
             self._exposed = 0.0

@@ -57,10 +57,21 @@ class FusedAdamW(torch.optim.Optimizer):
             steps = [float(st["step"]) for st in self.state.values() if "step" in st]
             self._step = int(max(steps)) if steps else 0
         tables = []
+        if old is not None and not self._restore:
+            # a group whose set of trainable parameters changed gets new flat buffers: the per-parameter step counts live
+            # only in the old tables' device-side `skipped` counters (state["step"] is written by state_dict() alone), so
+            # they are read back here -- otherwise a carried-over parameter would restart its bias correction at 0
+            for gi, group in enumerate(self.param_groups):
+                ps = [p for p in group["params"] if p.requires_grad]
+                if gi < len(old) and [id(p) for p in old[gi]["params"]] != [id(p) for p in ps]:
+                    for p, sk in zip(old[gi]["params"], old[gi]["skipped"].tolist()):
+                        if p in self.state:
+                            self.state[p]["step"] = float(self._step - int(sk))
         for gi, group in enumerate(self.param_groups):
             ps = [p for p in group["params"] if p.requires_grad]
             dev = ps[0].device
-            keep = old is not None and not self._restore and [id(p) for p in old[gi]["params"]] == [id(p) for p in ps]
+            keep = old is not None and not self._restore and gi < len(old) and \
+                [id(p) for p in old[gi]["params"]] == [id(p) for p in ps]
             if keep:
                 m, v, skipped = old[gi]["m"], old[gi]["v"], old[gi]["skipped"]
             else:

@@ -21,14 +21,16 @@ from dpft_amd.training.optimizer import FusedAdamW, build_optimizer
 
 class DataParallelTrainer:
     def __init__(self, model: torch.nn.Module, config: Dict[str, Any], device, bucket_mb: Optional[float] = None,
-                 comm_dtype: Optional[str] = None):
+                 comm_dtype: Optional[str] = None, force_collectives: bool = False):
+        """``force_collectives``: take the N>1 exchange path (bucket all-reduces on the communicator's stream, the
+        all-ranks step decision) even in a one-rank process group -- the RCCL path on a single GPU."""
+        device = torch.device(device)
         self.model = model.to(device)
         self.device = device
         # optional mixed precision (BASELINE.json configs[4]): config["computing"]["conv_compute"] = "bf16" runs the
         # forward / data-gradient conv GEMMs with bf16 operands and fp32 accumulation; default = the reference's fp32
-        if torch.device(device).type == "cuda":
+        if device.type == "cuda":
             from dpft_amd.hip import ops as _ops
-            import os
             _ops.conv_set_compute(config.get("computing", {}).get("conv_compute") or os.environ.get("DPFT_CONV_COMPUTE", "fp32"))
         train = config["train"]
         self.loss_fn = build_loss(train)
@@ -47,26 +49,27 @@ class DataParallelTrainer:
             parts = n.split(".")
             group_of[id(p)] = ".".join(parts[:2]) if parts[0] in ("backbones", "necks") else "decoder"
         # exchange knobs: argument > config["train"]["dp"] > environment > default (25 MiB fp32 buckets)
-        import os as _os
         dp = train.get("dp", {})
-        bucket_mb = float(bucket_mb or dp.get("bucket_mb") or _os.environ.get("DPFT_BUCKET_MB") or 25)
-        comm_dtype = comm_dtype or dp.get("comm_dtype") or _os.environ.get("DPFT_COMM_DTYPE") or "fp32"
+        bucket_mb = float(bucket_mb or dp.get("bucket_mb") or os.environ.get("DPFT_BUCKET_MB") or 25)
+        comm_dtype = comm_dtype or dp.get("comm_dtype") or os.environ.get("DPFT_COMM_DTYPE") or "fp32"
         wire = {"fp32": None, "float32": None, "bf16": torch.bfloat16, "bfloat16": torch.bfloat16}[comm_dtype]
         self.bucket_mb, self.comm_dtype = bucket_mb, comm_dtype
         self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=int(bucket_mb * (1 << 20)),
-                                         group_of=group_of, comm_dtype=wire)
+                                         group_of=group_of, comm_dtype=wire, force_collectives=force_collectives)
+        self.collective = self.reducer.collective
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         overwritten = []
         for m in self.model.modules():
             if hasattr(m, "grad_direct"):
                 m.grad_direct = self.reducer
-                overwritten += list(m.parameters())      # their gradients are written (not added) into the buckets
+                # the producer names exactly the parameters whose bucket views its backward OVERWRITES every step
+                overwritten += list(m.overwritten_parameters())
         if self.device.type == "cuda" and os.environ.get("DPFT_ZERO_ALL_GRADS", "0") != "1":
             self.reducer.set_overwritten(overwritten)
 
     def enable_graphs(self, sample_data: Dict[str, torch.Tensor]):
         """Replay the launch-bound decoder from hipGraphs (static shapes of ``sample_data``)."""
-        if self.world > 1:                    # no collective (parameter broadcast) may still be in flight during a capture
+        if self.collective:                   # no collective (parameter broadcast) may still be in flight during a capture
             dist.barrier()
         torch.cuda.synchronize()
         self.reducer.reset()
@@ -87,14 +90,16 @@ class DataParallelTrainer:
             if g is not None:
                 g.clone_outputs = True
         loss, losses = self.loss_fn(output, labels)
-        stepped = local = bool(loss > 0)                   # trainer.py:131 (host sync, as in the reference)
-        if self.world > 1:
+        if self.collective:
             # The global batch steps if ANY shard has a loss (MAX): a rank whose label shard is empty then runs the same
             # backward over a zero-valued loss, so it contributes zero gradients, issues its bucket collectives in the
             # same order and reports the same set of parameters-with-gradient as every other rank.
-            flag = torch.tensor([int(local)], device=self.device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            stepped = bool(flag.item())
+            # [local, any-rank] are read back together: still ONE host sync per step (trainer.py:131 has one).
+            flag = (loss.detach() > 0).to(torch.int32).reshape(1).repeat(2)
+            dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
+            local, stepped = (bool(v) for v in flag.tolist())
+        else:
+            stepped = local = bool(loss > 0)               # trainer.py:131 (host sync, as in the reference)
         if stepped:
             if not local:
                 loss = sum(v.sum() for v in output.values()) * 0.0

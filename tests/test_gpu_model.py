@@ -270,6 +270,86 @@ def test_full_size_train_backward_repeatable_and_linear():
     assert worst_rep < 2e-4 and worst_lin < 2e-4
 
 
+def test_full_size_train_step_matches_oracle():
+    """The step the headline number times (trainer.py:122-133; loss.py:486-564), at its size: kradar.json, batch 4,
+    dropout 0 -- forward + Hungarian set loss + backward of the HIP path vs the oracle in the reference's fp32 arithmetic,
+    with the fp64 oracle as yardstick (the tilings the bench runs -- parity-class / K-split data gradients, split-K,
+    128x128 weight gradients, side-stream scheduling -- are selected by size)."""
+    from dpft_amd.configs import load_config
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.loss import build_loss
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(41)
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["fuser"]["dropout"] = 0.0
+    model = _build(cfg, g)
+    sd64 = state_dict_f64(model)
+
+    def leafs(dtype):
+        return {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                    else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd64.items()}
+    batch = make_batch(cfg["model"]["inputs"], 4, seed=9)
+    labels = make_labels(4, seed=9)
+    w = cfg["train"]["loss_weights"]
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    res = {}
+    for name, dtype in (("f32", torch.float32), ("f64", torch.float64)):
+        sd = leafs(dtype)
+        b = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
+        lab = [{k: (v.to(dtype) if v.is_floating_point() else v) for k, v in l.items()} for l in labels]
+        out = O.dprt_forward(sd, cfg, b, train=True)
+        loss, losses = O.loss_forward(out, lab, w)
+        loss.backward()
+        match = [O.hungarian({k: v[i].detach() for k, v in out.items()}, lab[i], w)[:2] for i in range(4)]
+        res[name] = (float(loss), {k: v.detach() for k, v in out.items()}, {k: v.grad for k, v in sd.items()
+                                                                        if v.is_floating_point() and v.grad is not None}, match)
+        del sd, out, loss
+    model = model.to(DEV).train()
+    loss_fn = build_loss(cfg["train"])
+    dev_labels = [{k: v.to(DEV) for k, v in l.items()} for l in labels]
+    out = model({k: v.to(DEV) for k, v in batch.items()})
+    matches = loss_fn.anassigner({k: v.detach() for k, v in out.items()}, dev_labels)
+    loss, _ = loss_fn(out, dev_labels)
+    loss.backward()
+    l32, o32, g32, m32 = res["f32"]
+    l64, o64, g64, m64 = res["f64"]
+    # Hungarian assignments: bit-exact against the reference arithmetic (and its fp64 form)
+    for i in range(4):
+        for ref in (m32, m64):
+            assert torch.equal(matches[i][0].cpu(), ref[i][0]) and torch.equal(matches[i][1].cpu(), ref[i][1]), i
+    for k in out:
+        e, e32 = rel_l2(out[k], o64[k]), rel_l2(o32[k], o64[k])
+        print(f"full-size train out {k}: rel-L2 hip {e:.2e}  fp32 oracle {e32:.2e}")
+        assert e < max(1e-4, 4 * e32), (k, e, e32)
+    el, el32 = abs(float(loss) - l64) / abs(l64), abs(l32 - l64) / abs(l64)
+    print(f"full-size train loss: hip {float(loss):.6f} fp32 oracle {l32:.6f} fp64 {l64:.6f}")
+    assert el < max(1e-5, 4 * el32), (float(loss), l32, l64)
+    # gradients: per stage group and the whole network as one vector (relative L2, fp32 oracle vs fp64 as yardstick)
+    def group(n):
+        p = n.split(".")
+        if p[0] == "backbones":
+            return ".".join(p[:2] + [p[3] if p[2] == "body" and p[3].startswith("layer") else "stem"])
+        return ".".join(p[:2]) if p[0] == "necks" else p[0]
+    acc = {}
+    for n, p in model.named_parameters():
+        if n not in g64:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, n          # template head
+            continue
+        assert p.grad is not None, n
+        a = acc.setdefault(group(n), [0.0, 0.0, 0.0])
+        a[0] += float((p.grad.double().cpu() - g64[n]).pow(2).sum())
+        a[1] += float((g32[n].double() - g64[n]).pow(2).sum())
+        a[2] += float(g64[n].pow(2).sum())
+    tot = [sum(a[i] for a in acc.values()) for i in range(3)]
+    for k in sorted(acc):
+        e, e32 = (acc[k][0] / acc[k][2]) ** 0.5, (acc[k][1] / acc[k][2]) ** 0.5
+        print(f"full-size grad {k:40s} rel-L2 hip {e:.2e}  fp32 oracle {e32:.2e}")
+        assert e < max(5e-3, 6 * e32), (k, e, e32)
+    e, e32 = (tot[0] / tot[2]) ** 0.5, (tot[1] / tot[2]) ** 0.5
+    print(f"full-size whole-network gradient rel-L2: hip {e:.2e}  fp32 oracle {e32:.2e}")
+    assert e < max(2e-3, 4 * e32), (e, e32)
+
+
 def view_config(name, dropout=0.0):
     """One of the reference's single- / dual-view configs (config/kradar_*.json), camera encoder reduced to ResNet-50."""
     from dpft_amd.configs import load_config
@@ -280,7 +360,7 @@ def view_config(name, dropout=0.0):
     return cfg
 
 
-@pytest.mark.parametrize("name", ["kradar_radar_bev", "kradar_camera_mono", "kradar_radar"])
+@pytest.mark.parametrize("name", ["kradar_radar_bev", "kradar_radar_front", "kradar_camera_mono", "kradar_radar"])
 def test_view_subset_configs_match_oracle(name):
     """BASELINE.json configs[0]/[1] and the other view subsets the reference ships: eval forward (fused inference
     decoder with V = 1 / 2 views) and train forward + backward vs the oracle on the same weights."""

@@ -263,10 +263,42 @@ def test_load_reads_reference_whole_module_checkpoint(tmp_path):
     assert model.fuser.dropout == 0.05 and model.fuser.i_iter == 4 and model.inputs == m["inputs"]
     from dpft_amd.models.checkpoint import infer_config, read_foreign
     inferred = infer_config(read_foreign(str(ckpt)))["model"]
+    def covers(got, want, path):          # every key of the config with its value; extra inferred keys are checked below
+        if isinstance(want, dict):
+            for k, v in want.items():
+                assert k in got, (path, k)
+                covers(got[k], v, path + "." + k)
+        else:
+            assert got == want, (path, got, want)
     for section in ("inputs", "skiplinks", "backbones", "necks", "embeddings", "querent", "fuser", "head"):
-        assert inferred[section] == m[section], (section, inferred[section], m[section])
+        covers(inferred[section], m[section], section)
+    # hyper-parameters that are not tensors are READ from the pickled modules, here the reference's defaults
+    e0 = inferred["embeddings"][m["inputs"][0]]
+    assert (e0["temperature"], e0["eps"], e0["offset"]) == (10000, 1e-6, 0.0) and abs(e0["scale"] - 6.283185307179586) < 1e-12
+    assert inferred["querent"]["distribution"] == ["linear"] * 3 and inferred["fuser"]["ffn_layer"] == "Linear"
+    assert inferred["head"]["bias"] is False and inferred["head"]["dropout"] == 0.0
+    # ... and a non-default value survives the round trip instead of being replaced by a default
+    foreign = read_foreign(str(ckpt))
+    for layer in foreign.embeddings[m["inputs"][0]].embedding_layers.values():
+        layer.__dict__["temperature"] = 20
+    assert infer_config(foreign)["model"]["embeddings"][m["inputs"][0]]["temperature"] == 20
+    del foreign.head.__dict__["dropout"]
+    with pytest.raises(ValueError, match="dropout"):
+        infer_config(foreign)
     # this package's own whole-module checkpoints keep working
     own = tmp_path / "20240101-130000_checkpoint_0001.pt"
     torch.save(ours, str(own))
     again, e2, _ = load(str(own))
     assert e2 == 1 and type(again) is type(ours)
+
+
+def test_unpickler_does_not_replace_missing_native_classes(tmp_path):
+    """Only FOREIGN roots (dprt, torchvision, ...) become stand-ins; a missing class of this package or of torch raises."""
+    import pickle
+    from dpft_amd.models.checkpoint import ForeignModule, _Unpickler
+    import io
+    with pytest.raises((AttributeError, ImportError)):
+        _Unpickler(io.BytesIO(b"")).find_class("dpft_amd.models.dprt", "NoSuchClass")
+    with pytest.raises((AttributeError, ImportError)):
+        _Unpickler(io.BytesIO(b"")).find_class("torch.nn", "NoSuchLayer")
+    assert issubclass(_Unpickler(io.BytesIO(b"")).find_class("torchvision.models.resnet", "ResNet"), ForeignModule)
