@@ -379,7 +379,9 @@ def test_view_subset_configs_match_oracle(name):
     for k in out:
         close(out[k], ref[k], rtol=1e-4, atol_scale=1e-4, what=f"{name} eval out {k}")
     assert torch.equal(out["class"].argmax(-1).cpu(), ref["class"].argmax(-1))
-    _train_parity(view_config(name, dropout=0.0), seed=32)
+    # radar_front alone: its layer-4 maps are 2 x 4 pixels, so a batch of 2 leaves 16 samples per BatchNorm channel and a
+    # single ReLU-mask flip (a pre-activation within an ulp of 0) moves a gradient by ~1 %; batch 6 keeps the statistics sane
+    _train_parity(view_config(name, dropout=0.0), seed=32, batch=6 if name == "kradar_radar_front" else 2)
 
 
 @pytest.mark.parametrize("storage", ["fp32", "bf16"])
@@ -531,7 +533,7 @@ def test_dprt_train_forward_backward_matches_oracle():
     _train_parity(small_config(dropout=0.0), seed=4)
 
 
-def _train_parity(cfg, seed):
+def _train_parity(cfg, seed, batch=2):
     from dpft_amd.synthetic import make_batch
     from oracle import dprt_oracle as O
     g = torch.Generator().manual_seed(seed)
@@ -542,7 +544,7 @@ def _train_parity(cfg, seed):
         return {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
                     else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd.items()}
     sd_ref, sd32 = leafs(sd64, torch.float64), leafs(sd64, torch.float32)
-    batch = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=SHAPES)
+    batch = make_batch(cfg["model"]["inputs"], batch, seed=7, shapes=SHAPES)
     b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
     ref = O.dprt_forward(sd_ref, cfg, b64, train=True)
     ref32 = O.dprt_forward(sd32, cfg, batch, train=True)          # yardstick: CPU fp32 vs fp64
