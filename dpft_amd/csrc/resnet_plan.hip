@@ -58,11 +58,11 @@ struct ResnetPlan {
     bool g_valid;
     // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
     hipStream_t side = nullptr;
-    bool side_owned = true;
+    bool side_owned = true, side_set = false;      // side_set: side is valid (it may be the null stream)
     hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr, ev_wt = nullptr;
     int dyi = 0;
     ~ResnetPlan() {
-        if (side && side_owned) (void)hipStreamDestroy(side);
+        if (side_set && side_owned) (void)hipStreamDestroy(side);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_wt) (void)hipEventDestroy(ev_wt);
@@ -231,6 +231,16 @@ extern "C" int64_t dpft_resnet_plan_query(int64_t h, int32_t what, int32_t idx) 
         case 5: return (int64_t)p->fwd_floats;
         default: return -1;
     }
+}
+
+extern "C" int dpft_resnet_plan_set_side_stream(int64_t h, dpft_stream_t side) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    DPFT_REQUIRE(p, "resnet_plan_set_side_stream: null plan");
+    if (p->side_set && p->side_owned && p->side != (hipStream_t)side) (void)hipStreamDestroy(p->side);
+    p->side = (hipStream_t)side;      // may be 0: the null stream
+    p->side_owned = false;
+    p->side_set = true;
+    return DPFT_OK;
 }
 
 namespace dpft {
@@ -404,13 +414,16 @@ struct SideCtx {
     hipStream_t main;
     void* ws2;
     int init() {
-        if (!p->side) {
+        if (!p->side_set) {
             if (hipStream_t sh = shared_side_stream()) {
                 p->side = sh;
                 p->side_owned = false;
             } else {
                 DPFT_REQUIRE(hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking) == hipSuccess, "resnet_backward: side stream");
             }
+            p->side_set = true;
+        }
+        if (!p->ev_ready) {
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_ready, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_join, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");
             DPFT_REQUIRE(hipEventCreateWithFlags(&p->ev_wt, hipEventDisableTiming) == hipSuccess, "resnet_backward: event");

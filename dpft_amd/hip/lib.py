@@ -153,6 +153,8 @@ SIGNATURES = {
     "dpft_resnet_plan_query": (_L, [_L, _I, _I]),
     "dpft_resnet_forward": (_I, [_L, _P, C.POINTER(ResnetTables), _P, _I, _P]),
     "dpft_resnet_backward_stage": (_I, [_L, _I, _P, C.POINTER(ResnetTables), _P, _P, _P]),
+    "dpft_resnet_plan_set_side_stream": (_I, [_L, _P]),
+    "dpft_stream_set": (_I, [_P, _I, C.POINTER(C.c_void_p)]),
 }
 
 
@@ -233,3 +235,23 @@ def make_pyramid(levels: Sequence[torch.Tensor], grads: Optional[Sequence[torch.
         p.grad[i] = grads[i].data_ptr() if grads is not None else None
         p.grad_replicas[i] = grads[i].shape[0] if grads is not None and grads[i].dim() == l.dim() + 1 else 0
     return p
+
+
+_stream_sets = {}
+
+
+def stream_set(device, n: int = 3):
+    """``n`` torch streams on hardware queues distinct from the current (main) stream's and from each other (as far as the
+    device has queues) -- dpft_stream_set; cached per device.  Used for the view encoders' streams and the camera
+    encoder's weight-gradient stream (dpft_amd/models/dprt.py)."""
+    device = torch.device(device)
+    key = (device.index if device.index is not None else torch.cuda.current_device(), n)
+    got = _stream_sets.get(key)
+    if got is None:
+        arr = (C.c_void_p * n)()
+        with torch.cuda.device(key[0]):
+            distinct = int(lib.load().dpft_stream_set(stream(), n, arr))
+            if distinct < 0:
+                raise HipLibraryError("dpft_stream_set failed: " + lib.dpft_last_error().decode("utf-8", "replace"))
+            got = _stream_sets[key] = ([torch.cuda.ExternalStream(arr[i], device=key[0]) for i in range(n)], distinct)
+    return got

@@ -221,6 +221,10 @@ class _BodyFn(torch.autograd.Function):
         st = ctx.state
         owner, plan, direct = st["owner"], st["plan"], st["direct"]
         body = owner.body
+        side = owner.side_stream
+        if side is not None and plan.__dict__.get("_side") != side.cuda_stream:
+            lib.call("dpft_resnet_plan_set_side_stream", plan.handle, C.c_void_p(side.cuda_stream))
+            plan.__dict__["_side"] = side.cuda_stream
         douts = list(douts) + [None] * (4 - len(douts))
         # stage -> parameters whose gradients are complete after that stage's call
         stage_params = {li: [] for li in range(body.n_layers)}
@@ -258,6 +262,7 @@ class BackboneBase(nn.Module):
         self.multi_scale = multi_scale
         self.channel_last = channel_last
         self.grad_direct = None     # optional DP reducer (grad_buffer / mark_ready), installed by the trainer
+        self.side_stream = None     # optional torch stream for the plan's weight-gradient GEMMs (DPRT._place_streams)
         self.depths = tuple(depths)
         self._plans = {}
         # resnet.py:47-52 -- 1x1 conv (no bias) to 3 channels when the input is not RGB
@@ -297,6 +302,7 @@ class BackboneBase(nn.Module):
         st = self.__dict__.copy()
         st["_plans"] = {}
         st["grad_direct"] = None
+        st["side_stream"] = None
         for k in ("_ordered", "_infer_tables", "_plist"):
             st.pop(k, None)
         return st

@@ -115,11 +115,7 @@ class DPRT(nn.Module):
             return {i: self._encode_view(i, batch) for i in self.inputs}
         main = torch.cuda.current_stream(first.device)
         if self.__dict__.get("_view_streams") is None or len(self._view_streams) != len(self.inputs) - 1:
-            if os.environ.get("DPFT_SHARED_VIEW_STREAM", "0") == "1":      # the small views queue behind each other on ONE stream
-                one = torch.cuda.Stream(first.device)
-                self.__dict__["_view_streams"] = [one for _ in self.inputs[1:]]
-            else:
-                self.__dict__["_view_streams"] = [torch.cuda.Stream(first.device) for _ in self.inputs[1:]]
+            self._place_streams(first.device)
         features = {}
         if torch.is_grad_enabled():
             # training: the small views first.  The host runs ahead of the GPU here (the previous step's backward is still
@@ -148,6 +144,32 @@ class DPRT(nn.Module):
         return {i: features[i] for i in self.inputs}
 
     concurrent_views = True
+
+    def _place_streams(self, device):
+        """One hardware queue per concurrent chain.  The runtime multiplexes HIP streams onto 4 hardware queues and streams
+        that share a queue run in order, so the step's overlap exists only if the chains sit on different queues
+        (tools/probes/stream_queues.py).  dpft_stream_set finds streams on queues distinct from the main stream's and from
+        each other: view i > 0 runs (forward, backward AND its plan's weight gradients) on its own queue; the first
+        view -- the camera encoder, the critical path -- keeps the main stream and gets the remaining queue for its
+        weight-gradient GEMMs.  DPFT_STREAM_PLACEMENT=pool restores pool streams / plan-created side streams (A/B)."""
+        n_side = len(self.inputs) - 1
+        if os.environ.get("DPFT_STREAM_PLACEMENT", "probe") == "pool":
+            if os.environ.get("DPFT_SHARED_VIEW_STREAM", "0") == "1":
+                one = torch.cuda.Stream(device)
+                self.__dict__["_view_streams"] = [one for _ in self.inputs[1:]]
+            else:
+                self.__dict__["_view_streams"] = [torch.cuda.Stream(device) for _ in self.inputs[1:]]
+            return
+        from dpft_amd.hip.lib import stream_set
+        streams, distinct = stream_set(device, 3)
+        views = [streams[i % len(streams)] for i in range(n_side)]
+        self.__dict__["_view_streams"] = views
+        self.__dict__["_queues_found"] = distinct
+        for i, s in zip(self.inputs[1:], views):
+            if hasattr(self.backbones[i], "side_stream"):
+                self.backbones[i].side_stream = s                  # in order with the view's own chain
+        if hasattr(self.backbones[self.inputs[0]], "side_stream") and n_side < len(streams):
+            self.backbones[self.inputs[0]].side_stream = streams[n_side]
 
     def enable_fuser_graph(self, sample_batch: Dict[str, torch.Tensor], grad_direct=None):
         """Capture the launch-bound fusion decoder (forward and backward) into hipGraphs for training steps

@@ -205,6 +205,19 @@ int dpft_resnet_forward(int64_t plan, const float* x, const dpft_resnet_tables* 
 int dpft_resnet_backward_stage(int64_t plan, int32_t stage, const float* x,
                                const dpft_resnet_tables* tables, void* arena, const float* dout,
                                dpft_stream_t stream);
+/* The stream the plan's weight-gradient GEMMs run on while the data-gradient chain continues on the caller's stream
+ * (default: a stream the plan creates on first use).  Passing the caller's own stream keeps everything in order on it. */
+int dpft_resnet_plan_set_side_stream(int64_t plan, dpft_stream_t side);
+
+/* ------------------------------------------------------------------------------------------
+ * Streams on distinct hardware queues (MI355X-side addition; the reference is single-stream).
+ * The runtime multiplexes HIP streams onto 4 hardware queues and streams sharing a queue run in order; the step's
+ * concurrency (camera chain | its weight gradients | radar encoders) needs one queue each.  out[0..n-1] receive streams
+ * (library-owned, never destroyed) that share a queue neither with main_stream nor with each other -- found by probing
+ * with a spin kernel; when the device has fewer queues the entries repeat.  Returns the number of distinct queues found
+ * or a negative error code.  Synchronises the device: set-up time only.
+ * ---------------------------------------------------------------------------------------- */
+int32_t dpft_stream_set(dpft_stream_t main_stream, int32_t n, dpft_stream_t* out);
 
 /* ------------------------------------------------------------------------------------------
  * FPN glue + positional embedding
