@@ -1,0 +1,318 @@
+// Software-pipelined fp32 implicit-GEMM kernel (included by conv.hip after IgemmArgs / igemm_epilogue).
+//
+// Why a second main loop.  Ablation of igemm_vec_kernel on the layer-3 problems (tools/conv_ablate.sh, round 3): the MFMA
+// loop alone runs at ~88 % of what the grid's quantisation allows, but the step is  compute -> barrier -> [wait for the
+// register-staged tile, BatchNorm+ReLU prologue, 8 x ds_write_b128, issue the next loads] -> barrier  and in that second
+// phase no wave of the workgroup has an MFMA in the pipe: +25 % on the 3x3 forward (21 us of 112), +10 % on the data
+// gradients, and the loads' issue time on top.  Here a K-step has ONE barrier and nothing between the MFMAs but what has
+// to be there:
+//   * two LDS stages; the tile of step t+1 is brought in WHILE step t multiplies;
+//   * operands that need no arithmetic (weights always; the A operand of data gradients and of prologue-free forward
+//     convs) never touch a VGPR: `buffer_load_dwordx4 ... lds` (LDS-DMA, 1 KiB per wave instruction) writes them straight
+//     into the stage.  The hardware range check of the buffer descriptor still supplies the zeros of the padding, of rows
+//     >= M and of weight rows >= N;
+//   * LDS-DMA writes lane-linearly (wave base + 16 * lane), so rows cannot be padded against bank conflicts.  Instead the
+//     16-byte chunks of a row are XOR-swizzled: lane (row r, position p) FETCHES chunk p ^ key(r) from global memory (a
+//     permutation inside one 128 / 256-byte row segment: coalescing is unchanged) and a fragment read of chunk c of row r
+//     goes to position c ^ key(r).  key(r) = r % 16 for 256-byte rows, (r / 2) % 8 for 128-byte rows: the 16 lanes that a
+//     ds_read_b128 services together hit 16 different bank groups;
+//   * an A operand with the fused BatchNorm+ReLU prologue takes the register route (it needs the vector ALU), but its
+//     loads are issued at the START of the step and consumed behind the last MFMA groups of the same step -- the waits
+//     land a K-step after the issue;
+//   * per-lane LDS read addresses are precomputed (one VGPR per K-group and operand) and everything else of an address
+//     is an instruction immediate: the steady state has no address arithmetic at all.
+// The fp32 MFMA shares the vector ALUs on gfx950, so what remains per step is MFMA time + the
+// prologue's arithmetic; loads, LDS-DMA, ds_reads and the barrier ride in the MFMAs' shadow.
+//
+// Same numerics as igemm_vec_kernel: identical k order inside a K-group, identical fragment permutation, fp32 MFMA.
+#pragma once
+
+namespace dpft {
+
+template <typename Fn, int... I>
+__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant
+template <int N, typename Fn>
+__device__ __forceinline__ void static_for(Fn&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO>
+__global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
+    constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
+    constexpr int CH = PBK / 4;             // 16-byte chunks per LDS row
+    constexpr int RW = 64 / CH;             // rows one wave instruction covers
+    constexpr int RPP = 4 * RW;             // rows per pass of the 4 waves
+    constexpr int AP = BM / RPP, BP = BN / RPP;
+    constexpr int ROWB = PBK * 4;           // bytes per LDS row
+    constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+    constexpr int NG = PBK / 8;             // K-groups of 8 per step
+    static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1 && AP >= 1 && BP >= 1, "bad tile");
+    static_assert(2 * STAGE <= 65536, "LDS offsets must fit the ds_read immediate");
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // max(2 * STAGE, epilogue staging)
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    int mt, nt, split;
+    decode_tile(a, mt, nt, split);
+    const int m0 = mt * BM, n0 = nt * BN;
+
+    // ---- loader geometry: lane -> (row of the pass, position in the row); the chunk it fetches is swizzled ----------
+    const int rp = RW * wave + lane / CH;                 // row within a pass, 0 .. RPP-1
+    const int pos = lane % CH;                            // LDS position (lane-linear destination)
+    const int lkey = (CH == 16) ? (rp & 15) : ((rp >> 1) & 7);
+    const int chunk = pos ^ lkey;                         // global 16-byte chunk of the row segment
+    // ---- operand addressing (see igemm_vec_kernel: per-row tap masks, offsets rebuilt only when the tap changes) ---
+    const bool sub = DGRAD && a.sub_step > 1;
+    const int roww = sub ? a.sub_ow : a.OW;
+    const int ohw = sub ? a.sub_oh * a.sub_ow : a.OH * a.OW;
+    const int ntap_s = sub ? a.sub_ns : a.kw;
+    const int ntap_r = sub ? a.sub_nr : a.kh;
+    constexpr unsigned OOB = 0x80000000u;
+    int a_row[AP];
+    unsigned a_mask[AP];
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+        const int m = m0 + rp + RPP * i;
+        const bool ok = m < a.M;
+        const int mm = ok ? m : 0;
+        const int b = mm / ohw;
+        const int rem = mm - b * ohw;
+        const int oh = rem / roww, ow = rem - oh * roww;
+        int h0, w0;
+        if (!DGRAD) {
+            h0 = oh * a.stride - a.pad;
+            w0 = ow * a.stride - a.pad;
+        } else if (sub) {
+            h0 = oh + (a.sub_ph + a.pad - a.sub_r0) / a.sub_step;
+            w0 = ow + (a.sub_pw + a.pad - a.sub_s0) / a.sub_step;
+        } else {
+            h0 = oh + a.pad;
+            w0 = ow + a.pad;
+        }
+        a_row[i] = ((b * a.H + h0) * a.W + w0) * a.C;
+        unsigned mask = 0;
+        for (int ri = 0; ri < ntap_r; ++ri) {
+            const int hi = DGRAD ? h0 - ri : h0 + ri;
+            mask |= (ok && (unsigned)hi < (unsigned)a.H) ? (1u << ri) : 0u;
+        }
+        for (int si = 0; si < ntap_s; ++si) {
+            const int wi = DGRAD ? w0 - si : w0 + si;
+            mask |= (ok && (unsigned)wi < (unsigned)a.W) ? (256u << si) : 0u;
+        }
+        a_mask[i] = mask;
+    }
+    unsigned b_off[BP];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+        const int n = n0 + rp + RPP * i;
+        b_off[i] = n < a.N ? (unsigned)(n * a.Ktot + chunk * 4) * 4u : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.N * a.Ktot * 4, 0x00020000);
+    unsigned a_off[AP];
+    unsigned a_valid_tap = 0;
+    unsigned long long a_inv_tap[PRO ? AP : 1] = {};      // per loader quad: lanes of this wave whose tap misses the image
+    auto set_tap = [&](int tap) {
+        const int ri = tap / ntap_s, si = tap - ri * ntap_s;
+        const int tapoff = (DGRAD ? -1 : 1) * (ri * a.W + si) * a.C;
+        unsigned valid = 0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i) {
+            const bool v = ((a_mask[i] >> ri) & (a_mask[i] >> (8 + si)) & 1u) != 0;
+            a_off[i] = v ? (unsigned)(a_row[i] + tapoff + chunk * 4) * 4u : OOB;
+            valid |= v ? (1u << i) : 0u;
+            if constexpr (PRO) a_inv_tap[i] = __builtin_amdgcn_ballot_w64(!v);
+        }
+        a_valid_tap = valid;
+    };
+
+    const int kt_begin = split * a.ksteps_per_split;
+    const int kt_end = min(a.ksteps, kt_begin + a.ksteps_per_split);
+    const int nsteps = max(kt_end - kt_begin, 0);
+    const int cpt = a.C / PBK;      // K-steps per filter tap
+    // position of the NEXT tile to be issued: (tap, channel offset); prep() turns it into the loads' scalar operands
+    int run_tap = kt_begin / cpt, run_c0 = (kt_begin - run_tap * cpt) * PBK, run_koff = 0;
+    bool tap_dirty = true;
+    int so_a = 0, so_b = 0;          // byte soffsets of the A / weight loads of the next tile
+    auto prep = [&]() {
+        if (tap_dirty) {
+            set_tap(run_tap);
+            const int ri = run_tap / ntap_s, si = run_tap - ri * ntap_s;
+            run_koff = (sub ? (a.sub_r0 + a.sub_step * ri) * a.kw + a.sub_s0 + a.sub_step * si : run_tap) * a.C;
+            tap_dirty = false;
+        }
+        // (scalar operands of the loads: tell the compiler -- a VGPR here costs a waterfall loop per load)
+        so_a = __builtin_amdgcn_readfirstlane(run_c0 * 4);
+        so_b = __builtin_amdgcn_readfirstlane((run_koff + run_c0) * 4);
+    };
+    auto advance = [&]() {
+        run_c0 += PBK;
+        if (run_c0 == a.C) {
+            run_c0 = 0;
+            ++run_tap;
+            tap_dirty = true;
+        }
+    };
+
+    // register route of the A operand (PRO only)
+    f32x4 ra[PRO ? AP : 1], p_mu, p_sc, p_sh;
+    unsigned ra_valid = 0;
+    unsigned long long ra_inv[PRO ? AP : 1] = {};      // wave-uniform copies of a_inv_tap for the tile in the registers
+
+    // The loads of a tile as NOPS separately placeable operations (the main loop puts one behind each of the first MFMAs
+    // of a step: a vector-memory instruction takes tens of cycles to issue, which an MFMA in the pipe hides and an idle
+    // pipe does not).  Order: A operand, [prologue parameters], weights.
+    constexpr int NPAR = PRO ? 3 : 0;
+    constexpr int NOPS = AP + NPAR + BP;
+    auto vmem_op = [&](auto STG, auto K) {
+        constexpr int stg = decltype(STG)::value, k = decltype(K)::value;
+        if constexpr (k < AP) {
+            if constexpr (PRO) {
+                ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_off[k], so_a, 0));
+                if constexpr (k == 0) ra_valid = a_valid_tap;
+                ra_inv[k] = a_inv_tap[k];
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, lds0 + stg * STAGE + (RPP * k + RW * wave) * ROWB, 16,
+                                                         (int)a_off[k], so_a, 0, 0);
+            }
+        } else if constexpr (k < AP + NPAR) {
+            const float* src = a.pro + (k - AP) * a.C + (so_a >> 2) + chunk * 4;
+            if constexpr (k - AP == 0) p_mu = *reinterpret_cast<const f32x4*>(src);
+            if constexpr (k - AP == 1) p_sc = *reinterpret_cast<const f32x4*>(src);
+            if constexpr (k - AP == 2) p_sh = *reinterpret_cast<const f32x4*>(src);
+        } else {
+            constexpr int i = k - AP - NPAR;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, lds0 + stg * STAGE + A_BYTES + (RPP * i + RW * wave) * ROWB, 16,
+                                                     (int)b_off[i], so_b, 0, 0);
+        }
+    };
+    // BatchNorm + ReLU of register quad i, written to its (lane-linear) place in stage `stg`.  The launcher takes this
+    // kernel only for pro_relu != 0 (every prologue of the ResNet plan has the ReLU).  Padding must stay exactly zero
+    // (BN(0) != 0): the select runs only in waves that have such a lane for this quad and tap (a scalar test of a ballot
+    // taken when the tap changed) -- interior pixels, i.e. nearly all of them, pay no vector instruction for it.
+    char* const w_ptr = reinterpret_cast<char*>(smem) + rp * ROWB + pos * 16;
+    auto consume = [&](auto STG, auto I) {
+        constexpr int stg = decltype(STG)::value, i = decltype(I)::value;
+        f32x4 val = ra[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = fmaxf(fmaf(val[e] - p_mu[e], p_sc[e], p_sh[e]), 0.f);
+        if (ra_inv[i] != 0ull) {
+            asm volatile("" ::: "memory");      // keeps this a branch (the compiler would turn it back into selects)
+            if (!((ra_valid >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<f32x4*>(w_ptr + stg * STAGE + RPP * i * ROWB) = val;
+    };
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment read addresses: lane l reads row l % 32 of a 32-row block, K-group kg, half h = l / 32 -> chunk 2 * kg + h
+    const int fkey = (CH == 16) ? (lane & 15) : ((lane >> 1) & 7);
+    const int h = lane >> 5;
+    // 32-bit LDS addresses with the array's base folded in: a fragment read is one VGPR + an instruction immediate
+    typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
+    const unsigned lds_base = (unsigned)(size_t)lds0;
+    unsigned a_ad[NG], b_ad[NG];
+#pragma unroll
+    for (int kg = 0; kg < NG; ++kg) {
+        const int sw = ((2 * kg + h) ^ fkey) * 16;
+        a_ad[kg] = lds_base + (wm * RB * 32 + (lane & 31)) * ROWB + sw;
+        b_ad[kg] = lds_base + A_BYTES + (wn * CB * 32 + (lane & 31)) * ROWB + sw;
+        // opaque: otherwise the compiler keeps (row base, swizzle) apart and re-adds them in front of every read -- 2 * NG
+        // vector adds per K-step on the ALUs the fp32 MFMA needs
+        asm volatile("" : "+v"(a_ad[kg]), "+v"(b_ad[kg]));
+    }
+
+    // One K-step on stage STG; MORE: the next tile is brought into the other stage meanwhile.  The MFMAs of the step are
+    // SLOTS = NG * 4 * RB * CB; the instruction order is pinned (sched_barrier after every slot): fragment reads of the
+    // next K-group in front of a group's first MFMA, one load behind each of the first NOPS MFMAs, the prologue's quads
+    // behind MFMAs of the last groups.
+    constexpr int MPG = 4 * RB * CB, SLOTS = NG * MPG;
+    constexpr int LASTG = (NG >= 8) ? 4 : 2;      // K-groups (the last ones of a step) that carry the prologue
+    constexpr int QPG = PRO ? AP / LASTG : 1;     // register quads per such group
+    static_assert(NOPS <= SLOTS, "more loads than MFMA slots");
+    static_assert(!PRO || (AP % LASTG == 0 && QPG >= 1 && QPG <= MPG), "prologue schedule");
+    auto step = [&](auto STG, auto MORE) {
+        constexpr int stg = decltype(STG)::value;
+        constexpr bool more = decltype(MORE)::value;
+        using OTHER = std::integral_constant<int, (stg ^ 1)>;
+        if constexpr (more) prep();
+        f32x4 af[2][RB], bf[2][CB];
+        auto frags = [&](auto SET, auto KG) {
+            constexpr int set = decltype(SET)::value, kg = decltype(KG)::value;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) af[set][i] = *(lds_f32x4*)(size_t)(a_ad[kg] + (unsigned)(stg * STAGE + i * 32 * ROWB));
+#pragma unroll
+            for (int j = 0; j < CB; ++j) bf[set][j] = *(lds_f32x4*)(size_t)(b_ad[kg] + (unsigned)(stg * STAGE + j * 32 * ROWB));
+        };
+        frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<SLOTS>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            constexpr int g = sl / MPG, w = sl % MPG, e = w / (RB * CB), ij = w % (RB * CB), i = ij / CB, j = ij % CB;
+            if constexpr (w == 0 && g + 1 < NG)
+                frags(std::integral_constant<int, ((g + 1) & 1)>{}, std::integral_constant<int, (g + 1 < NG ? g + 1 : 0)>{});
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (more && sl < NOPS) {
+                vmem_op(OTHER{}, std::integral_constant<int, (sl < NOPS ? sl : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (more && PRO) {
+                constexpr int gq = g - (NG - LASTG);               // which of the last groups (negative: not one)
+                constexpr int sp = MPG / QPG;                      // quads of a group are spaced over its MFMAs
+                if constexpr (gq >= 0 && (w % sp) == sp - 1 && (w / sp) < QPG) {
+                    consume(OTHER{}, std::integral_constant<int, (gq >= 0 ? gq * QPG + w / sp : 0)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        });
+        if constexpr (more) advance();
+    };
+    auto fence = [&]() {      // everything this wave issued has landed (LDS-DMA counts on vmcnt), then the workgroup meets
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+
+    if (nsteps > 0) {      // first tile: nothing to hide the loads behind
+        prep();
+        static_for<NOPS>([&](auto K) { vmem_op(S0{}, K); });
+        if constexpr (PRO) static_for<AP>([&](auto I) { consume(S0{}, I); });
+        advance();
+    }
+    fence();
+    int s_ = 0;
+    for (; s_ + 2 < nsteps; s_ += 2) {
+        step(S0{}, T{});
+        fence();
+        step(S1{}, T{});
+        fence();
+    }
+    if (nsteps - s_ == 2) {
+        step(S0{}, T{});
+        fence();
+        step(S1{}, F{});
+    } else if (nsteps - s_ == 1) {
+        step(S0{}, F{});
+    }
+    igemm_epilogue<BM, BN, WGM, WGN, RB, CB, 256>(a, acc, m0, n0, mt, split, smem);
+}
+
+}  // namespace dpft

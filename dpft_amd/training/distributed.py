@@ -42,6 +42,7 @@ class GradBucketReducer:
         self.collective = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         # RCCL averages inside the collective (ncclAvg): no separate division pass over the 360 MB of buckets
         self._avg_op = average and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.comm_stream = None      # optional torch stream the collectives are enqueued on (set by the trainer)
         self.average = average
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.params = [p for p in params if p.requires_grad]
@@ -220,13 +221,32 @@ class GradBucketReducer:
             op = dist.ReduceOp.SUM
             if self._avg_op:
                 op = dist.ReduceOp.AVG
-            elif self.average and self.world > 1:
-                b["flat"].div_(self.world)
-            wire = b["flat"]
-            if b["stage"] is not None:
-                wire = b["stage"]
-                wire.copy_(b["flat"])                                 # round to the wire dtype (RNE)
-            self._pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), b))
+            comm = self.comm_stream if b["flat"].is_cuda else None
+            if comm is None:
+                # the process group's own stream (async_op=True): wherever the runtime put it among the hardware queues
+                if op == dist.ReduceOp.SUM and self.average and self.world > 1:
+                    b["flat"].div_(self.world)
+                wire = b["flat"]
+                if b["stage"] is not None:
+                    wire = b["stage"]
+                    wire.copy_(b["flat"])                             # round to the wire dtype (RNE)
+                self._pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), b))
+            else:
+                # a stream of OUR choosing (= a hardware queue of our choosing, DataParallelTrainer): a synchronous
+                # collective is enqueued on the current stream, so the exchange of a bucket -- scaling, wire rounding,
+                # all-reduce, widening -- is one in-order sequence there, fenced by two events
+                comm.wait_stream(torch.cuda.current_stream(b["flat"].device))
+                with torch.cuda.stream(comm):
+                    if op == dist.ReduceOp.SUM and self.average and self.world > 1:
+                        b["flat"].div_(self.world)
+                    wire = b["flat"]
+                    if b["stage"] is not None:
+                        wire = b["stage"]
+                        wire.copy_(b["flat"])
+                    dist.all_reduce(wire, op=op, group=self.group, async_op=False)
+                    if b["stage"] is not None:
+                        b["flat"].copy_(b["stage"])
+                    self._pending.append((comm.record_event(), None))
 
     def seen_ids(self):
         """ids of the parameters that received a gradient since the last reset()."""
@@ -256,8 +276,8 @@ class GradBucketReducer:
             import time
             t0 = time.perf_counter()
         for w, b in self._pending:
-            w.wait()                               # cuda: the current stream waits for the collective's stream
-            if b["stage"] is not None:
+            w.wait()                               # cuda: the current stream waits for the collective's stream / event
+            if b is not None and b["stage"] is not None:
                 b["flat"].copy_(b["stage"])
         if cuda:
             t1.record()

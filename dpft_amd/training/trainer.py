@@ -57,6 +57,10 @@ class DataParallelTrainer:
         self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=int(bucket_mb * (1 << 20)),
                                          group_of=group_of, comm_dtype=wire, force_collectives=force_collectives)
         self.collective = self.reducer.collective
+        # The collectives' hardware queue.  Four queues, four busy chains (main | camera weight gradients | two radar views):
+        # RCCL's own stream lands on whichever queue the runtime picks, possibly the critical chain's.  "front" / "side" put
+        # them (in order) on the last view's stream / the camera's weight-gradient stream; "pg" keeps the group's stream.
+        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "front")
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         overwritten = []
         for m in self.model.modules():
@@ -80,6 +84,13 @@ class DataParallelTrainer:
         """One step of CentralizedTrainer.train_one_epoch (trainer.py:122-136).  ``with_metrics`` also evaluates the
         configured detection metrics on the step's outputs (two more launches) and returns them as a third value."""
         self.model.train()
+        if self.collective and self.reducer.comm_stream is None and self.comm_placement != "pg" and self.device.type == "cuda" \
+                and dist.get_backend() == "nccl":
+            views = self.model.__dict__.get("_view_streams")
+            if views:
+                first = self.model.backbones[self.model.inputs[0]]
+                self.reducer.comm_stream = views[-1] if self.comm_placement == "front" or first.side_stream is None \
+                    else first.side_stream
         self.reducer.reset()                               # zero_grad (grads live in the buckets)
         g = self.model.__dict__.get("_graphed_fuser")
         if g is not None:
