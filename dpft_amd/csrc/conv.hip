@@ -1605,10 +1605,10 @@ static void fill_igemm(IgemmArgs& a, const dpft_conv_desc* d, bool dgrad) {
 // launch with dynamic LDS; raises the per-kernel dynamic-LDS cap once (tiles above 64 KiB)
 template <typename K, typename A>
 static void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& args) {
-    static bool configured = false;       // one static per kernel instantiation
-    if (!configured) {
+    static size_t configured = 0;       // one static per kernel instantiation: the largest size allowed so far
+    if (lds > configured) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = true;
+        configured = lds;
     }
     hipLaunchKernelGGL(kernel, grid, block, lds, st, args);
 }
@@ -2072,7 +2072,23 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     a.partial = splits > 1 ? (float*)workspace : nullptr;
     const int nwg = (int)(tiles * splits);
     dim3 grid(nwg), block(256);
-    if (vec) {
+    static const int wpipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 1;
+    if (vec && wpipe_env && g_conv_bf16 == 0 && !d->act16 && (!pro || pro_relu) && (bmn == 128 || bmn == 64)) {
+        // software-pipelined form (conv_pipe.h): psteps in units of its PK pixels
+        const int pk = bmn == 128 ? 32 : 64;
+        a.psteps = cdiv(a.M, pk);
+        a.psteps_per_split = cdiv(a.psteps, splits);
+        const size_t tbl = (size_t)a.psteps_per_split * pk * 4;      // per-workgroup input-pixel offset table
+        if (bmn == 128) {
+            const size_t lds = (size_t)2 * 32 * (128 + 128) * 4 + tbl;
+            if (pro) launch_lds(wgrad_pipe_kernel<128, 128, 2, 2, 32, true>, grid, block, lds, st, a);
+            else launch_lds(wgrad_pipe_kernel<128, 128, 2, 2, 32, false>, grid, block, lds, st, a);
+        } else {
+            const size_t lds = (size_t)2 * 64 * (64 + 64) * 4 + tbl;
+            if (pro) launch_lds(wgrad_pipe_kernel<64, 64, 2, 2, 64, true>, grid, block, lds, st, a);
+            else launch_lds(wgrad_pipe_kernel<64, 64, 2, 2, 64, false>, grid, block, lds, st, a);
+        }
+    } else if (vec) {
 #define LAUNCH_WG(BM_, BN_, WGM_, WGN_)                                                           \
     do {                                                                                          \
         if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \

@@ -315,4 +315,245 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     igemm_epilogue<BM, BN, WGM, WGN, RB, CB, 256>(a, acc, m0, n0, mt, split, smem);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient, same pipeline.  dW[n][tap][c] = sum over pixels p of dY[p][n] * act(x)[p @ tap][c]: both operands are
+// pixel-major in memory AND in LDS ([pixel][channels]: a lane's MFMA operand is one channel of one pixel, consecutive
+// lanes read consecutive words -- no swizzle needed), the reduction runs over pixels in steps of PK.  dY always arrives by
+// LDS-DMA; x too unless it carries the producer's BatchNorm+ReLU (register route, consumed behind the last MFMAs of the
+// step).  Fragment reads are one base VGPR per operand + immediates.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BMn, int BNc, int WGM, int WGN, int PK, bool PRO>
+__global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
+    constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
+    constexpr int YL = BMn / 4, XL = BNc / 4;              // lanes (16-byte chunks) per pixel row
+    constexpr int YRW = 64 / YL, XRW = 64 / XL;            // pixel rows per wave instruction
+    constexpr int YRPP = 4 * YRW, XRPP = 4 * XRW;          // pixel rows per pass of the 4 waves
+    constexpr int YP = PK / YRPP, XP = PK / XRPP;
+    constexpr int Y_BYTES = PK * BMn * 4, X_BYTES = PK * BNc * 4, STAGE = Y_BYTES + X_BYTES;
+    static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1 && YP >= 1 && XP >= 1 && YL <= 64 && XL <= 64, "bad wgrad tile");
+    static_assert(2 * STAGE <= 65536, "LDS offsets must fit the ds_read immediate");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int nwg = a.ktiles * a.ctiles * a.taps * a.splits;
+    int bid = xcd_remap(blockIdx.x, nwg);
+    const int split = bid / (a.ktiles * a.ctiles * a.taps);
+    bid -= split * (a.ktiles * a.ctiles * a.taps);
+    const int tap = bid / (a.ktiles * a.ctiles);
+    bid -= tap * (a.ktiles * a.ctiles);
+    const int kt_ = bid / a.ctiles, ct_ = bid - kt_ * a.ctiles;
+    const int n0 = kt_ * BMn, c0 = ct_ * BNc;
+    const int r = tap / a.kw, s = tap - r * a.kw;
+
+    const int yr = YRW * wave + lane / YL, ych = lane % YL;      // this lane's pixel row within a pass / channel chunk
+    const int xr = XRW * wave + lane / XL, xch = lane % XL;
+    const bool y_ok = (n0 + ych * 4) < a.K;
+    const bool x_ok = (c0 + xch * 4) < a.C;
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (PRO && x_ok) {
+        mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + xch * 4);
+        sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + xch * 4);
+        sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + xch * 4);
+    }
+    const int ohw = a.OH * a.OW;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_y =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    unsigned y_voff[YP];
+#pragma unroll
+    for (int i = 0; i < YP; ++i) y_voff[i] = y_ok ? (unsigned)((YRPP * i + yr) * a.K + n0 + ych * 4) * 4u : OOB;
+    const int ps_begin = split * a.psteps_per_split;
+    const int ps_end = min(a.psteps, ps_begin + a.psteps_per_split);
+    const int nsteps = max(ps_end - ps_begin, 0);
+    // x offsets.  The pixel -> (image, row, column) -> input pixel / validity arithmetic is ~25 vector instructions per
+    // loader row, and every one of the XL lanes of a row would repeat it every step, on the ALUs the fp32 MFMA needs.  It
+    // is done ONCE per workgroup instead: a table in LDS holds, for every pixel of this workgroup's pixel range, the byte
+    // offset of the input pixel its tap reads (or the out-of-range marker: padding, pixel tail).  A step then costs one
+    // ds_read_b32 + one add per loader row.
+    unsigned* const tbl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + 2 * STAGE);
+    {
+        const int npix = nsteps * PK;
+        for (int idx = tid; idx < npix; idx += 256) {
+            const int p = ps_begin * PK + idx;
+            const int b = p / ohw;
+            const int rem = p - b * ohw;
+            const int oh = rem / a.OW, ow = rem - oh * a.OW;
+            const int hi = oh * a.stride - a.pad + r, wi = ow * a.stride - a.pad + s;
+            const bool v = p < a.M && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            tbl[idx] = v ? ((((unsigned)b * a.H + hi) * a.W + wi) * a.C) * 4u : OOB;
+        }
+    }
+    __syncthreads();
+    typedef __attribute__((address_space(3))) const unsigned lds_u32;
+    unsigned tbl_ad = (unsigned)(size_t)lds0 + 2 * STAGE + xr * 4;      // LDS address of this lane's row in the next tile
+    const unsigned x_lane = x_ok ? (unsigned)(c0 + xch * 4) * 4u : OOB;  // channel chunks beyond C: out of range as well
+    int next_ps = ps_begin;
+    int so_y = 0;
+    unsigned xoffs[XP];
+    unsigned long long x_inv[PRO ? XP : 1] = {};
+    auto prep = [&]() {
+        so_y = __builtin_amdgcn_readfirstlane(next_ps * PK * a.K * 4);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const unsigned t = *(lds_u32*)(size_t)(tbl_ad + (unsigned)(XRPP * i * 4));
+            xoffs[i] = t + x_lane;      // marker + anything small stays beyond every tensor (< 2 GiB)
+            if constexpr (PRO) x_inv[i] = __builtin_amdgcn_ballot_w64((int)xoffs[i] < 0);
+        }
+        tbl_ad += PK * 4;
+        ++next_ps;
+    };
+    f32x4 rx[PRO ? XP : 1];
+    unsigned rxo[PRO ? XP : 1] = {};      // the offsets the quads in rx were loaded with (validity, read in the rare branch)
+    unsigned long long rx_inv[PRO ? XP : 1] = {};
+    constexpr int NOPS = YP + XP;
+    auto vmem_op = [&](auto STG, auto K) {      // dY first: the x offsets come out of LDS a few MFMAs after prep()
+        constexpr int stg = decltype(STG)::value, k = decltype(K)::value;
+        if constexpr (k < YP) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, lds0 + stg * STAGE + (YRPP * k + YRW * wave) * BMn * 4, 16,
+                                                     (int)y_voff[k], so_y, 0, 0);
+        } else {
+            constexpr int i = k - YP;
+            if constexpr (PRO) {
+                rx[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)xoffs[i], 0, 0));
+                rxo[i] = xoffs[i];
+                rx_inv[i] = x_inv[i];
+            } else {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, lds0 + stg * STAGE + Y_BYTES + (XRPP * i + XRW * wave) * BNc * 4, 16,
+                                                         (int)xoffs[i], 0, 0, 0);
+            }
+        }
+    };
+    char* const xw_ptr = reinterpret_cast<char*>(smem) + Y_BYTES + xr * BNc * 4 + xch * 16;
+    auto consume = [&](auto STG, auto I) {
+        constexpr int stg = decltype(STG)::value, i = decltype(I)::value;
+        f32x4 val = rx[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) val[e] = fmaxf(fmaf(val[e] - mu[e], sc[e], sh[e]), 0.f);
+        if (rx_inv[i] != 0ull) {      // padding / pixel tail: BN(0) != 0 (rare: a scalar test skips the selects)
+            asm volatile("" ::: "memory");
+            if ((int)rxo[i] < 0) val = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        *reinterpret_cast<f32x4*>(xw_ptr + stg * STAGE + XRPP * i * BNc * 4) = val;
+    };
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // volatile: keeps each fragment read a ds_read_b32 with a 16-bit immediate offset -- merged into ds_read2_b32 (8-bit
+    // offsets) every pair would need a vector add for its base
+    typedef __attribute__((address_space(3))) const volatile float lds_f32;
+    const unsigned lds_base = (unsigned)(size_t)lds0;
+    unsigned y_ad = lds_base + ((lane >> 5) * BMn + wm * RB * 32 + (lane & 31)) * 4;
+    unsigned x_ad = lds_base + Y_BYTES + ((lane >> 5) * BNc + wn * CB * 32 + (lane & 31)) * 4;
+    asm volatile("" : "+v"(y_ad), "+v"(x_ad));
+
+    constexpr int NPAIR = PK / 2, MPP = RB * CB, SLOTS = NPAIR * MPP, PF = 2, NS = PF + 1;
+    static_assert(NOPS <= SLOTS, "more loads than MFMA slots");
+    // the prologue's XP quads: behind MFMAs of the last quarter of the step, evenly spaced
+    constexpr int CSTART = SLOTS - SLOTS / 4, CSTEP = (SLOTS / 4) / (PRO ? XP : 1);
+    static_assert(!PRO || CSTEP >= 1, "prologue schedule");
+    auto step = [&](auto STG, auto MORE) {
+        constexpr int stg = decltype(STG)::value;
+        constexpr bool more = decltype(MORE)::value;
+        using OTHER = std::integral_constant<int, (stg ^ 1)>;
+        if constexpr (more) prep();
+        float av[NS][RB], bv[NS][CB];
+        auto frags = [&](auto SET, auto KK) {
+            constexpr int set = decltype(SET)::value, kk = decltype(KK)::value;
+#pragma unroll
+            for (int i = 0; i < RB; ++i) av[set][i] = *(lds_f32*)(size_t)(y_ad + (unsigned)(stg * STAGE + (kk * 2 * BMn + i * 32) * 4));
+#pragma unroll
+            for (int j = 0; j < CB; ++j) bv[set][j] = *(lds_f32*)(size_t)(x_ad + (unsigned)(stg * STAGE + (kk * 2 * BNc + j * 32) * 4));
+        };
+        static_for<PF>([&](auto Q) { frags(Q, Q); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<SLOTS>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            constexpr int kk = sl / MPP, w = sl % MPP, i = w / CB, j = w % CB;
+            if constexpr (w == 0 && kk + PF < NPAIR)
+                frags(std::integral_constant<int, ((kk + PF) % NS)>{}, std::integral_constant<int, (kk + PF < NPAIR ? kk + PF : 0)>{});
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk % NS][i], bv[kk % NS][j], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (more && sl < NOPS) {
+                vmem_op(OTHER{}, std::integral_constant<int, (sl < NOPS ? sl : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (more && PRO) {
+                if constexpr (sl >= CSTART && (sl - CSTART) % CSTEP == 0 && (sl - CSTART) / CSTEP < XP) {
+                    consume(OTHER{}, std::integral_constant<int, (sl >= CSTART ? ((sl - CSTART) / CSTEP) % XP : 0)>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        });
+    };
+    auto fence = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+    if (nsteps > 0) {
+        prep();
+        static_for<NOPS>([&](auto K) { vmem_op(S0{}, K); });
+        if constexpr (PRO) static_for<XP>([&](auto I) { consume(S0{}, I); });
+    }
+    fence();
+    int s_ = 0;
+    for (; s_ + 2 < nsteps; s_ += 2) {
+        step(S0{}, T{});
+        fence();
+        step(S1{}, T{});
+        fence();
+    }
+    if (nsteps - s_ == 2) {
+        step(S0{}, T{});
+        fence();
+        step(S1{}, F{});
+    } else if (nsteps - s_ == 1) {
+        step(S0{}, F{});
+    }
+    // epilogue: stage one wave-row of the tile at a time through LDS -> full 16-byte stores along c (as wgrad_vec_kernel)
+    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.K * a.taps * a.C : a.dw;
+    constexpr int RP = RB * 32;
+    constexpr int LDC = BNc + 4;
+    static_assert(RP * LDC * 4 <= 2 * STAGE, "wgrad epilogue staging does not fit the operand LDS");
+    float* Cs = smem;
+    for (int hh = 0; hh < WGM; ++hh) {
+        __syncthreads();
+        if (wm == hh) {
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                        Cs[row * LDC + wn * CB * 32 + j * 32 + (lane & 31)] = acc[i][j][q];
+                    }
+        }
+        __syncthreads();
+        constexpr int C4 = BNc / 4;
+        for (int idx = tid; idx < RP * C4; idx += 256) {
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int n = n0 + hh * RP + row, c = c0 + c4 * 4;
+            if (n < a.K && c < a.C)
+                *reinterpret_cast<f32x4*>(out + ((size_t)n * a.taps + tap) * a.C + c) =
+                    *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
+        }
+    }
+}
+
 }  // namespace dpft
