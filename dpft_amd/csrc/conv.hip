@@ -1648,8 +1648,8 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     }
     // fp32, linear taps: the software-pipelined kernel (conv_pipe.h) -- LDS-DMA operands, one barrier per K-step.
     // DPFT_PIPE=0 keeps igemm_vec_kernel (A/B measurements).
-    static const int pipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 1;
-    if (t.vec && g_conv_bf16 == 0 && pipe_env && !a.x16 && !a.y16 && (!pro || a.pro_relu)) {
+    static const int pipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;      // bit 0: igemm, bit 1: wgrad
+    if (t.vec && g_conv_bf16 == 0 && (pipe_env & 1) && !a.x16 && !a.y16 && (!pro || a.pro_relu)) {
         auto go = [&](auto kernel, int pbk, size_t lds) {
             a.ksteps = a.ksteps * BKV / pbk;
             a.ksteps_per_split = cdiv(a.ksteps, a.splits);
@@ -2072,8 +2072,8 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     a.partial = splits > 1 ? (float*)workspace : nullptr;
     const int nwg = (int)(tiles * splits);
     dim3 grid(nwg), block(256);
-    static const int wpipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 1;
-    if (vec && wpipe_env && g_conv_bf16 == 0 && !d->act16 && (!pro || pro_relu) && (bmn == 128 || bmn == 64)) {
+    static const int wpipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;
+    if (vec && (wpipe_env & 2) && g_conv_bf16 == 0 && !d->act16 && (!pro || pro_relu) && (bmn == 128 || bmn == 64)) {
         // software-pipelined form (conv_pipe.h): psteps in units of its PK pixels
         const int pk = bmn == 128 ? 32 : 64;
         a.psteps = cdiv(a.M, pk);
