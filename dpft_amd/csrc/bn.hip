@@ -63,6 +63,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_kernel(const float* __restri
                                    int K, const float* __restrict__ gamma, const float* __restrict__ beta,
                                    float eps, float momentum, float* running_mean, float* running_var,
                                    float* bnp) {
+    DPFT_SETPRIO_BN();
     __shared__ float s1s[32][33], s2s[32][33];
     const int cl = threadIdx.x & 31, g = threadIdx.x >> 5;
     const int c = blockIdx.x * 32 + cl;
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
                                                       const float* __restrict__ res, const float* __restrict__ rbnp,
                                                       int relu, float* __restrict__ out, float* __restrict__ out32,
                                                       int64_t n4, int K4, unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
     const int K = K4 * 4;
     // bf16 storage moves 8 bytes per lane and access: two independent groups per trip keep as many bytes in flight as
     // the fp32 form (these passes are pure HBM streaming)
@@ -203,6 +205,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                                float* __restrict__ out,
                                                                int B, int H, int W, int K4, int PH, int PW) {
+    DPFT_SETPRIO_BN();
     const int K = K4 * 4;
     const int64_t total = (int64_t)B * PH * PW * K4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -235,6 +238,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                                    const float* __restrict__ dout,
                                                                    float* __restrict__ dz, int B, int H, int W, int K4, int PH, int PW) {
+    DPFT_SETPRIO_BN();
     const int K = K4 * 4;
     const int64_t total = (int64_t)B * H * W * K4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -291,6 +295,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
                                                              const float* __restrict__ bnp, float* __restrict__ sums,
                                                              int64_t M, int K, int rows_per_block, int slab,
                                                              const unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
     __shared__ float red0[256 * 4];
     __shared__ float red1[256 * 4];
     const int K4 = K / 4;
@@ -376,6 +381,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                             int64_t n4, int K, float invM, float* __restrict__ zero_buf,
                                                             int zero_n, const unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
     const int K4 = K / 4;
     if (blockIdx.x == 0) {
         for (int c = threadIdx.x; c < K; c += blockDim.x) {

@@ -13,8 +13,22 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace dpft {
 
 void set_error(const char* fmt, ...);
+// First pass of a BatchNorm backward (sums[0][k] += sum d, sums[1][k] += sum d * xhat, d = dout under the layer's ReLU mask)
+// folded into the epilogue of the data-gradient GEMM that PRODUCES dout: `y` = the layer's input, `bnp` its BN block,
+// mask from `mask8` (byte mask of the block output) or recomputed as bn(y) > 0 (`self_mask`); `sums` pre-zeroed [2][K].
+// `applied` (out): the launch carried the reduction; otherwise the caller runs bn_bwd_reduce_prezeroed as before.
+struct BnReduceFuse {
+    const float* y;
+    const float* bnp;
+    const unsigned char* mask8;
+    int self_mask;
+    float* sums;
+    bool applied;
+};
 int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
-                        const float* res_mask, void* workspace, dpft_stream_t stream);      // conv.hip
+                        const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse = nullptr);      // conv.hip
+int conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, int32_t accumulate,
+                     void* workspace, dpft_stream_t stream, BnReduceFuse* fuse);
 // bn.hip -- `act16`: the activation / gradient tensors (y, dout, out, dy, res) are bf16 in memory (the pointers keep
 // their float* type); BN blocks, sums and parameter gradients are fp32
 // `mask8` (one byte per 4 channels: bit e = element e of the group passed the ReLU): written by bn_act_any next to the
@@ -83,6 +97,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 }  // namespace dpft
+
+// Wave priorities (s_setprio: the CU arbitrates between resident waves by priority, then age).  The BatchNorm passes and
+// the forward / data-gradient GEMMs sit on the step's critical chain; the weight-gradient GEMMs that run beside them on
+// their own stream do not, and their fp32 MFMAs occupy the vector ALUs every other kernel on the CU needs.
+// Measured (tools/ab_libs.sh, same box, alternating builds): BN 3 + GEMM 1 = 29.3-29.5 ms per step, none = 30.1 ms.
+#ifndef DPFT_PRIO_BN
+#define DPFT_PRIO_BN 3
+#endif
+#ifndef DPFT_PRIO_IGEMM
+#define DPFT_PRIO_IGEMM 1
+#endif
+#define DPFT_SETPRIO_BN() do { if (DPFT_PRIO_BN) __builtin_amdgcn_s_setprio(DPFT_PRIO_BN); } while (0)
+#define DPFT_SETPRIO_IGEMM() do { if (DPFT_PRIO_IGEMM) __builtin_amdgcn_s_setprio(DPFT_PRIO_IGEMM); } while (0)
 
 #define DPFT_REQUIRE(cond, ...)                 \
     do {                                        \

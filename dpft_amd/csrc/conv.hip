@@ -107,6 +107,15 @@ struct IgemmArgs {
     const float* oadd;
     int orelu;
     int ablate;       // tuning aid (DPFT_ABLATE): 1 no global loads, 2 no LDS stores, 4 no epilogue, 8 no MFMAs
+    // Fused first pass of a BatchNorm backward (dpft::BnReduceFuse): the tensor this launch writes IS the `dout` of a
+    // BatchNorm layer whose input y has the same shape; the epilogue adds sum(d) and sum(d * xhat) of its tile to
+    // bnr_sums[2][N] (d = stored value under that layer's ReLU mask) -- the separate reduction pass over (y, dout), its
+    // launch and its second read of dout disappear.
+    const float* bnr_y;
+    const float* bnr_bnp;              // BN block [4][N] of that layer (mean, scale, beta, invstd)
+    const unsigned char* bnr_mask8;    // ReLU byte mask of the layer's OUTPUT side (1 byte per 4 channels), or null
+    int bnr_self_mask;                 // mask = bn(y) > 0 (the ReLU sits directly behind this BatchNorm)
+    float* bnr_sums;                   // null = no fused reduction
 };
 
 // output row (GEMM row m) -> pixel index of the output tensor
@@ -209,6 +218,24 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         constexpr int ITER = BM * C4 / NT;
         static_assert(BM * C4 % NT == 0, "tile / thread count");
         f32x4 old[ITER];
+        // operands of the fused BatchNorm-backward reduction: requested here, consumed in the store loop below
+        const bool bnr_pre = (a.bnr_sums != nullptr) && (a.partial == nullptr);
+        f32x4 bnr_yv[ITER];
+        unsigned bnr_mk[ITER];
+        if (bnr_pre) {
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int idx = tid + it * NT;
+                const int row = idx / C4, c4 = idx - row * C4;
+                bnr_yv[it] = f32x4{0.f, 0.f, 0.f, 0.f};
+                bnr_mk[it] = 0u;
+                if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
+                    const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c4 * 4;
+                    bnr_yv[it] = *reinterpret_cast<const f32x4*>(a.bnr_y + off);
+                    if (a.bnr_mask8) bnr_mk[it] = a.bnr_mask8[off >> 2];
+                }
+            }
+        }
         const bool resid = (a.res_src != nullptr) && (a.partial == nullptr);
         const bool obn = (a.obn != nullptr) && (a.partial == nullptr);
         const bool oadd = obn && a.oadd != nullptr;
@@ -233,6 +260,19 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 }
             }
         }
+        // fused BatchNorm-backward reduction (see IgemmArgs::bnr_*): a thread owns ONE 4-channel chunk (NT % C4 == 0)
+        static_assert(NT % C4 == 0, "a thread's channel chunk must not depend on the pass");
+        const bool bnr = (a.bnr_sums != nullptr) && (a.partial == nullptr);
+        f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f}, bmu = bs0, bis = bs0, bsc = bs0, bbe = bs0;
+        const int bc = n0 + (tid % C4) * 4;
+        if (bnr && bc < a.N) {
+            bmu = *reinterpret_cast<const f32x4*>(a.bnr_bnp + bc);
+            bis = *reinterpret_cast<const f32x4*>(a.bnr_bnp + 3 * a.N + bc);
+            if (a.bnr_self_mask) {
+                bsc = *reinterpret_cast<const f32x4*>(a.bnr_bnp + a.N + bc);
+                bbe = *reinterpret_cast<const f32x4*>(a.bnr_bnp + 2 * a.N + bc);
+            }
+        }
         auto store_all = [&](auto H16) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
@@ -254,12 +294,47 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
 #pragma unroll
                         for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
                     }
-                    store4_act(out, out_pixel(a, m0 + row) * a.N + n0 + c4 * 4, v, decltype(H16)::value);
+                    const size_t ooff = out_pixel(a, m0 + row) * a.N + n0 + c4 * 4;
+                    store4_act(out, ooff, v, decltype(H16)::value);
+                    if (bnr) {
+                        const f32x4 yv = bnr_yv[it];
+                        f32x4 d = v;
+                        if (a.bnr_mask8) {
+                            const unsigned mk = bnr_mk[it];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e] = ((mk >> e) & 1u) ? d[e] : 0.f;
+                        } else if (a.bnr_self_mask) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) d[e] = fmaf(yv[e] - bmu[e], bsc[e], bbe[e]) > 0.f ? d[e] : 0.f;
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            bs0[e] += d[e];
+                            bs1[e] += d[e] * ((yv[e] - bmu[e]) * bis[e]);
+                        }
+                    }
                 }
             }
         };
         if (y16) store_all(std::true_type{});
         else store_all(std::false_type{});
+        if (bnr) {      // column sums over the tile's rows (NT / C4 threads per chunk), one atomic pair per column
+            __syncthreads();      // the staged tile has been read
+            float* red = smem;      // [NT][8]: s0[4], s1[4] of each thread
+            *reinterpret_cast<f32x4*>(red + tid * 8) = bs0;
+            *reinterpret_cast<f32x4*>(red + tid * 8 + 4) = bs1;
+            __syncthreads();
+            if (tid < BN && n0 + tid < a.N) {
+                const int ch = tid >> 2, e = tid & 3;
+                float t0 = 0.f, t1 = 0.f;
+                for (int g = 0; g < NT / C4; ++g) {
+                    t0 += red[(g * C4 + ch) * 8 + e];
+                    t1 += red[(g * C4 + ch) * 8 + 4 + e];
+                }
+                atomicAdd(a.bnr_sums + n0 + tid, t0);
+                atomicAdd(a.bnr_sums + a.N + n0 + tid, t1);
+            }
+        }
     } else {
         for (int idx = tid; idx < BM * BN; idx += NT) {
             const int row = idx / BN, c = idx - row * BN;
@@ -1885,6 +1960,18 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
 extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,
                                           float* dx, int32_t accumulate, void* workspace,
                                           dpft_stream_t stream) {
+    return dpft::conv_dgrad_fused(d, dy, w_t, dx, accumulate, workspace, stream, nullptr);
+}
+
+static void set_bnr(IgemmArgs& a, const dpft::BnReduceFuse* f) {
+    a.bnr_y = f->y; a.bnr_bnp = f->bnp; a.bnr_mask8 = f->mask8; a.bnr_self_mask = f->self_mask; a.bnr_sums = f->sums;
+}
+
+// Data gradient with an optional fused BatchNorm-backward reduction (BnReduceFuse, common.h): `fuse->applied` tells the
+// caller whether the launch(es) carried it -- split-K, thin-channel and bf16-storage paths do not.
+int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, int32_t accumulate,
+                           void* workspace, dpft_stream_t stream, BnReduceFuse* fuse) {
+    if (fuse) fuse->applied = false;
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(dy && w_t && dx, "conv dgrad: null tensor");
@@ -1909,6 +1996,7 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
     a.x16 = a.y16 = d->act16;
+    const bool fuse_ok = fuse && fuse->sums && !d->act16 && (a.N & 3) == 0;
     // Parity classes pay when each class fills the chip on its own (4x fewer MFMAs); on small maps (radar encoders) the
     // stride^2 classes are stride^2 dependent launches of a few workgroups with the whole tap x channel loop inside
     // (170 us for a 4x16x7 map) -- there one split-K launch over all taps is ~6x faster despite the wasted taps.
@@ -1938,9 +2026,11 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
                 q.ksteps = q.sub_nr * q.sub_ns * cpt;
                 TileChoice tq = choose_tile(q.M, q.N, q.C, q.ksteps);
                 tq.splits = 1;
+                if (fuse_ok && !empty_class) set_bnr(q, fuse);      // classes partition the pixels: every pixel is added once
                 rc = launch_igemm<true>(q, tq, false, st);
                 if (rc) return rc;
             }
+        if (fuse_ok && !empty_class) fuse->applied = true;
         return DPFT_OK;
     }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
@@ -1948,6 +2038,9 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
         a.partial = (float*)workspace;
+    } else if (fuse_ok) {
+        set_bnr(a, fuse);
+        fuse->applied = true;
     }
     rc = launch_igemm<true>(a, t, false, st);
     if (rc) return rc;
@@ -1962,7 +2055,8 @@ extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* 
 // dx = dgrad(dy) + (res_mask > 0 ? res_src : 0): stride-1 data gradient with the identity-branch ReLU backward folded
 // into the epilogue (internal: used by the ResNet launch plan)
 int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
-                              const float* res_mask, void* workspace, dpft_stream_t stream) {
+                              const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse) {
+    if (fuse) fuse->applied = false;
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(dy && w_t && dx && res_src && res_mask, "conv dgrad residual: null tensor");
@@ -1977,6 +2071,9 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
         a.partial = (float*)workspace;
+    } else if (fuse && fuse->sums && !d->act16 && (a.N & 3) == 0) {
+        set_bnr(a, fuse);
+        fuse->applied = true;
     }
     rc = launch_igemm<true>(a, t, false, st);
     if (rc) return rc;

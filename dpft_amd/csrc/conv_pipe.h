@@ -55,6 +55,7 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     typedef __attribute__((address_space(3))) char lds_char;
     lds_char* const lds0 = (lds_char*)smem;
 
+    DPFT_SETPRIO_IGEMM();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WGN, wn = wave % WGN;
     int mt, nt, split;

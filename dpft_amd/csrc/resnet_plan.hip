@@ -379,13 +379,15 @@ struct BnSums {
     float* buf[2];
     int cur;
 };
+// `reduced`: the reduction into bs.buf[bs.cur] has already been done by the kernel that produced `dout` (BnReduceFuse).
 static int bn_backward(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                        const float* gamma, BnSums& bs, float* dy, float* dgamma, float* dbeta, int64_t M, int K,
-                       dpft_stream_t st, bool act16 = false, const unsigned char* mask8 = nullptr) {
+                       dpft_stream_t st, bool act16 = false, const unsigned char* mask8 = nullptr, bool reduced = false) {
     float* sums = bs.buf[bs.cur];
     float* other = bs.buf[bs.cur ^ 1];
     bs.cur ^= 1;
-    RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st, mask8));
+    static const bool skip_reduce = getenv("DPFT_EXP_SKIP_BNREDUCE") != nullptr;      // timing experiment only (wrong gradients)
+    if (!reduced && !skip_reduce) RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st, mask8));
     return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, act16, st,
                                 mask8);
 }
@@ -484,43 +486,59 @@ struct SideCtx {
     }
 };
 
+// `bn3_reduced`: the kernel that produced `gp` already reduced this block's bn3 (see below).  `nextb`: the block whose
+// backward follows on the same running gradient (the previous block of the stage, or null) -- the reduction of ITS bn3 is
+// folded into the kernel that writes dx here; *next_reduced tells whether that happened.
 static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, float* A, void* ws, SideCtx& sc,
-                          BnSums& sums, const float* gp, float* dx, dpft_stream_t st) {
+                          BnSums& sums, const float* gp, float* dx, dpft_stream_t st, bool bn3_reduced,
+                          const BlockPlan* nextb, bool* next_reduced) {
     float* dyv[2] = {A + p->o_dy, A + p->o_dy2};
     float* dab = A + p->o_da;
     float* dyd = A + p->o_dd;
     float* wt = A + p->o_wt;
     const int planes = b.c1.d.K, K3 = b.c3.d.K;
     const bool a16 = p->desc.act16 != 0;
+    static const bool fuse_on = getenv("DPFT_BN_FUSE") == nullptr || atoi(getenv("DPFT_BN_FUSE")) != 0;      // A/B switch
     const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
     int& cur = p->dyi;
     // bn3 (+ the residual ReLU mask taken from the block output)
     RC(sc.acquire(cur));
     const unsigned char* m8 = (const unsigned char*)(A + b.mask);      // ReLU mask of the block output (written by the forward)
-    RC(bn_backward(A + b.y3, gp, nullptr, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16, m8));
+    RC(bn_backward(A + b.y3, gp, nullptr, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16, m8, bn3_reduced));
     RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c3.d, dyv[cur], wt + b.c3.wt, dab, 0, ws, st));
+    // the data gradient of conv3 produces bn2's dout: bn2's reduction rides in its epilogue (mask = bn2(y2) > 0)
+    BnReduceFuse f2{A + b.y2, A + b.p2, nullptr, 1, fuse_on ? sums.buf[sums.cur] : nullptr, false};
+    RC(conv_dgrad_fused(&b.c3.d, dyv[cur], wt + b.c3.wt, dab, 0, ws, st, &f2));
     cur ^= 1;
     // bn2 (fused-ReLU mask recomputed from its BN block)
     RC(sc.acquire(cur));
-    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st, a16));
+    RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st, a16, nullptr, f2.applied));
     RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
-    RC(dpft_conv2d_nhwc_dgrad_f32(&b.c2.d, dyv[cur], wt + b.c2.wt, dab, 0, ws, st));
+    BnReduceFuse f1{A + b.y1, A + b.p1, nullptr, 1, fuse_on ? sums.buf[sums.cur] : nullptr, false};
+    RC(conv_dgrad_fused(&b.c2.d, dyv[cur], wt + b.c2.wt, dab, 0, ws, st, &f1));
     cur ^= 1;
     // bn1
     RC(sc.acquire(cur));
-    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyv[cur], T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st, a16));
+    RC(bn_backward(A + b.y1, dab, nullptr, A + b.p1, A + b.p1, T.gamma(b.bn1), sums, dyv[cur], T.dgamma(b.bn1), T.dbeta(b.bn1), M1, planes, st, a16, nullptr, f1.applied));
     RC(sc.wgrad(cur, &b.c1.d, A + b.x, dyv[cur], nullptr, 0, T.dw(b.c1.w)));
+    // dx is the next block's gp: the reduction of that block's bn3 (input y3, ReLU byte mask of its output) rides in the
+    // epilogue of the LAST kernel that writes dx
+    BnReduceFuse fn{nullptr, nullptr, nullptr, 0, nullptr, false};
     if (b.has_ds) {
         RC(sc.acquire(2));
         RC(bn_backward(A + b.yd, gp, nullptr, nullptr, A + b.pd, T.gamma(b.bnd), sums, dyd, T.dgamma(b.bnd), T.dbeta(b.bnd), M2, K3, st, a16, m8));
         RC(sc.wgrad(2, &b.cd.d, A + b.x, dyd, nullptr, 0, T.dw(b.cd.w)));
         RC(dpft_conv2d_nhwc_dgrad_f32(&b.cd.d, dyd, wt + b.cd.wt, dx, 0, ws, st));
-        RC(dpft_conv2d_nhwc_dgrad_f32(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st));
+        if (nextb && fuse_on)
+            fn = BnReduceFuse{A + nextb->y3, A + nextb->p3, (const unsigned char*)(A + nextb->mask), 0, sums.buf[sums.cur], false};
+        RC(conv_dgrad_fused(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, 1, ws, st, nextb ? &fn : nullptr));
     } else {
+        if (nextb && fuse_on)
+            fn = BnReduceFuse{A + nextb->y3, A + nextb->p3, (const unsigned char*)(A + nextb->mask), 0, sums.buf[sums.cur], false};
         // identity branch dz = dout * (out > 0) folded into the epilogue of the conv1 data gradient
-        RC(conv_dgrad_residual(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, gp, A + b.out, ws, st));
+        RC(conv_dgrad_residual(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, gp, A + b.out, ws, st, nextb ? &fn : nullptr));
     }
+    if (next_reduced) *next_reduced = fn.applied;
     cur ^= 1;
     return DPFT_OK;
 }
@@ -560,11 +578,15 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
     BnSums sums{{A + p->o_sums, A + p->o_sums + 2 * 2048}, 0};
     RC((int)hipMemsetAsync(sums.buf[0], 0, 2 * 2 * 2048 * sizeof(float), (hipStream_t)st));
     RC(sc.transposes(T, A + p->o_wt, stage));
+    bool reduced = false;      // the stage's first gradient may still get an external term added: its bn3 reduces on its own
     for (int i = (int)p->blocks.size() - 1; i >= 0; --i) {
         const BlockPlan& b = p->blocks[i];
         if (b.layer != stage) continue;
         float* dx = A + p->g_off[p->g_cur ^ 1];
-        RC(block_backward(p, b, T, A, ws, sc, sums, gp, dx, st));
+        const BlockPlan* nextb = (i > 0 && p->blocks[i - 1].layer == stage) ? &p->blocks[i - 1] : nullptr;
+        bool next_reduced = false;
+        RC(block_backward(p, b, T, A, ws, sc, sums, gp, dx, st, reduced, nextb, &next_reduced));
+        reduced = next_reduced;
         p->g_cur ^= 1;
         gp = dx;
     }

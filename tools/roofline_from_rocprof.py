@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
+MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "wgrad_pipe_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
         "conv16_", "wgrad16_", "thin_wgrad")
 AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel")
 GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", "pack_"),
