@@ -1725,6 +1725,8 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     // DPFT_PIPE=0 keeps igemm_vec_kernel (A/B measurements).
     static const int pipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;      // bit 0: igemm, bit 1: wgrad
     if (t.vec && g_conv_bf16 == 0 && (pipe_env & 1) && !a.x16 && !a.y16 && (!pro || a.pro_relu)) {
+        static const int shortk_env = getenv("DPFT_SHORTK") ? atoi(getenv("DPFT_SHORTK")) : 0;      // tuning aid
+        const bool short_k = shortk_env > 0 && a.Ktot <= shortk_env;
         auto go = [&](auto kernel, int pbk, size_t lds) {
             a.ksteps = a.ksteps * BKV / pbk;
             a.ksteps_per_split = cdiv(a.ksteps, a.splits);
@@ -1738,6 +1740,8 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     } while (0)
         if (t.bm == 128 && t.bn == 128) LAUNCH_PIPE(128, 128, 32);
         else if (t.bm == 128 && t.bn == 64) LAUNCH_PIPE(128, 64, 32);
+        else if (t.bm == 64 && t.bn == 128) LAUNCH_PIPE(64, 128, 32);
+        else if (short_k) LAUNCH_PIPE(64, 64, 32);      // 32 KB of LDS: more resident workgroups to overlap prologues / epilogues
         else LAUNCH_PIPE(64, 64, 64);
 #undef LAUNCH_PIPE
 #undef PIPE_LDS

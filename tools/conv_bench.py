@@ -45,4 +45,4 @@ if __name__ == "__main__":
         ops.conv_set_compute(os.environ["DPFT_COMPUTE"])
     specs = sys.argv[1:] or DEFAULT
     for sp in specs:
-        run(sp)
+        run(sp, pro=os.environ.get("NOPRO") != "1", stats=os.environ.get("NOSTATS") != "1")
