@@ -27,6 +27,22 @@ struct BnReduceFuse {
 };
 int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
                         const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse = nullptr);      // conv.hip
+// Train-mode BatchNorm finalize folded into the producing forward conv: tiles add pivoted sums to `acc` [2][K] (zero
+// before the launch, like `ticket`), the workgroup with the last ticket writes the BN block `bnp` [4][K] and updates the
+// running statistics.  `applied` (out) as in BnReduceFuse.
+struct BnFinalFuse {
+    float* acc;
+    int* ticket;
+    const float* gamma;
+    const float* beta;
+    float* running_mean;
+    float* running_var;
+    float* bnp;
+    float eps, momentum;
+    bool applied;
+};
+int conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* pro_bn,
+                     int32_t pro_relu, float* y, float* stats, void* workspace, dpft_stream_t stream, BnFinalFuse* fuse);
 int conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, int32_t accumulate,
                      void* workspace, dpft_stream_t stream, BnReduceFuse* fuse);
 // bn.hip -- `act16`: the activation / gradient tensors (y, dout, out, dy, res) are bf16 in memory (the pointers keep

@@ -116,6 +116,19 @@ struct IgemmArgs {
     const unsigned char* bnr_mask8;    // ReLU byte mask of the layer's OUTPUT side (1 byte per 4 channels), or null
     int bnr_self_mask;                 // mask = bn(y) > 0 (the ReLU sits directly behind this BatchNorm)
     float* bnr_sums;                   // null = no fused reduction
+    // Fused BatchNorm FINALIZE of a train-mode forward conv (dpft::BnFinalFuse): instead of writing its (mean, M2) pair to
+    // the per-tile statistics table, a tile adds n (mean - p) and M2 + n (mean - p)^2 to two accumulators per channel
+    // (p = running mean: the pivot of bn_finalize_kernel's merge, same algebra); the workgroup that draws the last
+    // ticket turns them into the BN block and updates the running statistics -- no bn_finalize launch between the conv
+    // and its consumer.
+    float* bnf_acc;                    // [2][N], zero before the launch; null = off
+    int* bnf_ticket;                   // zero before the launch
+    const float* bnf_gamma;
+    const float* bnf_beta;
+    float* bnf_rm;                     // running mean / var (may be null)
+    float* bnf_rv;
+    float* bnf_bnp;                    // out: BN block [4][N]
+    float bnf_eps, bnf_mom;
 };
 
 // output row (GEMM row m) -> pixel index of the output tensor
@@ -142,7 +155,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     const int wm = wave / WGN, wn = wave % WGN;
     const int rbase = m0 + wm * RB * 32 + 4 * (lane >> 5);
     __syncthreads();  // LDS operand tiles are dead now
-    if (a.stats != nullptr) {
+    if (a.stats != nullptr || a.bnf_acc != nullptr) {
         // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
         float* red = smem;               // [WGM][BN]
         float* smean = smem + WGM * BN;  // [BN]
@@ -167,7 +180,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
             const float mean = s / (float)cnt;
             smean[tid] = mean;
-            if (n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
+            if (a.stats && n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
         }
         __syncthreads();
 #pragma unroll
@@ -190,7 +203,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
-            a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+            if (a.stats) a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+            if (a.bnf_acc) {      // fused finalize: this tile's share of the pivoted sums (device-scope atomics)
+                const int n = n0 + tid;
+                const float dlt = smean[tid] - (a.bnf_rm ? a.bnf_rm[n] : 0.f);
+                const float fc = (float)cnt;
+                atomicAdd(a.bnf_acc + n, fc * dlt);
+                atomicAdd(a.bnf_acc + a.N + n, fmaf(fc * dlt, dlt, s));
+            }
         }
         __syncthreads();
     }
@@ -346,6 +366,38 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 if (a.res_src != nullptr && a.partial == nullptr) v += a.res_mask[off] > 0.f ? a.res_src[off] : 0.f;
                 else if (accum) v += *o;
                 *o = v;
+            }
+        }
+    }
+    if (a.bnf_acc != nullptr) {
+        // Every tile has added its sums with device-scope atomics; an atomic is acknowledged (vmcnt) once it has been
+        // performed at the coherence point, so "wait for mine, then take a ticket" orders them before the last ticket --
+        // no release fence (nothing here publishes plain stores), the last workgroup reads the totals with device-scope
+        // atomic loads.  Its plain stores of the BN block are consumed by LATER kernels.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.bnf_ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag == a.mtiles * a.ntiles - 1) {
+            const float invN = 1.0f / (float)a.M;
+            for (int c = tid; c < a.N; c += NT) {
+                const float s1 = __hip_atomic_load(a.bnf_acc + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float s2 = __hip_atomic_load(a.bnf_acc + a.N + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const float pivot = a.bnf_rm ? a.bnf_rm[c] : 0.f;
+                const float mean = fmaf(s1, invN, pivot);
+                const float m2 = fmaxf(s2 - s1 * s1 * invN, 0.f);
+                const float var = m2 * invN;
+                const float invstd = 1.0f / sqrtf(var + a.bnf_eps);
+                a.bnf_bnp[c] = mean;
+                a.bnf_bnp[a.N + c] = a.bnf_gamma[c] * invstd;
+                a.bnf_bnp[2 * a.N + c] = a.bnf_beta[c];
+                a.bnf_bnp[3 * a.N + c] = invstd;
+                if (a.bnf_rm) {
+                    const float unbiased = a.M > 1 ? m2 / (float)(a.M - 1) : var;
+                    a.bnf_rm[c] = (1.f - a.bnf_mom) * pivot + a.bnf_mom * mean;
+                    a.bnf_rv[c] = (1.f - a.bnf_mom) * a.bnf_rv[c] + a.bnf_mom * unbiased;
+                }
             }
         }
     }
@@ -1897,6 +1949,16 @@ extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* til
 extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x, const float* w,
                                         const float* bias, const float* pro_bn, int32_t pro_relu,
                                         float* y, float* stats, void* workspace, dpft_stream_t stream) {
+    return dpft::conv_fwd_bnfinal(d, x, w, bias, pro_bn, pro_relu, y, stats, workspace, stream, nullptr);
+}
+
+// Forward conv with the train-mode BatchNorm finalize folded into its epilogue (BnFinalFuse, common.h).  `fuse->applied`
+// tells whether the launch carried it (not on split-K / thin-channel / bf16-storage paths: the caller then runs
+// dpft_bn_finalize_f32 on `stats` as before).
+int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* pro_bn,
+                           int32_t pro_relu, float* y, float* stats, void* workspace, dpft_stream_t stream,
+                           BnFinalFuse* fuse) {
+    if (fuse) fuse->applied = false;
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
@@ -1915,6 +1977,12 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
         DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
         a.partial = (float*)workspace;
         a.stats = nullptr;
+    } else if (fuse && fuse->acc && !bias && !d->act16 && t.vec && (a.N & 3) == 0) {
+        a.bnf_acc = fuse->acc; a.bnf_ticket = fuse->ticket; a.bnf_gamma = fuse->gamma; a.bnf_beta = fuse->beta;
+        a.bnf_rm = fuse->running_mean; a.bnf_rv = fuse->running_var; a.bnf_bnp = fuse->bnp;
+        a.bnf_eps = fuse->eps; a.bnf_mom = fuse->momentum;
+        a.stats = nullptr;
+        fuse->applied = true;
     }
     rc = launch_igemm<false>(a, t, pro, st);
     if (rc) return rc;

@@ -53,6 +53,8 @@ struct ResnetPlan {
     size_t g_off[2];
     size_t gmax;            // floats of the largest activation gradient
     size_t o_dy, o_da, o_dd, o_wt, o_sums;   // backward scratch offsets (floats)
+    std::vector<size_t> bnacc;      // per BatchNorm: float offset of its fused-finalize accumulators [2][K] + ticket (16 floats)
+    size_t o_bnacc = 0, bnacc_floats = 0;
     size_t o_dy2;           // second dy buffer: weight gradients run on a side stream while the data path moves on
     int g_cur;
     bool g_valid;
@@ -183,6 +185,18 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     }
     p->n_conv = nconv;
     p->n_bn = nbn;
+    {   // accumulators of the fused BatchNorm finalize (conv epilogue): one zero-fill per forward covers them all
+        p->bnacc.assign(nbn, 0);
+        size_t acc = 0;
+        auto add = [&](int bn, int K) { p->bnacc[bn] = acc; acc += align64((size_t)2 * K + 16); };
+        add(p->bn0, 64);
+        for (const BlockPlan& b : p->blocks) {
+            add(b.bn1, b.c1.d.K); add(b.bn2, b.c2.d.K); add(b.bn3, b.c3.d.K);
+            if (b.has_ds) add(b.bnd, b.cd.d.K);
+        }
+        p->bnacc_floats = acc;
+        p->o_bnacc = take(acc);
+    }
     p->fwd_floats = off;
     // ---- backward temporaries: two running-gradient buffers + per-block scratch -----------------------
     p->gmax = gmax;
@@ -277,6 +291,23 @@ static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* 
     return DPFT_OK;      // eval: every BN block was produced up front by eval_bn_blocks()
 }
 
+// train-mode forward conv + its BatchNorm block: the finalize rides in the conv's epilogue where the launch allows it
+// (BnFinalFuse), otherwise per-tile statistics + bn_finalize.  OFF by default (DPFT_BN_FINAL_FUSE=1 enables it): measured
+// -0.4 ... -1.1 ms per step, but the atomic accumulation makes the forward's BatchNorm blocks differ in the last bits from
+// run to run, which the encoders' backward amplifies (the full-size repeatability property no longer holds to 2e-4), and
+// the epilogue tail costs the forward GEMMs ~6 % of their rate.  The table + bn_finalize path is deterministic.
+static int conv_bn_train(const ResnetPlan* p, const Tables& T, const ConvRef& c, int bn, const float* x, const float* pro,
+                         float* A, float* y, float* stats, int tiles, int rows, int64_t M, float* bnp, void* ws,
+                         dpft_stream_t st) {
+    static const bool fuse_on = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
+    float* acc = A + p->o_bnacc + p->bnacc[bn];
+    BnFinalFuse f{acc, (int*)(acc + 2 * c.d.K), T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), bnp, p->desc.eps, p->desc.momentum, false};
+    RC(conv_fwd_bnfinal(&c.d, x, T.w(c.w), nullptr, pro, pro ? 1 : 0, y, stats, ws, st, fuse_on ? &f : nullptr));
+    if (f.applied) return DPFT_OK;
+    return dpft_bn_finalize_f32(stats, tiles, rows, M, c.d.K, T.gamma(bn), T.beta(bn), p->desc.eps, p->desc.momentum, T.rm(bn),
+                                T.rv(bn), bnp, st);
+}
+
 // eval mode: the BN blocks only depend on parameters/buffers -- all of them in ceil(n_bn / 16) launches
 static int eval_bn_blocks(const ResnetPlan* p, const Tables& T, float* A, dpft_stream_t st) {
     BnEvalBatch batch;
@@ -319,6 +350,8 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
         RC(dpft_conv2d_nhwc_fwd_f32(&p->adj.d, x, T.w(p->adj.w), nullptr, nullptr, 0, A + p->xa, nullptr, ws, st));
         xa = A + p->xa;
     }
+    static const bool final_fuse = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
+    if (tr && final_fuse) RC((int)hipMemsetAsync(A + p->o_bnacc, 0, p->bnacc_floats * sizeof(float), (hipStream_t)st));
     RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr ? A + p->s0 : nullptr, ws, st));
     RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr, st));
     const bool a16 = p->desc.act16 != 0;
@@ -350,15 +383,11 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
     }
     for (const BlockPlan& b : p->blocks) {
         const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
-        RC(dpft_conv2d_nhwc_fwd_f32(&b.c1.d, A + b.x, T.w(b.c1.w), nullptr, nullptr, 0, A + b.y1, tr ? A + b.s1 : nullptr, ws, st));
-        RC(bn_params(p, T, b.bn1, A + b.s1, b.t1, b.r1, M1, b.c1.d.K, A + b.p1, tr, st));
-        RC(dpft_conv2d_nhwc_fwd_f32(&b.c2.d, A + b.y1, T.w(b.c2.w), nullptr, A + b.p1, 1, A + b.y2, tr ? A + b.s2 : nullptr, ws, st));
-        RC(bn_params(p, T, b.bn2, A + b.s2, b.t2, b.r2, M2, b.c2.d.K, A + b.p2, tr, st));
-        RC(dpft_conv2d_nhwc_fwd_f32(&b.c3.d, A + b.y2, T.w(b.c3.w), nullptr, A + b.p2, 1, A + b.y3, tr ? A + b.s3 : nullptr, ws, st));
-        RC(bn_params(p, T, b.bn3, A + b.s3, b.t3, b.r3, M2, b.c3.d.K, A + b.p3, tr, st));
+        RC(conv_bn_train(p, T, b.c1, b.bn1, A + b.x, nullptr, A, A + b.y1, A + b.s1, b.t1, b.r1, M1, A + b.p1, ws, st));
+        RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st));
+        RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.y2, A + b.p2, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st));
         if (b.has_ds) {
-            RC(dpft_conv2d_nhwc_fwd_f32(&b.cd.d, A + b.x, T.w(b.cd.w), nullptr, nullptr, 0, A + b.yd, tr ? A + b.sd : nullptr, ws, st));
-            RC(bn_params(p, T, b.bnd, A + b.sd, b.td, b.rd, M2, b.cd.d.K, A + b.pd, tr, st));
+            RC(conv_bn_train(p, T, b.cd, b.bnd, A + b.x, nullptr, A, A + b.yd, A + b.sd, b.td, b.rd, M2, A + b.pd, ws, st));
             RC(bn_act_any(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st,
                           tr ? (unsigned char*)(A + b.mask) : nullptr));
         } else {
