@@ -26,7 +26,8 @@ struct BnReduceFuse {
     bool applied;
 };
 int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
-                        const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse = nullptr);      // conv.hip
+                        const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse = nullptr,
+                        const unsigned char* res_mask8 = nullptr);      // conv.hip
 // Train-mode BatchNorm finalize folded into the producing forward conv: tiles add pivoted sums to `acc` [2][K] (zero
 // before the launch, like `ticket`), the workgroup with the last ticket writes the BN block `bnp` [4][K] and updates the
 // running statistics.  `applied` (out) as in BnReduceFuse.

@@ -94,6 +94,7 @@ struct IgemmArgs {
     // bottleneck (dz = dout * (out > 0), src/.../resnet block) folded into the conv1 data gradient
     const float* res_src;
     const float* res_mask;
+    const unsigned char* res_mask8;   // the same mask as one byte per 4 channels (bit e = element e passed the ReLU): 1/16 of the bytes
     // dgrad of a strided conv as one launch per output-pixel parity class (sub_step = stride > 1): rows enumerate the
     // sub_oh x sub_ow output pixels (oh, ow) = (sub_step*i + sub_ph, sub_step*j + sub_pw) and only the taps
     // r = sub_r0 + sub_step*k, s = sub_s0 + sub_step*l can hit them (all others fall between the dy samples).
@@ -271,9 +272,15 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                         old[it] = load4_act(a.oadd, off, y16);
                     } else if (resid) {
                         const f32x4 g = load4_act(a.res_src, off, y16);
-                        const f32x4 o = load4_act(a.res_mask, off, y16);
+                        if (a.res_mask8) {
+                            const unsigned mk = a.res_mask8[off >> 2];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) old[it][e] = o[e] > 0.f ? g[e] : 0.f;
+                            for (int e = 0; e < 4; ++e) old[it][e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+                        } else {
+                            const f32x4 o = load4_act(a.res_mask, off, y16);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) old[it][e] = o[e] > 0.f ? g[e] : 0.f;
+                        }
                     } else {
                         old[it] = load4_act(out, off, y16);
                     }
@@ -2127,7 +2134,8 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
 // dx = dgrad(dy) + (res_mask > 0 ? res_src : 0): stride-1 data gradient with the identity-branch ReLU backward folded
 // into the epilogue (internal: used by the ResNet launch plan)
 int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
-                              const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse) {
+                              const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse,
+                              const unsigned char* res_mask8) {
     if (fuse) fuse->applied = false;
     int rc = check_desc(d);
     if (rc) return rc;
@@ -2138,6 +2146,7 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.res_src = res_src; a.res_mask = res_mask;
     a.x16 = a.y16 = d->act16;
+    if (res_mask8 && (a.N & 3) == 0) a.res_mask8 = res_mask8;      // (the split-K reduction and the scalar tail read res_mask)
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (d->act16) t.splits = 1;
     if (t.splits > 1) {
