@@ -311,7 +311,7 @@ def main():
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for name in ("r02_conv_traffic_pmc.json",):
+        for name in ("r03_conv_traffic_pmc.json", "r02_conv_traffic_pmc.json"):
             if os.path.exists(os.path.join(prof_dir, name)):
                 with open(os.path.join(prof_dir, name)) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -322,6 +322,8 @@ def main():
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         family = {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
                   "f32x3": "3 x bf16 split products on the bf16 MFMA, fp32 accumulation"}[args.dtype]
+        # (round 3: the data-gradient launches also carry the BatchNorm-backward reduction of the layer they feed; its
+        # time is inside their brackets although it is not conv work)
         # Accounting.  A bracket spans everything one dpft_conv2d_nhwc_* call launches: the implicit-GEMM
         # main loop AND the split-K / slab reduction kernels it needs.  `frac` uses the RAW bracket time.  rocprofv3's
         # kernel durations of the same serialized step (profiles/r02_serialized_step_kernel_stats.csv, recomputed by
@@ -332,14 +334,18 @@ def main():
         roof = {"bound": "mfma", "achieved": tot_f / raw_t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": tot_f / raw_t / 1e12 / peak,
                 "traffic": traffic if args.dtype == "f32" else None, "traffic_is": "HBM bytes per conv launch", "traffic_source": traffic_src,
-                "kernel": f"igemm_vec/igemm_gen/wgrad ({family} implicit-GEMM conv family, incl. their split-K reductions)",
+                "kernel": f"igemm_pipe/wgrad_pipe/igemm_gen ({family} implicit-GEMM conv family, incl. their split-K reductions "
+                          "and the BatchNorm-backward reductions fused into the data-gradient epilogues)",
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * raw_t / max(n_launch, 1),
                 "conv_ms_per_step": 1e3 * raw_t, "algorithmic_gflop_per_step": tot_f / 1e9,
                 "timing": "HIP events around every conv call of one serialized step, on the launch stream (raw bracket time)",
                 "frac_main_kernels_only": tot_f / tot_t / 1e12 / peak,
                 "event_bracket_overhead_us": 1e6 * ovh,
-                "rocprof_summary": ("profiles/r02_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py)"
+                "rocprof_summary": ("profiles/r03_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py)"
                                     if args.dtype == "f32" and B == 4 else None),
+                "peak_note": "157.3 TF = 2.4 GHz nominal; under sustained fp32 MFMA load the chip clocks ~2.16 GHz "
+                             "(64-cycle MFMA measured at 71 nominal cycles, tools/probes/mfma_valu_overlap.hip), i.e. ~142 TF "
+                             "is what the matrix pipe delivers; frac is priced against the nominal peak",
                 "per_kind_tflops": {k: v[0] / (v[1] + ovh * v[2]) / 1e12 for k, v in per_kind.items()},
                 "frac_flop_weighted": flop_weighted / 1e12 / peak,
                 "frac_camera_encoder": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
@@ -373,11 +379,13 @@ def main():
         dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
         # counter traffic of the decoder kernels (tools/r02_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
         dec_traffic, dec_src = None, None
-        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_decoder_traffic_pmc.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                dec_traffic = json.load(f).get("traffic_bytes_per_forward")
-            dec_src = "profiles/r02_decoder_traffic_pmc.json"
+        for pname in ("r03_decoder_traffic_pmc.json", "r02_decoder_traffic_pmc.json"):
+            pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)
+            if os.path.exists(pmc):
+                with open(pmc) as f:
+                    dec_traffic = json.load(f).get("traffic_bytes_per_forward")
+                dec_src = "profiles/" + pname
+                break
         dec = {"bound": "hbm", "achieved": dec_bytes / t_dec / 1e9, "peak": 8000.0, "unit": "GB/s",
                "frac": dec_bytes / t_dec / 8.0e12, "traffic": dec_traffic, "traffic_is": "HBM bytes per forward (counters)",
                "traffic_source": dec_src, "decoder_fwd_us": t_dec * 1e6,
@@ -416,6 +424,10 @@ def main():
                                     "backward work to the completion of the last bucket's collective, bracketed by events on "
                                     "that stream; collectives of view-stream buckets that finish earlier are not in it",
             "dp_bucket_mb": trainer.bucket_mb,
+            "hardware_queues": {"distinct_besides_main": trainer.model.__dict__.get("_queues_found"),
+                                "placement": os.environ.get("DPFT_STREAM_PLACEMENT", "probe"),
+                                "note": "views and the camera's weight-gradient stream sit on probed, distinct hardware queues "
+                                        "(dpft_stream_set); RCCL's stream is the process group's own"},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
             "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,

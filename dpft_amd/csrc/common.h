@@ -80,6 +80,7 @@ struct TransposeBatch {      // [K][taps][C] -> [C][taps][K] of up to MAX weight
     int K[MAX], taps[MAX], C[MAX];
     int blk_start[MAX + 1];
     int n;
+    int mode = 0;      // 0: transposed fp32 copy; 1: transposed, rounded to bf16; 2: rounded to bf16 in place order (no transpose)
     void add(const float* src, float* dst, int k, int t, int c) {
         w[n] = src; wt[n] = dst; K[n] = k; taps[n] = t; C[n] = c;
         if (n == 0) blk_start[0] = 0;
@@ -89,6 +90,11 @@ struct TransposeBatch {      // [K][taps][C] -> [C][taps][K] of up to MAX weight
 };
 int weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream);
 bool profiling_active();      // conv.hip: true between dpft_profile_start / dpft_profile_stop
+// zero `bytes` (multiple of 4) of device memory with a KERNEL (conv.hip).  hipMemsetAsync becomes a memset node when the
+// call is captured into a hipGraph, and replayed backward stages with memset nodes intermittently produced garbage
+// gradients (round 3, tools/plan_graph_check.py: never with a device sync around the graph launch, never in the
+// memset-free forward graphs); kernel nodes only is also what the decoder graphs consist of.
+int zero_fill(void* ptr, size_t bytes, dpft_stream_t stream);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

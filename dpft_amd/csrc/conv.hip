@@ -101,6 +101,7 @@ struct IgemmArgs {
     // A plain launch over all pixels and taps would spend stride^2 = 4x the MFMA work on structural zeros.
     int sub_step, sub_ph, sub_pw, sub_oh, sub_ow, sub_r0, sub_s0, sub_nr, sub_ns;
     int x16, y16;     // the A-source tensor / the output tensor (and res_src, res_mask, accumulate source) are bf16
+    int w16;          // the weight operand is bf16 too (dpft_conv_desc.act16 = 2): LDS-DMA bf16 kernel
     // inference epilogue (dpft_conv2d_nhwc_fwd_bnact_f32): y = [relu](bn(result) [+ oadd]) with a BN block [4][N] of the OUTPUT
     // channels -- BatchNorm + ReLU + residual add without a separate elementwise pass and without an operand prologue
     // in the consumer (which applies them once per tap and column tile instead of once per element)
@@ -1597,12 +1598,20 @@ __global__ void weight_transpose_batch_kernel(TransposeBatch tb) {
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
     for (int j = ty; j < 32; j += 8) {
         const int k = k0 + j, c = c0 + tx;
-        tile[j][tx] = (k < K && c < C) ? w[((size_t)k * taps + tap) * C + c] : 0.f;
+        const size_t idx = ((size_t)k * taps + tap) * C + c;
+        const float v = (k < K && c < C) ? w[idx] : 0.f;
+        tile[j][tx] = v;
+        if (tb.mode == 2 && k < K && c < C) reinterpret_cast<__bf16*>(wt)[idx] = (__bf16)v;      // bf16 shadow, same order
     }
+    if (tb.mode == 2) return;
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int c = c0 + j, k = k0 + tx;
-        if (c < C && k < K) wt[((size_t)c * taps + tap) * K + k] = tile[tx][j];
+        if (c < C && k < K) {
+            const size_t o = ((size_t)c * taps + tap) * K + k;
+            if (tb.mode == 1) reinterpret_cast<__bf16*>(wt)[o] = (__bf16)tile[tx][j];
+            else wt[o] = tile[tx][j];
+        }
     }
 }
 
@@ -1780,6 +1789,22 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
         }
         return check_launch("conv igemm (strided dgrad, all taps)");
     }
+    // bf16 activations AND bf16 weights (act16 = 2): both operands go to the matrix cores untouched -- the pipelined kernel
+    // with 2-byte elements, everything by LDS-DMA
+    if (t.vec && a.w16 && a.x16 && !pro && !nonlin) {
+        auto go16 = [&](auto kernel, int pbk, size_t lds) {
+            a.ksteps = a.Ktot / pbk;
+            a.ksteps_per_split = cdiv(a.ksteps, a.splits);
+            launch_lds(kernel, grid, block, lds, st, a);
+        };
+#define PIPE16_LDS(BM_, BN_, PBK_) std::max((size_t)2 * (BM_ + BN_) * PBK_ * 2, (size_t)BM_ * (BN_ + 4) * 4 + (size_t)3 * BN_ * 4)
+        if (t.bm == 128 && t.bn == 128) go16(igemm_pipe_kernel<128, 128, 2, 2, 64, DGRAD, false, true>, 64, PIPE16_LDS(128, 128, 64));
+        else if (t.bm == 128 && t.bn == 64) go16(igemm_pipe_kernel<128, 64, 2, 2, 64, DGRAD, false, true>, 64, PIPE16_LDS(128, 64, 64));
+        else if (a.C % 128 == 0) go16(igemm_pipe_kernel<64, 64, 2, 2, 128, DGRAD, false, true>, 128, PIPE16_LDS(64, 64, 128));
+        else go16(igemm_pipe_kernel<64, 64, 2, 2, 64, DGRAD, false, true>, 64, PIPE16_LDS(64, 64, 64));
+#undef PIPE16_LDS
+        return check_launch("conv igemm (pipelined, bf16 operands)");
+    }
     // fp32, linear taps: the software-pipelined kernel (conv_pipe.h) -- LDS-DMA operands, one barrier per K-step.
     // DPFT_PIPE=0 keeps igemm_vec_kernel (A/B measurements).
     static const int pipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;      // bit 0: igemm, bit 1: wgrad
@@ -1901,7 +1926,7 @@ static int check_desc(const dpft_conv_desc* d) {
                  d->OH, d->OW, oh, ow);
     DPFT_REQUIRE((int64_t)d->B * d->H * d->W * d->C < (1ll << 31) &&
                  (int64_t)d->B * d->OH * d->OW * d->K < (1ll << 31), "conv: tensor too large for 32-bit row indices");
-    DPFT_REQUIRE(d->act16 == 0 || d->act16 == 1, "conv: act16 must be 0 or 1 (is the descriptor zero-initialised?)");
+    DPFT_REQUIRE(d->act16 >= 0 && d->act16 <= 2, "conv: act16 must be 0, 1 or 2 (is the descriptor zero-initialised?)");
     // bf16 activation storage rides on the vector loaders / the staged epilogue only
     DPFT_REQUIRE(!d->act16 || (d->C % BKV == 0 && d->K % BKV == 0 && d->kh <= 8 && d->kw <= 8),
                  "conv: act16 (bf16 activation storage) needs C %% 64 == 0 and K %% 64 == 0 (C=%d, K=%d)", d->C, d->K);
@@ -1975,7 +2000,9 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
     a.pro = pro_bn; a.pro_relu = pro_relu;
-    a.x16 = a.y16 = d->act16;
+    a.x16 = a.y16 = d->act16 != 0;
+    a.w16 = d->act16 == 2;
+    DPFT_REQUIRE(!(a.w16 && (pro_bn || bias)), "conv fwd: act16 = 2 (bf16 weights) takes no operand prologue and no bias");
     const bool pro = pro_bn != nullptr;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (d->act16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors
@@ -2031,7 +2058,7 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
     }
     ProfScope prof(0, d, st);
     a.x = x; a.w = w; a.y = y; a.bias = nullptr; a.stats = nullptr; a.pro = nullptr; a.pro_relu = 0;
-    a.x16 = a.y16 = d->act16;
+    a.x16 = a.y16 = d->act16 != 0;
     a.obn = out_bn; a.oadd = residual; a.orelu = relu;
     return launch_igemm<false>(a, t, false, st);
 }
@@ -2074,7 +2101,8 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
     }
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
-    a.x16 = a.y16 = d->act16;
+    a.x16 = a.y16 = d->act16 != 0;
+    a.w16 = d->act16 == 2;
     const bool fuse_ok = fuse && fuse->sums && !d->act16 && (a.N & 3) == 0;
     // Parity classes pay when each class fills the chip on its own (4x fewer MFMAs); on small maps (radar encoders) the
     // stride^2 classes are stride^2 dependent launches of a few workgroups with the whole tap x channel loop inside
@@ -2090,8 +2118,8 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
                 if (r0 >= d->kh || s0 >= d->kw) empty_class = true;
             }
         if (empty_class && !accumulate)      // pixels no tap reaches (1x1 stride-2: three of four) are plain zeros
-            DPFT_REQUIRE(hipMemsetAsync(dx, 0, (d->act16 ? 2 : sizeof(float)) * (size_t)a.B * a.OH * a.OW * a.N, st) == hipSuccess,
-                         "conv dgrad: memset failed");
+            DPFT_REQUIRE(zero_fill(dx, (d->act16 ? 2 : sizeof(float)) * (size_t)a.B * a.OH * a.OW * a.N, st) == DPFT_OK,
+                         "conv dgrad: zero fill failed");
         for (int ph = 0; ph < sp; ++ph)
             for (int pw = 0; pw < sp; ++pw) {
                 const int r0 = (ph + d->pad) % sp, s0 = (pw + d->pad) % sp;
@@ -2145,7 +2173,8 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     ProfScope prof(1, d, st);
     IgemmArgs a; fill_igemm(a, d, true);
     a.x = dy; a.w = w_t; a.y = dx; a.res_src = res_src; a.res_mask = res_mask;
-    a.x16 = a.y16 = d->act16;
+    a.x16 = a.y16 = d->act16 != 0;
+    a.w16 = d->act16 == 2;
     if (res_mask8 && (a.N & 3) == 0) a.res_mask8 = res_mask8;      // (the split-K reduction and the scalar tail read res_mask)
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (d->act16) t.splits = 1;
@@ -2182,7 +2211,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     }
     WgradArgs a; memset(&a, 0, sizeof(a));
     a.x = x; a.dy = dy; a.dw = dw; a.pro = pro_bn; a.pro_relu = pro_relu;
-    a.x16 = a.dy16 = d->act16;
+    a.x16 = a.dy16 = d->act16 != 0;
     a.B = d->B; a.H = d->H; a.W = d->W; a.C = d->C; a.OH = d->OH; a.OW = d->OW; a.K = d->K;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad;
     a.M = d->B * d->OH * d->OW;
@@ -2315,6 +2344,23 @@ int dpft::weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream)
     DPFT_REQUIRE(tb.n >= 1 && tb.n <= TransposeBatch::MAX, "weight_transpose_batch: 1..%d tensors", TransposeBatch::MAX);
     hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(tb.blk_start[tb.n]), dim3(256), 0, (hipStream_t)stream, tb);
     return check_launch("weight_transpose_batch");
+}
+
+namespace dpft {
+__global__ __launch_bounds__(256) void zero_fill_kernel(unsigned* __restrict__ p, size_t n4, size_t n) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) reinterpret_cast<uint4*>(p)[i] = uint4{0u, 0u, 0u, 0u};
+    if (blockIdx.x == 0)
+        for (size_t i = n4 * 4 + threadIdx.x; i < n; i += 256) p[i] = 0u;
+}
+}  // namespace dpft
+
+int dpft::zero_fill(void* ptr, size_t bytes, dpft_stream_t stream) {
+    DPFT_REQUIRE(ptr && (bytes & 3) == 0 && ((uintptr_t)ptr & 15) == 0, "zero_fill: 16-byte aligned pointer, size a multiple of 4");
+    const size_t n = bytes / 4, n4 = n / 4;
+    const int blocks = (int)std::max<size_t>(1, std::min<size_t>(kNumCU * 8, (n4 + 255) / 256));
+    hipLaunchKernelGGL(zero_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned*)ptr, n4, n);
+    return check_launch("zero_fill");
 }
 
 extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K,

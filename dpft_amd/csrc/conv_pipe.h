@@ -39,16 +39,25 @@ __device__ __forceinline__ void static_for(Fn&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
-template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO>
+// B16: BOTH operands are bf16 in memory (activations in bf16 storage, dpft_conv_desc.act16 = 2: the caller also passes
+// bf16 weights) -- the same kernel with 2-byte elements: a 16-byte chunk is 8 reduction indices, a K-group is 16 of them
+// and one v_mfma_f32_32x32x16_bf16 (fp32 accumulation) per 32x32 block and group.  No arithmetic touches an operand on
+// its way to the matrix cores, so nothing but LDS-DMA feeds the stages (PRO is not available: the mixed-precision plan
+// materialises BatchNorm+ReLU outputs instead).
+template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO, bool B16 = false>
 __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
+    static_assert(!(B16 && PRO), "bf16 operands: no fused prologue");
+    constexpr int EB = B16 ? 2 : 4;         // bytes per element
+    constexpr int EPC = 16 / EB;            // elements per 16-byte chunk
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
-    constexpr int CH = PBK / 4;             // 16-byte chunks per LDS row
+    constexpr int CH = PBK / EPC;           // 16-byte chunks per LDS row
     constexpr int RW = 64 / CH;             // rows one wave instruction covers
     constexpr int RPP = 4 * RW;             // rows per pass of the 4 waves
     constexpr int AP = BM / RPP, BP = BN / RPP;
-    constexpr int ROWB = PBK * 4;           // bytes per LDS row
+    constexpr int ROWB = PBK * EB;          // bytes per LDS row
     constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
-    constexpr int NG = PBK / 8;             // K-groups of 8 per step
+    constexpr int NG = PBK / (2 * EPC);     // K-groups (two chunks: one per lane half) per step
+    static_assert(CH == 8 || CH == 16, "rows of 128 or 256 bytes");
     static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1 && AP >= 1 && BP >= 1, "bad tile");
     static_assert(2 * STAGE <= 65536, "LDS offsets must fit the ds_read immediate");
     extern __shared__ __attribute__((aligned(16))) float smem[];   // max(2 * STAGE, epilogue staging)
@@ -111,12 +120,12 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
         const int n = n0 + rp + RPP * i;
-        b_off[i] = n < a.N ? (unsigned)(n * a.Ktot + chunk * 4) * 4u : OOB;
+        b_off[i] = n < a.N ? (unsigned)(n * a.Ktot + chunk * EPC) * (unsigned)EB : OOB;
     }
     const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * EB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.N * a.Ktot * 4, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.N * a.Ktot * EB, 0x00020000);
     unsigned a_off[AP];
     unsigned a_valid_tap = 0;
     unsigned long long a_inv_tap[PRO ? AP : 1] = {};      // per loader quad: lanes of this wave whose tap misses the image
@@ -127,7 +136,7 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
 #pragma unroll
         for (int i = 0; i < AP; ++i) {
             const bool v = ((a_mask[i] >> ri) & (a_mask[i] >> (8 + si)) & 1u) != 0;
-            a_off[i] = v ? (unsigned)(a_row[i] + tapoff + chunk * 4) * 4u : OOB;
+            a_off[i] = v ? (unsigned)(a_row[i] + tapoff + chunk * EPC) * (unsigned)EB : OOB;
             valid |= v ? (1u << i) : 0u;
             if constexpr (PRO) a_inv_tap[i] = __builtin_amdgcn_ballot_w64(!v);
         }
@@ -150,8 +159,8 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
             tap_dirty = false;
         }
         // (scalar operands of the loads: tell the compiler -- a VGPR here costs a waterfall loop per load)
-        so_a = __builtin_amdgcn_readfirstlane(run_c0 * 4);
-        so_b = __builtin_amdgcn_readfirstlane((run_koff + run_c0) * 4);
+        so_a = __builtin_amdgcn_readfirstlane(run_c0 * EB);
+        so_b = __builtin_amdgcn_readfirstlane((run_koff + run_c0) * EB);
     };
     auto advance = [&]() {
         run_c0 += PBK;
@@ -240,11 +249,13 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     // SLOTS = NG * 4 * RB * CB; the instruction order is pinned (sched_barrier after every slot): fragment reads of the
     // next K-group in front of a group's first MFMA, one load behind each of the first NOPS MFMAs, the prologue's quads
     // behind MFMAs of the last groups.
-    constexpr int MPG = 4 * RB * CB, SLOTS = NG * MPG;
+    constexpr int EPG = B16 ? 1 : 4;              // MFMAs per 32x32 block and K-group (fp32: one per k pair)
+    constexpr int MPG = EPG * RB * CB, SLOTS = NG * MPG;
     constexpr int LASTG = (NG >= 8) ? 4 : 2;      // K-groups (the last ones of a step) that carry the prologue
     constexpr int QPG = PRO ? AP / LASTG : 1;     // register quads per such group
     static_assert(NOPS <= SLOTS, "more loads than MFMA slots");
     static_assert(!PRO || (AP % LASTG == 0 && QPG >= 1 && QPG <= MPG), "prologue schedule");
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
     auto step = [&](auto STG, auto MORE) {
         constexpr int stg = decltype(STG)::value;
         constexpr bool more = decltype(MORE)::value;
@@ -265,7 +276,11 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
             constexpr int g = sl / MPG, w = sl % MPG, e = w / (RB * CB), ij = w % (RB * CB), i = ij / CB, j = ij % CB;
             if constexpr (w == 0 && g + 1 < NG)
                 frags(std::integral_constant<int, ((g + 1) & 1)>{}, std::integral_constant<int, (g + 1 < NG ? g + 1 : 0)>{});
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
+            if constexpr (B16)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[g & 1][i]),
+                                                                    __builtin_bit_cast(bf16x8, bf[g & 1][j]), acc[i][j], 0, 0, 0);
+            else
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][e], bf[g & 1][j][e], acc[i][j], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (more && sl < NOPS) {
                 vmem_op(OTHER{}, std::integral_constant<int, (sl < NOPS ? sl : 0)>{});

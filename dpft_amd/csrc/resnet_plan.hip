@@ -18,6 +18,7 @@ struct ConvRef {
     dpft_conv_desc d;
     int w;  // index into the conv table
     size_t wt = 0;  // float offset (inside the wt region) of this conv's transposed weights during its stage's backward
+    size_t w16 = 0; // act16 = 2: float offset (in the arena) of this conv's bf16 shadow weights [K][taps][C]
 };
 
 struct BlockPlan {
@@ -27,6 +28,7 @@ struct BlockPlan {
     int layer;
     // arena offsets (floats)
     size_t x, y1, y2, y3, yd, out, mask;   // mask: ReLU byte mask of `out` (1 byte per 4 channels)
+    size_t a1 = 0, a2 = 0;      // act16 = 2: materialised relu(bn1(y1)), relu(bn2(y2)) in bf16 (no operand prologues there)
     size_t p1, p2, p3, pd;      // BN blocks [4][K]
     size_t s1, s2, s3, sd;      // stats [tiles][2][K]
     int t1, t2, t3, td, r1, r2, r3, rd;   // stats tiles / tile rows
@@ -61,10 +63,25 @@ struct ResnetPlan {
     // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
     hipStream_t side = nullptr;
     bool side_owned = true, side_set = false;      // side_set: side is valid (it may be the null stream)
+    bool ev_valid[3] = {false, false, false};      // ev_done[slot] has been recorded in THIS stage call
+    // hipGraph replay of the launch sequences (dpft_resnet_plan_set_graph): one executable graph per (call kind, pointer
+    // arguments); used when the whole call is a single-stream sequence (weight-gradient stream == launch stream)
+    bool use_graph = false;
+    struct GraphEntry {
+        int kind;                    // -1 forward (train), 0..3 backward stage
+        const void *x, *arena, *dout, *st;
+        uint64_t tables_hash;
+        int warm;                    // eager calls so far
+        hipGraphExec_t exec;         // null until captured
+        bool failed;
+    };
+    std::vector<GraphEntry> graphs;
     hipEvent_t ev_ready = nullptr, ev_done[3] = {nullptr, nullptr, nullptr}, ev_join = nullptr, ev_wt = nullptr;
     int dyi = 0;
     ~ResnetPlan() {
         if (side_set && side_owned) (void)hipStreamDestroy(side);
+        for (auto& g : graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
         if (ev_ready) (void)hipEventDestroy(ev_ready);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_wt) (void)hipEventDestroy(ev_wt);
@@ -93,7 +110,8 @@ static size_t nelem_w(const dpft_conv_desc& d) { return (size_t)d.K * d.kh * d.k
 using namespace dpft;
 
 extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
-    if (!desc || desc->B <= 0 || desc->H <= 0 || desc->W <= 0 || desc->n_layers < 1 || desc->n_layers > 4) {
+    if (!desc || desc->B <= 0 || desc->H <= 0 || desc->W <= 0 || desc->n_layers < 1 || desc->n_layers > 4 ||
+        desc->act16 < 0 || desc->act16 > 2) {
         set_error("resnet_plan_create: bad descriptor");
         return 0;
     }
@@ -160,8 +178,17 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
             } else {
                 bp.cd.w = -1; bp.bnd = -1;
             }
-            bp.c1.d.act16 = bp.c2.d.act16 = bp.c3.d.act16 = desc->act16 ? 1 : 0;      // bf16 activation storage inside the body
-            if (bp.has_ds) bp.cd.d.act16 = desc->act16 ? 1 : 0;
+            // bf16 activation storage inside the body; 2: bf16 weights too (LDS-DMA bf16 kernels, no operand prologues)
+            bp.c1.d.act16 = bp.c2.d.act16 = bp.c3.d.act16 = desc->act16;
+            if (bp.has_ds) bp.cd.d.act16 = desc->act16;
+            if (desc->act16 == 2) {
+                bp.a1 = take(nelem_out(bp.c1.d) / 2);
+                bp.a2 = take(nelem_out(bp.c2.d) / 2);
+                bp.c1.w16 = take((nelem_w(bp.c1.d) + 1) / 2);
+                bp.c2.w16 = take((nelem_w(bp.c2.d) + 1) / 2);
+                bp.c3.w16 = take((nelem_w(bp.c3.d) + 1) / 2);
+                if (bp.has_ds) bp.cd.w16 = take((nelem_w(bp.cd.d) + 1) / 2);
+            }
             bp.y1 = take(nelem_out(bp.c1.d));  bp.p1 = take(4 * planes);  bp.s1 = take(stats_of(bp.c1.d, bp.t1, bp.r1));
             bp.y2 = take(nelem_out(bp.c2.d));  bp.p2 = take(4 * planes);  bp.s2 = take(stats_of(bp.c2.d, bp.t2, bp.r2));
             bp.y3 = take(nelem_out(bp.c3.d));  bp.p3 = take(4 * planes * 4);  bp.s3 = take(stats_of(bp.c3.d, bp.t3, bp.r3));
@@ -298,11 +325,12 @@ static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* 
 // the epilogue tail costs the forward GEMMs ~6 % of their rate.  The table + bn_finalize path is deterministic.
 static int conv_bn_train(const ResnetPlan* p, const Tables& T, const ConvRef& c, int bn, const float* x, const float* pro,
                          float* A, float* y, float* stats, int tiles, int rows, int64_t M, float* bnp, void* ws,
-                         dpft_stream_t st) {
+                         dpft_stream_t st, const float* w = nullptr) {
+    if (!w) w = T.w(c.w);
     static const bool fuse_on = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
     float* acc = A + p->o_bnacc + p->bnacc[bn];
     BnFinalFuse f{acc, (int*)(acc + 2 * c.d.K), T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), bnp, p->desc.eps, p->desc.momentum, false};
-    RC(conv_fwd_bnfinal(&c.d, x, T.w(c.w), nullptr, pro, pro ? 1 : 0, y, stats, ws, st, fuse_on ? &f : nullptr));
+    RC(conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, stats, ws, st, fuse_on ? &f : nullptr));
     if (f.applied) return DPFT_OK;
     return dpft_bn_finalize_f32(stats, tiles, rows, M, c.d.K, T.gamma(bn), T.beta(bn), p->desc.eps, p->desc.momentum, T.rm(bn),
                                 T.rv(bn), bnp, st);
@@ -336,10 +364,8 @@ static int eval_bn_blocks(const ResnetPlan* p, const Tables& T, float* A, dpft_s
 
 }  // namespace dpft
 
-extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_tables* tables, void* arena,
-                                   int32_t train, dpft_stream_t st) {
-    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
-    DPFT_REQUIRE(p && x && tables && arena, "resnet_forward: null argument");
+static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables* tables, void* arena, int32_t train,
+                        dpft_stream_t st) {
     Tables T{tables};
     float* A = (float*)arena;
     void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
@@ -351,7 +377,7 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
         xa = A + p->xa;
     }
     static const bool final_fuse = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
-    if (tr && final_fuse) RC((int)hipMemsetAsync(A + p->o_bnacc, 0, p->bnacc_floats * sizeof(float), (hipStream_t)st));
+    if (tr && final_fuse) RC(zero_fill(A + p->o_bnacc, p->bnacc_floats * sizeof(float), st));
     RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr ? A + p->s0 : nullptr, ws, st));
     RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr, st));
     const bool a16 = p->desc.act16 != 0;
@@ -363,31 +389,63 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
         // tensors in this mode.
         for (const BlockPlan& b : p->blocks) {
             const int64_t M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
-            RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.c1.d, A + b.x, T.w(b.c1.w), A + b.p1, 1, nullptr, A + b.y1, ws, st));
-            RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.c2.d, A + b.y1, T.w(b.c2.w), A + b.p2, 1, nullptr, A + b.y2, ws, st));
+            // (inference keeps the fp32 weights: descriptors with act16 <= 1)
+            dpft_conv_desc d1 = b.c1.d, d2 = b.c2.d, d3 = b.c3.d, dd = b.cd.d;
+            d1.act16 = d2.act16 = d3.act16 = dd.act16 = a16 ? 1 : 0;
+            RC(dpft_conv2d_nhwc_fwd_bnact_f32(&d1, A + b.x, T.w(b.c1.w), A + b.p1, 1, nullptr, A + b.y1, ws, st));
+            RC(dpft_conv2d_nhwc_fwd_bnact_f32(&d2, A + b.y1, T.w(b.c2.w), A + b.p2, 1, nullptr, A + b.y2, ws, st));
             const float* identity = A + b.x;
             if (b.has_ds) {
-                RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.cd.d, A + b.x, T.w(b.cd.w), A + b.pd, 0, nullptr, A + b.yd, ws, st));
+                RC(dpft_conv2d_nhwc_fwd_bnact_f32(&dd, A + b.x, T.w(b.cd.w), A + b.pd, 0, nullptr, A + b.yd, ws, st));
                 identity = A + b.yd;
             }
             float* o32 = stage_out32(p, b, A);
             if (o32) {      // bf16 storage: the stage output also needs its fp32 copy -- the elementwise pass writes both
-                RC(dpft_conv2d_nhwc_fwd_f32(&b.c3.d, A + b.y2, T.w(b.c3.w), nullptr, nullptr, 0, A + b.y3, nullptr, ws, st));
+                RC(dpft_conv2d_nhwc_fwd_f32(&d3, A + b.y2, T.w(b.c3.w), nullptr, nullptr, 0, A + b.y3, nullptr, ws, st));
                 RC(bn_act_any(A + b.y3, A + b.p3, identity, nullptr, 1, A + b.out, o32, M2, b.c3.d.K, a16, st));
             } else {
-                RC(dpft_conv2d_nhwc_fwd_bnact_f32(&b.c3.d, A + b.y2, T.w(b.c3.w), A + b.p3, 1, identity, A + b.out, ws, st));
+                RC(dpft_conv2d_nhwc_fwd_bnact_f32(&d3, A + b.y2, T.w(b.c3.w), A + b.p3, 1, identity, A + b.out, ws, st));
             }
         }
         p->g_valid = false;
         return DPFT_OK;
     }
+    const bool w16 = p->desc.act16 == 2;
+    if (w16) {      // bf16 shadow copies of the body's weights (they change with every optimizer step): ceil(n / 80) launches
+        TransposeBatch tb;
+        tb.n = 0;
+        tb.mode = 2;
+        for (const BlockPlan& b : p->blocks) {
+            const ConvRef* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
+            for (const ConvRef* c : cs) {
+                if (!c) continue;
+                tb.add(T.w(c->w), A + c->w16, c->d.K, c->d.kh * c->d.kw, c->d.C);
+                if (tb.n == TransposeBatch::MAX) {
+                    RC(weight_transpose_batch(tb, st));
+                    tb.n = 0;
+                }
+            }
+        }
+        if (tb.n > 0) RC(weight_transpose_batch(tb, st));
+    }
     for (const BlockPlan& b : p->blocks) {
         const int64_t M1 = (int64_t)b.c1.d.B * b.c1.d.OH * b.c1.d.OW, M2 = (int64_t)b.c2.d.B * b.c2.d.OH * b.c2.d.OW;
+        if (w16) {
+            // bf16 weights: no operand prologues -- relu(bn(y)) is materialised (bf16) by one elementwise pass per layer and
+            // every GEMM is the LDS-DMA kernel
+            RC(conv_bn_train(p, T, b.c1, b.bn1, A + b.x, nullptr, A, A + b.y1, A + b.s1, b.t1, b.r1, M1, A + b.p1, ws, st, A + b.c1.w16));
+            RC(bn_act_any(A + b.y1, A + b.p1, nullptr, nullptr, 1, A + b.a1, nullptr, M1, b.c1.d.K, true, st));
+            RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.a1, nullptr, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st, A + b.c2.w16));
+            RC(bn_act_any(A + b.y2, A + b.p2, nullptr, nullptr, 1, A + b.a2, nullptr, M2, b.c2.d.K, true, st));
+            RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.a2, nullptr, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st, A + b.c3.w16));
+        } else {
         RC(conv_bn_train(p, T, b.c1, b.bn1, A + b.x, nullptr, A, A + b.y1, A + b.s1, b.t1, b.r1, M1, A + b.p1, ws, st));
         RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st));
         RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.y2, A + b.p2, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st));
+        }
         if (b.has_ds) {
-            RC(conv_bn_train(p, T, b.cd, b.bnd, A + b.x, nullptr, A, A + b.yd, A + b.sd, b.td, b.rd, M2, A + b.pd, ws, st));
+            RC(conv_bn_train(p, T, b.cd, b.bnd, A + b.x, nullptr, A, A + b.yd, A + b.sd, b.td, b.rd, M2, A + b.pd, ws, st,
+                             w16 ? A + b.cd.w16 : nullptr));
             RC(bn_act_any(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st,
                           tr ? (unsigned char*)(A + b.mask) : nullptr));
         } else {
@@ -465,6 +523,9 @@ struct SideCtx {
     }
     // main stream is about to overwrite dy buffer `slot`
     int acquire(int slot) {
+        // (a slot's previous reader of an EARLIER stage call is already ordered before this one: every stage call ends with
+        // join(); waiting only on events of this call also keeps a captured call free of outside dependencies)
+        if (!p->ev_valid[slot]) return DPFT_OK;
         DPFT_REQUIRE(hipStreamWaitEvent(main, p->ev_done[slot], 0) == hipSuccess, "resnet_backward: wait event");
         return DPFT_OK;
     }
@@ -476,6 +537,7 @@ struct SideCtx {
         DPFT_REQUIRE(hipStreamWaitEvent(p->side, p->ev_ready, 0) == hipSuccess, "resnet_backward: wait event");
         RC(dpft_conv2d_nhwc_wgrad_f32(d, x, dy, pro, relu, dw, ws2, (dpft_stream_t)p->side));
         DPFT_REQUIRE(hipEventRecord(p->ev_done[slot], p->side) == hipSuccess, "resnet_backward: record event");
+        p->ev_valid[slot] = true;
         return DPFT_OK;
     }
     // transposed copies [I][kh][kw][O] of every conv weight of `stage` (the dgrad operand) on the side stream; the
@@ -488,6 +550,7 @@ struct SideCtx {
         }
         TransposeBatch tb;
         tb.n = 0;
+        tb.mode = p->desc.act16 == 2 ? 1 : 0;      // bf16 weights: the data-gradient operand is bf16 as well
         for (auto& b : p->blocks) {
             if (b.layer != stage) continue;
             const ConvRef* cs[4] = {&b.c3, &b.c2, &b.c1, b.has_ds ? &b.cd : nullptr};
@@ -534,7 +597,9 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     RC(sc.acquire(cur));
     const unsigned char* m8 = (const unsigned char*)(A + b.mask);      // ReLU mask of the block output (written by the forward)
     RC(bn_backward(A + b.y3, gp, nullptr, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16, m8, bn3_reduced));
-    RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
+    const bool w16 = p->desc.act16 == 2;      // materialised activations a1 / a2: no prologue in the weight gradients either
+    if (w16) RC(sc.wgrad(cur, &b.c3.d, A + b.a2, dyv[cur], nullptr, 0, T.dw(b.c3.w)));
+    else RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
     // the data gradient of conv3 produces bn2's dout: bn2's reduction rides in its epilogue (mask = bn2(y2) > 0)
     BnReduceFuse f2{A + b.y2, A + b.p2, nullptr, 1, fuse_on ? sums.buf[sums.cur] : nullptr, false};
     RC(conv_dgrad_fused(&b.c3.d, dyv[cur], wt + b.c3.wt, dab, 0, ws, st, &f2));
@@ -542,7 +607,8 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     // bn2 (fused-ReLU mask recomputed from its BN block)
     RC(sc.acquire(cur));
     RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st, a16, nullptr, f2.applied));
-    RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
+    if (w16) RC(sc.wgrad(cur, &b.c2.d, A + b.a1, dyv[cur], nullptr, 0, T.dw(b.c2.w)));
+    else RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
     BnReduceFuse f1{A + b.y1, A + b.p1, nullptr, 1, fuse_on ? sums.buf[sums.cur] : nullptr, false};
     RC(conv_dgrad_fused(&b.c2.d, dyv[cur], wt + b.c2.wt, dab, 0, ws, st, &f1));
     cur ^= 1;
@@ -577,16 +643,23 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
 // Backward of one stage (stage = n_layers-1 ... 0; stage 0 also runs the stem).  `dout` is the external
 // gradient of that stage's output (may be NULL).  Parameter gradients are written to tables->conv_dw /
 // bn_dgamma / bn_dbeta (overwritten).  Stages must be called in descending order after a train forward.
-extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float* x, const dpft_resnet_tables* tables,
-                                          void* arena, const float* dout, dpft_stream_t st) {
-    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
-    DPFT_REQUIRE(p && x && tables && arena, "resnet_backward: null argument");
-    DPFT_REQUIRE(stage >= 0 && stage < p->desc.n_layers, "resnet_backward: bad stage %d", stage);
+static int backward_stage_impl(ResnetPlan* p, int32_t stage, const float* x, const dpft_resnet_tables* tables,
+                               void* arena, const float* dout, dpft_stream_t st) {
     Tables T{tables};
     float* A = (float*)arena;
     void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
     SideCtx sc{p, (hipStream_t)st, (char*)arena + (p->arena_bytes - p->ws_bytes - 128)};
     RC(sc.init());
+    {   // The call's buffer choices are a function of (plan, stage) alone -- not of what earlier calls left behind -- so that
+        // an executed call and a replayed graph of it are interchangeable: running-gradient buffer and dy slot alternate
+        // once per block, counted from the last stage.
+        int done = 0;
+        for (const BlockPlan& b : p->blocks) done += b.layer > stage ? 1 : 0;
+        p->g_cur = done & 1;
+        p->dyi = done & 1;
+        p->g_valid = stage != p->desc.n_layers - 1;
+        p->ev_valid[0] = p->ev_valid[1] = p->ev_valid[2] = false;
+    }
     const size_t out_n = (size_t)p->out_shape[stage][0] * p->out_shape[stage][1] * p->out_shape[stage][2] * p->out_shape[stage][3];
     const float* gp;
     if (!p->g_valid) {
@@ -597,7 +670,7 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         } else if (dout) {
             gp = dout;
         } else {
-            RC((int)hipMemsetAsync(A + p->g_off[p->g_cur], 0, out_n * sizeof(float), (hipStream_t)st));
+            RC(zero_fill(A + p->g_off[p->g_cur], out_n * sizeof(float), st));
             gp = A + p->g_off[p->g_cur];
         }
     } else {
@@ -605,7 +678,7 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         gp = A + p->g_off[p->g_cur];
     }
     BnSums sums{{A + p->o_sums, A + p->o_sums + 2 * 2048}, 0};
-    RC((int)hipMemsetAsync(sums.buf[0], 0, 2 * 2 * 2048 * sizeof(float), (hipStream_t)st));
+    RC(zero_fill(sums.buf[0], 2 * 2 * 2048 * sizeof(float), st));
     RC(sc.transposes(T, A + p->o_wt, stage));
     bool reduced = false;      // the stage's first gradient may still get an external term added: its bn3 reduces on its own
     for (int i = (int)p->blocks.size() - 1; i >= 0; --i) {
@@ -642,4 +715,101 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
         p->g_valid = false;
     }
     return sc.join();      // parameter gradients of this stage are complete for whatever follows on `st`
+}
+
+namespace dpft {
+
+static uint64_t tables_hash(const ResnetPlan* p, const dpft_resnet_tables* t) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* q) { h = (h ^ (uint64_t)(uintptr_t)q) * 1099511628211ull; };
+    for (int i = 0; i < p->n_conv; ++i) { mix(t->conv_w[i]); mix(t->conv_dw ? t->conv_dw[i] : nullptr); }
+    for (int i = 0; i < p->n_bn; ++i) {
+        mix(t->bn_gamma[i]); mix(t->bn_beta[i]); mix(t->bn_rm[i]); mix(t->bn_rv[i]);
+        mix(t->bn_dgamma ? t->bn_dgamma[i] : nullptr); mix(t->bn_dbeta ? t->bn_dbeta[i] : nullptr);
+    }
+    return h;
+}
+
+// Run `fn(st)` eagerly, or -- for a plan with graphs enabled whose call is a single-stream sequence -- capture it once per
+// argument set (after two eager warm-up calls: lazy stream / event / attribute set-up must not happen inside a capture)
+// and replay the executable graph afterwards: one launch from the host instead of several hundred.
+template <typename Fn>
+static int run_graphed(ResnetPlan* p, int kind, const void* x, const void* arena, const void* dout,
+                       const dpft_resnet_tables* tables, dpft_stream_t st, Fn&& fn) {
+    const bool single_stream = kind < 0 || (p->side_set && p->side == (hipStream_t)st);
+    static const char* kinds = getenv("DPFT_PLAN_GRAPH_KINDS");      // debugging aid: "f" / "b" restrict the captured calls
+    if (kinds && ((kind < 0 && !strchr(kinds, 'f')) || (kind >= 0 && !strchr(kinds, 'b')))) return fn();
+    if (!p->use_graph || profiling_active() || !single_stream) return fn();
+    const uint64_t th = tables_hash(p, tables);
+    ResnetPlan::GraphEntry* e = nullptr;
+    for (auto& g : p->graphs)
+        if (g.kind == kind && g.x == x && g.arena == arena && g.dout == dout && g.st == st && g.tables_hash == th) e = &g;
+    if (!e) {
+        if (p->graphs.size() > 64) return fn();      // pointers keep changing: the caller is not holding its buffers still
+        p->graphs.push_back(ResnetPlan::GraphEntry{kind, x, arena, dout, st, th, 0, nullptr, false});
+        e = &p->graphs.back();
+    }
+    if (e->exec) {
+        static const int dbg_sync = getenv("DPFT_PLAN_GRAPH_SYNC") ? atoi(getenv("DPFT_PLAN_GRAPH_SYNC")) : 0;      // debugging aid
+        if (dbg_sync & 1) (void)hipDeviceSynchronize();
+        DPFT_REQUIRE(hipGraphLaunch(e->exec, (hipStream_t)st) == hipSuccess, "resnet plan: graph launch failed");
+        if (dbg_sync & 2) (void)hipDeviceSynchronize();
+        return DPFT_OK;
+    }
+    if (e->failed || e->warm < 2) {
+        ++e->warm;
+        return fn();
+    }
+    hipStream_t hs = (hipStream_t)st;
+    if (hipStreamBeginCapture(hs, hipStreamCaptureModeRelaxed) != hipSuccess) {
+        (void)hipGetLastError();
+        e->failed = true;
+        return fn();
+    }
+    const int rc = fn();
+    hipGraph_t graph = nullptr;
+    const hipError_t ec = hipStreamEndCapture(hs, &graph);
+    if (rc != DPFT_OK || ec != hipSuccess || !graph) {
+        (void)hipGetLastError();
+        if (graph) (void)hipGraphDestroy(graph);
+        e->failed = true;
+        return rc != DPFT_OK ? rc : fn();      // nothing was executed during the capture
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess || !exec) {
+        (void)hipGetLastError();
+        e->failed = true;
+        return fn();
+    }
+    e->exec = exec;
+    DPFT_REQUIRE(hipGraphLaunch(exec, hs) == hipSuccess, "resnet plan: graph launch failed");
+    return DPFT_OK;
+}
+
+}  // namespace dpft
+
+extern "C" int dpft_resnet_plan_set_graph(int64_t h, int32_t on) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    DPFT_REQUIRE(p, "resnet_plan_set_graph: null plan");
+    p->use_graph = on != 0;
+    return DPFT_OK;
+}
+
+extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_tables* tables, void* arena,
+                                   int32_t train, dpft_stream_t st) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    DPFT_REQUIRE(p && x && tables && arena, "resnet_forward: null argument");
+    if (!train) return forward_impl(p, x, tables, arena, train, st);
+    return run_graphed(p, -1, x, arena, nullptr, tables, st, [&]() { return forward_impl(p, x, tables, arena, train, st); });
+}
+
+extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float* x, const dpft_resnet_tables* tables,
+                                          void* arena, const float* dout, dpft_stream_t st) {
+    ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
+    DPFT_REQUIRE(p && x && tables && arena, "resnet_backward: null argument");
+    DPFT_REQUIRE(stage >= 0 && stage < p->desc.n_layers, "resnet_backward: bad stage %d", stage);
+    return run_graphed(p, stage, x, arena, dout, tables, st,
+                       [&]() { return backward_stage_impl(p, stage, x, tables, arena, dout, st); });
 }

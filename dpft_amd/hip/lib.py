@@ -154,6 +154,7 @@ SIGNATURES = {
     "dpft_resnet_forward": (_I, [_L, _P, C.POINTER(ResnetTables), _P, _I, _P]),
     "dpft_resnet_backward_stage": (_I, [_L, _I, _P, C.POINTER(ResnetTables), _P, _P, _P]),
     "dpft_resnet_plan_set_side_stream": (_I, [_L, _P]),
+    "dpft_resnet_plan_set_graph": (_I, [_L, _I]),
     "dpft_stream_set": (_I, [_P, _I, C.POINTER(C.c_void_p)]),
 }
 

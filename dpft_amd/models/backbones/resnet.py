@@ -102,6 +102,13 @@ class _Plan:
         q = lambda what, idx=0: int(lib.dpft_resnet_plan_query(self.handle, what, idx))
         self.arena_bytes, self.n_conv, self.n_bn = q(0), q(1), q(2)
         self.outs = [(q(3, li), tuple(q(4, li * 4 + k) for k in range(4))) for li in range(body.n_layers)]
+        # hipGraph replay (dpft_resnet_plan_set_graph): the C side keys its graphs on the pointer arguments, so this side
+        # keeps them still -- one arena for the plan's lifetime, static copies of the input and of the external gradients
+        self.graphed = False
+        self.arena = None
+        self.x_static = None
+        self.dout_static = {}
+        self.tables_cache = None
 
     def __del__(self):
         try:
@@ -156,7 +163,17 @@ class _BodyFn(torch.autograd.Function):
         plan = owner._plan(B, H, W)
         convs, bns = _ordered_modules(owner)
         assert len(convs) == plan.n_conv and len(bns) == plan.n_bn
-        arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
+        if need_grad and owner.use_plan_graphs(plan):
+            if plan.arena is None:
+                plan.arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
+            if plan.x_static is None or plan.x_static.shape != x.shape:
+                plan.x_static = torch.empty_like(x)
+            if x.data_ptr() != plan.x_static.data_ptr():
+                plan.x_static.copy_(x)
+                x = plan.x_static
+            arena = plan.arena
+        else:
+            arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
         # inference: the pointer tables only depend on where the parameters live -- rebuilt when a tensor moved
         # (building them costs ~0.4 ms of host time per backbone, in front of the forward's first kernel)
         sig = None if need_grad else (weights_generation(), tuple(c.weight.data_ptr() for c in convs),
@@ -239,6 +256,13 @@ class _BodyFn(torch.autograd.Function):
             d = douts[li]
             if d is not None:
                 d = d.contiguous()
+                if plan.graphed:      # the captured stage reads its external gradient from a fixed address
+                    sd = plan.dout_static.get(li)
+                    if sd is None or sd.shape != d.shape:
+                        sd = plan.dout_static[li] = torch.empty_like(d)
+                    if sd.data_ptr() != d.data_ptr():
+                        sd.copy_(d)
+                    d = sd
                 keep_alive.append(d)
             lib.call("dpft_resnet_backward_stage", plan.handle, li, ptr(st["x"]), C.byref(st["tables"]),
                      ptr(st["arena"]), ptr(d), stream())
@@ -284,13 +308,31 @@ class BackboneBase(nn.Module):
     def _plan(self, B: int, H: int, W: int) -> "_Plan":
         from dpft_amd.hip import ops as _ops
         import os as _os
-        act16 = _ops.conv_get_compute() == "bf16" and B * H * W >= self.ACT16_MIN_PIXELS \
-            and _os.environ.get("DPFT_ACT16", "1") != "0"           # DPFT_ACT16=0: keep fp32 storage (A/B measurements)
+        # DPFT_ACT16: 0 = keep fp32 storage, 1 = bf16 activations / fp32 weights with operand prologues (round 2),
+        # 2 (default) = bf16 activations AND bf16 shadow weights, materialised BatchNorm+ReLU outputs, LDS-DMA bf16 GEMMs
+        level = int(_os.environ.get("DPFT_ACT16", "2"))
+        act16 = level if (_ops.conv_get_compute() == "bf16" and B * H * W >= self.ACT16_MIN_PIXELS) else 0
         key = (B, H, W, act16)
         p = self._plans.get(key)
         if p is None:
             p = self._plans[key] = _Plan(self, B, H, W, act16)
         return p
+
+    def use_plan_graphs(self, plan: "_Plan") -> bool:
+        """hipGraph replay of this plan's launch sequences (DPFT_PLAN_GRAPHS, default on): taken for an encoder whose
+        weight-gradient stream is the stream it runs on (the small views under DPRT._place_streams) -- such a backward is a
+        single-stream sequence; the camera encoder keeps eager launches (its weight gradients need their own hardware
+        queue, which a graph's internal branches do not guarantee)."""
+        if plan.graphed:
+            return True
+        import os as _os
+        if _os.environ.get("DPFT_PLAN_GRAPHS", "1") == "0" or self.side_stream is None:
+            return False
+        if self.side_stream.cuda_stream != torch.cuda.current_stream().cuda_stream or self.side_stream.cuda_stream == 0:
+            return False
+        lib.call("dpft_resnet_plan_set_graph", plan.handle, 1)
+        plan.graphed = True
+        return True
 
     def overwritten_parameters(self):
         """Parameters whose gradients the native backward plan writes (not adds) into an attached reducer's bucket views:

@@ -265,6 +265,18 @@ class GradBucketReducer:
                     if id(p) in self._overwritten and id(p) not in b["seen"]:
                         b["views"][id(p)].zero_()
                 self._fire(b)
+        if self.arena.is_cuda:
+            # Gradients are written straight into the buckets by kernels on several streams (view encoders, their weight-
+            # gradient streams, replayed graphs) and no AccumulateGrad node runs for them, so the autograd engine has no
+            # leaf stream to join at the end of backward(): whatever follows finish() on the current stream (the
+            # optimizer) is ordered here behind every stream that produced a gradient.
+            cur = torch.cuda.current_stream(self.arena.device)
+            joined = set()
+            for b in self.buckets:
+                for sid, st in b["streams"].items():
+                    if sid != cur.cuda_stream and sid not in joined:
+                        cur.wait_stream(st)
+                        joined.add(sid)
         if not self._pending:
             self._exposed = 0.0
             return

@@ -59,8 +59,9 @@ class DataParallelTrainer:
         self.collective = self.reducer.collective
         # The collectives' hardware queue.  Four queues, four busy chains (main | camera weight gradients | two radar views):
         # RCCL's own stream lands on whichever queue the runtime picks, possibly the critical chain's.  "front" / "side" put
-        # them (in order) on the last view's stream / the camera's weight-gradient stream; "pg" keeps the group's stream.
-        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "front")
+        # them (in order) on the last view's stream / the camera's weight-gradient stream; "pg" (default: 32.5 vs 35.5 ms forced,
+        # tools/r03_comm_ab.sh) keeps the group's stream.
+        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "pg")
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         overwritten = []
         for m in self.model.modules():

@@ -208,6 +208,11 @@ int dpft_resnet_backward_stage(int64_t plan, int32_t stage, const float* x,
 /* The stream the plan's weight-gradient GEMMs run on while the data-gradient chain continues on the caller's stream
  * (default: a stream the plan creates on first use).  Passing the caller's own stream keeps everything in order on it. */
 int dpft_resnet_plan_set_side_stream(int64_t plan, dpft_stream_t side);
+/* on != 0: a train-mode forward and each backward stage are captured into hipGraphs (after two eager calls per argument
+ * set) and replayed -- one host-side launch instead of several hundred.  Only calls that are a single-stream sequence are
+ * captured (the forward always; a backward stage when the weight-gradient stream IS the launch stream); the caller must
+ * keep x / arena / dout / the tables' pointers the same from call to call (a new set is captured anew). */
+int dpft_resnet_plan_set_graph(int64_t plan, int32_t on);
 
 /* ------------------------------------------------------------------------------------------
  * Streams on distinct hardware queues (MI355X-side addition; the reference is single-stream).

@@ -979,3 +979,40 @@ def test_detection_metrics_match_oracle(seed, B, N, counts, ncls, one):
     mean = build_metric({"metrics": {"mAP": "mAP3D", "mGIoU": "mGIoU3D"}})(
         {k: v.to(DEV) for k, v in out.items()}, [{k: v.to(DEV) for k, v in t.items()} for t in gts])
     close(mean["mAP"], ref["mAP"].mean(), rtol=1e-5, atol_scale=1e-5, what="mean mAP")
+
+
+def test_replayed_encoder_plans_train_like_eager_launches(monkeypatch):
+    """hipGraph replay of the small views' launch plans (dpft_resnet_plan_set_graph: train forward + backward stages, captured
+    after two eager calls): a run of trainer steps follows the eager run -- same first steps, and no step's gradient leaves
+    the eager run's range (a replay that mis-orders a single node shows up as a gradient norm orders of magnitude off:
+    that is how the memset-node problem was found, tools/plan_graph_check.py)."""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    shapes = {"camera_mono": (128, 224, 3), "radar_bev": (128, 43, 6), "radar_front": (37, 107, 6)}
+    data = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=shapes, device=DEV)
+    labels = make_labels(2, seed=3, device=DEV)
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DPFT_PLAN_GRAPHS", mode)
+        torch.manual_seed(3)
+        tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+        hist = []
+        for _ in range(12):
+            loss, _ = tr.train_step(data, labels)
+            g = torch.cat([b["flat"] for b in tr.reducer.buckets]).double()
+            hist.append((float(loss), float(g.norm())))
+        torch.cuda.synchronize()
+        graphed = [p.graphed for i in tr.model.inputs for p in tr.model.backbones[i]._plans.values()]
+        assert any(graphed) == (mode == "1"), graphed
+        runs[mode] = hist
+    e, g = runs["0"], runs["1"]
+    print("eager :", [(round(a, 3), round(b, 1)) for a, b in e])
+    print("graphs:", [(round(a, 3), round(b, 1)) for a, b in g])
+    for i in range(2):      # the two warm-up steps are eager launches in both runs: only the atomics' order differs
+        assert abs(e[i][0] - g[i][0]) < 1e-4 * abs(e[i][0]) and abs(e[i][1] - g[i][1]) < 5e-3 * e[i][1], (i, e[i], g[i])
+    top = max(b for _, b in e)
+    for i in range(12):
+        assert g[i][0] == g[i][0] and abs(g[i][0] - e[i][0]) < 2e-2 * abs(e[i][0]), (i, e[i], g[i])
+        assert g[i][1] < 1.5 * top, (i, g[i], top)
