@@ -253,7 +253,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 bnr_mk[it] = 0u;
                 if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
                     const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c4 * 4;
-                    bnr_yv[it] = *reinterpret_cast<const f32x4*>(a.bnr_y + off);
+                    bnr_yv[it] = load4_act(a.bnr_y, off, y16);      // that layer's conv output: bf16 where this one's is
                     if (a.bnr_mask8) bnr_mk[it] = a.bnr_mask8[off >> 2];
                 }
             }
@@ -327,6 +327,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                     if (bnr) {
                         const f32x4 yv = bnr_yv[it];
                         f32x4 d = v;
+                        // bf16 storage: reduce what the stand-alone pass would read back, i.e. the rounded value
+                        if (decltype(H16)::value) d = __builtin_convertvector(__builtin_convertvector(v, bf16x4s), f32x4);
                         if (a.bnr_mask8) {
                             const unsigned mk = bnr_mk[it];
 #pragma unroll
@@ -1793,7 +1795,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     // with 2-byte elements, everything by LDS-DMA
     if (t.vec && a.w16 && a.x16 && !pro && !nonlin) {
         auto go16 = [&](auto kernel, int pbk, size_t lds) {
-            a.ksteps = a.Ktot / pbk;
+            a.ksteps = a.ksteps * BKV / pbk;      // (a parity class of a strided data gradient covers a subset of the taps)
             a.ksteps_per_split = cdiv(a.ksteps, a.splits);
             launch_lds(kernel, grid, block, lds, st, a);
         };
@@ -2074,7 +2076,7 @@ static void set_bnr(IgemmArgs& a, const dpft::BnReduceFuse* f) {
 }
 
 // Data gradient with an optional fused BatchNorm-backward reduction (BnReduceFuse, common.h): `fuse->applied` tells the
-// caller whether the launch(es) carried it -- split-K, thin-channel and bf16-storage paths do not.
+// caller whether the launch(es) carried it -- split-K and thin-channel paths do not.
 int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, int32_t accumulate,
                            void* workspace, dpft_stream_t stream, BnReduceFuse* fuse) {
     if (fuse) fuse->applied = false;
@@ -2103,7 +2105,7 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
     a.x = dy; a.w = w_t; a.y = dx; a.accumulate = accumulate;
     a.x16 = a.y16 = d->act16 != 0;
     a.w16 = d->act16 == 2;
-    const bool fuse_ok = fuse && fuse->sums && !d->act16 && (a.N & 3) == 0;
+    const bool fuse_ok = fuse && fuse->sums && (a.N & 3) == 0;
     // Parity classes pay when each class fills the chip on its own (4x fewer MFMAs); on small maps (radar encoders) the
     // stride^2 classes are stride^2 dependent launches of a few workgroups with the whole tap x channel loop inside
     // (170 us for a 4x16x7 map) -- there one split-K launch over all taps is ~6x faster despite the wasted taps.
@@ -2181,7 +2183,7 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
         a.partial = (float*)workspace;
-    } else if (fuse && fuse->sums && !d->act16 && (a.N & 3) == 0) {
+    } else if (fuse && fuse->sums && (a.N & 3) == 0) {
         set_bnr(a, fuse);
         fuse->applied = true;
     }
@@ -2280,7 +2282,16 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     const int nwg = (int)(tiles * splits);
     dim3 grid(nwg), block(256);
     static const int wpipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;
-    if (vec && (wpipe_env & 2) && g_conv_bf16 == 0 && !d->act16 && (!pro || pro_relu) && (bmn == 128 || bmn == 64)) {
+    static const int w16_env = getenv("DPFT_WGRAD16_PIPE") ? atoi(getenv("DPFT_WGRAD16_PIPE")) : 1;      // A/B switch
+    if (vec && d->act16 && !pro && w16_env && (bmn == 128 || bmn == 64) && (d->C % 8) == 0 && (d->K % 8) == 0) {
+        // both operands bf16 in memory, no prologue: LDS-DMA + transpose reads + bf16 MFMA (wgrad_pipe16_kernel)
+        const int pk = bmn == 128 ? 64 : 128;
+        a.psteps = cdiv(a.M, pk);
+        a.psteps_per_split = cdiv(a.psteps, splits);
+        const size_t lds = (size_t)2 * pk * (bmn + bnc) * 2 + (size_t)a.psteps_per_split * pk * 4;
+        if (bmn == 128) launch_lds(wgrad_pipe16_kernel<128, 128, 2, 2, 64>, grid, block, lds, st, a);
+        else launch_lds(wgrad_pipe16_kernel<64, 64, 2, 2, 128>, grid, block, lds, st, a);
+    } else if (vec && (wpipe_env & 2) && g_conv_bf16 == 0 && !d->act16 && (!pro || pro_relu) && (bmn == 128 || bmn == 64)) {
         // software-pipelined form (conv_pipe.h): psteps in units of its PK pixels
         const int pk = bmn == 128 ? 32 : 64;
         a.psteps = cdiv(a.M, pk);

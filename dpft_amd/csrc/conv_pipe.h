@@ -572,4 +572,273 @@ __global__ __launch_bounds__(256) void wgrad_pipe_kernel(WgradArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient on bf16 tensors (dpft_conv_desc.act16 = 2: dY and the materialised activation are bf16 in memory, no
+// prologue).  Same pipeline: two LDS stages filled by LDS-DMA, a per-workgroup pixel -> input-offset table, one barrier
+// per step.  v_mfma_f32_32x32x16_bf16 wants 8 consecutive PIXELS of one channel per lane, the tensors are pixel-major
+// ([pixel][channel]) and LDS-DMA cannot transpose -- ds_read_b64_tr_b16 does: within a 16-lane group lane s supplies the
+// 8-byte address of (pixel s / 4, channels 4 (s % 4) .. + 3) and lane i receives channel i of the four pixels
+// (tools/probes/tr16_probe.hip).  Two such reads (pixels +0..3, +4..7) make one operand of the MFMA.
+// Bank conflicts: a group reads 4 pixel rows x 32 bytes and rows are 256 (128) bytes apart, so the 16-byte chunks of a row
+// are XOR-swizzled by the pixel: key = (pixel % 4) * 4 for 16-chunk rows, ((pixel / 2) % 2) * 4 for 8-chunk rows -- the
+// loader lane at position p of a row FETCHES chunk p ^ key (coalescing unchanged), the reader looks for chunk c at c ^ key;
+// the 32 lanes of a half-wave then cover all 64 banks once.  The key does not depend on the K-group / half / stage, so a
+// lane keeps ONE address per 32-channel block and everything else is an instruction immediate.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BMn, int BNc, int WGM, int WGN, int PK>
+__global__ __launch_bounds__(256) void wgrad_pipe16_kernel(WgradArgs a) {
+    constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
+    constexpr int YL = BMn / 8, XL = BNc / 8;              // lanes (16-byte chunks of 8 channels) per pixel row
+    constexpr int YRW = 64 / YL, XRW = 64 / XL;            // pixel rows per wave instruction
+    constexpr int YRPP = 4 * YRW, XRPP = 4 * XRW;          // pixel rows per pass of the 4 waves
+    constexpr int YP = PK / YRPP, XP = PK / XRPP;
+    constexpr int Y_ROWB = BMn * 2, X_ROWB = BNc * 2;
+    constexpr int Y_BYTES = PK * Y_ROWB, X_BYTES = PK * X_ROWB, STAGE = Y_BYTES + X_BYTES;
+    static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1 && YP >= 1 && XP >= 1, "bad wgrad tile");
+    static_assert((YL == 16 || YL == 8) && (XL == 16 || XL == 8), "rows of 256 or 128 bytes");
+    static_assert(2 * STAGE <= 65536 && PK % 16 == 0, "LDS offsets must fit the ds_read immediate");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    typedef __attribute__((address_space(3))) char lds_char;
+    lds_char* const lds0 = (lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int nwg = a.ktiles * a.ctiles * a.taps * a.splits;
+    int bid = xcd_remap(blockIdx.x, nwg);
+    const int split = bid / (a.ktiles * a.ctiles * a.taps);
+    bid -= split * (a.ktiles * a.ctiles * a.taps);
+    const int tap = bid / (a.ktiles * a.ctiles);
+    bid -= tap * (a.ktiles * a.ctiles);
+    const int kt_ = bid / a.ctiles, ct_ = bid - kt_ * a.ctiles;
+    const int n0 = kt_ * BMn, c0 = ct_ * BNc;
+    const int r = tap / a.kw, s = tap - r * a.kw;
+
+    // loaders: pixel row within a pass / position in the row; the chunk fetched is the position XOR the row's key
+    const int yr = YRW * wave + lane / YL, xr = XRW * wave + lane / XL;
+    const int ykey = YL == 16 ? (yr & 3) << 2 : ((yr >> 1) & 1) << 2;
+    const int xkey = XL == 16 ? (xr & 3) << 2 : ((xr >> 1) & 1) << 2;
+    const int ych = (lane % YL) ^ ykey, xch = (lane % XL) ^ xkey;
+    const bool y_ok = (n0 + ych * 8) < a.K;
+    const bool x_ok = (c0 + xch * 8) < a.C;
+    const int ohw = a.OH * a.OW;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_y =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * 2, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 2, 0x00020000);
+    unsigned y_voff[YP];
+#pragma unroll
+    for (int i = 0; i < YP; ++i) y_voff[i] = y_ok ? (unsigned)((YRPP * i + yr) * a.K + n0 + ych * 8) * 2u : OOB;
+    const int ps_begin = split * a.psteps_per_split;
+    const int ps_end = min(a.psteps, ps_begin + a.psteps_per_split);
+    const int nsteps = max(ps_end - ps_begin, 0);
+    unsigned* const tbl = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(smem) + 2 * STAGE);
+    {      // input-pixel byte offsets of this workgroup's pixel range (see wgrad_pipe_kernel)
+        const int npix = nsteps * PK;
+        for (int idx = tid; idx < npix; idx += 256) {
+            const int p = ps_begin * PK + idx;
+            const int b = p / ohw;
+            const int rem = p - b * ohw;
+            const int oh = rem / a.OW, ow = rem - oh * a.OW;
+            const int hi = oh * a.stride - a.pad + r, wi = ow * a.stride - a.pad + s;
+            const bool v = p < a.M && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            tbl[idx] = v ? ((((unsigned)b * a.H + hi) * a.W + wi) * a.C) * 2u : OOB;
+        }
+    }
+    __syncthreads();
+    typedef __attribute__((address_space(3))) const unsigned lds_u32;
+    unsigned tbl_ad = (unsigned)(size_t)lds0 + 2 * STAGE + xr * 4;
+    const unsigned x_lane = x_ok ? (unsigned)(c0 + xch * 8) * 2u : OOB;
+    int next_ps = ps_begin;
+    int so_y = 0;
+    unsigned xoffs[XP], traw[XP];
+    // Every LDS read of the main loop is inline assembly with hand-placed s_waitcnt lgkmcnt: a compiler-visible LDS read
+    // behind an LDS-DMA gets an s_waitcnt vmcnt(0) in front of it (the DMA's LDS store "may alias"), which would expose the
+    // HBM latency of the tile in flight in the middle of every step.
+    auto tbl_read = [&](auto I) {
+        constexpr int i = decltype(I)::value;
+        unsigned& dst = traw[i];      // (named outside the asm: operands alone do not capture in a generic lambda)
+        const unsigned ad = tbl_ad;
+        asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(XRPP * i * 4));
+    };
+    auto tbl_use = [&](auto I) {      // behind a wait that covers the reads of tbl_read
+        constexpr int i = decltype(I)::value;
+        unsigned& t = traw[i];
+        asm volatile("" : "+v"(t));
+        xoffs[i] = t + x_lane;      // marker + anything small stays beyond every tensor (< 2 GiB)
+    };
+    auto prep = [&]() {      // issue: the table entries of the next tile's loader rows
+        so_y = __builtin_amdgcn_readfirstlane(next_ps * PK * a.K * 2);
+        static_for<XP>(tbl_read);
+        tbl_ad += PK * 4;
+        ++next_ps;
+    };
+    constexpr int NOPS = YP + XP;
+    auto vmem_op = [&](auto STG, auto K) {
+        constexpr int stg = decltype(STG)::value, k = decltype(K)::value;
+        if constexpr (k < YP) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_y, lds0 + stg * STAGE + (YRPP * k + YRW * wave) * Y_ROWB, 16,
+                                                     (int)y_voff[k], so_y, 0, 0);
+        } else {
+            constexpr int i = k - YP;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, lds0 + stg * STAGE + Y_BYTES + (XRPP * i + XRW * wave) * X_ROWB, 16,
+                                                     (int)xoffs[i], 0, 0, 0);
+        }
+    };
+
+    f32x16 acc[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.f;
+
+    // transpose-read addresses: supplier lane (group G = lane / 16, s = lane % 16) -> pixel (G / 2) * 8 + s / 4 of the K-group,
+    // channel quad s % 4 of the 16 channels (G % 2) of a 32-channel block
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    const unsigned lds_base = (unsigned)(size_t)lds0;
+    unsigned y_ad[RB], x_ad[CB];
+    {
+        const int G = lane >> 4, sl = lane & 15, r2 = sl >> 2, q = sl & 3;
+        const int pix = (G >> 1) * 8 + r2;
+        const int yk = YL == 16 ? r2 << 2 : (r2 >> 1) << 2;
+        const int xk = XL == 16 ? r2 << 2 : (r2 >> 1) << 2;
+#pragma unroll
+        for (int i = 0; i < RB; ++i) {
+            const int c = (wm * RB + i) * 4 + 2 * (G & 1) + (q >> 1);
+            y_ad[i] = lds_base + pix * Y_ROWB + ((c ^ yk) << 4) + (q & 1) * 8;
+        }
+#pragma unroll
+        for (int j = 0; j < CB; ++j) {
+            const int c = (wn * CB + j) * 4 + 2 * (G & 1) + (q >> 1);
+            x_ad[j] = lds_base + Y_BYTES + pix * X_ROWB + ((c ^ xk) << 4) + (q & 1) * 8;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) asm volatile("" : "+v"(y_ad[i]));
+#pragma unroll
+    for (int j = 0; j < CB; ++j) asm volatile("" : "+v"(x_ad[j]));
+
+    constexpr int NG = PK / 16, MPG = RB * CB, SLOTS = NG * MPG, RPG = 2 * (RB + CB);      // RPG: reads per K-group
+    static_assert(NOPS <= SLOTS, "more loads than MFMA slots");
+    static_assert(XRPP * (XP - 1) * 4 < 65536, "table offsets");
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    // LDS returns data in order: "at most n reads outstanding" = everything older than the last n has landed.  The
+    // registers are operands of the wait so that nothing that uses them can be placed in front of it.
+    auto wait_set = [&](auto N, u32x2 (&ya)[RB][2], u32x2 (&xa)[CB][2]) {
+        constexpr int n = decltype(N)::value;
+        static_assert(RB <= 2 && CB <= 2, "operand lists below");
+        if constexpr (RB == 2 && CB == 2)
+            asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(ya[0][0]), "+v"(ya[0][1]), "+v"(ya[1][0]), "+v"(ya[1][1]), "+v"(xa[0][0]),
+                         "+v"(xa[0][1]), "+v"(xa[1][0]), "+v"(xa[1][1]) : "n"(n));
+        else
+            asm volatile("s_waitcnt lgkmcnt(%4)" : "+v"(ya[0][0]), "+v"(ya[0][1]), "+v"(xa[0][0]), "+v"(xa[0][1]) : "n"(n));
+    };
+    auto step = [&](auto STG, auto MORE) {
+        constexpr int stg = decltype(STG)::value;
+        constexpr bool more = decltype(MORE)::value;
+        using OTHER = std::integral_constant<int, (stg ^ 1)>;
+        if constexpr (more) prep();
+        u32x2 av[2][RB][2], bv[2][CB][2];
+        auto frags = [&](auto SET, auto KK) {
+            constexpr int set = decltype(SET)::value, kk = decltype(KK)::value;
+            static_for<RB * 2>([&](auto Q) {
+                constexpr int i = decltype(Q)::value / 2, h = decltype(Q)::value % 2;
+                u32x2& dst = av[set][i][h];
+                const unsigned ad = y_ad[i];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(stg * STAGE + (kk * 16 + h * 4) * Y_ROWB));
+            });
+            static_for<CB * 2>([&](auto Q) {
+                constexpr int j = decltype(Q)::value / 2, h = decltype(Q)::value % 2;
+                u32x2& dst = bv[set][j][h];
+                const unsigned ad = x_ad[j];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(stg * STAGE + (kk * 16 + h * 4) * X_ROWB));
+            });
+        };
+        frags(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{});
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<SLOTS>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            constexpr int g = sl / MPG, w = sl % MPG, i = w / CB, j = w % CB;
+            if constexpr (w == 0) {
+                if constexpr (g + 1 < NG)
+                    frags(std::integral_constant<int, ((g + 1) & 1)>{}, std::integral_constant<int, (g + 1 < NG ? g + 1 : 0)>{});
+                wait_set(std::integral_constant<int, (g + 1 < NG ? RPG : 0)>{}, av[g & 1], bv[g & 1]);
+                if constexpr (more && g == 0) static_for<XP>(tbl_use);      // older than this K-group's fragments: landed too
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            const u32x4 fa = __builtin_shufflevector(av[g & 1][i][0], av[g & 1][i][1], 0, 1, 2, 3);
+            const u32x4 fb = __builtin_shufflevector(bv[g & 1][j][0], bv[g & 1][j][1], 0, 1, 2, 3);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb),
+                                                                acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (more && sl < NOPS) {
+                vmem_op(OTHER{}, std::integral_constant<int, (sl < NOPS ? sl : 0)>{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        });
+    };
+    auto fence = [&]() {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+    if (nsteps > 0) {
+        prep();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        static_for<XP>(tbl_use);
+        static_for<NOPS>([&](auto K) { vmem_op(S0{}, K); });
+    }
+    fence();
+    int s_ = 0;
+    for (; s_ + 2 < nsteps; s_ += 2) {
+        step(S0{}, T{});
+        fence();
+        step(S1{}, T{});
+        fence();
+    }
+    if (nsteps - s_ == 2) {
+        step(S0{}, T{});
+        fence();
+        step(S1{}, F{});
+    } else if (nsteps - s_ == 1) {
+        step(S0{}, F{});
+    }
+    // epilogue: as wgrad_pipe_kernel (fp32 weight gradients / split-K partials)
+    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.K * a.taps * a.C : a.dw;
+    constexpr int RP = RB * 32;
+    constexpr int LDC = BNc + 4;
+    static_assert(RP * LDC * 4 <= 2 * STAGE, "wgrad epilogue staging does not fit the operand LDS");
+    float* Cs = smem;
+    for (int hh = 0; hh < WGM; ++hh) {
+        __syncthreads();
+        if (wm == hh) {
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                        Cs[row * LDC + wn * CB * 32 + j * 32 + (lane & 31)] = acc[i][j][q];
+                    }
+        }
+        __syncthreads();
+        constexpr int C4 = BNc / 4;
+        for (int idx = tid; idx < RP * C4; idx += 256) {
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int n = n0 + hh * RP + row, c = c0 + c4 * 4;
+            if (n < a.K && c < a.C)
+                *reinterpret_cast<f32x4*>(out + ((size_t)n * a.taps + tap) * a.C + c) =
+                    *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
+        }
+    }
+}
+
 }  // namespace dpft

@@ -865,6 +865,116 @@ def test_conv_bf16_activation_storage(B, H, W, Cin, K, k, stride):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,K,k,stride", [(2, 24, 40, 64, 128, 3, 1), (2, 24, 40, 128, 64, 1, 1), (1, 33, 29, 64, 64, 3, 2),
+                                                    (2, 32, 57, 256, 256, 3, 1), (2, 32, 57, 1024, 256, 1, 1), (3, 17, 23, 128, 512, 1, 2),
+                                                    (4, 64, 114, 128, 128, 3, 1), (1, 9, 7, 192, 320, 3, 1)])
+def test_conv_bf16_native_operands(B, H, W, Cin, K, k, stride):
+    """dpft_conv_desc.act16 = 2: bf16 activations AND bf16 weights -- both operands reach v_mfma_f32_32x32x16_bf16 untouched
+    (igemm_pipe_kernel<..., B16>).  Forward (with the BN-statistics epilogue) and data gradient vs fp64 on the SAME
+    bf16-valued operands: the products are exact in fp32, so what is left is the accumulation order and the bf16 rounding
+    of the stored output (2^-9 relative per element, ~1.2e-3 in the L2 norm)."""
+    import ctypes as C
+    import torch.nn.functional as F
+    from dpft_amd.hip import ops
+    from dpft_amd.hip.lib import lib, make_desc, ptr, stream
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(17)
+    pad = k // 2
+    d = make_desc(B, H, W, Cin, K, k, k, stride, pad)
+    d.act16 = 2
+    x = torch.randn(B, H, W, Cin, generator=g).bfloat16().to(dev)
+    w = (torch.randn(K, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16().to(dev)
+    dy = torch.randn(B, d.OH, d.OW, K, generator=g).bfloat16().to(dev)
+    wt = w.permute(3, 1, 2, 0).contiguous()          # [C][kh][kw][K]: the data gradient's operand
+    tr = C.c_int32(0)
+    tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(d), C.byref(tr)))
+    ws = torch.empty(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (64 << 20), dtype=torch.uint8, device=dev)
+    ops.conv_set_compute("bf16")
+    try:
+        y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device=dev)
+        stats = torch.empty(tiles, 2, K, dtype=torch.float32, device=dev)
+        lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(d), ptr(x), ptr(w), None, None, 0, ptr(y), ptr(stats), ptr(ws), stream())
+        dx = torch.full((B, H, W, Cin), 7.0, dtype=torch.bfloat16, device=dev)
+        lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(d), ptr(dy), ptr(wt), ptr(dx), 0, ptr(ws), stream())
+        # weight gradient: dY and x are bf16 in memory, no prologue -> wgrad_pipe16_kernel (transpose reads), fp32 result
+        dw = torch.full((K, k, k, Cin), 3.0, dtype=torch.float32, device=dev)
+        lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(d), ptr(x), ptr(dy), None, 0, ptr(dw), ptr(ws), stream())
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_set_compute("fp32")
+    w64 = w.double().cpu().permute(0, 3, 1, 2)
+    wv = w.double().cpu().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wv, stride=stride, padding=pad).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    dw_ref = wv.grad.permute(0, 2, 3, 1)
+    e_dw = float((dw.double().cpu() - dw_ref).norm() / dw_ref.norm())
+    assert e_dw < 2e-5, e_dw          # exact products, fp32 accumulation (split over pixel ranges), fp32 output
+    assert float((dw.double().cpu() - dw_ref).abs().max()) < 1e-4 * float(dw_ref.abs().max())
+    y_ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w64, stride=stride, padding=pad).permute(0, 2, 3, 1)
+    xin = torch.zeros(B, Cin, H, W, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin, w64, stride=stride, padding=pad).backward(dy.double().cpu().permute(0, 3, 1, 2))
+    dx_ref = xin.grad.permute(0, 2, 3, 1)
+    rel = lambda a, b: float((a.double().cpu() - b).norm() / b.norm())
+    assert rel(y, y_ref) < 2.5e-3, rel(y, y_ref)
+    assert rel(dx, dx_ref) < 2.5e-3, rel(dx, dx_ref)
+    # element-wise: within one bf16 ulp of the fp64 value (+ fp32 accumulation noise)
+    assert float(((y.double().cpu() - y_ref).abs() - 2.0 ** -8 * y_ref.abs()).max()) < 1e-4 * float(y_ref.abs().max())
+    assert float(((dx.double().cpu() - dx_ref).abs() - 2.0 ** -8 * dx_ref.abs()).max()) < 1e-4 * float(dx_ref.abs().max())
+    # statistics come from the fp32 accumulators: merged per-channel mean and centred second moment
+    M = B * d.OH * d.OW
+    cnt = torch.full((tiles,), float(tr.value), dtype=torch.float64); cnt[-1] = M - tr.value * (tiles - 1)
+    st = stats.double().cpu()
+    mean = (st[:, 0] * cnt[:, None]).sum(0) / M
+    m2 = st[:, 1].sum(0) + (cnt[:, None] * (st[:, 0] - mean) ** 2).sum(0)
+    yr = y_ref.reshape(-1, K)
+    assert float((mean - yr.mean(0)).abs().max()) < 1e-5 * float(yr.abs().max()) + 1e-6
+    assert float((m2 / M - yr.var(0, unbiased=False)).abs().max()) < 1e-4 * float(yr.var(0).max())
+
+
+@pytest.mark.gpu
+def test_bf16_plan_bn_reduce_in_dgrad_epilogue_equals_separate_pass(tmp_path):
+    """bf16 storage (act16 = 2): the BatchNorm-backward reduction carried by the data-gradient epilogues (rounded value
+    under the ReLU mask, x-hat from the bf16 conv output: what the stand-alone pass reads back) against the plan with
+    DPFT_BN_FUSE=0.  Same kernels otherwise; the sums differ in summation order only, a bf16 rounding of a gradient that
+    flips on such a difference moves one element by 2^-8 -- the weight gradients of the whole body agree to ~1e-3."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for fuse in ("0", "1"):
+        f = str(tmp_path / f"g{fuse}.pt")
+        env = dict(os.environ, DPFT_BN_FUSE=fuse, DPFT_ACT16="2")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "backbone_grad_dump.py"), f, "resnet50", "2,96,160", "bf16"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[fuse] = torch.load(f)
+    a, b = outs["0"], outs["1"]
+    for k in a["feats"]:
+        assert torch.equal(a["feats"][k], b["feats"][k]), k          # the forward is the same program
+    err = {}
+    for n in a["grads"]:
+        ga, gb = a["grads"][n].double(), b["grads"][n].double()
+        assert bool(torch.isfinite(gb).all()), n
+        err[n] = float((ga - gb).norm() / (ga.norm() + 1e-30))
+    worst = max(err.items(), key=lambda kv: kv[1])
+    print("bf16 plan, fused vs separate BN-backward reduction: worst relative L2", worst,
+          {n: f"{e:.1e}" for n, e in err.items() if n.startswith("body.layer4.2") or n.startswith("body.layer4.1.conv3")})
+    # The last block runs first in the backward: its bn2 / bn1 reductions ride in the conv3 / conv2 data gradients, and the
+    # reduction of the previous block's bn3 in its conv1 data gradient -- there the two programs agree to summation order.
+    for n, e in err.items():
+        if n.startswith("body.layer4.2."):
+            assert e < 1e-4, (n, e)
+        if n.startswith("body.layer4.1.conv3") or n.startswith("body.layer4.1.bn3"):
+            assert e < 1e-3, (n, e)
+    # Further down every bf16 rounding of a stored gradient that flips on such a difference moves an element by 2^-8 and
+    # each BatchNorm backward amplifies it: the difference grows by x5-10 per block until it sits at the rounding noise of
+    # the bf16 gradients themselves (~1e-2; the same size as the run-to-run spread of the atomics' order, measured
+    # 2.5e-3 at layer2 with identical programs).  Bounded, not tight:
+    assert all(e < 0.3 for e in err.values()), worst
+    tot = float(torch.cat([(a["grads"][n].double() - b["grads"][n].double()).flatten() for n in a["grads"]]).norm() /
+                torch.cat([a["grads"][n].double().flatten() for n in a["grads"]]).norm())
+    assert tot < 5e-2, tot
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,K,k,stride,res,relu", [
     (2, 32, 57, 256, 256, 3, 1, False, True),      # vector path, epilogue form
     (2, 32, 57, 256, 1024, 1, 1, True, True),      # conv3 + identity + ReLU

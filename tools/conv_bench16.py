@@ -27,10 +27,13 @@ def run(spec, mode, reps=20, check=True):
     ws = torch.empty(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16), dtype=torch.uint8, device="cuda")
     y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device="cuda")
     dx = torch.empty(B, H, W, Cc, dtype=torch.bfloat16, device="cuda")
+    dw = torch.empty(K, k, k, Cc, dtype=torch.float32, device="cuda")
 
     def go():
         if kind == "fwd":
             lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(d), ptr(x), ptr(wq), None, None, 0, ptr(y), None, ptr(ws), stream())
+        elif kind == "wgrad":      # no prologue: DPFT_WGRAD16_PIPE=0 -> the round-2 kernel (A/B in two processes)
+            lib.call("dpft_conv2d_nhwc_wgrad_f32", C.byref(d), ptr(x), ptr(dy), None, 0, ptr(dw), ptr(ws), stream())
         else:
             lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(d), ptr(dy), ptr(wtq), ptr(dx), 0, ptr(ws), stream())
     for _ in range(3):
@@ -42,6 +45,11 @@ def run(spec, mode, reps=20, check=True):
         if kind == "fwd":
             ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wr, stride=s, padding=pad).permute(0, 2, 3, 1)
             got = y.double().cpu()
+        elif kind == "wgrad":
+            wv = wr.clone().requires_grad_(True)
+            F.conv2d(x.double().cpu().permute(0, 3, 1, 2), wv, stride=s, padding=pad).backward(dy.double().cpu().permute(0, 3, 1, 2))
+            ref = wv.grad.permute(0, 2, 3, 1)
+            got = dw.double().cpu()
         else:
             xin = torch.zeros(B, Cc, H, W, dtype=torch.float64, requires_grad=True)
             out = F.conv2d(xin, wr, stride=s, padding=pad)

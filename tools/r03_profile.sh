@@ -76,6 +76,10 @@ bash /root/repo/tools/pmc_conv_sq.sh > $OUT/r03_conv_sq_mfma_busy.txt 2>&1
 # (6) mixed precision (configs[4]): bf16 operands + bf16 activation storage, batch 8 per GPU: bench line + serialized kernel summary
 DPFT_CONV_TABLE=$OUT/r03_conv_table_bf16_b8.txt timeout 600 python /root/repo/bench.py --dtype bf16 --batch 8 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r03_bench_bf16_b8.json 2> $OUT/r03_bench_bf16_b8.err
 timeout 600 python /root/repo/bench.py --dtype bf16 --batch 4 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r03_bench_bf16_b4.json 2>> $OUT/r03_bench_bf16_b8.err
+for b in 8 4; do
+  SERIAL=1 STEPS=10 DTYPE=bf16 BATCH=$b timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_serial16_$b -- python /root/repo/tools/train_only.py </dev/null > $OUT/r03_serial_bf16_b$b.log 2>&1
+  f=$(find /tmp/p_serial16_$b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/r03_serialized_step_kernel_stats_bf16_b$b.csv
+done
 # (7) radar tesseract projection
 bash /root/repo/tools/radar_prof.sh > $OUT/r03_radar_projection.txt 2>&1
 # (8) the default bench line of this state

@@ -27,6 +27,13 @@ for r in sec:
     prev_end = max(prev_end or 0, e); tot_busy += e - s
 span = (max(int(r["End_Timestamp"]) for r in sec) - t0) / 1e3
 print(f"serial section: {len(sec)} kernels, span {span:.0f} us, kernel time {tot_busy/1e3:.0f} us")
+import os
+if os.environ.get("SEQ") == "1":      # the launches in order: start (us), duration, idle before, stream
+    pe = None
+    for r in sec:
+        s_, e_ = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print(f"   {(s_ - t0)/1e3:8.1f} {(e_ - s_)/1e3:7.1f} us  gap {0 if pe is None else (s_ - pe)/1e3:6.1f}  q{r.get('Queue_Id', '?')}  {short(r['Kernel_Name'])}")
+        pe = max(pe or 0, e_)
 for n, (c, t, g) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
     print(f"  {n:40s} x{c:3d}  kernel {t/1e3:7.1f} us  idle before {g/1e3:7.1f} us")
 PY

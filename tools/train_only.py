@@ -8,11 +8,14 @@ from dpft_amd.training.trainer import DataParallelTrainer
 
 steps = int(os.environ.get("STEPS", "20"))
 cfg = load_config("kradar")
+B = int(os.environ.get("BATCH", "4"))
+if os.environ.get("DTYPE", "f32") == "bf16":          # configs[4]: bf16 operands / activations, fp32 accumulation
+    cfg["computing"]["conv_compute"] = "bf16"
 torch.manual_seed(0)
 dev = torch.device("cuda", 0)
 tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
-data = make_batch(cfg["model"]["inputs"], 4, device=dev)
-labels = make_labels(4, device=dev)
+data = make_batch(cfg["model"]["inputs"], B, device=dev)
+labels = make_labels(B, device=dev)
 if os.environ.get("SERIAL") == "1":        # the serialized step bench.py brackets: one view stream, no wgrad side stream
     from dpft_amd.hip.lib import lib
     lib.call("dpft_profile_serialize", 1)
