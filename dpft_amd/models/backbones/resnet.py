@@ -91,7 +91,7 @@ class _Plan:
         body = owner.body
         d = ResnetDesc()
         d.B, d.H, d.W, d.in_channels = B, H, W, owner.in_channels
-        d.act16 = int(act16)
+        d.act16 = self.act16 = int(act16)      # 0 fp32 storage | 1 bf16 activations | 2 bf16 activations and weights
         for i, n in enumerate(owner.depths):
             d.depths[i] = n
         d.n_layers = body.n_layers

@@ -469,6 +469,71 @@ def test_mixed_precision_mode_close_to_fp32(storage, monkeypatch):
     assert all(v == v and v < 10 for k, v in e_grp.items() if k != "head"), e_grp
 
 
+def test_bf16_step_bounded_by_fp64_oracle(monkeypatch):
+    """BASELINE.json configs[4] against the ORACLE (not against the library's own fp32 step): reduced size, bf16 operands
+    and bf16 activation storage with bf16 weights for every view (act16 = 2: the bf16-native forward, data-gradient and
+    weight-gradient kernels), one training forward + set loss + backward.  Bounds vs oracle/dprt_oracle.py in fp64:
+    outputs and loss within bf16 rounding accumulated over the depth (2^-9 per operand and per stored activation),
+    decoder / FPN gradients within 20 % (measured 0.7 % / 1.3 %), every gradient finite.  The encoders' gradients are
+    ill-conditioned at random init: the CPU fp32 oracle already differs from the fp64 one by ~1e-3 there (the yardstick of
+    _train_parity), i.e. a rounding of 6e-8 is amplified ~1e4 times, and bf16's 4e-3 saturates at O(1)
+    (tools/mixed_precision_grad_check.py shows the same for a 2^-9 perturbation of the INPUT in pure fp32) -- for the bf16
+    kernels themselves test_conv_bf16_native_operands and test_bf16_plan_bn_reduce_* hold.  DPFT_TEST_VERBOSE=1 lists them."""
+    from dpft_amd.hip import ops
+    from dpft_amd.models.backbones.resnet import BackboneBase
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.loss import build_loss
+    from oracle import dprt_oracle as O
+    monkeypatch.setattr(BackboneBase, "ACT16_MIN_PIXELS", 0)
+    monkeypatch.setenv("DPFT_ACT16", "2")
+    cfg = small_config(dropout=0.0)
+    g = torch.Generator().manual_seed(21)
+    model = _build(cfg, g)
+    sd64 = state_dict_f64(model)
+    sd_ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v) for k, v in sd64.items()}
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=SHAPES)
+    labels = make_labels(2, seed=3)
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    ref = O.dprt_forward(sd_ref, cfg, b64, train=True)
+    labels64 = [{k: (v.double() if v.is_floating_point() else v) for k, v in l.items()} for l in labels]
+    ref_loss, _ = O.loss_forward(ref, labels64, cfg["train"]["loss_weights"])
+    ref_loss.backward()
+    ops.conv_set_compute("bf16")
+    try:
+        model = model.to(DEV).train()
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+        plans = [p for i in model.inputs for p in model.backbones[i]._plans.values()]
+        assert plans and all(p.act16 == 2 for p in plans), [p.act16 for p in plans]
+        loss, _ = build_loss(cfg["train"])(out, [{k: v.to(DEV) for k, v in l.items()} for l in labels])
+        loss.backward()
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_set_compute("fp32")
+    errs = {k: rel_l2(out[k], ref[k]) for k in out}
+    e_loss = abs(float(loss) - float(ref_loss)) / abs(float(ref_loss))
+    print("bf16 step vs fp64 oracle: outputs", {k: f"{v:.1e}" for k, v in errs.items()}, f"loss {e_loss:.1e}")
+    assert 0 < errs["center"] < 3e-2 and 0 < errs["class"] < 6e-2, errs
+    assert errs["size"] < 0.15 and errs["angle"] < 0.15, errs
+    assert e_loss < 2e-2, (float(loss), float(ref_loss))
+    groups = {}
+    for n, p in model.named_parameters():
+        gref = sd_ref[n].grad
+        if gref is None:
+            continue
+        assert p.grad is not None and bool(torch.isfinite(p.grad).all()), n
+        key = n.split(".")[0]
+        a, b = groups.setdefault(key, ([], []))
+        a.append(p.grad.detach().double().cpu().flatten()); b.append(gref.flatten())
+    e_grp = {k: float((torch.cat(a) - torch.cat(b)).norm() / torch.cat(b).norm()) for k, (a, b) in groups.items()}
+    print("gradient groups vs fp64 oracle:", {k: round(v, 4) for k, v in e_grp.items()})
+    assert e_grp["necks"] < 0.2 and e_grp["fuser"] < 0.2, e_grp
+    import os
+    if os.environ.get("DPFT_TEST_VERBOSE"):
+        for n, p in model.named_parameters():
+            if sd_ref[n].grad is not None and n.startswith("backbones") and ("conv" in n or "downsample.0" in n):
+                print(f"   {n:60s} {rel_l2(p.grad, sd_ref[n].grad):.3e}")
+
+
 def test_config4_bf16_mixed_precision_batch8_trains_at_full_size():
     """BASELINE.json configs[4] at ITS size on one GPU: kradar.json full C+R, bf16 mixed precision, batch 8 per GPU
     (global batch 64 = 8 such ranks).  Graphed trainer steps on a fixed synthetic batch: finite, decreasing loss, every
