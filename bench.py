@@ -419,6 +419,9 @@ def main():
             "step_definition": "zero_grad, forward, Hungarian set loss, backward, bucketed all-reduce, AdamW; the per-step "
                                "eval_fn of the reference's loop (trainer.py:134-136) is not part of the timed step",
             "rccl_ranks": world, "collectives_forced": bool(args.force_collectives and world == 1),
+            "collective_op": (trainer.reducer.collective_op + (" (one rank: avg == sum; RCCL's one-rank AVG is a pre-multiply pass "
+                              "over every bucket, +0.8 ms/step, DPFT_COLLECTIVE_OP=avg)" if world == 1 else ""))
+                             if trainer.collective else None,
             "exposed_allreduce_ms": exposed_ms,
             "exposed_allreduce_is": "last timed step: from the point the rank's CURRENT (main) stream has finished its own "
                                     "backward work to the completion of the last bucket's collective, bracketed by events on "

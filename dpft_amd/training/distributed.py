@@ -28,6 +28,10 @@ import torch
 import torch.distributed as dist
 
 
+# timing experiment only (tools/r03_forced_breakdown.sh): buckets fire without their collective
+_EXP_SKIP_BUCKET_COLLECTIVES = __import__("os").environ.get("DPFT_EXP_SKIP_BUCKET_COLLECTIVES") == "1"
+
+
 class GradBucketReducer:
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 25 << 20, process_group=None,
                  average: bool = True, group_of: Dict[int, str] = None, comm_dtype: Optional[torch.dtype] = None,
@@ -42,6 +46,15 @@ class GradBucketReducer:
         self.collective = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         # RCCL averages inside the collective (ncclAvg): no separate division pass over the 360 MB of buckets
         self._avg_op = average and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        # One rank (bench.py --force-collectives, tests): the average over one rank IS the sum, and RCCL implements a one-rank
+        # AVG as a pre-multiply kernel over the whole bucket (oneRankReduce<FuncPreMulSum>: 20 launches, 0.5 ms of memory
+        # passes per step that the all-reduce kernel of N > 1 ranks does not add) but a one-rank SUM as nothing -- so SUM
+        # there.  DPFT_COLLECTIVE_OP=avg|sum forces either (A/B, tools/r03_forced_breakdown.sh).
+        self.collective_op = "avg" if self._avg_op else "sum"
+        forced_op = __import__("os").environ.get("DPFT_COLLECTIVE_OP")
+        if self._avg_op and (forced_op == "sum" or (forced_op is None and self.world == 1)):
+            self._avg_op = False
+            self.collective_op = "sum"
         self.comm_stream = None      # optional torch stream the collectives are enqueued on (set by the trainer)
         self.average = average
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
@@ -212,16 +225,20 @@ class GradBucketReducer:
 
     def _fire(self, b):
         b["fired"] = True
-        if b["flat"].is_cuda and self.collective:     # single process: backward() itself joins the streams
+        comm = self.comm_stream if b["flat"].is_cuda else None
+        if b["flat"].is_cuda and self.collective and comm is None:     # single process: finish() joins the streams
+            # The process group's stream orders itself behind the CURRENT stream only, so the current stream has to wait for
+            # the other producers of this bucket.  That stalls a compute chain at every bucket boundary (the main stream
+            # waits for the weight-gradient stream it is supposed to run ahead of) -- the reason a comm stream of our own
+            # is the default on the GPU: there only the communication stream waits (below).
             cur = torch.cuda.current_stream(b["flat"].device)
             for sid, st in b["streams"].items():
                 if sid != cur.cuda_stream:          # tail of that stream is after its last contribution
                     cur.wait_stream(st)
-        if self.collective:
+        if self.collective and not _EXP_SKIP_BUCKET_COLLECTIVES:
             op = dist.ReduceOp.SUM
             if self._avg_op:
                 op = dist.ReduceOp.AVG
-            comm = self.comm_stream if b["flat"].is_cuda else None
             if comm is None:
                 # the process group's own stream (async_op=True): wherever the runtime put it among the hardware queues
                 if op == dist.ReduceOp.SUM and self.average and self.world > 1:
@@ -235,7 +252,13 @@ class GradBucketReducer:
                 # a stream of OUR choosing (= a hardware queue of our choosing, DataParallelTrainer): a synchronous
                 # collective is enqueued on the current stream, so the exchange of a bucket -- scaling, wire rounding,
                 # all-reduce, widening -- is one in-order sequence there, fenced by two events
-                comm.wait_stream(torch.cuda.current_stream(b["flat"].device))
+                # the COMMUNICATION stream waits for every producer of the bucket; no compute stream waits for another
+                cur = torch.cuda.current_stream(b["flat"].device)
+                if cur.cuda_stream != comm.cuda_stream:
+                    comm.wait_stream(cur)
+                for sid, st in b["streams"].items():
+                    if sid != comm.cuda_stream and sid != cur.cuda_stream:
+                        comm.wait_stream(st)
                 with torch.cuda.stream(comm):
                     if op == dist.ReduceOp.SUM and self.average and self.world > 1:
                         b["flat"].div_(self.world)

@@ -102,7 +102,7 @@ class DataParallelTrainer:
             if g is not None:
                 g.clone_outputs = True
         loss, losses = self.loss_fn(output, labels)
-        if self.collective:
+        if self.collective and os.environ.get("DPFT_EXP_LOCAL_DECISION") != "1":      # (timing experiment switch)
             # The global batch steps if ANY shard has a loss (MAX): a rank whose label shard is empty then runs the same
             # backward over a zero-valued loss, so it contributes zero gradients, issues its bucket collectives in the
             # same order and reports the same set of parameters-with-gradient as every other rank.
