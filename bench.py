@@ -306,7 +306,7 @@ def main():
         cam_w = {910, 455, 228, 114, 57, 29}          # widths of the camera feature maps (input of the conv)
         cam = [v for key, v in shapes.items() if key[3] in cam_w]
         cam_f, cam_t = sum(v[0] for v in cam), sum(v[1] for v in cam)
-        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/r02_profile.sh: FETCH_SIZE and
+        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/r03_profile.sh: FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  It is a
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
@@ -326,7 +326,7 @@ def main():
         # time is inside their brackets although it is not conv work)
         # Accounting.  A bracket spans everything one dpft_conv2d_nhwc_* call launches: the implicit-GEMM
         # main loop AND the split-K / slab reduction kernels it needs.  `frac` uses the RAW bracket time.  rocprofv3's
-        # kernel durations of the same serialized step (profiles/r02_serialized_step_kernel_stats.csv, recomputed by
+        # kernel durations of the same serialized step (profiles/r03_serialized_step_kernel_stats.csv, recomputed by
         # tools/roofline_from_rocprof.py) give the same number within a few %; `frac_main_kernels_only` removes the
         # reduction kernels and the ~4.5 us an empty event bracket costs, i.e. what round 1 reported as `frac`.
         ovh = float(ops.lib.dpft_profile_overhead_ms()) * 1e-3
@@ -377,7 +377,7 @@ def main():
         fcfg = cfg["model"]["fuser"]
         n_calls = fcfg["i_iter"] * len(m.inputs)
         dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
-        # counter traffic of the decoder kernels (tools/r02_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
+        # counter traffic of the decoder kernels (tools/r03_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
         dec_traffic, dec_src = None, None
         for pname in ("r03_decoder_traffic_pmc.json", "r02_decoder_traffic_pmc.json"):
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)
@@ -430,7 +430,10 @@ def main():
             "hardware_queues": {"distinct_besides_main": trainer.model.__dict__.get("_queues_found"),
                                 "placement": os.environ.get("DPFT_STREAM_PLACEMENT", "probe"),
                                 "note": "views and the camera's weight-gradient stream sit on probed, distinct hardware queues "
-                                        "(dpft_stream_set); RCCL's stream is the process group's own"},
+                                        "(dpft_stream_set); collectives: " + {"side": "in order on the camera's weight-gradient stream",
+                                                                            "front": "in order on the last view's stream",
+                                                                            "pg": "the process group's own stream"}.get(
+                                            trainer.comm_placement, trainer.comm_placement)},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
             "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,

@@ -58,10 +58,12 @@ class DataParallelTrainer:
                                          group_of=group_of, comm_dtype=wire, force_collectives=force_collectives)
         self.collective = self.reducer.collective
         # The collectives' hardware queue.  Four queues, four busy chains (main | camera weight gradients | two radar views):
-        # RCCL's own stream lands on whichever queue the runtime picks, possibly the critical chain's.  "front" / "side" put
-        # them (in order) on the last view's stream / the camera's weight-gradient stream; "pg" (default: 32.5 vs 35.5 ms forced,
-        # tools/r03_comm_ab.sh) keeps the group's stream.
-        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "pg")
+        # RCCL's own stream ("pg") lands on whichever queue the runtime picks, possibly the critical chain's, where an
+        # all-reduce kernel of N > 1 ranks would hold up the data-gradient chain for its whole duration.  "side" (default)
+        # enqueues them, in order, on the camera's weight-gradient stream: the one chain with slack (6.5 ms of GEMMs in a 19 ms
+        # backward) and the producer of most of every camera bucket; "front" = the last view's stream.  Forced one-rank
+        # collectives (tools/r03_comm_ab.sh): side 29.2, pg 29.4, front 31.7 ms against 28.7 ms plain.
+        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "side")
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         overwritten = []
         for m in self.model.modules():

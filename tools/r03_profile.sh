@@ -78,10 +78,46 @@ DPFT_CONV_TABLE=$OUT/r03_conv_table_bf16_b8.txt timeout 600 python /root/repo/be
 timeout 600 python /root/repo/bench.py --dtype bf16 --batch 4 --steps 20 --warmup 5 --no-cpu-baseline --latency-reps 50 > $OUT/r03_bench_bf16_b4.json 2>> $OUT/r03_bench_bf16_b8.err
 for b in 8 4; do
   SERIAL=1 STEPS=10 DTYPE=bf16 BATCH=$b timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_serial16_$b -- python /root/repo/tools/train_only.py </dev/null > $OUT/r03_serial_bf16_b$b.log 2>&1
-  f=$(find /tmp/p_serial16_$b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/r03_serialized_step_kernel_stats_bf16_b$b.csv
+  f=$(find /tmp/p_serial16_$b -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/r03_bf16_b${b}_serialized_step_kernel_stats.csv
+  python /root/repo/tools/roofline_from_rocprof.py $OUT/r03_bf16_b${b}_serialized_step_kernel_stats.csv 13 $(python -c "print(1839.439164384 * $b / 4)") 2500 > $OUT/r03_bf16_b${b}_roofline_from_rocprof.json
 done
+# conv family HBM traffic of the bf16 step at batch 8 (FETCH_SIZE / WRITE_SIZE, separate passes)
+for c in FETCH_SIZE WRITE_SIZE; do
+  STEPS=2 DTYPE=bf16 BATCH=8 timeout 600 rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc16_$c -- python /root/repo/tools/train_only.py </dev/null > /tmp/pmc16_$c.log 2>&1
+done
+python - <<PY
+import csv, glob, collections, json
+raw = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"/tmp/pmc16_{c}/**/*counter_collection.csv", recursive=True)
+    agg = collections.defaultdict(lambda: [0.0, 0])
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if r.get("Counter_Name") != c: continue
+            n = r["Kernel_Name"]
+            key = "igemm" if ("igemm" in n or "conv16_" in n or "thin_dgrad" in n) else "wgrad" if ("wgrad" in n) else "splitk" if ("splitk" in n or "slab_reduce" in n) else "bn" if "bn_" in n else None
+            if key is None: continue
+            agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
+    raw[c] = {k: {"sum_kb": v[0], "launches": v[1]} for k, v in agg.items()}
+try:
+    conv = ("igemm", "wgrad", "splitk")
+    launches = raw["FETCH_SIZE"]["igemm"]["launches"] + raw["FETCH_SIZE"]["wgrad"]["launches"]
+    steps = 5.0      # STEPS=2 + 3 warm-up steps of tools/train_only.py
+    fetch = 2.0 * 1024 * sum(raw["FETCH_SIZE"][k]["sum_kb"] for k in conv if k in raw["FETCH_SIZE"])
+    write = 1024 * sum(raw["WRITE_SIZE"][k]["sum_kb"] for k in conv if k in raw["WRITE_SIZE"])
+    out = {"method": "as r03_conv_traffic_pmc.json (FETCH_SIZE doubled, WRITE_SIZE as is, KB units), bf16 mode (configs[4]) at batch 8; bn = the BatchNorm kernels of the same passes",
+           "raw": raw, "steps_profiled": steps, "conv_launches_per_step": launches / steps, "conv_fetch_gb_per_step": fetch / steps / 1e9, "conv_write_gb_per_step": write / steps / 1e9,
+           "conv_traffic_gb_per_step": (fetch + write) / steps / 1e9,
+           "bn_traffic_gb_per_step": (2.0 * 1024 * raw["FETCH_SIZE"].get("bn", {"sum_kb": 0})["sum_kb"] + 1024 * raw["WRITE_SIZE"].get("bn", {"sum_kb": 0})["sum_kb"]) / steps / 1e9}
+except Exception as e:
+    out = {"error": repr(e), "raw": raw}
+json.dump(out, open("$OUT/r03_bf16_b8_conv_traffic_pmc.json", "w"), indent=1)
+print({k: v for k, v in out.items() if k not in ("raw", "method")})
+PY
 # (7) radar tesseract projection
 bash /root/repo/tools/radar_prof.sh > $OUT/r03_radar_projection.txt 2>&1
+# (7b) the RCCL path on one rank: forced collectives (line carries rccl_ranks 1, collectives_forced true)
+timeout 900 python /root/repo/bench.py --gpus 1 --force-collectives --no-cpu-baseline --latency-reps 20 > $OUT/r03_bench_forced_collectives.json 2> $OUT/r03_bench_forced.err
 # (8) the default bench line of this state
 DPFT_CONV_TABLE=$OUT/r03_conv_table_fp32.txt timeout 900 python /root/repo/bench.py > $OUT/r03_bench.json 2> $OUT/r03_bench.err
 tail -2 $OUT/r03_serial.log; grep "ms/step" $OUT/r03_plain.log; grep decoder_fwd $OUT/r03_decoder.log; head -c 600 $OUT/r03_roofline_from_rocprof.json

@@ -1,18 +1,18 @@
 """Conv-family roofline recomputed from a rocprofv3 --kernel-trace --stats summary (the bench line's
 `roofline.frac` must follow from what is committed under profiles/).
 
-    python tools/roofline_from_rocprof.py <kernel_stats.csv> <steps> [algorithmic_gflop_per_step]
+    python tools/roofline_from_rocprof.py <kernel_stats.csv> <steps> [algorithmic_gflop_per_step] [peak_tflops]
 
 Kernel time of the conv family per step = sum of TotalDurationNs of every kernel a dpft_conv2d_nhwc_* call launches
-(main loops AND the split-K / slab reductions they need) / steps.  frac = algorithmic flops / that time / 157.3 TF."""
+(main loops AND the split-K / slab reductions they need) / steps.  frac = algorithmic flops / that time / peak (157.3 TF)."""
 import csv
 import json
 import re
 import sys
 
-MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "wgrad_pipe_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
+MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "wgrad_pipe_kernel", "wgrad_pipe16_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
         "conv16_", "wgrad16_", "thin_wgrad")
-AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel")
+AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel", "zero_fill_kernel")
 GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", "pack_"),
           "decoder_infer": ("decoder_selfattn", "decoder_xattn"), "loss": ("match_cost", "set_loss", "giou3d"),
           "optimizer": ("adamw",), "weight_transpose": ("weight_transpose",), "fpn_misc": ("fpn_topdown", "add_pos", "add_inplace", "relu_bwd"),
@@ -22,6 +22,7 @@ GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", 
 def main():
     path, steps = sys.argv[1], int(sys.argv[2])
     gflop = float(sys.argv[3]) if len(sys.argv) > 3 else 1839.439164384       # kradar, B=4: 3 x 4 x 153.29 (bench.py log)
+    peak = float(sys.argv[4]) if len(sys.argv) > 4 else 157.3      # fp32 MFMA; 2500 for the bf16 mode's summaries
     t = {"conv_main": 0.0, "conv_aux": 0.0, "other_dpft": 0.0}
     t.update({k: 0.0 for k in GROUPS})
     n = dict.fromkeys(t, 0)
@@ -42,7 +43,7 @@ def main():
            "launches_per_step": {k: round(v / steps, 1) for k, v in n.items()},
            "algorithmic_gflop_per_step": gflop,
            "conv_family_tflops_main_only": gflop / ms["conv_main"], "conv_family_tflops": gflop / conv,
-           "frac_main_only": gflop / ms["conv_main"] / 157.3, "frac": gflop / conv / 157.3,
+           "peak_tflops": peak, "frac_main_only": gflop / ms["conv_main"] / peak, "frac": gflop / conv / peak,
            "total_kernel_ms_per_step": round(sum(ms.values()), 3)}
     print(json.dumps(out, indent=1))
 
