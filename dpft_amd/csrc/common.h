@@ -41,6 +41,7 @@ struct BnFinalFuse {
     float* bnp;
     float eps, momentum;
     bool applied;
+    int slab = 0;      // > 0: deterministic form for launches of at most `slab` row tiles (statistics slab + per-column-tile tickets)
 };
 int conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* pro_bn,
                      int32_t pro_relu, float* y, float* stats, void* workspace, dpft_stream_t stream, BnFinalFuse* fuse);

@@ -125,6 +125,7 @@ struct IgemmArgs {
     // and its consumer.
     float* bnf_acc;                    // [2][N], zero before the launch; null = off
     int* bnf_ticket;                   // zero before the launch
+    int bnf_slab;                      // deterministic form: per-tile statistics slab + one ticket per column tile (below)
     const float* bnf_gamma;
     const float* bnf_beta;
     float* bnf_rm;                     // running mean / var (may be null)
@@ -182,7 +183,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
             const float mean = s / (float)cnt;
             smean[tid] = mean;
-            if (a.stats && n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
+            if (a.stats && n0 + tid < a.N) {
+                float* dst = a.stats + ((size_t)mt * 2 + 0) * a.N + n0 + tid;
+                if (a.bnf_slab) __hip_atomic_store(dst, mean, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // read by ANOTHER workgroup of this launch
+                else *dst = mean;
+            }
         }
         __syncthreads();
 #pragma unroll
@@ -205,7 +210,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
-            if (a.stats) a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+            if (a.stats) {
+                float* dst = a.stats + ((size_t)mt * 2 + 1) * a.N + n0 + tid;
+                if (a.bnf_slab) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                else *dst = s;
+            }
             if (a.bnf_acc) {      // fused finalize: this tile's share of the pivoted sums (device-scope atomics)
                 const int n = n0 + tid;
                 const float dlt = smean[tid] - (a.bnf_rm ? a.bnf_rm[n] : 0.f);
@@ -376,6 +385,79 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 if (a.res_src != nullptr && a.partial == nullptr) v += a.res_mask[off] > 0.f ? a.res_src[off] : 0.f;
                 else if (accum) v += *o;
                 *o = v;
+            }
+        }
+    }
+    if (a.bnf_slab) {
+        // Deterministic BatchNorm finalize inside the forward conv: the workgroups of one COLUMN tile take tickets; whoever
+        // draws the last one merges that tile's columns of the statistics slab with the arithmetic of bn_finalize_kernel
+        // (bn.hip: 32 tile groups per channel, pivot = tile 0, groups summed in order) -- bit-identical to the separate
+        // launch, whichever workgroup ends up doing it.  No fences: the slab entries were written with agent-scope stores
+        // (performed at the coherence point once vmcnt acknowledges them), the tickets are agent-scope RMWs, the merger reads
+        // the slab with agent-scope loads; its plain stores of the BN block are consumed by LATER kernels.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        if (tid == 0) *flag = __hip_atomic_fetch_add(a.bnf_ticket + n0 / BN, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag == a.mtiles - 1) {
+            constexpr int R = NT / BN;      // threads per channel
+            float* s1s = smem + 64;         // [32][BN]
+            float* s2s = s1s + 32 * BN;
+            const int cl = tid % BN, r = tid / BN, c = n0 + cl;
+            const bool ok = c < a.N;
+            auto ld = [&](size_t i) { return __hip_atomic_load(a.stats + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+            const float pivot = ok ? ld(c) : 0.f;
+            const float full = (float)BM;
+            const float last = (float)((int64_t)a.M - (int64_t)(a.mtiles - 1) * BM);
+            // all of this thread's slab entries are requested before the first is used (atomic loads are not hoisted or
+            // pipelined by the compiler: one at a time they cost 57 memory round trips, ~14 us at the end of the conv)
+            constexpr int GP = 32 / R, TPG = 2;      // groups per thread, tiles per group (launches of <= 64 row tiles)
+            float mv[GP][TPG], qv[GP][TPG];
+#pragma unroll
+            for (int gi = 0; gi < GP; ++gi)
+#pragma unroll
+                for (int ti = 0; ti < TPG; ++ti) {
+                    const int t = r + gi * R + ti * 32;
+                    const bool on = ok && t < a.mtiles;
+                    mv[gi][ti] = on ? ld(((size_t)t * 2 + 0) * a.N + c) : 0.f;
+                    qv[gi][ti] = on ? ld(((size_t)t * 2 + 1) * a.N + c) : 0.f;
+                }
+#pragma unroll
+            for (int gi = 0; gi < GP; ++gi) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int ti = 0; ti < TPG; ++ti) {
+                    const int t = r + gi * R + ti * 32;
+                    if (ok && t < a.mtiles) {
+                        const float cnt = t == a.mtiles - 1 ? last : full;
+                        const float d = mv[gi][ti] - pivot;
+                        s1 = fmaf(cnt, d, s1);
+                        s2 += fmaf(cnt * d, d, qv[gi][ti]);
+                    }
+                }
+                s1s[(r + gi * R) * BN + cl] = s1;
+                s2s[(r + gi * R) * BN + cl] = s2;
+            }
+            __syncthreads();
+            if (tid < BN && ok) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 32; ++i) { s1 += s1s[i * BN + cl]; s2 += s2s[i * BN + cl]; }
+                const float invN = 1.0f / (float)a.M;
+                const float mean = fmaf(s1, invN, pivot);
+                const float m2 = fmaxf(s2 - s1 * s1 * invN, 0.f);
+                const float var = m2 * invN;
+                const float invstd = 1.0f / sqrtf(var + a.bnf_eps);
+                a.bnf_bnp[c] = mean;
+                a.bnf_bnp[a.N + c] = a.bnf_gamma[c] * invstd;
+                a.bnf_bnp[2 * a.N + c] = a.bnf_beta[c];
+                a.bnf_bnp[3 * a.N + c] = invstd;
+                if (a.bnf_rm) {
+                    const float unbiased = a.M > 1 ? m2 / (float)(a.M - 1) : var;
+                    a.bnf_rm[c] = (1.f - a.bnf_mom) * a.bnf_rm[c] + a.bnf_mom * mean;
+                    a.bnf_rv[c] = (1.f - a.bnf_mom) * a.bnf_rv[c] + a.bnf_mom * unbiased;
+                }
             }
         }
     }
@@ -2013,7 +2095,14 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
         DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
         a.partial = (float*)workspace;
         a.stats = nullptr;
-    } else if (fuse && fuse->acc && !bias && !d->act16 && t.vec && (a.N & 3) == 0) {
+    } else if (fuse && fuse->acc && fuse->slab && stats && !bias && !d->act16 && t.vec && (a.N & 3) == 0 &&
+               cdiv(a.M, t.bm) <= fuse->slab) {
+        // deterministic form: the slab stays, one ticket per column tile (the zeroed accumulator region holds them: 2 K >= tiles)
+        a.bnf_slab = 1; a.bnf_ticket = reinterpret_cast<int*>(fuse->acc); a.bnf_gamma = fuse->gamma; a.bnf_beta = fuse->beta;
+        a.bnf_rm = fuse->running_mean; a.bnf_rv = fuse->running_var; a.bnf_bnp = fuse->bnp;
+        a.bnf_eps = fuse->eps; a.bnf_mom = fuse->momentum;
+        fuse->applied = true;
+    } else if (fuse && fuse->acc && !fuse->slab && !bias && !d->act16 && t.vec && (a.N & 3) == 0) {
         a.bnf_acc = fuse->acc; a.bnf_ticket = fuse->ticket; a.bnf_gamma = fuse->gamma; a.bnf_beta = fuse->beta;
         a.bnf_rm = fuse->running_mean; a.bnf_rv = fuse->running_var; a.bnf_bnp = fuse->bnp;
         a.bnf_eps = fuse->eps; a.bnf_mom = fuse->momentum;

@@ -318,19 +318,27 @@ static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* 
     return DPFT_OK;      // eval: every BN block was produced up front by eval_bn_blocks()
 }
 
-// train-mode forward conv + its BatchNorm block: the finalize rides in the conv's epilogue where the launch allows it
-// (BnFinalFuse), otherwise per-tile statistics + bn_finalize.  OFF by default (DPFT_BN_FINAL_FUSE=1 enables it): measured
-// -0.4 ... -1.1 ms per step, but the atomic accumulation makes the forward's BatchNorm blocks differ in the last bits from
-// run to run, which the encoders' backward amplifies (the full-size repeatability property no longer holds to 2e-4), and
-// the epilogue tail costs the forward GEMMs ~6 % of their rate.  The table + bn_finalize path is deterministic.
+// train-mode forward conv + its BatchNorm block.  Default: per-tile statistics in the conv epilogue + bn_finalize.  The
+// finalize can ride in the conv's epilogue instead (BnFinalFuse, DPFT_BN_FINAL_FUSE):
+//   1  atomic accumulation + last-ticket workgroup: -0.4 ... -1.1 ms per step, but the forward's BatchNorm blocks then differ
+//      in the last bits from run to run, which the encoders' backward amplifies (the full-size repeatability property no
+//      longer holds to 2e-4);
+//   2  deterministic: the statistics slab stays, the workgroups of a column tile take tickets and the last one merges that
+//      tile's columns with bn_finalize_kernel's own arithmetic (bit-identical results, all parity tests green), for launches
+//      of <= 64 row tiles (camera layers 3-4: 80 of its 104 BatchNorms).  Measured: 80 launches fewer, step time unchanged
+//      (28.95 vs 29.0 ms) -- the merger's ~3 us at the end of each conv (one ticket round trip + 64 slab loads in flight; a
+//      first form with the loads one at a time cost 14 us and LOST 0.5 ms) are what the removed kernel boundary cost.
+// Both stay off: neither beats the separate 5 us kernel by enough to carry the extra memory-ordering argument.
 static int conv_bn_train(const ResnetPlan* p, const Tables& T, const ConvRef& c, int bn, const float* x, const float* pro,
                          float* A, float* y, float* stats, int tiles, int rows, int64_t M, float* bnp, void* ws,
                          dpft_stream_t st, const float* w = nullptr) {
     if (!w) w = T.w(c.w);
-    static const bool fuse_on = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
+    static const int fuse_mode = getenv("DPFT_BN_FINAL_FUSE") ? atoi(getenv("DPFT_BN_FINAL_FUSE")) : 0;      // 0 off | 1 atomics | 2 slab
+    static const int slab_tiles = getenv("DPFT_BN_FINAL_TILES") ? std::min(64, atoi(getenv("DPFT_BN_FINAL_TILES"))) : 64;      // the merger holds two tiles per group in registers
     float* acc = A + p->o_bnacc + p->bnacc[bn];
-    BnFinalFuse f{acc, (int*)(acc + 2 * c.d.K), T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), bnp, p->desc.eps, p->desc.momentum, false};
-    RC(conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, stats, ws, st, fuse_on ? &f : nullptr));
+    BnFinalFuse f{acc, (int*)(acc + 2 * c.d.K), T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), bnp, p->desc.eps, p->desc.momentum, false,
+                  fuse_mode == 2 ? slab_tiles : 0};
+    RC(conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, stats, ws, st, fuse_mode ? &f : nullptr));
     if (f.applied) return DPFT_OK;
     return dpft_bn_finalize_f32(stats, tiles, rows, M, c.d.K, T.gamma(bn), T.beta(bn), p->desc.eps, p->desc.momentum, T.rm(bn),
                                 T.rv(bn), bnp, st);
