@@ -1782,7 +1782,15 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps) {
     }
     // candidate tiles ordered by per-flop efficiency; pick the one that fills the chip best
     const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    const double eff[3] = {1.0, 0.92, 0.80};
+    double eff[3] = {1.0, 0.92, 0.80};
+    // Short reductions over many row tiles (the 1x1 convs of camera layers 1-2, K <= 256): the kernel is its epilogue
+    // (statistics / residual / BatchNorm-reduction operands, staged stores), and with 128 x 128 tiles all workgroups of a
+    // wave reach it together; 128 x 64 measured 10-25 % faster there (tools/r03_tile_ab.sh: 176 -> 129 us on the
+    // 128x228 256<-64 data gradient), not on the 57-row-tile grids of layer 3.
+    static const bool shortk_rule = getenv("DPFT_SHORTK_TILE") == nullptr || atoi(getenv("DPFT_SHORTK_TILE")) != 0;      // A/B switch
+    if (shortk_rule && (int64_t)ksteps * BKV <= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 768) {
+        eff[0] = 0.88; eff[1] = 1.0; eff[2] = 0.85;
+    }
     double best = -1;
     t.bm = 64; t.bn = 64;
     for (int i = 0; i < 3; ++i) {
