@@ -1812,7 +1812,11 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps) {
     // split-K when even the smallest tile leaves most CUs idle (radar branches, layer4)
     const int64_t nwg = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
     t.splits = 1;
-    if (nwg < kNumCU && ksteps >= 8) {
+    // DPFT_SPLIT_BELOW (tuning aid): the isolated 232-tile layer-4 1x1 forward runs 52.9 us split in three vs 35.9 us
+    // unsplit (tools/r03_tile_ab.sh), but over the whole step 128 / 192 / 256 are within run-to-run noise (conv time 28.2 /
+    // 27.9 / 28.0 ms): the threshold stays at one workgroup per CU.
+    static const int split_below = getenv("DPFT_SPLIT_BELOW") ? atoi(getenv("DPFT_SPLIT_BELOW")) : kNumCU;
+    if (nwg < split_below && ksteps >= 8) {
         int s = (int)((kNumCU * 2 + nwg - 1) / nwg);
         s = s > 16 ? 16 : s;
         while (s > 1 && ksteps / s < 4) --s;
