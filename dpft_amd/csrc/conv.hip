@@ -1979,9 +1979,18 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
     if (!workspace) return DPFT_OK;
     if (conv16_matches(d)) {
         handled = true;
-        const int nb = conv16_wgrad_blocks(d);
-        Wgrad16Args a{x, dy, (float*)workspace, d->B, d->H, d->W, cdiv(d->W, 4), (long)d->B * d->H * cdiv(d->W, 4)};
-        hipLaunchKernelGGL(wgrad16_3x3_kernel, dim3(nb), dim3(256), 0, st, a);
+        static const bool tiled = getenv("DPFT_WGRAD16_TILED") == nullptr || atoi(getenv("DPFT_WGRAD16_TILED")) != 0;      // A/B switch
+        int nb;
+        if (tiled) {
+            nb = conv16_wgrad_tiled_blocks(d);
+            Wgrad16TArgs a{x, dy, (float*)workspace, d->B, d->H, d->W, cdiv(d->W, T16W), cdiv(d->H, T16H),
+                           d->B * cdiv(d->H, T16H) * cdiv(d->W, T16W)};
+            hipLaunchKernelGGL(wgrad16_3x3_tiled_kernel, dim3(nb), dim3(256), 0, st, a);
+        } else {
+            nb = conv16_wgrad_blocks(d);
+            Wgrad16Args a{x, dy, (float*)workspace, d->B, d->H, d->W, cdiv(d->W, 4), (long)d->B * d->H * cdiv(d->W, 4)};
+            hipLaunchKernelGGL(wgrad16_3x3_kernel, dim3(nb), dim3(256), 0, st, a);
+        }
         int rc = check_launch("conv16 wgrad");
         if (rc) return rc;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(2304, 16)), dim3(256), 0, st, (const float*)workspace, dw, 2304, nb);

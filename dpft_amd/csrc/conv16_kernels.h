@@ -156,6 +156,117 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_kernel(Wgrad16Args a) {
     }
 }
 
+// LDS-tiled form of the 3x3 16 -> 16 weight gradient (round 3).  The streaming form above loads every operand element as a
+// scalar, once per TAP, with a division chain per pixel group: ~100 vector instructions per 9 MFMAs (240 us = 36 TF on the
+// camera's 512 x 910 level).  Here a block walks 8 x 32-pixel tiles like conv16_3x3_kernel: dy tile and x halo tile are
+// brought into LDS with 16-byte loads (each element read once from memory, 1.14x with the halo), a wave owns two rows of
+// the tile = 16 groups of 4 pixels, and a group costs 10 conflict-free ds_read_b32 (A = dy^T once, B = x at the nine taps)
+// for its nine v_mfma_f32_16x16x4_f32.  Accumulators stay in registers over all tiles of the block; same per-block partial
+// slabs and deterministic reduction as before.
+struct Wgrad16TArgs {
+    const float* x;
+    const float* dy;
+    float* partial;      // [gridDim.x][16][9][16]
+    int B, H, W;
+    int tiles_w, tiles_h;      // ceil(W / 32), ceil(H / 8)
+    int total_tiles;           // B * tiles_h * tiles_w
+};
+
+__global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) {
+    constexpr int XW = T16W + 2, XH = T16H + 2;
+    __shared__ __attribute__((aligned(16))) float tiles[XH * XW * 16 + T16H * T16W * 16];
+    float* const xt = tiles;                      // halo tile of x, zero outside the image
+    float* const yt = tiles + XH * XW * 16;       // dy tile, zero outside the image
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kk = lane >> 4;      // A: row k = col, pixel kk;  B: column c = col, pixel kk
+    f32x4v acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    // The next tile travels global -> registers WHILE this one multiplies (10 independent 16-byte loads per thread in
+    // flight behind ~2 us of MFMAs); loaded one loop trip at a time the tile cost ~10 us of exposed latency.
+    constexpr int XQ = XH * XW * 4, YQ = T16H * T16W * 4;      // 16-byte quads per tile
+    constexpr int XS = (XQ + 255) / 256, YS = YQ / 256;
+    f32x4v rx[XS], ry[YS];
+    auto load_tile = [&](int tile) {
+        const int tw = tile % a.tiles_w;
+        const int rest = tile / a.tiles_w;
+        const int th = rest % a.tiles_h, b = rest / a.tiles_h;
+        const int h0 = th * T16H, w0 = tw * T16W;
+        const float* xb = a.x + (size_t)b * a.H * a.W * 16;
+        const float* yb = a.dy + (size_t)b * a.H * a.W * 16;
+#pragma unroll
+        for (int s_ = 0; s_ < XS; ++s_) {
+            const int i = tid + s_ * 256;
+            const int px = i >> 2, q = i & 3;
+            const int r = px / XW, c = px - r * XW;
+            const int h = h0 + r - 1, w = w0 + c - 1;
+            const bool ok = i < XQ && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(xb + (ok ? ((size_t)h * a.W + w) * 16 + q * 4 : 0));
+            rx[s_] = ok ? v : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < YS; ++s_) {
+            const int i = tid + s_ * 256;
+            const int px = i >> 2, q = i & 3;
+            const int r = px / T16W, c = px - r * T16W;
+            const int h = h0 + r, w = w0 + c;
+            const bool ok = h < a.H && w < a.W;
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(yb + (ok ? ((size_t)h * a.W + w) * 16 + q * 4 : 0));
+            ry[s_] = ok ? v : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < a.total_tiles) load_tile(tile);
+    while (tile < a.total_tiles) {
+        __syncthreads();      // the previous tile's fragments have been read
+#pragma unroll
+        for (int s_ = 0; s_ < XS; ++s_) {
+            const int i = tid + s_ * 256;
+            if (i < XQ) *reinterpret_cast<f32x4v*>(xt + i * 4) = rx[s_];
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < YS; ++s_) *reinterpret_cast<f32x4v*>(yt + (tid + s_ * 256) * 4) = ry[s_];
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < a.total_tiles) load_tile(next);
+        // wave wv: tile rows 2 wv, 2 wv + 1; group g: row 2 wv + g / 8, columns 4 (g % 8) .. + 3; this lane: pixel kk of it
+#pragma unroll 4
+        for (int g = 0; g < 16; ++g) {
+            const int r = wv * 2 + (g >> 3), c = (g & 7) * 4 + kk;
+            const float av = yt[(r * T16W + c) * 16 + col];
+            float bv[9];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) bv[t] = xt[((r + t / 3) * XW + c + t % 3) * 16 + col];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[t], acc[t], 0, 0, 0);
+        }
+        tile = next;
+    }
+    // D[t]: column c = lane % 16, rows k = 4 * (lane / 16) + i.  Reduce the 4 waves, then store the block's slab.
+    __syncthreads();
+    float* red = tiles;      // [3][9 * 256] over both tiles
+    static_assert(3 * 9 * 256 <= XH * XW * 16 + T16H * T16W * 16, "wave reduction does not fit the tiles");
+    if (wv > 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) red[(wv - 1) * 2304 + (t * 4 + i) * 64 + lane] = acc[t][i];
+    }
+    __syncthreads();
+    if (wv == 0) {
+        float* out = a.partial + (size_t)blockIdx.x * 2304;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int e = (t * 4 + i) * 64 + lane;
+                const float s = acc[t][i] + red[e] + red[2304 + e] + red[4608 + e];
+                out[((kk * 4 + i) * 9 + t) * 16 + col] = s;      // [k][tap][c]
+            }
+    }
+}
+
 // 1x1 weight gradient with very few channels: dW[k][c] = sum_p dy[p][k] * x[p][c]; one thread walks a pixel stripe
 template <int K, int C>
 __global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -269,9 +380,13 @@ static int conv16_dgrad(const dpft_conv_desc* d, const float* dy, const float* w
     return check_launch("conv16 dgrad");
 }
 
-static int conv16_wgrad_blocks(const dpft_conv_desc* d) {
+static int conv16_wgrad_blocks(const dpft_conv_desc* d) {      // streaming form; also the workspace bound of both forms
     const long groups = (long)d->B * d->H * cdiv(d->W, 4);
     return (int)std::max<long>(1, std::min<long>(kNumCU * 4, groups / 64));
+}
+static int conv16_wgrad_tiled_blocks(const dpft_conv_desc* d) {
+    const long tiles = (long)d->B * cdiv(d->H, T16H) * cdiv(d->W, T16W);
+    return (int)std::max<long>(1, std::min<long>(std::min<long>(kNumCU * 4, conv16_wgrad_blocks(d)), tiles));
 }
 
 }  // namespace dpft
