@@ -2102,6 +2102,8 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(0, d, st);
     if (conv16_matches(d) && !pro_bn && !stats) return conv16_forward(d, x, w, bias, y, st);
+    static const bool thin_fwd = getenv("DPFT_THIN_FWD") == nullptr || atoi(getenv("DPFT_THIN_FWD")) != 0;      // A/B switch
+    if (thin_fwd && conv1x1_to16_matches(d) && !pro_bn && !stats) return conv1x1_to16_forward(d, x, w, bias, y, st);
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
     a.pro = pro_bn; a.pro_relu = pro_relu;

@@ -865,6 +865,32 @@ def test_conv_bf16_activation_storage(B, H, W, Cin, K, k, stride):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,bias", [(2, 300, 500, 3, True), (1, 512, 910, 3, False), (3, 301, 299, 6, True)])
+def test_conv1x1_to16_streaming_forward(B, H, W, Cin, bias):
+    """The FPN lateral on the raw-input level (1x1, C = 3 / 6 -> 16, >= 256 k pixels: conv1x1_to16_kernel, four lanes per
+    pixel) vs fp64 -- and equal, to the last bit, to the generic implicit-GEMM path it replaces there (DPFT_THIN_FWD=0
+    is a process-wide switch, so the generic result comes from the same problem below the size threshold, tiled up)."""
+    import torch.nn.functional as F
+    from dpft_amd.hip import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B * 7 + Cin)
+    x = torch.randn(B, H, W, Cin, generator=g).to(dev)
+    w = (torch.randn(16, 1, 1, Cin, generator=g) * 0.3).to(dev)
+    b = torch.randn(16, generator=g).to(dev) if bias else None
+    cv = ops.conv_problem(B, H, W, Cin, 16, 1, 1, 1, 0)
+    y, _ = ops.conv_fwd(cv, x, w, bias=b)
+    ref = F.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu().permute(0, 3, 1, 2),
+                   None if b is None else b.double().cpu()).permute(0, 2, 3, 1)
+    err = float((y.double().cpu() - ref).abs().max())
+    assert err < 2e-6 * float(ref.abs().max()) + 1e-6, err
+    # the generic path on a slice that stays below the threshold (1 x 64 x W pixels): same values as the streaming kernel
+    rows = min(H, 262143 // W)
+    cv2 = ops.conv_problem(1, rows, W, Cin, 16, 1, 1, 1, 0)
+    y2, _ = ops.conv_fwd(cv2, x[:1, :rows].contiguous(), w, bias=b)
+    assert float((y2 - y[:1, :rows]).abs().max()) < 1e-6 * float(ref.abs().max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,K,k,stride", [(2, 24, 40, 64, 128, 3, 1), (2, 24, 40, 128, 64, 1, 1), (1, 33, 29, 64, 64, 3, 2),
                                                     (2, 32, 57, 256, 256, 3, 1), (2, 32, 57, 1024, 256, 1, 1), (3, 17, 23, 128, 512, 1, 2),
                                                     (4, 64, 114, 128, 128, 3, 1), (1, 9, 7, 192, 320, 3, 1)])
