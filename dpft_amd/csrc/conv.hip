@@ -1996,6 +1996,19 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(2304, 16)), dim3(256), 0, st, (const float*)workspace, dw, 2304, nb);
         return check_launch("conv16 wgrad reduce");
     }
+    static const bool stem_tiled = getenv("DPFT_WGRAD_STEM") == nullptr || atoi(getenv("DPFT_WGRAD_STEM")) != 0;      // A/B switch
+    if (stem_tiled && wgrad_stem7_matches(d)) {
+        handled = true;
+        const int tw = cdiv(d->OW, STEM_OW), th = cdiv(d->OH, STEM_OH);
+        const int tiles = d->B * th * tw;
+        const int nb = std::max(1, std::min(kNumCU * 2, tiles));      // (<= 512 slabs: the workspace bound of the pixel-split path)
+        WgradStemArgs a{x, dy, (float*)workspace, d->B, d->H, d->W, d->OH, d->OW, tw, th, tiles};
+        hipLaunchKernelGGL(wgrad_stem7_kernel, dim3(nb), dim3(256), 0, st, a);
+        int rc = check_launch("stem wgrad");
+        if (rc) return rc;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv(64 * 147, 16)), dim3(256), 0, st, (const float*)workspace, dw, 64 * 147, nb);
+        return check_launch("stem wgrad reduce");
+    }
     if (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0) {
         const long M = (long)d->B * d->H * d->W;
         const int nb = (int)std::max<long>(1, std::min<long>(kNumCU * 2, M / 1024));

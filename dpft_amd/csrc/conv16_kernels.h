@@ -267,6 +267,160 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) 
     }
 }
 
+// Weight gradient of the ResNet stem (7x7, stride 2, pad 3, 3 -> 64): dW[k][n] = sum_pixels dy[p][k] * patch(p)[n], n = (r, s, c)
+// flattened = 147 columns.  The generic gather kernel runs it at 38 TF (227 us on the camera's 4 x 512 x 910 input).  LDS-tiled
+// like wgrad16_3x3_tiled_kernel: a block walks 4 x 16-pixel output tiles; the dy tile (64 pixels x 64 channels) and the
+// 13 x 37-pixel input tile go to LDS (the next tile is prefetched into registers while this one multiplies).  For a fixed
+// filter row r the 21 values (s, c) an output pixel needs are CONTIGUOUS in the input row (element 6 ow + 3 s + c), so the
+// B operand of v_mfma_f32_16x16x4_f32 is one ds_read_b32 at  pixel base + column offset  with a per-lane constant offset
+// (147 columns padded to 160: 10 column blocks x 4 channel blocks = 40 accumulators per wave, 92 % useful MFMAs).  A wave
+// owns one output row of the tile (4 groups of 4 pixels) and the full 64 x 160 result; waves are summed through LDS at the
+// end; per-block slabs + the deterministic reduction as everywhere.
+struct WgradStemArgs {
+    const float* x;      // (B,H,W,3)
+    const float* dy;     // (B,OH,OW,64)
+    float* partial;      // [gridDim.x][64][147]
+    int B, H, W, OH, OW;
+    int tiles_w, tiles_h, total_tiles;
+};
+
+constexpr int STEM_OH = 4, STEM_OW = 16, STEM_IH = 2 * STEM_OH + 5, STEM_IW = 2 * STEM_OW + 5, STEM_ROW = 112;
+
+__global__ __launch_bounds__(256) void wgrad_stem7_kernel(WgradStemArgs a) {
+    constexpr int XN = STEM_IH * STEM_ROW;             // x tile floats (rows padded 111 -> 112)
+    constexpr int YN = STEM_OH * STEM_OW * 64;         // dy tile floats
+    constexpr int RED = 40 * 256;                      // one wave's accumulators
+    __shared__ __attribute__((aligned(16))) float sm[RED > XN + YN ? RED : XN + YN];
+    float* const xt = sm;
+    float* const yt = sm + XN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int col = lane & 15, kk = lane >> 4;
+    // column n = nb * 16 + col of the flattened (r, s, c) axis -> offset of its first element relative to the pixel base
+    int coloff[10];
+    bool colok[10];
+#pragma unroll
+    for (int nb = 0; nb < 10; ++nb) {
+        const int n = nb * 16 + col;
+        colok[nb] = n < 147;
+        const int r = n / 21, rem = n - r * 21;
+        coloff[nb] = colok[nb] ? r * STEM_ROW + rem : 0;
+    }
+    f32x4v acc[4][10];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 10; ++j) acc[i][j] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    constexpr int XS = (STEM_IH * 111 + 255) / 256, YS = YN / 4 / 256;
+    float rx[XS];
+    f32x4v ry[YS];
+    auto load_tile = [&](int tile) {
+        const int tw = tile % a.tiles_w;
+        const int rest = tile / a.tiles_w;
+        const int th = rest % a.tiles_h, b = rest / a.tiles_h;
+        const int oh0 = th * STEM_OH, ow0 = tw * STEM_OW;
+        const float* xb = a.x + (size_t)b * a.H * a.W * 3;
+        const float* yb = a.dy + (size_t)b * a.OH * a.OW * 64;
+#pragma unroll
+        for (int s_ = 0; s_ < XS; ++s_) {
+            const int i = tid + s_ * 256;
+            const int r = i / 111, e = i - r * 111;      // input row of the tile, element (w, c) of the row
+            const int h = 2 * oh0 - 3 + r, w = 2 * ow0 - 3 + e / 3;
+            const bool ok = i < STEM_IH * 111 && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+            const float v = xb[ok ? ((size_t)h * a.W + w) * 3 + e % 3 : 0];
+            rx[s_] = ok ? v : 0.f;
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < YS; ++s_) {
+            const int i = tid + s_ * 256;
+            const int px = i >> 4, q = i & 15;
+            const int oh = oh0 + px / STEM_OW, ow = ow0 + px % STEM_OW;
+            const bool ok = oh < a.OH && ow < a.OW;
+            const f32x4v v = *reinterpret_cast<const f32x4v*>(yb + (ok ? ((size_t)oh * a.OW + ow) * 64 + q * 4 : 0));
+            ry[s_] = ok ? v : f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    int tile = blockIdx.x;
+    if (tile < a.total_tiles) load_tile(tile);
+    while (tile < a.total_tiles) {
+        __syncthreads();      // the previous tile's fragments have been read
+#pragma unroll
+        for (int s_ = 0; s_ < XS; ++s_) {
+            const int i = tid + s_ * 256;
+            if (i < STEM_IH * 111) {
+                const int r = i / 111, e = i - r * 111;
+                xt[r * STEM_ROW + e] = rx[s_];
+            }
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < YS; ++s_) *reinterpret_cast<f32x4v*>(yt + (tid + s_ * 256) * 4) = ry[s_];
+        __syncthreads();
+        const int next = tile + gridDim.x;
+        if (next < a.total_tiles) load_tile(next);
+        // wave wv: output row wv of the tile; group g: columns 4 g .. 4 g + 3; this lane: pixel kk of the group
+#pragma unroll 1
+        for (int g = 0; g < 4; ++g) {
+            const int px = wv * STEM_OW + g * 4 + kk;
+            const int base = 2 * wv * STEM_ROW + 6 * (g * 4 + kk);
+            float av[4], bv[10];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) av[i] = yt[px * 64 + i * 16 + col];
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const float t = xt[base + coloff[j]];
+                bv[j] = colok[j] ? t : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 10; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+        tile = next;
+    }
+    // acc[i][j][e]: channel k = 16 i + 4 (lane / 16) + e, column n = 16 j + lane % 16.  Sum the waves (one at a time
+    // through LDS: 40 KB), then wave 0 stores the block's slab [64][147].
+    for (int w = 1; w < 4; ++w) {
+        __syncthreads();
+        if (wv == w) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) sm[((i * 10 + j) * 4 + e) * 64 + lane] = acc[i][j][e];
+        }
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 10; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][e] += sm[((i * 10 + j) * 4 + e) * 64 + lane];
+        }
+    }
+    if (wv == 0) {
+        float* out = a.partial + (size_t)blockIdx.x * (64 * 147);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 10; ++j) {
+                const int n = j * 16 + col;
+                if (n < 147) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[(i * 16 + kk * 4 + e) * 147 + n] = acc[i][j][e];
+                }
+            }
+    }
+}
+
+static bool wgrad_stem7_matches(const dpft_conv_desc* d) {
+    // (each block ends with a 3-round wave reduction and a 37 KB slab: worth it from ~8 tiles per block on -- the radar stems,
+    // 27 k output pixels, stay with the generic kernel: 26.6 vs 37.0 us)
+    return d->kh == 7 && d->kw == 7 && d->stride == 2 && d->pad == 3 && d->C == 3 && d->K == 64 && !d->act16 &&
+           (int64_t)d->B * d->OH * d->OW >= 131072;
+}
+
 // 1x1 weight gradient with very few channels: dW[k][c] = sum_p dy[p][k] * x[p][c]; one thread walks a pixel stripe
 template <int K, int C>
 __global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ dy,

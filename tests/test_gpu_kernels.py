@@ -39,6 +39,7 @@ CONV_CASES = [
     (4, 64, 114, 128, 128, 3, 2, 1),    # stride 2 on a big map: one dgrad launch per pixel parity class
     (4, 64, 114, 256, 512, 1, 2, 0),    # 1x1 stride 2 on a big map: parity classes with empty ones (memset)
     (4, 256, 107, 3, 64, 7, 2, 3),      # radar BEV stem at its real size: thin-input dgrad kernel
+    (2, 333, 821, 3, 64, 7, 2, 3),      # stem over >= 128 k output pixels: LDS-tiled weight gradient (wgrad_stem7_kernel), ragged tiles
     (2, 20, 17, 2, 32, 5, 3, 2),        # thin-input dgrad, stride 3, two input channels
 ]
 
