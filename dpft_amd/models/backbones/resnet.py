@@ -319,16 +319,20 @@ class BackboneBase(nn.Module):
         return p
 
     def use_plan_graphs(self, plan: "_Plan") -> bool:
-        """hipGraph replay of this plan's launch sequences (DPFT_PLAN_GRAPHS, default on): taken for an encoder whose
-        weight-gradient stream is the stream it runs on (the small views under DPRT._place_streams) -- such a backward is a
-        single-stream sequence; the camera encoder keeps eager launches (its weight gradients need their own hardware
-        queue, which a graph's internal branches do not guarantee)."""
+        """hipGraph replay of this plan's launch sequences (DPFT_PLAN_GRAPHS: 0 off | 1 small views only | 2 default).  An
+        encoder whose weight-gradient stream is the stream it runs on (the small views under DPRT._place_streams) has a
+        single-stream backward: train forward and every backward stage are replayed.  The camera encoder's weight
+        gradients need their own hardware queue, which a graph's internal branches do not guarantee: its backward stages
+        stay eager launches, its train forward (single-stream, ~350 launches) is replayed (2)."""
         if plan.graphed:
             return True
         import os as _os
-        if _os.environ.get("DPFT_PLAN_GRAPHS", "1") == "0" or self.side_stream is None:
+        if _os.environ.get("DPFT_PLAN_GRAPHS", "2") == "0" or self.side_stream is None:
             return False
-        if self.side_stream.cuda_stream != torch.cuda.current_stream().cuda_stream or self.side_stream.cuda_stream == 0:
+        own = self.side_stream.cuda_stream == torch.cuda.current_stream().cuda_stream and self.side_stream.cuda_stream != 0
+        # an encoder with its weight gradients on ANOTHER stream (the camera): its train forward is still a single-stream
+        # sequence and is replayed; the C side (run_graphed) keeps such a plan's backward stages eager
+        if not own and _os.environ.get("DPFT_PLAN_GRAPHS", "2") != "2":
             return False
         lib.call("dpft_resnet_plan_set_graph", plan.handle, 1)
         plan.graphed = True
