@@ -82,10 +82,16 @@ struct TransposeBatch {      // [K][taps][C] -> [C][taps][K] of up to MAX weight
     int blk_start[MAX + 1];
     int n;
     int mode = 0;      // 0: transposed fp32 copy; 1: transposed, rounded to bf16; 2: rounded to bf16 in place order (no transpose)
+    // tile edge of the launch: 64 (16-byte accesses on both sides, 256-byte row segments) for the tensors of a ResNet body
+    // (K, C multiples of 64); the caller flushes the batch when a tensor that needs the 32-wide form arrives (fits())
+    int tile = 0;
+    static int tile_of(int k, int c) { return (k % 64 == 0 && c % 64 == 0) ? 64 : 32; }
+    bool fits(int k, int c) const { return n == 0 || tile == tile_of(k, c); }
     void add(const float* src, float* dst, int k, int t, int c) {
+        if (n == 0) tile = tile_of(k, c);
         w[n] = src; wt[n] = dst; K[n] = k; taps[n] = t; C[n] = c;
         if (n == 0) blk_start[0] = 0;
-        blk_start[n + 1] = blk_start[n] + ((c + 31) / 32) * ((k + 31) / 32) * t;
+        blk_start[n + 1] = blk_start[n] + ((c + tile - 1) / tile) * ((k + tile - 1) / tile) * t;
         ++n;
     }
 };

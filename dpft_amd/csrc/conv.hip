@@ -1666,6 +1666,48 @@ __global__ void weight_transpose_kernel(const float* __restrict__ w, float* __re
     }
 }
 
+// 64 x 64 tiles (all K, C of the batch multiples of 64): float4 reads along c, float4 writes along k (bf16: 8-byte writes),
+// the transposition through a 65-float-pitch LDS tile -- 256-byte row segments on both sides instead of 128-byte ones and a
+// quarter of the blocks (0.45 -> 0.25 ms per step for the 44.5 M camera weights)
+__global__ __launch_bounds__(256) void weight_transpose_batch64_kernel(TransposeBatch tb) {
+    __shared__ float tile[64 * 65];
+    int i = 0;
+    while (i + 1 < tb.n && (int)blockIdx.x >= tb.blk_start[i + 1]) ++i;      // wave-uniform scan (n <= 80)
+    const int K = tb.K[i], taps = tb.taps[i], C = tb.C[i];
+    const float* __restrict__ w = tb.w[i];
+    float* __restrict__ wt = tb.wt[i];
+    int rel = blockIdx.x - tb.blk_start[i];
+    const int cb = C / 64, kb = K / 64;
+    const int tap = rel / (cb * kb);
+    rel -= tap * cb * kb;
+    const int k0 = (rel / cb) * 64, c0 = (rel % cb) * 64;
+    const int q = threadIdx.x & 15, r = threadIdx.x >> 4;      // 16 quads per row x 16 rows per pass
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int k = r + p * 16;
+        const size_t idx = ((size_t)(k0 + k) * taps + tap) * C + c0 + q * 4;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(w + idx);
+        if (tb.mode == 2) {
+            *reinterpret_cast<bf16x4s*>(reinterpret_cast<__bf16*>(wt) + idx) = __builtin_convertvector(v, bf16x4s);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) tile[k * 65 + q * 4 + e] = v[e];
+        }
+    }
+    if (tb.mode == 2) return;
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int c = r + p * 16;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[(q * 4 + e) * 65 + c];
+        const size_t o = ((size_t)(c0 + c) * taps + tap) * K + k0 + q * 4;
+        if (tb.mode == 1) *reinterpret_cast<bf16x4s*>(reinterpret_cast<__bf16*>(wt) + o) = __builtin_convertvector(v, bf16x4s);
+        else *reinterpret_cast<f32x4*>(wt + o) = v;
+    }
+}
+
 // the same for up to 80 weight tensors in ONE launch (a ResNet stage's convs: 236 launches of ~5 us per step otherwise)
 __global__ void weight_transpose_batch_kernel(TransposeBatch tb) {
     __shared__ float tile[32][33];
@@ -2478,7 +2520,8 @@ extern "C" int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, 
 
 int dpft::weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream) {
     DPFT_REQUIRE(tb.n >= 1 && tb.n <= TransposeBatch::MAX, "weight_transpose_batch: 1..%d tensors", TransposeBatch::MAX);
-    hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(tb.blk_start[tb.n]), dim3(256), 0, (hipStream_t)stream, tb);
+    if (tb.tile == 64) hipLaunchKernelGGL(weight_transpose_batch64_kernel, dim3(tb.blk_start[tb.n]), dim3(256), 0, (hipStream_t)stream, tb);
+    else hipLaunchKernelGGL(weight_transpose_batch_kernel, dim3(tb.blk_start[tb.n]), dim3(256), 0, (hipStream_t)stream, tb);
     return check_launch("weight_transpose_batch");
 }
 

@@ -427,6 +427,10 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
             const ConvRef* cs[4] = {&b.c1, &b.c2, &b.c3, b.has_ds ? &b.cd : nullptr};
             for (const ConvRef* c : cs) {
                 if (!c) continue;
+                if (!tb.fits(c->d.K, c->d.C)) {
+                    RC(weight_transpose_batch(tb, st));
+                    tb.n = 0;
+                }
                 tb.add(T.w(c->w), A + c->w16, c->d.K, c->d.kh * c->d.kw, c->d.C);
                 if (tb.n == TransposeBatch::MAX) {
                     RC(weight_transpose_batch(tb, st));
@@ -564,6 +568,10 @@ struct SideCtx {
             const ConvRef* cs[4] = {&b.c3, &b.c2, &b.c1, b.has_ds ? &b.cd : nullptr};
             for (const ConvRef* c : cs) {
                 if (!c) continue;
+                if (!tb.fits(c->d.K, c->d.C)) {      // (tile edge of a launch: 64 or 32, common.h)
+                    RC(weight_transpose_batch(tb, (dpft_stream_t)ts));
+                    tb.n = 0;
+                }
                 tb.add(T.w(c->w), wt_base + c->wt, c->d.K, c->d.kh * c->d.kw, c->d.C);
                 if (tb.n == TransposeBatch::MAX) {
                     RC(weight_transpose_batch(tb, (dpft_stream_t)ts));
