@@ -117,7 +117,11 @@ PY
 # (7) radar tesseract projection
 bash /root/repo/tools/radar_prof.sh > $OUT/r03_radar_projection.txt 2>&1
 # (7b) the RCCL path on one rank: forced collectives (line carries rccl_ranks 1, collectives_forced true)
-timeout 900 python /root/repo/bench.py --gpus 1 --force-collectives --no-cpu-baseline --latency-reps 20 > $OUT/r03_bench_forced_collectives.json 2> $OUT/r03_bench_forced.err
+# (30 timed steps each, plain and forced back to back in the same call: the 10-step default is too short for a 2 % comparison)
+timeout 900 python /root/repo/bench.py --gpus 1 --steps 30 --warmup 8 --no-cpu-baseline --latency-reps 20 > $OUT/r03_bench_plain_30steps_1.json 2> $OUT/r03_bench_forced.err
+timeout 900 python /root/repo/bench.py --gpus 1 --steps 30 --warmup 8 --force-collectives --no-cpu-baseline --latency-reps 20 > $OUT/r03_bench_forced_collectives_1.json 2>> $OUT/r03_bench_forced.err
+timeout 900 python /root/repo/bench.py --gpus 1 --steps 30 --warmup 8 --no-cpu-baseline --latency-reps 20 > $OUT/r03_bench_plain_30steps_2.json 2>> $OUT/r03_bench_forced.err
+timeout 900 python /root/repo/bench.py --gpus 1 --steps 30 --warmup 8 --force-collectives --no-cpu-baseline --latency-reps 20 > $OUT/r03_bench_forced_collectives_2.json 2>> $OUT/r03_bench_forced.err
 # (8) the default bench line of this state
 DPFT_CONV_TABLE=$OUT/r03_conv_table_fp32.txt timeout 900 python /root/repo/bench.py > $OUT/r03_bench.json 2> $OUT/r03_bench.err
 tail -2 $OUT/r03_serial.log; grep "ms/step" $OUT/r03_plain.log; grep decoder_fwd $OUT/r03_decoder.log; head -c 600 $OUT/r03_roofline_from_rocprof.json
