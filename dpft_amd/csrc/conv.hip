@@ -2518,6 +2518,24 @@ extern "C" int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, 
     return check_launch("weight_transpose");
 }
 
+extern "C" int dpft_weight_transpose_batch_f32(int32_t n, const float* const* w, float* const* w_t, const int32_t* K,
+                                               const int32_t* taps, const int32_t* C, dpft_stream_t stream) {
+    DPFT_REQUIRE(n >= 1 && n <= dpft::TransposeBatch::MAX && w && w_t && K && taps && C, "weight_transpose_batch: 1..80 tensors");
+    dpft::TransposeBatch tb;
+    tb.n = 0;
+    tb.mode = 0;
+    for (int i = 0; i < n; ++i) {
+        DPFT_REQUIRE(w[i] && w_t[i] && K[i] > 0 && taps[i] > 0 && C[i] > 0, "weight_transpose_batch: bad entry %d", i);
+        if (!tb.fits(K[i], C[i])) {      // tile edge of a launch (64 / 32): a second launch for the other kind
+            int rc = dpft::weight_transpose_batch(tb, stream);
+            if (rc) return rc;
+            tb.n = 0;
+        }
+        tb.add(w[i], w_t[i], K[i], taps[i], C[i]);
+    }
+    return dpft::weight_transpose_batch(tb, stream);
+}
+
 int dpft::weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream) {
     DPFT_REQUIRE(tb.n >= 1 && tb.n <= TransposeBatch::MAX, "weight_transpose_batch: 1..%d tensors", TransposeBatch::MAX);
     if (tb.tile == 64) hipLaunchKernelGGL(weight_transpose_batch64_kernel, dim3(tb.blk_start[tb.n]), dim3(256), 0, (hipStream_t)stream, tb);

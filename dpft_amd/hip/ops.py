@@ -142,6 +142,27 @@ def weight_transpose(w_khwc: torch.Tensor) -> torch.Tensor:
     return wt
 
 
+def weight_transpose_many(ws) -> list:
+    """``weight_transpose`` of up to 80 [K][kh][kw][C] weights in one launch (one flat buffer behind the results)."""
+    ws = list(ws)
+    n = len(ws)
+    sizes = [w.numel() for w in ws]
+    flat = torch.empty(sum(sizes), dtype=torch.float32, device=ws[0].device)
+    outs, off = [], 0
+    for w, sz in zip(ws, sizes):
+        K, kh, kw, Cin = w.shape
+        outs.append(flat[off:off + sz].view(Cin, kh, kw, K))
+        off += sz
+    src = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    dst = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    Ks = (C.c_int32 * n)(*[w.shape[0] for w in ws])
+    taps = (C.c_int32 * n)(*[w.shape[1] * w.shape[2] for w in ws])
+    Cs = (C.c_int32 * n)(*[w.shape[3] for w in ws])
+    lib.call("dpft_weight_transpose_batch_f32", n, C.cast(src, C.c_void_p), C.cast(dst, C.c_void_p), C.cast(Ks, C.c_void_p),
+             C.cast(taps, C.c_void_p), C.cast(Cs, C.c_void_p), stream())
+    return outs
+
+
 def bias_grad(dy: torch.Tensor, out=None) -> torch.Tensor:
     K = dy.shape[-1]
     db = out if out is not None else torch.empty((K,), dtype=torch.float32, device=dy.device)

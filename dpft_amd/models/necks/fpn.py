@@ -77,6 +77,10 @@ class _FPNFn(torch.autograd.Function):
                 grads[conv.weight] = ops.conv_wgrad(cv, x, dy).permute(0, 3, 1, 2)
                 grads[conv.bias] = ops.bias_grad(dy)
 
+        # the data gradients' transposed weights of all convs of this pyramid in one launch (they were 2 n launches)
+        need = [fpn.layer_blocks[i][0] for i in range(n) if douts[i] is not None] + \
+               [fpn.inner_blocks[i][0] for i in range(n) if ctx.x_needs[i]]
+        wts = dict(zip(need, ops.weight_transpose_many([khwc(c.weight) for c in need]))) if need else {}
         dxs: List[Optional[torch.Tensor]] = [None] * n
         g_prev = None
         for i in range(n):
@@ -89,13 +93,13 @@ class _FPNFn(torch.autograd.Function):
             else:
                 do = douts[i].contiguous()
                 wgrad(cl[i], lasts[i], do, conv)
-                g = ops.conv_dgrad(cl[i], do, ops.weight_transpose(khwc(conv.weight)))
+                g = ops.conv_dgrad(cl[i], do, wts[conv])
             if g_prev is not None:
                 ops.fpn_topdown_add_bwd_(g_prev, g)       # grad(last_i) += upsample_bwd(grad(last_{i-1}))
             conv = fpn.inner_blocks[i][0]
             wgrad(ci[i], xs[i], g, conv)
             if ctx.x_needs[i]:
-                dxs[i] = ops.conv_dgrad(ci[i], g, ops.weight_transpose(khwc(conv.weight)))
+                dxs[i] = ops.conv_dgrad(ci[i], g, wts[conv])
             g_prev = g
         if direct is not None:
             direct.mark_ready_many(list(fpn.parameters()))

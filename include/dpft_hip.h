@@ -112,6 +112,10 @@ int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const fl
 /* [K][taps][C] -> [C][taps][K] */
 int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, int32_t taps, int32_t C,
                               dpft_stream_t stream);
+/* The same for n (<= 80) weight tensors in ONE launch: w[i] is [K[i]][taps[i]][C[i]], w_t[i] receives [C[i]][taps[i]][K[i]]
+ * (an FPN's ten convs per backward, `necks/fpn.py:39-43`; pointer / size arrays live on the host). */
+int dpft_weight_transpose_batch_f32(int32_t n, const float* const* w, float* const* w_t, const int32_t* K,
+                                    const int32_t* taps, const int32_t* C, dpft_stream_t stream);
 /* db[K] = sum over rows of dy[M][K] */
 int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K, dpft_stream_t stream);
 
