@@ -2015,9 +2015,11 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
 namespace dpft {
 
 // thin-channel fast paths (conv16_kernels.h); `handled` tells the caller whether the launch was taken
+// `db` (may be null): also wanted -- the bias gradient sum_p dy[p][k]; *bias_done tells whether the launch carried it
 static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, float* dw, void* workspace,
-                      hipStream_t st, bool& handled) {
+                      hipStream_t st, bool& handled, float* db = nullptr, bool* bias_done = nullptr) {
     handled = false;
+    if (bias_done) *bias_done = false;
     if (!workspace) return DPFT_OK;
     if (conv16_matches(d)) {
         handled = true;
@@ -2026,8 +2028,16 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
         if (tiled) {
             nb = conv16_wgrad_tiled_blocks(d);
             Wgrad16TArgs a{x, dy, (float*)workspace, d->B, d->H, d->W, cdiv(d->W, T16W), cdiv(d->H, T16H),
-                           d->B * cdiv(d->H, T16H) * cdiv(d->W, T16W)};
+                           d->B * cdiv(d->H, T16H) * cdiv(d->W, T16W), db ? 1 : 0};
             hipLaunchKernelGGL(wgrad16_3x3_tiled_kernel, dim3(nb), dim3(256), 0, st, a);
+            if (db) {
+                int rc = check_launch("conv16 wgrad");
+                if (rc) return rc;
+                hipLaunchKernelGGL(slab_reduce_bias_kernel, dim3(cdiv(2320, 16)), dim3(256), 0, st, (const float*)workspace, dw, db,
+                                   2320, nb, 0, 2304);
+                *bias_done = true;
+                return check_launch("conv16 wgrad + bias reduce");
+            }
         } else {
             nb = conv16_wgrad_blocks(d);
             Wgrad16Args a{x, dy, (float*)workspace, d->B, d->H, d->W, cdiv(d->W, 4), (long)d->B * d->H * cdiv(d->W, 4)};
@@ -2062,6 +2072,17 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
     }
         if (d->K == 16 && (d->C == 3 || d->C == 6)) {
             handled = true;
+            if (db) {      // bias gradient as a virtual input channel of ones
+                if (d->C == 3) hipLaunchKernelGGL((wgrad1x1_k16_kernel<3, true>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M);
+                else hipLaunchKernelGGL((wgrad1x1_k16_kernel<6, true>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M);
+                int rc = check_launch("thin 1x1 wgrad");
+                if (rc) return rc;
+                const int cols = d->C + 1;
+                hipLaunchKernelGGL(slab_reduce_bias_kernel, dim3(cdiv(16 * cols, 16)), dim3(256), 0, st, (const float*)workspace, dw, db,
+                                   16 * cols, nb, cols, 0);
+                *bias_done = true;
+                return check_launch("thin 1x1 wgrad + bias reduce");
+            }
             if (d->C == 3) hipLaunchKernelGGL((wgrad1x1_k16_kernel<3>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M);
             else hipLaunchKernelGGL((wgrad1x1_k16_kernel<6>), dim3(nb), dim3(256), 0, st, x, dy, (float*)workspace, M);
         } else THIN_1X1(3, 6)
@@ -2101,8 +2122,8 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
     if (check_desc(d) != DPFT_OK) return -1;
     // worst case over fwd / dgrad / wgrad split-K partials
     int64_t best = 0;
-    if (conv16_matches(d)) best = std::max<int64_t>(best, (int64_t)conv16_wgrad_blocks(d) * 2304 * 4);
-    if (d->kh == 1 && d->kw == 1 && d->K <= 16 && d->C <= 8) best = std::max<int64_t>(best, (int64_t)kNumCU * 2 * d->K * d->C * 4);
+    if (conv16_matches(d)) best = std::max<int64_t>(best, (int64_t)conv16_wgrad_blocks(d) * 2320 * 4);      // (+ bias column sums)
+    if (d->kh == 1 && d->kw == 1 && d->K <= 16 && d->C <= 8) best = std::max<int64_t>(best, (int64_t)kNumCU * 2 * d->K * (d->C + 1) * 4);
     {
         IgemmArgs a; fill_igemm(a, d, false);
         TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
@@ -2568,6 +2589,29 @@ extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t
     int blocks = (int)std::min<int64_t>(1024, (M + rpi - 1) / rpi);
     hipLaunchKernelGGL(bias_grad_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, M, K);
     return check_launch("bias_grad");
+}
+
+// Weight gradient AND bias gradient of a conv with bias (the FPN's convs): one pass over dy where the weight-gradient kernel
+// has dy at hand (3x3 16 -> 16, thin 1x1 -> 16), the two separate launches otherwise.  Same results either way.
+extern "C" int dpft_conv2d_nhwc_wgrad_bias_f32(const dpft_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                                               void* workspace, dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(x && dy && dw && db, "conv wgrad_bias: null tensor");
+    static const bool fuse = getenv("DPFT_BIAS_FUSE") == nullptr || atoi(getenv("DPFT_BIAS_FUSE")) != 0;      // A/B switch
+    const bool fusable = dpft::conv16_matches(d) ||
+                         (d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->K == 16 && (d->C == 3 || d->C == 6));
+    if (fuse && fusable && workspace && !d->act16) {
+        dpft::ProfScope prof(2, d, (hipStream_t)stream);
+        bool handled = false, bias_done = false;
+        rc = dpft::thin_wgrad(d, x, dy, dw, workspace, (hipStream_t)stream, handled, db, &bias_done);
+        if (rc) return rc;
+        if (handled && bias_done) return DPFT_OK;
+        if (handled) return dpft_bias_grad_f32(dy, db, (int64_t)d->B * d->OH * d->OW, d->K, stream);
+    }
+    rc = dpft_conv2d_nhwc_wgrad_f32(d, x, dy, nullptr, 0, dw, workspace, stream);
+    if (rc) return rc;
+    return dpft_bias_grad_f32(dy, db, (int64_t)d->B * d->OH * d->OW, d->K, stream);
 }
 
 static float g_prof_overhead_ms = 0.f;      // elapsed time of an EMPTY event bracket (subtracted from every record)

@@ -166,10 +166,11 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_kernel(Wgrad16Args a) {
 struct Wgrad16TArgs {
     const float* x;
     const float* dy;
-    float* partial;      // [gridDim.x][16][9][16]
+    float* partial;      // [gridDim.x][16][9][16] (+ [16] column sums of dy behind each slab when `bias` is set: slabs of 2320)
     int B, H, W;
     int tiles_w, tiles_h;      // ceil(W / 32), ceil(H / 8)
     int total_tiles;           // B * tiles_h * tiles_w
+    int bias;                  // also produce sum_p dy[p][k] (the conv's bias gradient: dy is in LDS anyway)
 };
 
 __global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) {
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) 
     f32x4v acc[9];
 #pragma unroll
     for (int t = 0; t < 9; ++t) acc[t] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;      // sum of dy[.][col] over this lane's pixels
     // The next tile travels global -> registers WHILE this one multiplies (10 independent 16-byte loads per thread in
     // flight behind ~2 us of MFMAs); loaded one loop trip at a time the tile cost ~10 us of exposed latency.
     constexpr int XQ = XH * XW * 4, YQ = T16H * T16W * 4;      // 16-byte quads per tile
@@ -235,6 +237,7 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) 
         for (int g = 0; g < 16; ++g) {
             const int r = wv * 2 + (g >> 3), c = (g & 7) * 4 + kk;
             const float av = yt[(r * T16W + c) * 16 + col];
+            bsum += av;
             float bv[9];
 #pragma unroll
             for (int t = 0; t < 9; ++t) bv[t] = xt[((r + t / 3) * XW + c + t % 3) * 16 + col];
@@ -254,8 +257,9 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) 
             for (int i = 0; i < 4; ++i) red[(wv - 1) * 2304 + (t * 4 + i) * 64 + lane] = acc[t][i];
     }
     __syncthreads();
+    const int slab = a.bias ? 2320 : 2304;
     if (wv == 0) {
-        float* out = a.partial + (size_t)blockIdx.x * 2304;
+        float* out = a.partial + (size_t)blockIdx.x * slab;
 #pragma unroll
         for (int t = 0; t < 9; ++t)
 #pragma unroll
@@ -264,6 +268,14 @@ __global__ __launch_bounds__(256) void wgrad16_3x3_tiled_kernel(Wgrad16TArgs a) 
                 const float s = acc[t][i] + red[e] + red[2304 + e] + red[4608 + e];
                 out[((kk * 4 + i) * 9 + t) * 16 + col] = s;      // [k][tap][c]
             }
+    }
+    if (a.bias) {      // column sums of dy: the four pixel lanes of a column, then the four waves (fixed order)
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        __syncthreads();      // the wave reduction above has been read
+        if (lane < 16) red[wv * 16 + lane] = bsum;
+        __syncthreads();
+        if (tid < 16) a.partial[(size_t)blockIdx.x * slab + 2304 + tid] = red[tid] + red[16 + tid] + red[32 + tid] + red[48 + tid];
     }
 }
 
@@ -461,39 +473,68 @@ __global__ __launch_bounds__(256) void wgrad1x1_small_kernel(const float* __rest
 // K = 16 variant with coalesced operand reads: 4 lanes per pixel, each owns 4 consecutive output channels (one 16-byte
 // load of dy) and all C input channels; 64 pixels per block iteration.  (One thread per pixel made every dy load
 // instruction touch 64 cache lines: 290 us for the camera's raw-input lateral instead of ~40.)
-template <int C>
+// BIAS: a virtual input channel of ones -- partial slabs are [16][C + 1], column C = sum_p dy[p][k] (the bias gradient)
+template <int C, bool BIAS = false>
 __global__ __launch_bounds__(256) void wgrad1x1_k16_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             float* __restrict__ partial, long M) {
-    __shared__ float red[4][16 * C];
+    constexpr int CC = C + (BIAS ? 1 : 0);
+    __shared__ float red[4][16 * CC];
     const int tid = threadIdx.x, kq = tid & 3, pl = tid >> 2;
-    float acc[4][C];
+    float acc[4][CC];
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc[e][c] = 0.f;
+        for (int c = 0; c < CC; ++c) acc[e][c] = 0.f;
     for (long p = (long)blockIdx.x * 64 + pl; p < M; p += (long)gridDim.x * 64) {
         const f32x4v d4 = *reinterpret_cast<const f32x4v*>(dy + p * 16 + kq * 4);
-        float xv[C];
+        float xv[CC];
 #pragma unroll
         for (int c = 0; c < C; ++c) xv[c] = x[p * C + c];
+        if (BIAS) xv[CC - 1] = 1.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e)
 #pragma unroll
-            for (int c = 0; c < C; ++c) acc[e][c] = fmaf(d4[e], xv[c], acc[e][c]);
+            for (int c = 0; c < CC; ++c) acc[e][c] = c < C ? fmaf(d4[e], xv[c], acc[e][c]) : acc[e][c] + d4[e];
     }
     const int lane = tid & 63, wv = tid >> 6;
 #pragma unroll
     for (int e = 0; e < 4; ++e)
 #pragma unroll
-        for (int c = 0; c < C; ++c) {
+        for (int c = 0; c < CC; ++c) {
             float v = acc[e][c];
 #pragma unroll
             for (int o = 4; o < 64; o <<= 1) v += __shfl_xor(v, o);      // lanes with the same kq
-            if (lane < 4) red[wv][(lane * 4 + e) * C + c] = v;
+            if (lane < 4) red[wv][(lane * 4 + e) * CC + c] = v;
         }
     __syncthreads();
-    if (tid < 16 * C)
-        partial[(size_t)blockIdx.x * 16 * C + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+    if (tid < 16 * CC)
+        partial[(size_t)blockIdx.x * 16 * CC + tid] = red[0][tid] + red[1][tid] + red[2][tid] + red[3][tid];
+}
+
+// slab reduction of a weight gradient whose slabs carry the bias gradient as well: rows of `cols` floats, the first
+// `cols - 1` (or, tail form, the first `split`) belong to dw, the rest to db
+__global__ __launch_bounds__(256) void slab_reduce_bias_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                               float* __restrict__ db, int MN, int slabs, int cols, int split) {
+    const int j = blockIdx.x * 16 + (threadIdx.x & 15), part = threadIdx.x >> 4;
+    float s = 0.f;
+    if (j < MN)
+        for (int k = part; k < slabs; k += 16) s += partial[(size_t)k * MN + j];
+    s += __shfl_xor(s, 16);
+    s += __shfl_xor(s, 32);
+    __shared__ float red[4][16];
+    if ((threadIdx.x & 63) < 16) red[threadIdx.x >> 6][threadIdx.x & 15] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && j < MN) {
+        const float t = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        if (cols > 0) {      // interleaved: row k = j / cols, column c = j % cols; column cols - 1 is the bias
+            const int k = j / cols, c = j - k * cols;
+            if (c == cols - 1) db[k] = t;
+            else dw[k * (cols - 1) + c] = t;
+        } else {             // tail: dw first, db behind it
+            if (j < split) dw[j] = t;
+            else db[j - split] = t;
+        }
+    }
 }
 
 // out[j] = sum_s partial[s][j] for MANY slabs of a SMALL result (hundreds of workgroup partials of a 48..2304-element

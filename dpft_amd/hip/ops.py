@@ -134,6 +134,16 @@ def conv_wgrad(cv: Conv, x, dy, pro=None, out=None):
     return dw
 
 
+def conv_wgrad_bias(cv: Conv, x, dy, out=None, bias_out=None):
+    """(dw, db) of a conv with bias in one call (dpft_conv2d_nhwc_wgrad_bias_f32); ``out`` / ``bias_out`` as in conv_wgrad /
+    bias_grad."""
+    dw = out if out is not None else torch.empty((cv.K, cv.kh, cv.kw, cv.C), dtype=torch.float32, device=x.device)
+    db = bias_out if bias_out is not None else torch.empty(cv.K, dtype=torch.float32, device=x.device)
+    ws = workspace(cv.ws_bytes, x.device)
+    lib.call("dpft_conv2d_nhwc_wgrad_bias_f32", C.byref(cv.desc), ptr(x), ptr(dy), ptr(dw), ptr(db), ptr(ws), stream())
+    return dw, db
+
+
 def weight_transpose(w_khwc: torch.Tensor) -> torch.Tensor:
     """[K][kh][kw][C] -> [C][kh][kw][K]"""
     K, kh, kw, Cin = w_khwc.shape

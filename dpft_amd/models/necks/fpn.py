@@ -71,11 +71,12 @@ class _FPNFn(torch.autograd.Function):
 
         def wgrad(cv, x, dy, conv):
             if direct is not None:          # bucket view of a conv weight: physically [K][kh][kw][C]
-                ops.conv_wgrad(cv, x, dy, out=direct.grad_buffer(conv.weight).permute(0, 2, 3, 1))
-                ops.bias_grad(dy, out=direct.grad_buffer(conv.bias))
+                ops.conv_wgrad_bias(cv, x, dy, out=direct.grad_buffer(conv.weight).permute(0, 2, 3, 1),
+                                    bias_out=direct.grad_buffer(conv.bias))
             else:
-                grads[conv.weight] = ops.conv_wgrad(cv, x, dy).permute(0, 3, 1, 2)
-                grads[conv.bias] = ops.bias_grad(dy)
+                dw, db = ops.conv_wgrad_bias(cv, x, dy)
+                grads[conv.weight] = dw.permute(0, 3, 1, 2)
+                grads[conv.bias] = db
 
         # the data gradients' transposed weights of all convs of this pyramid in one launch (they were 2 n launches)
         need = [fpn.layer_blocks[i][0] for i in range(n) if douts[i] is not None] + \

@@ -116,6 +116,10 @@ int dpft_weight_transpose_f32(const float* w, float* w_t, int32_t K, int32_t tap
  * (an FPN's ten convs per backward, `necks/fpn.py:39-43`; pointer / size arrays live on the host). */
 int dpft_weight_transpose_batch_f32(int32_t n, const float* const* w, float* const* w_t, const int32_t* K,
                                     const int32_t* taps, const int32_t* C, dpft_stream_t stream);
+/* dw as dpft_conv2d_nhwc_wgrad_f32 (no prologue) AND db = the bias gradient of a conv with bias (`necks/fpn.py:39-43`:
+ * torchvision's FPN convs), in one pass over dy where the weight-gradient kernel has dy at hand. */
+int dpft_conv2d_nhwc_wgrad_bias_f32(const dpft_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
+                                    void* workspace, dpft_stream_t stream);
 /* db[K] = sum over rows of dy[M][K] */
 int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t K, dpft_stream_t stream);
 
