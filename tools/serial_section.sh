@@ -3,7 +3,7 @@ cd /tmp && export TMPDIR=/tmp
 STEPS=3 timeout 500 rocprofv3 --kernel-trace --output-format csv -d /tmp/proft7 -- python /root/repo/tools/train_only.py </dev/null > /tmp/proft7.log 2>&1
 f=$(find /tmp/proft7 -name "*kernel_trace.csv" | head -1)
 python - "$f" <<'PY'
-import csv, sys, re, collections
+import csv, sys, re, collections, os
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "adamw_kernel" in r["Kernel_Name"]]
@@ -14,7 +14,7 @@ def short(n):
     return re.sub(r"<.*", "", n)[:40]
 first = next(i for i, r in enumerate(step) if "hd_train_fwd" in r["Kernel_Name"] or "sa_train_fwd" in r["Kernel_Name"])
 last = max(i for i, r in enumerate(step) if "sa_train_bwd" in r["Kernel_Name"])
-sec = step[first - 30:last + 12]
+sec = step[first - int(os.environ.get("BEFORE", "30")):last + int(os.environ.get("AFTER", "12"))]
 t0 = int(sec[0]["Start_Timestamp"])
 agg = collections.OrderedDict()
 prev_end = None
