@@ -2,7 +2,7 @@
 """Headline benchmark: training samples/s of the full camera+radar DPFT hot path (config kradar,
 batch 4 per GPU, fp32, synthetic K-Radar-shaped tensors resident in HBM), plus fwd ms/frame.
 
-    python bench.py --gpus 1 --steps 10 --warmup 3
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,8 +35,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (same table); only used by --dty
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE: 4)")
     ap.add_argument("--config", default="kradar")
     ap.add_argument("--latency-reps", type=int, default=300,
@@ -256,6 +256,10 @@ def main():
                   file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             trainer.model.disable_fuser_graph()
+    # set-up, like enable_graphs() above: the encoders' launch plans capture their hipGraphs on the third call (two eager
+    # executions first) -- with fewer than three warm-up steps that capture would fall into the timed region
+    for _ in range(max(0, 3 - args.warmup)):
+        trainer.train_step(data, labels)
     for _ in range(args.warmup):
         trainer.train_step(data, labels)
     sync()
