@@ -2,7 +2,7 @@
 """Headline benchmark: training samples/s of the full camera+radar DPFT hot path (config kradar,
 batch 4 per GPU, fp32, synthetic K-Radar-shaped tensors resident in HBM), plus fwd ms/frame.
 
-    python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 1 --steps 100 --warmup 20
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -35,8 +35,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0     # dense bf16 (same table); only used by --dty
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # SURVEY 8d / BASELINE.md: 20 warm-up + >= 100 timed steps
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4, help="per-GPU batch (BASELINE: 4)")
     ap.add_argument("--config", default="kradar")
     ap.add_argument("--latency-reps", type=int, default=300,
@@ -57,13 +57,30 @@ def parse():
     return ap.parse_args()
 
 
+def cpu_model_name() -> str:
+    """'model name' of /proc/cpuinfo (+ socket count); platform.processor() only says 'x86_64' on Linux."""
+    import platform
+    try:
+        names, sockets = [], set()
+        with open("/proc/cpuinfo") as f:
+            for ln in f:
+                if ln.startswith("model name"):
+                    names.append(ln.split(":", 1)[1].strip())
+                elif ln.startswith("physical id"):
+                    sockets.add(ln.split(":", 1)[1].strip())
+        if names:
+            return f"{names[0]} ({len(names)} logical CPUs, {max(len(sockets), 1)} socket(s))"
+    except OSError:
+        pass
+    return platform.processor() or platform.machine()
+
+
 def cpu_baseline(threads: int = 0, budget_s: float = 200.0):
     """The oracle (CPU restatement of the reference path, torch fp32; pinned to the imported reference by
     tests/test_oracle_golden.py) timed on the host cores with the protocol of BASELINE.md section 3: configs 1-3,
     forward 2 warm-up + 5 timed, train step (forward + Hungarian set loss + backward + AdamW) 1 warm-up + 3 timed,
     ``torch.set_num_threads(all host cores)``.  ``budget_s`` bounds the sample: a leg that would not fit is cut to
     fewer timed repetitions (reported)."""
-    import platform
     from dpft_amd.configs import load_config
     from dpft_amd.models import build
     from dpft_amd.synthetic import make_batch, make_labels
@@ -146,7 +163,7 @@ def cpu_baseline(threads: int = 0, budget_s: float = 200.0):
             legs[name] = {"ms": None, "samples_per_s": None, "timed_reps": 0}
     head = legs["config3 kradar B=4 train"]
     return {"value": head["samples_per_s"], "unit": "samples/s", "cores": cores, "kind": "port",
-            "host_cores": os.cpu_count(), "cpu_model": platform.processor() or platform.machine(),
+            "host_cores": os.cpu_count(), "cpu_model": cpu_model_name(),
             "sample": "BASELINE.md section 3 protocol on the torch-CPU fp32 oracle: configs 1-3, forward 2 warm-up + 5 timed, "
                       "train step (fwd + Hungarian set loss + bwd + AdamW) 1 warm-up + 3 timed; value = config 3 "
                       f"(kradar, batch 4) train samples/s; {cores} threads (fastest of a conv thread sweep on {host} host cores); "
@@ -263,12 +280,19 @@ def main():
     for _ in range(args.warmup):
         trainer.train_step(data, labels)
     sync()
+    # per-step spread: one event per step boundary on the main stream (no sync inside the timed region -- the events
+    # cost ~1 us of queue time each); a step's figure is the GPU time between two consecutive boundaries
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         loss, _ = trainer.train_step(data, labels)
+        marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
-    exposed_ms = trainer.reducer.exposed_ms() if collective else 0.0     # last step: exchange time not hidden by backward
+    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    # None at one rank without forced collectives: there is no exchange to expose (0.0 would read like a measurement)
+    exposed_ms = trainer.reducer.exposed_ms() if collective else None
     if collective:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -303,6 +327,14 @@ def main():
                 for key, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f}\n")
         n_launch = sum(k[2] for k in per_kind.values())
+        # algorithmic HBM bytes of the same calls: every conv call (fwd / dgrad / wgrad alike) touches its input map, its
+        # output map and its weights once -- x + y + w fp32 elements (shape key = kind, B, H, W, C, K, k, s; H x W = the
+        # conv's INPUT map, output = ceil(H / s) x ceil(W / s) with "same" padding)
+        alg_bytes = 0.0
+        for key, v in shapes.items():
+            _, b_, h_, w_, c_, k_, ks_, st_ = key
+            oh, ow = -(-h_ // st_), -(-w_ // st_)
+            alg_bytes += v[2] * 4.0 * (b_ * h_ * w_ * c_ + b_ * oh * ow * k_ + k_ * c_ * ks_ * ks_)
         # two more views of the same launch log: FLOP-weighted mean of the per-shape rates (SURVEY 8d wording), and
         # the camera encoder alone (94 % of the FLOPs; the radar encoders' tiny GEMMs are launch-bound and, in the
         # real step, hidden behind the camera on their own streams -- in this serialized step they count in full)
@@ -315,7 +347,7 @@ def main():
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for name in ("r03_conv_traffic_pmc.json", "r02_conv_traffic_pmc.json"):
+        for name in ("r04_conv_traffic_pmc.json", "r03_conv_traffic_pmc.json", "r02_conv_traffic_pmc.json"):
             if os.path.exists(os.path.join(prof_dir, name)):
                 with open(os.path.join(prof_dir, name)) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -338,6 +370,10 @@ def main():
         roof = {"bound": "mfma", "achieved": tot_f / raw_t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": tot_f / raw_t / 1e12 / peak,
                 "traffic": traffic if args.dtype == "f32" else None, "traffic_is": "HBM bytes per conv launch", "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": alg_bytes / max(n_launch, 1),
+                "algorithmic_bytes_is": "x + y + w fp32 elements of every conv call (input map, output map, weights once each), "
+                                        "mean over the step's conv calls",
+                "traffic_over_algorithmic": (traffic * n_launch / alg_bytes) if (traffic and args.dtype == "f32" and alg_bytes) else None,
                 "kernel": f"igemm_pipe/wgrad_pipe/igemm_gen ({family} implicit-GEMM conv family, incl. their split-K reductions "
                           "and the BatchNorm-backward reductions fused into the data-gradient epilogues)",
                 "launches_per_step": n_launch, "avg_launch_us": 1e6 * raw_t / max(n_launch, 1),
@@ -361,7 +397,7 @@ def main():
     # ---- HBM roofline of the deformable fusion decoder (SURVEY 8d "Roofline B") -------------------------
     # unit of work = one IMPFusion.forward (eval); algorithmic bytes = every cross-attention call streams its
     # view's 16-channel fp32 pyramid once + query-side I/O + parameters
-    dec = None
+    dec = dec_train = None
     if rank == 0:
         m = trainer.model
         with torch.no_grad():
@@ -383,7 +419,7 @@ def main():
         dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
         # counter traffic of the decoder kernels (tools/r03_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
         dec_traffic, dec_src = None, None
-        for pname in ("r03_decoder_traffic_pmc.json", "r02_decoder_traffic_pmc.json"):
+        for pname in ("r04_decoder_traffic_pmc.json", "r03_decoder_traffic_pmc.json", "r02_decoder_traffic_pmc.json"):
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)
             if os.path.exists(pmc):
                 with open(pmc) as f:
@@ -397,7 +433,52 @@ def main():
                f"({2 * fcfg['i_iter'] + 1} launches per forward)",
                "note": "frac prices the measured time against the time 8 TB/s needs for the ALGORITHMIC bytes of SURVEY 8d "
                        "(every cross-attention call streaming its pyramid once); the sample-then-project kernels touch far "
-                       "fewer HBM bytes (traffic), they are bound by L2 line requests and kernel-boundary latency"}
+                       "fewer HBM bytes (traffic), they are bound by L2 line requests and kernel-boundary latency",
+               "timing": f"{reps} back-to-back dpft_decoder_forward_f32 calls between two HIP events on the launch stream"}
+        # second accounting: the SUM of the decoder kernels' durations per forward in the committed rocprofv3
+        # summary (tools/roofline_from_rocprof.py --decoder) -- a constant read from profiles/, named in the line
+        for pname in ("r04_decoder_roofline_from_rocprof.json",):
+            pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)
+            if os.path.exists(pj) and args.dtype == "f32" and B == 4:
+                with open(pj) as f:
+                    rj = json.load(f)
+                dec["rocprof_kernel_sum_us"] = rj.get("kernel_sum_us_per_forward")
+                dec["frac_rocprof_kernel_sum"] = rj.get("frac")
+                dec["rocprof_summary"] = "profiles/" + pname + " <- " + str(rj.get("source"))
+        # ---- training decoder (forward + backward graphs of the fusion decoder, SURVEY 8d "Backward") ----------------
+        # unit = one IMPFusion forward + backward at B: bytes_fwd + bytes_bwd, bytes_bwd = bytes_fwd + the gradient
+        # pyramids written once.  Timed as `reps` replays of the trainer's captured forward and backward graphs
+        # back to back (everything the decoder section of a step launches: fused blocks, rows_outer, pack kernels and
+        # the few ATen nodes left), between two HIP events.  The backward ACCUMULATES into the pyramid-gradient buffers
+        # and the gradient buckets: the values are garbage afterwards, which is why this runs after the timed region.
+        dec_train = None
+        g = trainer.model.__dict__.get("_graphed_fuser")
+        if g is not None:
+            bwd_bytes = dec_bytes + B * tokens * 64
+            for _ in range(3):
+                g.fwd_graph.replay(); g.bwd_graph.replay()
+            torch.cuda.synchronize()
+            tr_reps = max(20, min(reps, 100))
+            e0.record()
+            for _ in range(tr_reps):
+                g.fwd_graph.replay()
+                g.bwd_graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t_tr = e0.elapsed_time(e1) * 1e-3 / tr_reps
+            e0.record()
+            for _ in range(tr_reps):
+                g.fwd_graph.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t_trf = e0.elapsed_time(e1) * 1e-3 / tr_reps
+            dec_train = {"bound": "hbm", "achieved": (dec_bytes + bwd_bytes) / t_tr / 1e9, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (dec_bytes + bwd_bytes) / t_tr / 8.0e12, "traffic": None,
+                         "algorithmic_mb": (dec_bytes + bwd_bytes) / 1e6, "decoder_train_fwd_bwd_us": t_tr * 1e6,
+                         "decoder_train_fwd_us": t_trf * 1e6, "decoder_train_bwd_us": (t_tr - t_trf) * 1e6,
+                         "kernel": "sa_train_* + xf_train_* + hd_train_* + rows_outer + pack kernels (the decoder's forward "
+                                   "and backward hipGraphs, dropout on)",
+                         "timing": f"{tr_reps} replays of the captured forward + backward graphs between two HIP events"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -407,6 +488,8 @@ def main():
         line = {
             "metric": f"training samples/sec (K-Radar C+R, bs{B}/GPU)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "step_ms_min": step_ms[0], "step_ms_median": step_ms[len(step_ms) // 2], "step_ms_max": step_ms[-1],
+            "step_ms_is": "rank 0, per step: HIP events on the main stream at every step boundary of the timed region",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.config}.json full C+R dual-perspective fusion train step, batch {B}/GPU "
                                    "(camera 512x910x3 ResNet-101, radar BEV 256x107x6 + front 37x107x6 ResNet-50, "
@@ -440,7 +523,7 @@ def main():
                                             trainer.comm_placement, trainer.comm_placement)},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
-            "roofline": roof, "roofline_decoder": dec, "cpu_baseline": cpu,
+            "roofline": roof, "roofline_decoder": dec, "roofline_decoder_train": dec_train, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if collective:

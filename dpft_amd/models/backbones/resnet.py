@@ -23,6 +23,7 @@ import torch
 from torch import nn
 
 import ctypes as C
+import weakref
 
 from dpft_amd.hip import ops
 from dpft_amd.hip.lib import HipLibraryError, ResnetDesc, ResnetTables, lib, ptr, stream, weights_generation
@@ -105,6 +106,7 @@ class _Plan:
         # hipGraph replay (dpft_resnet_plan_set_graph): the C side keys its graphs on the pointer arguments, so this side
         # keeps them still -- one arena for the plan's lifetime, static copies of the input and of the external gradients
         self.graphed = False
+        self.lease = None            # weakref to the _ArenaLease of the forward whose saved activations live in self.arena
         self.arena = None
         self.x_static = None
         self.dout_static = {}
@@ -115,6 +117,14 @@ class _Plan:
             lib.dpft_resnet_plan_destroy(self.handle)
         except Exception:
             pass
+
+
+class _ArenaLease:
+    """Held by the autograd context of the ONE forward whose saved activations live in a plan's persistent arena / static
+    input copy (hipGraph replay keeps those addresses still).  While it is alive -- until that forward's backward has run
+    or its graph was dropped -- another grad-enabled forward of the same plan must not overwrite them (two batches per
+    loss, teacher / student passes, checkpoint recompute): it takes a fresh arena and eager launches instead."""
+    __slots__ = ("__weakref__",)
 
 
 def _ordered_modules(owner: "BackboneBase"):
@@ -163,7 +173,10 @@ class _BodyFn(torch.autograd.Function):
         plan = owner._plan(B, H, W)
         convs, bns = _ordered_modules(owner)
         assert len(convs) == plan.n_conv and len(bns) == plan.n_bn
-        if need_grad and owner.use_plan_graphs(plan):
+        lease = None
+        if need_grad and owner.use_plan_graphs(plan) and (plan.lease is None or plan.lease() is None):
+            lease = _ArenaLease()
+            plan.lease = weakref.ref(lease)
             if plan.arena is None:
                 plan.arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
             if plan.x_static is None or plan.x_static.shape != x.shape:
@@ -187,6 +200,14 @@ class _BodyFn(torch.autograd.Function):
             weights = [khwc(c.weight) for c in convs]                       # physical [K][kh][kw][C]
             # gradient buffers: straight into the DP buckets when a reducer is attached, else one flat buffer
             direct = owner.grad_direct if need_grad else None
+            if direct is not None:
+                # direct-to-bucket gradients are WRITTEN, not added: a second grad-enabled forward before the first one's
+                # backward would silently lose one of the two contributions -- refuse loudly (detach the reducer, i.e. use
+                # the module without DataParallelTrainer, for multi-forward losses: autograd then accumulates)
+                prev = owner.__dict__.get("_direct_lease")
+                if prev is not None and prev() is not None:
+                    raise RuntimeError("dpft_amd backbone: a second grad-enabled forward while the previous one's backward "
+                                       "is outstanding is not supported with direct-to-bucket gradients (grad_direct)")
             conv_g, bn_g, bn_b, flat = [None] * len(convs), [None] * len(bns), [None] * len(bns), None
             if need_grad:
                 if direct is not None:
@@ -230,7 +251,10 @@ class _BodyFn(torch.autograd.Function):
         if need_grad:
             ctx.state = dict(owner=owner, plan=plan, x=x, arena=arena, tables=t, keep=keep, weights=weights,
                              convs=convs, bns=bns, conv_g=conv_g, bn_g=bn_g, bn_b=bn_b, flat=flat, direct=direct,
-                             params=params)
+                             params=params, lease=lease)
+            if direct is not None:
+                ctx.state["direct_lease"] = dl = _ArenaLease()
+                owner.__dict__["_direct_lease"] = weakref.ref(dl)
         return tuple(outs)
 
     @staticmethod
@@ -256,7 +280,7 @@ class _BodyFn(torch.autograd.Function):
             d = douts[li]
             if d is not None:
                 d = d.contiguous()
-                if plan.graphed:      # the captured stage reads its external gradient from a fixed address
+                if plan.graphed and st["lease"] is not None:   # the captured stage reads its gradient from a fixed address
                     sd = plan.dout_static.get(li)
                     if sd is None or sd.shape != d.shape:
                         sd = plan.dout_static[li] = torch.empty_like(d)
@@ -349,7 +373,7 @@ class BackboneBase(nn.Module):
         st["_plans"] = {}
         st["grad_direct"] = None
         st["side_stream"] = None
-        for k in ("_ordered", "_infer_tables", "_plist"):
+        for k in ("_ordered", "_infer_tables", "_plist", "_direct_lease"):
             st.pop(k, None)
         return st
 

@@ -134,7 +134,9 @@ def infer_config(model: nn.Module) -> Dict[str, Any]:
                                  "ResNet-50 / -101 / -152 bottleneck bodies with at least three stages")
             # IntermediateLayerGetter drops every stage behind the last returned one: multi_scale is visible in the tensors
             multi_scale = len(layers)
-            ms_attr = _attr(bmod, "multi_scale")
+            ms_attr = _attr(bmod, "_multi_scale")      # the reference stores it behind a property (resnet.py:62-68)
+            if ms_attr is None:
+                ms_attr = _attr(bmod, "multi_scale")
             if ms_attr is not None and max(1, min(4, int(ms_attr))) != len(layers):
                 raise ValueError(f"checkpoint: backbone {v!r} has multi_scale={ms_attr} but {len(layers)} stages")
             # norm layer: torchvision's BatchNorm2d keeps running statistics AND counts batches; anything else

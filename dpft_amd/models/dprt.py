@@ -181,6 +181,17 @@ class DPRT(nn.Module):
     def disable_fuser_graph(self):
         self.__dict__.pop("_graphed_fuser", None)
 
+    # process-local execution state parked in __dict__ (HIP streams, the probed queue set, the captured decoder graphs):
+    # none of it belongs in ``torch.save(model)`` (trainer.py:256-258 pickles the whole module every epoch) or in a
+    # deepcopy; all of it is rebuilt lazily by the next forward / ``enable_fuser_graph``
+    _RUNTIME_STATE = ("_view_streams", "_queues_found", "_graphed_fuser")
+
+    def __getstate__(self):
+        st = self.__dict__.copy()
+        for k in self._RUNTIME_STATE:
+            st.pop(k, None)
+        return st
+
 
 def build_dprt(*args, **kwargs):
     return DPRT.from_config(*args, **kwargs)

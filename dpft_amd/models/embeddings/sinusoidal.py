@@ -55,6 +55,11 @@ class SinusoidalEmbedding(nn.Module):
     def from_config(cls, config: Dict[str, Any]) -> "SinusoidalEmbedding":
         return cls(**config)
 
+    def __getstate__(self):          # the per-(H, W, device) tables are device tensors: rebuilt on demand
+        st = self.__dict__.copy()
+        st["_tables"] = {}
+        return st
+
     def tables(self, H: int, W: int, device):
         key = (H, W, str(device))
         t = self._tables.get(key)

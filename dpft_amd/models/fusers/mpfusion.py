@@ -183,6 +183,11 @@ class IMPFusion(nn.Module):
     def reset_parameters(self) -> None:
         self.q_init(self.query)
 
+    def __getstate__(self):          # the fused inference decoder holds packed device blobs + a native descriptor:
+        st = self.__dict__.copy()    # rebuilt on the next eval forward (torch.save(model), deepcopy)
+        st.pop("_fused_decoder", None)
+        return st
+
     @staticmethod
     def get_reference_points(query, transformation, projection, shape, has_transformation: bool = None):
         """mpfusion.py:617-696 -> (B,N,2) ordered (u = x/W, v = y/H), clipped to [0,1]."""

@@ -75,6 +75,7 @@ class DataAgnosticStaticQueries(nn.Module):
     def __getstate__(self):          # caches are rebuilt on demand (torch.save(model), deepcopy)
         st = self.__dict__.copy()
         st.pop("_batched", None)
+        st["_cache"] = {}
         return st
 
     def forward(self, batch: Union[torch.Tensor, Sequence[torch.Tensor], Dict[str, torch.Tensor]]):

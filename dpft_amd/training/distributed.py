@@ -44,6 +44,14 @@ class GradBucketReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
+        if self.world > 1:
+            # the one-rank timing switches of tools/r03_forced_breakdown.sh would let ranks diverge (no gradient exchange) or
+            # hang (ranks disagreeing on the step decision mismatch their collectives): refused outside one-rank runs
+            env = __import__("os").environ
+            bad = [k for k in ("DPFT_EXP_SKIP_BUCKET_COLLECTIVES", "DPFT_EXP_LOCAL_DECISION") if env.get(k) == "1"]
+            if bad or _EXP_SKIP_BUCKET_COLLECTIVES:
+                raise RuntimeError(f"{bad or ['DPFT_EXP_SKIP_BUCKET_COLLECTIVES']}: one-rank timing experiment switches "
+                                   f"are not allowed with world_size {self.world}")
         # RCCL averages inside the collective (ncclAvg): no separate division pass over the 360 MB of buckets
         self._avg_op = average and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         # One rank (bench.py --force-collectives, tests): the average over one rank IS the sum, and RCCL implements a one-rank

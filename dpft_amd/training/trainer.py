@@ -1,15 +1,22 @@
-"""Training / latency loops with the reference's step order and timing protocol.
+"""Training / validation / latency loops with the reference's step order and timing protocol.
 
 Mirror of ``CentralizedTrainer.train_one_epoch`` (src/dprt/training/trainer.py:99-160: zero_grad ->
 forward -> loss -> if loss > 0: backward, optimizer.step) and of
 ``CentralizedEvaluator.evaluate_inference_time`` (src/dprt/evaluation/evaluator.py:97-135: 10 warm-up
-+ 300 event-timed forwards), extended to one-process-per-GPU data parallelism.
++ 300 event-timed forwards), extended to one-process-per-GPU data parallelism; the epoch loop
+(``train`` / ``train_one_epoch`` / ``validate_one_epoch``, trainer.py:99-263) is the DP counterpart of the
+reference's: every rank walks its shard, scalars are averaged over ranks, rank 0 alone writes logs and the
+whole-module checkpoint ``<timestamp>_checkpoint_<epoch>.pt`` that ``dpft_amd.models.load`` (and the reference's
+``dprt.train --checkpoint``, train.py:47-48) resumes from.
 """
 from __future__ import annotations
 
+import datetime
+import json
 import os
+import os.path as osp
 
-from typing import Any, Dict, List, Optional
+from typing import Any, Dict, Iterable, List, Optional
 
 import torch
 import torch.distributed as dist
@@ -17,6 +24,33 @@ import torch.distributed as dist
 from dpft_amd.training.distributed import GradBucketReducer, broadcast_module
 from dpft_amd.training.loss import build_loss
 from dpft_amd.training.optimizer import FusedAdamW, build_optimizer
+
+
+class _ScalarLog:
+    """Rank-0 scalar sink with ``SummaryWriter``'s ``add_scalar`` signature.  TensorBoard when it is importable (the
+    reference's writer, trainer.py:225), else one JSON line per scalar in ``<log_dir>/scalars.jsonl``."""
+
+    def __init__(self, log_dir: str):
+        os.makedirs(log_dir, exist_ok=True)
+        self._tb, self._fh = None, None
+        try:
+            from torch.utils.tensorboard import SummaryWriter
+            self._tb = SummaryWriter(log_dir=log_dir)
+        except Exception:
+            self._fh = open(osp.join(log_dir, "scalars.jsonl"), "a")
+
+    def add_scalar(self, tag: str, value, step: int):
+        if self._tb is not None:
+            self._tb.add_scalar(tag, value, step)
+        else:
+            self._fh.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    def close(self):
+        if self._tb is not None:
+            self._tb.flush()
+            self._tb.close()
+        else:
+            self._fh.close()
 
 
 class DataParallelTrainer:
@@ -65,6 +99,13 @@ class DataParallelTrainer:
         # collectives (tools/r03_comm_ab.sh): side 29.2, pg 29.4, front 31.7 ms against 28.7 ms plain.
         self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "side")
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
+        # epoch loop (trainer.py:21-47,64-67): epochs, schedule, logging frequency (None | 'step' | 'epoch')
+        self.epochs = int(train.get("epochs", 1))
+        self.logging = train.get("logging")
+        sched = dict(train.get("scheduler") or {"name": "ConstantLR", "factor": 1.0})
+        from dpft_amd.training.scheduler import build_scheduler
+        self.scheduler = build_scheduler(sched.pop("name"), **sched)(self.optimizer)             # trainer.py:236
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
         overwritten = []
         for m in self.model.modules():
             if hasattr(m, "grad_direct"):
@@ -143,6 +184,144 @@ class DataParallelTrainer:
             return False
         g.backward_from(write)
         return bool(done and done[0])
+
+    # ------------------------------------------------------------------------------------------ epoch loop
+    @classmethod
+    def from_config(cls, model: torch.nn.Module, config: Dict[str, Any], **kwargs) -> "DataParallelTrainer":
+        """``CentralizedTrainer.from_config`` (trainer.py:49-80) plus the module to shard: device from
+        ``computing.device`` (rank-local: ``cuda`` -> ``cuda:LOCAL_RANK``)."""
+        device = torch.device(config["computing"]["device"])
+        if device.type == "cuda" and device.index is None:
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", 0)))
+        return cls(model, config, device, **kwargs)
+
+    def _dict_to(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
+
+    def _rank_mean(self, scalars: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """Mean over ranks of every scalar (ONE collective).  Every rank calls it with the same keys."""
+        if not scalars:
+            return scalars
+        keys = sorted(scalars)
+        vec = torch.stack([torch.as_tensor(scalars[k], dtype=torch.float32, device=self.device).reshape(()) for k in keys])
+        if self.world > 1:
+            dist.all_reduce(vec, op=dist.ReduceOp.SUM)
+            vec = vec / self.world
+        return dict(zip(keys, vec.unbind()))
+
+    def _log(self, writer, scalars: Dict[str, Any], step: int, prefix: str):
+        if writer is not None:
+            for name, v in scalars.items():
+                writer.add_scalar(f"{prefix}/{name}", float(v), step)
+
+    def train_one_epoch(self, epoch: int, data_loader: Iterable, writer=None) -> Dict[str, float]:
+        """trainer.py:99-160 on this rank's shard: per step zero_grad -> forward -> loss -> (backward, all-reduce,
+        optimizer) -> metrics.  Per-step values stay on the device; they are summed there and read back once per epoch
+        (``logging == 'step'`` reads them every step, as the reference's writer does)."""
+        self.model.train()
+        self.loss_fn.train()
+        sums: Dict[str, torch.Tensor] = {}
+        n = 0
+        for i, (data, labels) in enumerate(data_loader):
+            step = i + epoch * len(data_loader)
+            if self.logging == "step" and writer is not None:
+                writer.add_scalar("train/learning_rate", self.optimizer.param_groups[0]["lr"], step)
+            labels = [self._dict_to(l) for l in labels]
+            data = self._dict_to(data)
+            res = self.train_step(data, labels, with_metrics=True)
+            loss, losses = res[0], res[1]
+            metrics = res[2] if len(res) > 2 else {}
+            scalars = {f"loss_{k}": v for k, v in losses.items()}
+            scalars["loss"] = loss
+            scalars.update(metrics)
+            if self.logging == "step":
+                self._log(writer if self.rank == 0 else None, self._rank_mean(scalars), step, "train")
+            for k, v in scalars.items():
+                v = torch.as_tensor(v, device=self.device).detach().float().reshape(())
+                sums[k] = sums[k] + v if k in sums else v.clone()
+            n += 1
+        means = self._rank_mean({k: v / max(n, 1) for k, v in sums.items()})
+        if self.logging == "epoch" and self.rank == 0 and writer is not None:
+            self._log(writer, means, epoch, "train")
+            writer.add_scalar("train/learning_rate", self.optimizer.param_groups[0]["lr"], epoch)
+        return {k: float(v) for k, v in means.items()}
+
+    @torch.no_grad()
+    def validate_one_epoch(self, epoch: int, data_loader: Iterable, writer=None) -> Dict[str, float]:
+        """trainer.py:162-213: eval-mode forward (the fused inference decoder), loss and metrics on this rank's shard,
+        averaged over steps and ranks.  Returns ``{'loss': ...}`` like the reference (plus the other means)."""
+        self.model.eval()
+        self.loss_fn.eval()
+        sums: Dict[str, torch.Tensor] = {}
+        n = 0
+        for i, (data, labels) in enumerate(data_loader):
+            labels = [self._dict_to(l) for l in labels]
+            data = self._dict_to(data)
+            output = self.model(data)
+            loss, losses = self.loss_fn(output, labels)
+            metrics = self.eval_fn(output, labels) if self.eval_fn is not None else {}
+            scalars = {f"loss_{k}": v for k, v in losses.items()}
+            scalars["loss"] = loss
+            scalars.update(metrics)
+            if self.logging == "step":
+                self._log(writer if self.rank == 0 else None, self._rank_mean(scalars), i + epoch * len(data_loader), "val")
+            for k, v in scalars.items():
+                v = torch.as_tensor(v, device=self.device).detach().float().reshape(())
+                sums[k] = sums[k] + v if k in sums else v.clone()
+            n += 1
+        means = self._rank_mean({k: v / max(n, 1) for k, v in sums.items()})
+        if self.logging == "epoch" and self.rank == 0 and writer is not None:
+            self._log(writer, means, epoch, "val")
+        return {k: float(v) for k, v in means.items()}
+
+    def save_checkpoint(self, path: str) -> None:
+        """``torch.save(model, path)`` (trainer.py:256-258) by rank 0; every rank returns after the file exists.  The
+        module's process-local state (streams, graphs, plans, reducer links: ``__getstate__`` of DPRT / IMPFusion /
+        BackboneBase / FPN) is not part of the pickle, so the live model keeps training afterwards."""
+        if self.device.type == "cuda":
+            torch.cuda.synchronize(self.device)
+        if self.rank == 0:
+            tmp = path + ".tmp"
+            torch.save(self.model, tmp)
+            os.replace(tmp, path)
+        if self.world > 1:
+            dist.barrier()
+
+    def train(self, data_loader: Iterable, val_loader: Iterable = None, start_epoch: int = 0, timestamp: str = None,
+              dst: str = None, sampler=None) -> List[str]:
+        """trainer.py:215-263.  ``sampler``: an optional ``ShardedSampler`` whose ``set_epoch`` is called per epoch.
+        Returns the checkpoint paths written."""
+        if timestamp is None:
+            timestamp = datetime.datetime.now().strftime("%Y%m%d-%H%M%S-%f")[:-3]
+            if self.world > 1:                       # one directory for the job: rank 0's clock
+                box = [timestamp]
+                dist.broadcast_object_list(box, src=0)
+                timestamp = box[0]
+        assert dst is not None, "train() needs a destination directory for checkpoints"
+        ckpt_dir = osp.join(dst, timestamp, "checkpoints")
+        writer = None
+        if self.rank == 0:
+            os.makedirs(ckpt_dir, exist_ok=True)
+            if self.logging is not None:
+                writer = _ScalarLog(osp.join(dst, timestamp))
+        for _ in range(start_epoch):                 # a resumed run continues the schedule where it stopped (the
+            self.scheduler.step()                    # reference restarts it: optimizer and scheduler are not pickled)
+        written = []
+        for epoch in range(start_epoch, self.epochs):
+            if sampler is not None:
+                sampler.set_epoch(epoch)
+            self.last_train = self.train_one_epoch(epoch, data_loader, writer)
+            if val_loader is not None:
+                self.last_val = self.validate_one_epoch(epoch, val_loader, writer)
+            self.scheduler.step()
+            path = osp.join(ckpt_dir, f"{timestamp}_checkpoint_{str(epoch).zfill(4)}.pt")
+            self.save_checkpoint(path)
+            written.append(path)
+        if writer is not None:
+            writer.close()
+        return written
+
+    __call__ = train
 
     @torch.no_grad()
     def inference_time(self, data: Dict[str, torch.Tensor], warmup: int = 10, reps: int = 300):

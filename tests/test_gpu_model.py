@@ -1083,3 +1083,63 @@ def test_replayed_encoder_plans_train_like_eager_launches(monkeypatch):
     for i in range(12):
         assert g[i][0] == g[i][0] and abs(g[i][0] - e[i][0]) < 2e-2 * abs(e[i][0]), (i, e[i], g[i])
         assert g[i][1] < 1.5 * top, (i, g[i], top)
+
+
+def test_two_forwards_before_their_backwards_with_replayed_plans():
+    """with plan graphs on, a plan's saved activations live in ONE persistent arena.  A second
+    grad-enabled forward before the first one's backward (two batches per loss) must not overwrite them: it takes a fresh
+    arena (``_ArenaLease``).  Gradients of loss(a) + loss(b) from two outstanding forwards == the sum of the gradients of
+    the two separate passes; with direct-to-bucket gradients (a trainer's reducer attached) the second forward refuses."""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    a = make_batch(cfg["model"]["inputs"], 2, seed=21, shapes=SHAPES, device=DEV)
+    b = make_batch(cfg["model"]["inputs"], 2, seed=22, shapes=SHAPES, device=DEV)
+    torch.manual_seed(0)
+    model = build("dprt", cfg).to(DEV).train()
+    w = {k: torch.randn(2, 400, n, device=DEV, generator=torch.Generator(DEV).manual_seed(5)) for k, n in
+         (("center", 3), ("size", 3), ("angle", 2), ("class", 2))}
+
+    def loss_of(out):
+        return sum((out[k] * w[k]).sum() for k in w)
+
+    def grads():
+        g = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+        model.zero_grad(set_to_none=True)
+        return g
+    for _ in range(4):                       # warm-up + capture: from here on the plans replay graphs
+        loss_of(model(a)).backward()
+    grads()
+    assert all(p.graphed for i in model.inputs for p in model.backbones[i]._plans.values())
+    loss_of(model(a)).backward(); ga = grads()
+    loss_of(model(b)).backward(); gb = grads()
+    oa = model(a)
+    plan = next(iter(model.backbones["radar_bev"]._plans.values()))
+    assert plan.lease is not None and plan.lease() is not None            # a's activations own the arena ...
+    ob = model(b)                                                          # ... so b must not land in it
+    (loss_of(oa) + loss_of(ob)).backward()
+    gab = grads()
+    assert plan.lease() is None                                            # released by a's backward
+    worst = []
+    for k in ga:
+        ref = ga[k].double() + gb[k].double()
+        den = float(ref.norm()) + 1e-6 * ref.numel() ** 0.5
+        worst.append((float((gab[k].double() - ref).norm()) / den, k))
+        # had b overwritten a's arena, a's share would be b's: the error would be ~|ga - gb| / |ga + gb| = O(1)
+    worst.sort(reverse=True)
+    print("two outstanding forwards vs separate passes, worst rel-L2:", worst[:3])
+    assert worst[0][0] < 2e-2, worst[:5]
+    assert sum(e for e, _ in worst) / len(worst) < 2e-3
+    # a dropped graph (forward under grad, never backpropagated) releases the arena as well
+    oa = model(a)
+    assert plan.lease() is not None
+    del oa
+    assert plan.lease() is None
+    # with a reducer attached the gradients are written, not added: the second outstanding forward is refused
+    tr = DataParallelTrainer(model, cfg, torch.device(DEV))
+    tr.reducer.reset()
+    oa = tr.model(a)
+    with pytest.raises(RuntimeError, match="second grad-enabled forward"):
+        tr.model(b)
+    del oa

@@ -1,0 +1,137 @@
+"""The drop-in boundary of ``dprt.train``: whole-module checkpoints of a LIVE (trained, graphed, multi-stream) model and
+the DP counterpart of the reference's epoch loop (src/dprt/training/trainer.py:162-263, src/dprt/train.py:47-48)."""
+import copy
+import json
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+SHAPES = {"camera_mono": (96, 160, 3), "radar_bev": (128, 43, 6), "radar_front": (37, 107, 6)}
+
+
+def _config(dropout=0.0):
+    from dpft_amd.configs import load_config
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    cfg["model"]["fuser"]["dropout"] = dropout
+    return cfg
+
+
+def _eval_out(model, batch):
+    model.eval()
+    with torch.no_grad():
+        return {k: v.detach().clone() for k, v in model(batch).items()}
+
+
+def test_torch_save_of_a_live_graphed_model_round_trips(tmp_path):
+    """after a multi-view GPU forward the module holds HIP streams, the probed queue set, the
+    captured decoder graphs, native plans and the fused inference decoder.  ``torch.save(model)`` (trainer.py:256-258)
+    must drop them, ``dpft_amd.models.load`` must give a model whose eval outputs are BIT-equal to the live one's, the
+    loaded model must train, and the live model must keep training."""
+    from dpft_amd.models import build, load
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = _config()
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=9, shapes=SHAPES, device=DEV)
+    labels = make_labels(2, seed=9, device=DEV)
+    torch.manual_seed(0)
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+    tr.enable_graphs(batch)
+    for _ in range(3):
+        loss, _ = tr.train_step(batch, labels)
+        assert torch.isfinite(loss)
+    live = _eval_out(tr.model, batch)                      # also instantiates the fused inference decoder
+    m = tr.model
+    assert m.__dict__.get("_view_streams") and m.__dict__.get("_graphed_fuser") is not None
+    assert m.fuser.__dict__.get("_fused_decoder"), "the fused inference decoder should be live"
+    assert any(b._plans for b in m.backbones.values())
+    path = tmp_path / "20240101-120000-000_checkpoint_0003.pt"
+    torch.save(m, str(path))                               # raised TypeError: cannot pickle 'torch.Stream' before round 4
+    loaded, epoch, stamp = load(str(path))
+    assert (epoch, stamp) == (3, "20240101-120000-000") and type(loaded) is type(m)
+    for k in ("_view_streams", "_queues_found", "_graphed_fuser"):
+        assert k not in loaded.__dict__, k
+    assert "_fused_decoder" not in loaded.fuser.__dict__
+    assert all(not b._plans and b.grad_direct is None and b.side_stream is None for b in loaded.backbones.values())
+    assert all(n.grad_direct is None for n in loaded.necks.values())
+    sd_live, sd_load = m.state_dict(), loaded.state_dict()
+    assert list(sd_live) == list(sd_load)
+    for k in sd_live:
+        assert torch.equal(sd_live[k], sd_load[k]) and sd_live[k].stride() == sd_load[k].stride(), k
+    got = _eval_out(loaded.to(DEV), batch)
+    for k in live:
+        assert torch.equal(got[k], live[k]), (k, float((got[k] - live[k]).abs().max()))
+    # resume: a new trainer around the loaded module (dprt/train.py:47-66), graphs again, one more step
+    tr2 = DataParallelTrainer(loaded, cfg, torch.device(DEV))
+    tr2.enable_graphs(batch)
+    l2, _ = tr2.train_step(batch, labels)
+    # ... and the live model was not disturbed by being pickled: same next step as the resumed copy up to the optimizer
+    # state (fresh moments in tr2: the reference loses them too), i.e. the same loss
+    l1, _ = tr.train_step(batch, labels)
+    assert torch.isfinite(l1) and torch.isfinite(l2)
+    assert abs(float(l1) - float(l2)) <= 1e-5 * abs(float(l1)), (float(l1), float(l2))
+    # deepcopy goes through the same __getstate__
+    twin = copy.deepcopy(tr.model)
+    assert "_graphed_fuser" not in twin.__dict__ and "_view_streams" not in twin.__dict__
+
+
+class _Listed(torch.utils.data.Dataset):
+    def __init__(self, cfg, n, seed):
+        from dpft_amd.synthetic import make_batch, make_labels
+        self.items = []
+        for i in range(n):
+            b = make_batch(cfg["model"]["inputs"], 1, seed=seed + i, shapes=SHAPES)
+            l = make_labels(1, seed=seed + i)[0]
+            self.items.append(({k: v[0] for k, v in b.items()}, l))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def test_epoch_loop_trains_validates_and_checkpoints(tmp_path):
+    """``DataParallelTrainer.train`` = trainer.py:215-263 on one rank: epochs x (train shard, validate, scheduler step,
+    whole-module checkpoint named ``<timestamp>_checkpoint_<epoch>.pt``), scalars logged per epoch, resumable."""
+    from dpft_amd.data.loader import load_listed
+    from dpft_amd.models import build, load
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = _config(dropout=0.1)
+    cfg["train"]["epochs"] = 2
+    cfg["train"]["batch_size"] = 2
+    cfg["train"]["optimizer"]["lr"] = 1e-3
+    cfg["train"]["scheduler"] = {"name": "StepLR", "step_size": 1, "gamma": 0.5}
+    cfg["computing"]["workers"] = 0
+    torch.manual_seed(0)
+    tr = DataParallelTrainer.from_config(build("dprt", cfg), cfg)
+    train_loader, sampler = load_listed(_Listed(cfg, 6, 100), cfg, device=tr.device)
+    val_loader, _ = load_listed(_Listed(cfg, 4, 200), cfg, device=tr.device)
+    w0 = tr.model.fuser.query.detach().clone()
+    written = tr.train(train_loader, val_loader, timestamp="20250101-000000-000", dst=str(tmp_path), sampler=sampler)
+    assert [os.path.basename(p) for p in written] == ["20250101-000000-000_checkpoint_0000.pt",
+                                                      "20250101-000000-000_checkpoint_0001.pt"]
+    assert all(os.path.isfile(p) for p in written)
+    assert not torch.equal(tr.model.fuser.query.detach(), w0), "the epoch loop did not train"
+    assert abs(tr.optimizer.param_groups[0]["lr"] - 1e-3 * 0.25) < 1e-12          # two scheduler steps
+    assert set(tr.last_train) >= {"loss", "loss_total_class", "loss_center", "mAP", "mGIoU"}
+    assert "loss" in tr.last_val and all(v == v for v in tr.last_val.values())      # finite (not NaN)
+    log = os.path.join(str(tmp_path), "20250101-000000-000")
+    assert os.path.isfile(os.path.join(log, "scalars.jsonl")) or any(f.startswith("events.") for f in os.listdir(log))
+    if os.path.isfile(os.path.join(log, "scalars.jsonl")):
+        tags = {json.loads(l)["tag"] for l in open(os.path.join(log, "scalars.jsonl"))}
+        assert {"train/loss", "val/loss", "train/learning_rate", "train/mAP"} <= tags
+    # resume from the last checkpoint for one more epoch (dprt/train.py:47-66: start_epoch = epoch + 1 in spirit)
+    model, epoch, stamp = load(written[-1])
+    assert epoch == 1 and stamp == "20250101-000000-000"
+    for k, v in tr.model.state_dict().items():
+        assert torch.equal(model.state_dict()[k], v), k
+    cfg["train"]["epochs"] = 3
+    tr2 = DataParallelTrainer.from_config(model, cfg)
+    more = tr2.train(train_loader, None, start_epoch=epoch + 1, timestamp=stamp, dst=str(tmp_path), sampler=sampler)
+    assert [os.path.basename(p) for p in more] == ["20250101-000000-000_checkpoint_0002.pt"]
+    assert abs(tr2.optimizer.param_groups[0]["lr"] - 1e-3 * 0.125) < 1e-12

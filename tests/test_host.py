@@ -1,4 +1,5 @@
 """CPU-only checks: C-ABI surface, host-side mirror of the reference interface, configs."""
+import copy
 import json
 import os
 import re
@@ -302,3 +303,62 @@ def test_unpickler_does_not_replace_missing_native_classes(tmp_path):
     with pytest.raises((AttributeError, ImportError)):
         _Unpickler(io.BytesIO(b"")).find_class("torch.nn", "NoSuchLayer")
     assert issubclass(_Unpickler(io.BytesIO(b"")).find_class("torchvision.models.resnet", "ResNet"), ForeignModule)
+
+
+def test_whole_module_pickle_drops_process_local_state():
+    """``torch.save(model)`` of a model that has run on the GPU (trainer.py:256-258): the HIP streams, the captured decoder
+    graphs and the fused inference decoder parked in ``__dict__`` must not reach the pickle (a ``torch.Stream`` cannot be
+    pickled at all), nor the trainer's reducer links or device-side table caches.  The GPU round trip is
+    tests/test_gpu_trainer.py; this is the mechanism, on the CPU."""
+    import io
+    from dpft_amd.configs import load_config
+    from dpft_amd.models import build
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    model = build("dprt", cfg)
+    tr = DataParallelTrainer(model, cfg, "cpu")
+    assert model.necks["camera_mono"].grad_direct is tr.reducer
+    model.__dict__["_view_streams"] = [torch.Stream(device="cpu")]          # what DPRT._place_streams leaves behind
+    model.__dict__["_queues_found"] = 3
+    model.__dict__["_graphed_fuser"] = lambda: None                          # unpicklable stand-ins
+    model.fuser.__dict__["_fused_decoder"] = lambda: None
+    emb = model.embeddings["camera_mono"].embedding_layers["embedding0"]
+    emb._tables[(1, 1, "cpu")] = (torch.zeros(1), torch.zeros(1))
+    model.querent._cache[("k",)] = torch.zeros(1)
+    buf = io.BytesIO()
+    torch.save(model, buf)
+    buf.seek(0)
+    again = torch.load(buf, weights_only=False)
+    for k in ("_view_streams", "_queues_found", "_graphed_fuser"):
+        assert k not in again.__dict__ and k in model.__dict__          # dropped from the pickle, kept on the live model
+    assert "_fused_decoder" not in again.fuser.__dict__
+    assert again.necks["camera_mono"].grad_direct is None and again.backbones["radar_bev"].grad_direct is None
+    assert again.embeddings["camera_mono"].embedding_layers["embedding0"]._tables == {} and again.querent._cache == {}
+    for (k, a), (k2, b) in zip(model.state_dict().items(), again.state_dict().items()):
+        assert k == k2 and torch.equal(a, b) and a.stride() == b.stride(), k
+
+
+def test_scheduler_factory_matches_torch():
+    """``build_scheduler`` (src/dprt/training/scheduler.py:30-36): plain, chained and sequential schedules."""
+    from dpft_amd.training.scheduler import build_scheduler
+    def lrs(spec, n=6):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=1.0)
+        spec = copy.deepcopy(spec)
+        sch = build_scheduler(spec.pop("name"), **spec)(opt)
+        out = []
+        for _ in range(n):
+            out.append(opt.param_groups[0]["lr"])
+            opt.step()
+            sch.step()
+        return out
+    assert lrs({"name": "ConstantLR", "factor": 1.0}) == [1.0] * 6
+    assert lrs({"name": "StepLR", "step_size": 2, "gamma": 0.1})[:5] == pytest.approx([1, 1, 0.1, 0.1, 0.01])
+    seq = {"name": "SequentialLR", "milestones": [2],
+           "schedulers": [{"name": "ConstantLR", "factor": 0.5, "total_iters": 2}, {"name": "ExponentialLR", "gamma": 0.5}]}
+    assert lrs(seq)[:5] == pytest.approx([0.5, 0.5, 1.0, 0.5, 0.25])
+    ch = {"name": "ChainedScheduler",
+          "schedulers": [{"name": "ExponentialLR", "gamma": 0.5}, {"name": "ConstantLR", "factor": 0.1, "total_iters": 1}]}
+    assert lrs(ch)[:3] == pytest.approx([0.1, 0.5, 0.25])
+    assert seq["schedulers"][0]["name"] == "ConstantLR"      # the config is not consumed (the reference pops from it)

@@ -3,6 +3,13 @@
 
     python tools/roofline_from_rocprof.py <kernel_stats.csv> <steps> [algorithmic_gflop_per_step] [peak_tflops]
 
+    python tools/roofline_from_rocprof.py --decoder <decoder_kernel_stats.csv> [iterations_per_forward] [algorithmic_MB]
+
+--decoder: the second accounting of `roofline_decoder`: the SUM of the fused inference decoder's kernel
+durations per forward (forwards = decoder_xattn launches / iterations; weight-pack kernels, which only run when a
+parameter changed, are listed but not counted), priced against the SURVEY 8d bytes at 8 TB/s.  The bench line's
+event-timed figure includes the gaps between the 9 launches and excludes nothing; this one is kernels only.
+
 Kernel time of the conv family per step = sum of TotalDurationNs of every kernel a dpft_conv2d_nhwc_* call launches
 (main loops AND the split-K / slab reductions they need) / steps.  frac = algorithmic flops / that time / peak (157.3 TF)."""
 import csv
@@ -19,7 +26,30 @@ GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", 
           "vendor_aten": ("at::native", "Cijk_", "__amd_rocclr", "rocclr")}
 
 
+def decoder_main(argv):
+    path = argv[0]
+    iters = int(argv[1]) if len(argv) > 1 else 4
+    mb = float(argv[2]) if len(argv) > 2 else 555.917472          # kradar, B=4
+    rows = list(csv.DictReader(open(path)))
+    kern = {re.sub(r"\(.*", "", r["Name"]): (int(r["Calls"]), float(r["TotalDurationNs"])) for r in rows}
+    xattn = [v for k, v in kern.items() if "decoder_xattn_kernel" in k]
+    fwds = sum(c for c, _ in xattn) / iters
+    counted = {k: v for k, v in kern.items() if "decoder_" in k and "pack" not in k}
+    total_ns = sum(ns for _, ns in counted.values())
+    us = total_ns / fwds / 1e3
+    out = {"source": path, "forwards": fwds, "iterations_per_forward": iters,
+           "kernels": {k: {"calls_per_forward": c / fwds, "avg_us": ns / c / 1e3, "us_per_forward": ns / fwds / 1e3}
+                       for k, (c, ns) in counted.items()},
+           "not_counted": {k: {"calls": c, "total_us": ns / 1e3} for k, (c, ns) in kern.items() if k not in counted},
+           "launches_per_forward": sum(c for c, _ in counted.values()) / fwds,
+           "kernel_sum_us_per_forward": us, "algorithmic_mb": mb, "peak_gbps": 8000.0,
+           "achieved_gbps": mb * 1e6 / (us * 1e-6) / 1e9, "frac": mb * 1e6 / (us * 1e-6) / 8.0e12}
+    print(json.dumps(out, indent=1))
+
+
 def main():
+    if sys.argv[1] == "--decoder":
+        return decoder_main(sys.argv[2:])
     path, steps = sys.argv[1], int(sys.argv[2])
     gflop = float(sys.argv[3]) if len(sys.argv) > 3 else 1839.439164384       # kradar, B=4: 3 x 4 x 153.29 (bench.py log)
     peak = float(sys.argv[4]) if len(sys.argv) > 4 else 157.3      # fp32 MFMA; 2500 for the bf16 mode's summaries
