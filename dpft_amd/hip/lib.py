@@ -129,8 +129,10 @@ SIGNATURES = {
     "dpft_head_train_row_floats": (_L, []),
     "dpft_head_train_fwd_f32": (_I, [C.POINTER(HeadTrain), _I, _I, _I, _P]),
     "dpft_head_train_bwd_f32": (_I, [C.POINTER(HeadTrain), _I, _I, _I, _P]),
-    "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _I, _I, _P]),
-    "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "dpft_xattn_ffn_train_saved_floats": (_L, []),
+    "dpft_xattn_ffn_train_scratch_floats": (_L, []),
+    "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P]),
+    "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
     "dpft_pack_targets_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dpft_match_cost_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _P, _I, _I, _I, _I, _P]),

@@ -8,6 +8,7 @@ persistent int64 tensor that the captured ``advance_seed`` kernels bump on every
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, List
 
 import torch
@@ -117,6 +118,7 @@ def _rows_outer(rows: torch.Tensor, specs, out_floats: int) -> torch.Tensor:
 # ---------------------------------------------------------------------------------------------------------
 # deformable cross-attention + FFN block of all views (decoder_train_x.hip)
 # ---------------------------------------------------------------------------------------------------------
+XF_SCATTER = os.environ.get("DPFT_XF_SCATTER", "1") != "0"
 _XR = dict(DLIN=0, DF=480, DPRE=496, DOUT=528, G3=544, B3=560, G2=576, B2=592, DBV=608, DVEC=624, QP=640, HD=656,
            Y2=688, VEC=704, SAMP=720, FLOATS=848)
 
@@ -165,16 +167,18 @@ class XattnFfnBlocksFn(torch.autograd.Function):
             pyrs[v] = make_pyramid(states[v].levels)
         npts = (C.c_int32 * V)(*n_points)
         y3 = torch.empty_like(y1)
+        # the one expensive intermediate of a row (gathered features + masses, 544 B) is kept for the backward
+        saved = torch.empty((V, B * Q, int(lib.dpft_xattn_ffn_train_saved_floats())), dtype=torch.float32, device=dev)
         lib.call("dpft_xattn_ffn_train_fwd_f32", C.cast(pyrs, C.c_void_p), C.cast(views, C.c_void_p), packed.data_ptr(),
                  V, C.cast(npts, C.c_void_p), y1.data_ptr(), pos.data_ptr(), refs.data_ptr(), float(p_drop),
-                 seed.data_ptr(), int(salt), y3.data_ptr(), B, Q, stream())
-        ctx.save_for_backward(y1, pos, refs, seed, packed, *params)
+                 seed.data_ptr(), int(salt), y3.data_ptr(), saved.data_ptr(), B, Q, stream())
+        ctx.save_for_backward(y1, pos, refs, seed, packed, saved, *params)
         ctx.states, ctx.meta = states, (V, int(salt), float(p_drop), list(n_points), n_levels)
         return y3
 
     @staticmethod
     def backward(ctx, dy3):
-        y1, pos, refs, seed, packed, *params = ctx.saved_tensors
+        y1, pos, refs, seed, packed, saved, *params = ctx.saved_tensors
         V, salt, p_drop, n_points, n_levels = ctx.meta
         states = ctx.states
         _, B, Q, _ = y1.shape
@@ -188,11 +192,17 @@ class XattnFfnBlocksFn(torch.autograd.Function):
         pyrs = (Pyramid * V)()
         for v in range(V):
             views[v] = DecoderView(*[t.data_ptr() for t in params[22 * v:22 * v + 22]])
-            pyrs[v] = make_pyramid(states[v].levels, states[v].replicated_grad_buffers())
+            # small maps (incl. the tiny ones that used to need gradient replicas) are scattered through LDS images by
+            # the backward's second launch: plain buffers, nothing to fold afterwards (DPFT_XF_SCATTER=0: atomics + replicas)
+            pyrs[v] = make_pyramid(states[v].levels, states[v].grad_buffers() if XF_SCATTER
+                                   else states[v].replicated_grad_buffers())
         npts = (C.c_int32 * V)(*n_points)
+        scratch = torch.empty((V, R, int(lib.dpft_xattn_ffn_train_scratch_floats())), dtype=torch.float32,
+                              device=dev) if XF_SCATTER else None
         lib.call("dpft_xattn_ffn_train_bwd_f32", C.cast(pyrs, C.c_void_p), C.cast(views, C.c_void_p), packed.data_ptr(),
                  V, C.cast(npts, C.c_void_p), y1.data_ptr(), pos.data_ptr(), refs.data_ptr(), p_drop, seed.data_ptr(),
-                 salt, dy3.data_ptr(), dy1.data_ptr(), dqp.data_ptr(), dref.data_ptr(), rows.data_ptr(), B, Q, stream())
+                 salt, saved.data_ptr(), dy3.data_ptr(), dy1.data_ptr(), dqp.data_ptr(), dref.data_ptr(), rows.data_ptr(),
+                 scratch.data_ptr() if scratch is not None else None, B, Q, stream())
         X = _XR
         # every weight gradient = a product of two column blocks of `rows`, summed over the rows: one launch
         specs, off = [], 0

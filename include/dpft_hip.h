@@ -386,22 +386,31 @@ int64_t dpft_selfattn_train_scratch_floats(int32_t B, int32_t Q, int32_t V);
  * = MLFusion.forward_cross_attn + forward_ffn, src/dprt/models/fusers/mpfusion.py:150-229 and
  * src/dprt/models/layers/ms_deform_attn.py:138-217.  `views` are the torch-layout parameters, `packed` the V
  * blobs made from them by dpft_decoder_pack_view_f32 (the caller re-packs after every weight update).
- * y1, y3, dy3, dy1, dqp are (V,B,Q,16); ref/dref (V,B,Q,2); pos (Q,16).  The backward recomputes the row's
- * forward, scatters the pyramid gradients into pyr[v].grad[] (fp32 atomics, caller zero-fills) and writes the
- * per-row factors of the parameter gradients into rows (V,B*Q,dpft_xattn_ffn_train_row_floats()); the column
- * layout is documented at the top of dpft_amd/csrc/decoder_train_x.hip (XR_*) and consumed by
- * dpft_amd/models/fusers/train_fused.py.
+ * y1, y3, dy3, dy1, dqp are (V,B,Q,16); ref/dref (V,B,Q,2); pos (Q,16).
+ * Forward: `saved` (V,B*Q,dpft_xattn_ffn_train_saved_floats()) or NULL receives what the backward would otherwise have to
+ * gather again (the attention-weighted sampled features and in-bounds masses of every head).
+ * Backward: recomputes the ALU-only part of the row's forward (takes the gathered part from `saved`; NULL = gathers
+ * again), adds the pyramid gradients into pyr[v].grad[] (caller zero-fills) and writes the per-row factors of the
+ * parameter gradients into rows (V,B*Q,dpft_xattn_ffn_train_row_floats()); the column layout is documented at the top
+ * of dpft_amd/csrc/decoder_train_x.hip (XR_*) and consumed by dpft_amd/models/fusers/train_fused.py.
+ * Pyramid gradients: `scratch` (V,B*Q,dpft_xattn_ffn_train_scratch_floats()) or NULL.  With it, maps of at most 2048
+ * pixels whose gradient buffer is not replicated (grad_replicas <= 1) are scattered through an LDS image of the map by a
+ * second launch (one fp32 atomic per touched element and query chunk instead of one per sample corner); larger maps, and
+ * every map when scratch is NULL, take one fp32 atomic per sample corner and channel.  Both forms add the same terms;
+ * only the order of the fp32 additions differs.
  * ---------------------------------------------------------------------------------------- */
 int64_t dpft_xattn_ffn_train_row_floats(void);
+int64_t dpft_xattn_ffn_train_saved_floats(void);
+int64_t dpft_xattn_ffn_train_scratch_floats(void);
 int dpft_xattn_ffn_train_fwd_f32(const dpft_pyramid* pyr, const dpft_decoder_view* views, const float* packed,
                                  int32_t V, const int32_t* n_points, const float* y1, const float* pos,
                                  const float* ref, float p_drop, const int64_t* seed, int32_t salt, float* y3,
-                                 int32_t B, int32_t Q, dpft_stream_t stream);
+                                 float* saved, int32_t B, int32_t Q, dpft_stream_t stream);
 int dpft_xattn_ffn_train_bwd_f32(const dpft_pyramid* pyr, const dpft_decoder_view* views, const float* packed,
                                  int32_t V, const int32_t* n_points, const float* y1, const float* pos,
                                  const float* ref, float p_drop, const int64_t* seed, int32_t salt,
-                                 const float* dy3, float* dy1, float* dqp, float* dref, float* rows,
-                                 int32_t B, int32_t Q, dpft_stream_t stream);
+                                 const float* saved, const float* dy3, float* dy1, float* dqp, float* dref,
+                                 float* rows, float* scratch, int32_t B, int32_t Q, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Training path of the decoder's view reduction + detection head + next reference points (one layer):

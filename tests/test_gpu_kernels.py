@@ -745,6 +745,64 @@ def test_fused_xattn_ffn_block_vs_oracle(B, Q, V, L, P):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,Q,P,sizes", [(2, 150, 4, [(70, 45), (40, 51), (18, 23), (9, 12), (2, 3)]),      # 2 large maps, 3 recorded
+                                         (4, 400, 4, [(37, 107), (10, 27), (5, 14), (3, 7), (2, 4)]),      # radar_front's pyramid
+                                         (1, 50, 2, [(60, 40), (45, 44), (46, 44), (45, 45), (44, 46), (20, 20), (8, 8)])])   # 6 small maps > 5 slots: the largest of them keeps atomics
+def test_xattn_ffn_backward_small_map_scatter_equals_atomics(B, Q, P, sizes, monkeypatch):
+    """Round 4: pyramid gradients of maps <= 2048 pixels go through scatter records + an LDS image per (map, batch element,
+    query chunk) (xf_scatter_small_kernel); larger maps keep per-sample atomics, now issued per level.  Both forms add the
+    same terms: every gradient of the block must agree with the all-atomics path (scratch = NULL, replicated tiny maps) to
+    fp32 summation-order noise, and with the fp64 oracle."""
+    from dpft_amd.models.fusers import train_fused as tf
+    from dpft_amd.models.fusers.mpfusion import MLFusion
+    from dpft_amd.models.layers.ms_deform_attn import make_pyramid_state as mk
+    from oracle import dprt_oracle as O
+    import torch.nn.functional as F
+    dev = torch.device("cuda", 0)
+    V, L = 2, len(sizes)
+    torch.manual_seed(11)
+    layers = [MLFusion(d_model=16, d_ffn=32, n_levels=L, n_heads=8, n_points=P, activation="Mish", dropout=0.0,
+                       norm=True).to(dev) for _ in range(V)]
+    for ml in layers:
+        for n, p in ml.named_parameters():
+            if "sampling_offsets.weight" in n or "attention_weights.weight" in n:
+                torch.nn.init.normal_(p, 0.0, 0.3)
+            elif "sampling_offsets.bias" in n:
+                p.data.mul_(1.5)                                   # some samples leave the maps
+    feats = [[(torch.randn(B, h, w, 16, device=dev) * 0.8).requires_grad_(True) for h, w in sizes] for _ in range(V)]
+    y1 = (torch.randn(V, B, Q, 16, device=dev) * 0.7).requires_grad_(True)
+    pos = (torch.randn(Q, 16, device=dev) * 0.5).requires_grad_(True)
+    refs = (torch.rand(V, B, Q, 2, device=dev) * 1.2 - 0.1).clamp(0, 1).requires_grad_(True)
+    gy = torch.randn(V, B, Q, 16, device=dev)
+    flat = [t for fv in feats for t in fv]
+    plist = [t for ml in layers for t in tf.view_params(ml)[6:]]
+    seed = torch.zeros(1, dtype=torch.int64, device=dev)
+    res = {}
+    for scatter in (True, False):
+        monkeypatch.setattr(tf, "XF_SCATTER", scatter)
+        out = tf.xattn_ffn_blocks(layers, [mk(fv) for fv in feats], y1, pos, refs, seed, 1, 0.0)
+        res[scatter] = (out.detach().clone(), [g.detach().clone() for g in
+                                               torch.autograd.grad(out, [y1, pos, refs] + flat + plist, gy)])
+    names = ["y1", "pos", "refs"] + [f"feat{v}.{l}" for v in range(V) for l in range(L)] + [f"p{i}" for i in range(len(plist))]
+    assert torch.equal(res[True][0], res[False][0])
+    for a, b_, n in zip(res[True][1], res[False][1], names):
+        err = float((a - b_).norm() / b_.norm().clamp_min(1e-12))
+        assert err < 2e-6, (n, err)                                # fp32 summation order only
+    # the recorded path against the fp64 oracle, map by map
+    y64, pos64, refs64 = _leaf64(y1), _leaf64(pos), _leaf64(refs)
+    feats64 = [[_leaf64(t) for t in fv] for fv in feats]
+    outs = []
+    for v, ml in enumerate(layers):
+        sd = _sd64(ml, "ml")
+        ca = O.ms_deform_attn(y64[v] + pos64.unsqueeze(0), refs64[v], feats64[v], sd, "ml.ms_deform_attn", 8, P)
+        y2 = O._ln(y64[v] + ca, sd, "ml.norm2")
+        ff = F.linear(F.mish(F.linear(y2, sd["ml.ffn1.weight"], sd["ml.ffn1.bias"])), sd["ml.ffn2.weight"], sd["ml.ffn2.bias"])
+        outs.append(O._ln(y2 + ff, sd, "ml.norm3"))
+    gref = torch.autograd.grad(torch.stack(outs), [y64, pos64, refs64] + [t for fv in feats64 for t in fv], gy.double().cpu())
+    _check_grads(res[True][1][:3 + V * L], gref, names[:3 + V * L], 5e-4)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,Q,V,ncls,flags", [(2, 100, 3, 2, (0, 1, 1)), (1, 33, 2, 5, (1, 0))])
 def test_fused_head_block_vs_oracle(B, Q, V, ncls, flags):
     """hd_train_fwd / hd_train_bwd == oracle view reduction (channel-major / view-minor, mpfusion.py:434-438) +

@@ -60,8 +60,8 @@ def test_torch_save_of_a_live_graphed_model_round_trips(tmp_path):
     assert all(n.grad_direct is None for n in loaded.necks.values())
     sd_live, sd_load = m.state_dict(), loaded.state_dict()
     assert list(sd_live) == list(sd_load)
-    for k in sd_live:
-        assert torch.equal(sd_live[k], sd_load[k]) and sd_live[k].stride() == sd_load[k].stride(), k
+    for k in sd_live:      # (dpft_amd.models.load maps the pickle to the CPU; the module is moved by its next owner)
+        assert torch.equal(sd_live[k].cpu(), sd_load[k].cpu()) and sd_live[k].stride() == sd_load[k].stride(), k
     got = _eval_out(loaded.to(DEV), batch)
     for k in live:
         assert torch.equal(got[k], live[k]), (k, float((got[k] - live[k]).abs().max()))
@@ -129,7 +129,7 @@ def test_epoch_loop_trains_validates_and_checkpoints(tmp_path):
     model, epoch, stamp = load(written[-1])
     assert epoch == 1 and stamp == "20250101-000000-000"
     for k, v in tr.model.state_dict().items():
-        assert torch.equal(model.state_dict()[k], v), k
+        assert torch.equal(model.state_dict()[k].cpu(), v.cpu()), k
     cfg["train"]["epochs"] = 3
     tr2 = DataParallelTrainer.from_config(model, cfg)
     more = tr2.train(train_loader, None, start_epoch=epoch + 1, timestamp=stamp, dst=str(tmp_path), sampler=sampler)
