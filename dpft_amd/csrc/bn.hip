@@ -696,15 +696,18 @@ extern "C" int dpft_bn_bwd_apply_f32(const float* y, const float* dout, const fl
 int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp,
                                const float* bnp, const float* gamma, const float* sums, float* dy, float* dgamma,
                                float* dbeta, int64_t M, int32_t K, float* zero_buf, int32_t zero_n, bool act16,
-                               dpft_stream_t stream, const unsigned char* mask8) {
+                               dpft_stream_t stream, const unsigned char* mask8, bool frozen) {
     DPFT_REQUIRE(y && dout && bnp && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = M * K / 4;
+    // frozen (running-statistics) BatchNorm: mean and variance do not depend on the batch, so dy = gamma invstd d -- the
+    // batch form with its two mean terms weighted by 1/M = 0; dgamma = sum d xhat and dbeta = sum d are the same sums
+    const float invM = frozen ? 0.f : 1.0f / (float)M;
     if (act16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n, mask8);
+                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, 1.0f / (float)M, zero_buf, (int)zero_n, mask8);
+                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
     return check_launch("bn_bwd_apply");
 }
 

@@ -57,7 +57,7 @@ int bn_bwd_reduce_prezeroed(const float* y, const float* dout, const float* out,
 int bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
                          const float* gamma, const float* sums, float* dy, float* dgamma, float* dbeta, int64_t M,
                          int32_t K, float* zero_buf, int32_t zero_n, bool act16, dpft_stream_t stream,
-                         const unsigned char* mask8 = nullptr);
+                         const unsigned char* mask8 = nullptr, bool frozen = false);      // frozen: running-statistics BN (no mean terms)
 int bn_act_any(const float* y, const float* bnp, const float* res, const float* res_bnp, int32_t relu, float* out,
                float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream, unsigned char* mask8 = nullptr);
 int bn_relu_maxpool_any(const float* y, const float* bnp, float* out, int32_t B, int32_t H, int32_t W, int32_t K,

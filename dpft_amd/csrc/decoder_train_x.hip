@@ -72,6 +72,7 @@ struct XfArgs {
     int B, Q, salt;
     int P[4];
     float p_drop;
+    int exp;                    // timing experiments only (DPFT_XF_EXP; wrong gradients): 1 = no large-map atomics
 };
 // what the forward saves per row for the backward
 constexpr int XS_ACC = 0;                     // [8 heads][16] attention-weighted sampled raw features (= XR_SAMP)
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
             float* dst = rec + XC_SLOT + slot * XC_SLOT_FLOATS;
             if (lane < 32) reinterpret_cast<f32x4*>(dst)[lane] = reinterpret_cast<const f32x4*>(sc_w)[lane];
             else reinterpret_cast<int*>(dst + 128)[lane - 32] = sc_o[lane - 32];
-        } else {
+        } else if (!(a.exp & 1)) {
             // tiny maps without a record buffer: replica (row % R) of the gradient buffer, so that the fp32 atomics of
             // 1600 rows x 8 heads do not serialise on a few hundred addresses
             float* gl = pyr.grad[l] + (int64_t)(bq % pyr.rep[l]) * a.B * H * W * DC + (int64_t)b * H * W * DC;
@@ -546,6 +547,7 @@ struct XsArgs {
     float* grad[4 * XC_MAX_SLOTS];               // per small map
     int H[4 * XC_MAX_SLOTS], W[4 * XC_MAX_SLOTS], view[4 * XC_MAX_SLOTS], slot[4 * XC_MAX_SLOTS];
     int B, Q, qchunk;
+    int exp;      // timing experiments (DPFT_XF_EXP): 2 = no LDS atomics, 4 = no flush, 8 = no row loop
 };
 __global__ __launch_bounds__(512) void xf_scatter_small_kernel(XsArgs a) {
     extern __shared__ __attribute__((aligned(16))) float img[];
@@ -557,7 +559,7 @@ __global__ __launch_bounds__(512) void xf_scatter_small_kernel(XsArgs a) {
     __syncthreads();
     const int q0 = blockIdx.x * a.qchunk, q1 = min(a.Q, q0 + a.qchunk);
     const int h4 = lane >> 4, ch = lane & 15;
-    for (int q = q0 + wave; q < q1; q += 8) {
+    for (int q = q0 + wave; q < q1 && !(a.exp & 8); q += 8) {
         const float* rec = a.scratch + (((size_t)view * a.B + b) * a.Q + q) * XC_FLOATS;
         const float* wrec = rec + XC_SLOT + slot * XC_SLOT_FLOATS;
         const int* orec = reinterpret_cast<const int*>(wrec + 128);
@@ -574,6 +576,13 @@ __global__ __launch_bounds__(512) void xf_scatter_small_kernel(XsArgs a) {
                 off[half][p] = orec[p * 8 + m2];
             }
         }
+        if (a.exp & 2) {
+            float acc = val[0] + val[1];
+            for (int half = 0; half < 2; ++half)
+                for (int p = 0; p < 4; ++p) acc += cw[half][p][0] + cw[half][p][3] + (float)off[half][p];
+            if (acc == 12345.678f) img[0] = acc;
+            continue;
+        }
 #pragma unroll
         for (int half = 0; half < 2; ++half)
 #pragma unroll
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(512) void xf_scatter_small_kernel(XsArgs a) {
     }
     __syncthreads();
     float* g = a.grad[mi] + (size_t)b * n;
-    for (int i = tid; i < n; i += 512) {
+    for (int i = tid; i < n && !(a.exp & 4); i += 512) {
         const float v = img[i];
         if (v != 0.f) atomicAdd(g + i, v);
     }
@@ -658,6 +667,8 @@ extern "C" int dpft_xattn_ffn_train_bwd_f32(const dpft_pyramid* pyr, const dpft_
     DPFT_REQUIRE(dy3 && dy1 && dqp && dref && rows, "xattn_ffn_train_bwd: null argument");
     a.dy3 = dy3; a.dy1 = dy1; a.dqp = dqp; a.dref = dref; a.rows = rows;
     a.fsave = const_cast<float*>(saved);
+    static const int exp = getenv("DPFT_XF_EXP") ? atoi(getenv("DPFT_XF_EXP")) : 0;
+    a.exp = exp;
     // small maps (<= XC_MAX_PIXELS pixels, unreplicated gradient buffer) are recorded and scattered through LDS; a view with
     // more than XC_MAX_SLOTS of them keeps atomics for its largest ones
     XsArgs xs;
@@ -695,7 +706,7 @@ extern "C" int dpft_xattn_ffn_train_bwd_f32(const dpft_pyramid* pyr, const dpft_
     // about one workgroup per CU: fewer query chunks = fewer flushes of a map (one atomic line per touched pixel and chunk)
     int nchunk = kNumCU / (n_maps * B);
     nchunk = nchunk < 1 ? 1 : (nchunk > 8 ? 8 : nchunk);
-    xs.scratch = scratch; xs.B = B; xs.Q = Q; xs.qchunk = cdiv(Q, nchunk);
+    xs.scratch = scratch; xs.B = B; xs.Q = Q; xs.qchunk = cdiv(Q, nchunk); xs.exp = exp;
     nchunk = cdiv(Q, xs.qchunk);
     const size_t lds = (size_t)max_px * DC * sizeof(float);
     static bool attr_set = false;

@@ -60,6 +60,10 @@ struct ResnetPlan {
     size_t o_dy2;           // second dy buffer: weight gradients run on a side stream while the data path moves on
     int g_cur;
     bool g_valid;
+    // frozen BatchNorm (train = 2: a gradient is wanted through an eval-mode body, resnet.py:169-176 accepts
+    // FrozenBatchNorm2d): the forward keeps the train path's tensors but normalises with the running statistics, the
+    // backward's apply pass drops the batch-statistics terms (dy = gamma invstd d); set by the forward, read by the stages
+    bool frozen = false;
     // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
     hipStream_t side = nullptr;
     bool side_owned = true, side_set = false;      // side_set: side is valid (it may be the null stream)
@@ -333,6 +337,8 @@ static int conv_bn_train(const ResnetPlan* p, const Tables& T, const ConvRef& c,
                          float* A, float* y, float* stats, int tiles, int rows, int64_t M, float* bnp, void* ws,
                          dpft_stream_t st, const float* w = nullptr) {
     if (!w) w = T.w(c.w);
+    if (p->frozen)      // the BN block comes from the running statistics (eval_bn_blocks): no statistics, no finalize
+        return conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, nullptr, ws, st, nullptr);
     static const int fuse_mode = getenv("DPFT_BN_FINAL_FUSE") ? atoi(getenv("DPFT_BN_FINAL_FUSE")) : 0;      // 0 off | 1 atomics | 2 slab
     static const int slab_tiles = getenv("DPFT_BN_FINAL_TILES") ? std::min(64, atoi(getenv("DPFT_BN_FINAL_TILES"))) : 64;      // the merger holds two tiles per group in registers
     float* acc = A + p->o_bnacc + p->bnacc[bn];
@@ -378,7 +384,8 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
     float* A = (float*)arena;
     void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
     const bool tr = train != 0;
-    if (!tr) RC(eval_bn_blocks(p, T, A, st));
+    p->frozen = train == 2;
+    if (!tr || p->frozen) RC(eval_bn_blocks(p, T, A, st));
     const float* xa = x;
     if (p->adj.w >= 0) {
         RC(dpft_conv2d_nhwc_fwd_f32(&p->adj.d, x, T.w(p->adj.w), nullptr, nullptr, 0, A + p->xa, nullptr, ws, st));
@@ -386,8 +393,8 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
     }
     static const bool final_fuse = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
     if (tr && final_fuse) RC(zero_fill(A + p->o_bnacc, p->bnacc_floats * sizeof(float), st));
-    RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr ? A + p->s0 : nullptr, ws, st));
-    RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr, st));
+    RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr && !p->frozen ? A + p->s0 : nullptr, ws, st));
+    RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr && !p->frozen, st));
     const bool a16 = p->desc.act16 != 0;
     RC(bn_relu_maxpool_any(A + p->y0, A + p->p0, A + p->pool, p->c0.d.B, p->c0.d.OH, p->c0.d.OW, 64, p->PH, p->PW, a16, st));
     if (!tr) {
@@ -477,6 +484,7 @@ namespace dpft {
 struct BnSums {
     float* buf[2];
     int cur;
+    bool frozen;      // running-statistics BatchNorm: the apply pass keeps dgamma / dbeta and drops the mean terms
 };
 // `reduced`: the reduction into bs.buf[bs.cur] has already been done by the kernel that produced `dout` (BnReduceFuse).
 static int bn_backward(const float* y, const float* dout, const float* out, const float* mask_bnp, const float* bnp,
@@ -488,7 +496,7 @@ static int bn_backward(const float* y, const float* dout, const float* out, cons
     static const bool skip_reduce = getenv("DPFT_EXP_SKIP_BNREDUCE") != nullptr;      // timing experiment only (wrong gradients)
     if (!reduced && !skip_reduce) RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st, mask8));
     return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, act16, st,
-                                mask8);
+                                mask8, bs.frozen);
 }
 
 // Weight gradients do not feed the rest of the backward, so they run on the plan's side stream while the main
@@ -693,7 +701,7 @@ static int backward_stage_impl(ResnetPlan* p, int32_t stage, const float* x, con
         if (dout) RC(add_inplace_any(A + p->g_off[p->g_cur], dout, (int64_t)out_n, p->desc.act16 != 0, st));
         gp = A + p->g_off[p->g_cur];
     }
-    BnSums sums{{A + p->o_sums, A + p->o_sums + 2 * 2048}, 0};
+    BnSums sums{{A + p->o_sums, A + p->o_sums + 2 * 2048}, 0, p->frozen};
     RC(zero_fill(sums.buf[0], 2 * 2 * 2048 * sizeof(float), st));
     RC(sc.transposes(T, A + p->o_wt, stage));
     bool reduced = false;      // the stage's first gradient may still get an external term added: its bn3 reduces on its own
@@ -817,7 +825,7 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
                                    int32_t train, dpft_stream_t st) {
     ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
     DPFT_REQUIRE(p && x && tables && arena, "resnet_forward: null argument");
-    if (!train) return forward_impl(p, x, tables, arena, train, st);
+    if (train != 1) return forward_impl(p, x, tables, arena, train, st);      // eval, frozen-BN: eager launches
     return run_graphed(p, -1, x, arena, nullptr, tables, st, [&]() { return forward_impl(p, x, tables, arena, train, st); });
 }
 
@@ -826,6 +834,7 @@ extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float*
     ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
     DPFT_REQUIRE(p && x && tables && arena, "resnet_backward: null argument");
     DPFT_REQUIRE(stage >= 0 && stage < p->desc.n_layers, "resnet_backward: bad stage %d", stage);
+    if (p->frozen) return backward_stage_impl(p, stage, x, tables, arena, dout, st);
     return run_graphed(p, stage, x, arena, dout, tables, st,
                        [&]() { return backward_stage_impl(p, stage, x, tables, arena, dout, st); });
 }

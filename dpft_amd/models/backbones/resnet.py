@@ -164,8 +164,10 @@ class _BodyFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, owner: "BackboneBase", need_grad: bool, x: torch.Tensor, *params: torch.Tensor):
         train = owner.training
-        if need_grad and not train:
-            raise NotImplementedError("dpft_amd: backward through eval-mode BatchNorm is not implemented")
+        # plan mode: 0 eval | 1 train | 2 frozen BatchNorm = a gradient through an eval-mode body (running statistics in the
+        # forward, no batch-statistics terms in the backward, running buffers untouched) -- what torchvision's
+        # FrozenBatchNorm2d / an eval()-ed BatchNorm2d under autograd computes (resnet.py:169-176)
+        mode = 1 if train else (2 if need_grad else 0)
         x = x.contiguous()
         if not x.is_cuda or x.dtype != torch.float32:
             raise HipLibraryError("dpft_amd ops need CUDA (ROCm) fp32 tensors; there is no CPU path")
@@ -240,7 +242,7 @@ class _BodyFn(torch.autograd.Function):
             # [K][kh][kw][C] (p.data reassigned, load_state_dict(assign=True)), and a cached copy would go stale
             if sig is not None and all(wk.data_ptr() == c.weight.data_ptr() for wk, c in zip(weights, convs)):
                 owner.__dict__["_infer_tables"] = (sig, t, keep, weights)
-        lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), int(train), stream())
+        lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), mode, stream())
         if train:
             torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
         af = arena.view(torch.float32)

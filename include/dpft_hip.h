@@ -205,7 +205,10 @@ void dpft_resnet_plan_destroy(int64_t plan);
 /* what: 0 arena bytes, 1 #convs, 2 #bns, 3 float offset of stage output idx in the arena,
  *       4 shape entry (idx = stage*4 + dim of (B,H,W,C)), 5 floats kept for backward */
 int64_t dpft_resnet_plan_query(int64_t plan, int32_t what, int32_t idx);
-/* x (B,H,W,in_channels).  train != 0: batch statistics + running-stat update, activations kept. */
+/* x (B,H,W,in_channels).  train = 1: batch statistics + running-stat update, activations kept for the backward stages;
+ * train = 2: frozen BatchNorm -- activations kept as well, but every BatchNorm normalises with its running statistics
+ * (nothing is updated) and the backward stages drop the batch-statistics terms (dy = gamma invstd d): the gradient through
+ * an eval-mode body / torchvision's FrozenBatchNorm2d; train = 0: inference (BatchNorm folded into the conv epilogues). */
 int dpft_resnet_forward(int64_t plan, const float* x, const dpft_resnet_tables* tables, void* arena,
                         int32_t train, dpft_stream_t stream);
 /* Backward of stage `stage` (call n_layers-1 ... 0 after a train forward; stage 0 also runs the

@@ -1143,3 +1143,59 @@ def test_two_forwards_before_their_backwards_with_replayed_plans():
     with pytest.raises(RuntimeError, match="second grad-enabled forward"):
         tr.model(b)
     del oa
+
+
+def test_frozen_batchnorm_backward_matches_oracle():
+    """Missing #6 of VERDICT r3: a gradient through eval-mode bodies (``model.eval()`` under autograd = what torchvision's
+    FrozenBatchNorm2d computes, resnet.py:169-176) used to raise.  Plan mode 2: the train path's tensors, BatchNorm blocks
+    from the running statistics, backward without the batch-statistics terms.  Forward == the eval oracle, every gradient
+    (incl. dgamma / dbeta of every BatchNorm) vs the fp64 oracle with the fp32 oracle as yardstick, running buffers untouched."""
+    from dpft_amd.synthetic import make_batch
+    from oracle import dprt_oracle as O
+    cfg = small_config(dropout=0.0)
+    g = torch.Generator().manual_seed(12)
+    model = _build(cfg, g)
+    sd64 = state_dict_f64(model)
+
+    def leafs(dtype):
+        return {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                    else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd64.items()}
+    sd_ref, sd32 = leafs(torch.float64), leafs(torch.float32)
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=SHAPES)
+    b64 = {k: (v.double() if v.is_floating_point() else v) for k, v in batch.items()}
+    ref = O.dprt_forward(sd_ref, cfg, b64, train=False)
+    ref32 = O.dprt_forward(sd32, cfg, batch, train=False)
+    model = model.to(DEV).eval()
+    before = {k: v.clone() for k, v in model.state_dict().items() if "running" in k or "num_batches" in k}
+    out = model({k: v.to(DEV) for k, v in batch.items()})            # grad mode on: plan mode 2, training decoder kernels
+    for k in out:
+        e, e32 = rel_l2(out[k], ref[k]), rel_l2(ref32[k], ref[k])
+        assert e < max(1e-4, 4 * e32), (k, e, e32)
+    cots = {k: torch.randn(ref[k].shape, generator=g, dtype=torch.float64) for k in ref}
+    sum((ref[k] * cots[k]).sum() for k in ref).backward()
+    sum((ref32[k] * cots[k].float()).sum() for k in ref32).backward()
+    sum((out[k] * cots[k].float().to(DEV)).sum() for k in out).backward()
+    for k, v in model.state_dict().items():
+        if k in before:
+            assert torch.equal(v, before[k]), k                      # frozen: no running-statistics update
+    tot, report, n_bn = [0.0, 0.0, 0.0], [], 0
+    for n, p in model.named_parameters():
+        gref = sd_ref[n].grad
+        if gref is None:
+            continue
+        assert p.grad is not None, n
+        e, e32 = rel_l2(p.grad, gref), rel_l2(sd32[n].grad, gref)
+        report.append((e / max(e32, 1e-7), e, e32, n))
+        tot[0] += float((p.grad.double().cpu() - gref).pow(2).sum()); tot[1] += float((sd32[n].grad.double() - gref).pow(2).sum())
+        tot[2] += float(gref.pow(2).sum())
+        n_bn += ".bn" in n
+        assert e < max(5e-3, 6 * e32), (n, e, e32)
+    report.sort(reverse=True)
+    e, e32 = (tot[0] / tot[2]) ** 0.5, (tot[1] / tot[2]) ** 0.5
+    print(f"frozen-BN whole-network gradient rel-L2: hip {e:.2e} cpu-fp32 {e32:.2e}; worst (ratio, hip, fp32, name):", report[:3])
+    assert n_bn > 100 and e < max(1e-4, 3 * e32), (e, e32)
+    # eval + no_grad still takes the inference path (BatchNorm folded into the conv epilogues) and agrees with mode 2
+    with torch.no_grad():
+        out2 = model({k: v.to(DEV) for k, v in batch.items()})
+    for k in out:
+        close(out2[k], out[k], rtol=1e-4, atol_scale=1e-4, what=f"inference vs frozen forward {k}")

@@ -1,0 +1,212 @@
+"""Why is the HIP path's full-size gradient 2-4x further from the fp64 oracle than the CPU-fp32 oracle is?  
+
+kradar.json, batch 4, dropout 0, random init, seeded noise batch -- the state tests/test_gpu_model.py::
+test_full_size_train_step_matches_oracle compares at.  Every block prints relative-L2 distances to the fp64 oracle of
+(a) the HIP path and (b) the CPU fp32 oracle, per parameter group:
+
+  1. whole step, train-mode BatchNorm (the r03 table), HIP variants: default | conv GEMMs as 3 x bf16 split products
+     (2-3e-7 per conv instead of 6-8e-7) | eager (unfused) decoder;
+  2. the same with FROZEN BatchNorm (eval-mode bodies, train = 2 plans): no batch-4 statistics in the chain;
+  3. the decoder alone on IDENTICAL fp32 pyramids (the HIP forward's own, copied to the host): HIP fused training decoder
+     vs oracle fp32 vs oracle fp64 -- no encoder in the comparison at all;
+  4. reference points (head -> projection -> normalise): error in PIXELS of the finest level against fp64, HIP vs CPU fp32,
+     and the share of sampling positions whose floor() differs from fp64's (a bilinear sample that lands on the other side
+     of a pixel boundary has a continuous value but a different gradient).
+
+    python tools/grad_gap_probe.py > profiles/r04_grad_gap_probe.txt
+"""
+import copy
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dpft_amd.configs import load_config          # noqa: E402
+from dpft_amd.hip import ops                      # noqa: E402
+from dpft_amd.models import build                 # noqa: E402
+from dpft_amd.synthetic import make_batch, make_labels      # noqa: E402
+from dpft_amd.training.loss import build_loss     # noqa: E402
+from oracle import dprt_oracle as O               # noqa: E402
+
+DEV = "cuda"
+torch.set_num_threads(min(64, os.cpu_count() or 1))
+
+
+def group(n):
+    p = n.split(".")
+    if p[0] == "backbones":
+        return ".".join(p[:2])
+    return ".".join(p[:2]) if p[0] == "necks" else p[0]
+
+
+def table(title, got, g32, g64):
+    acc = {}
+    for n, g in g64.items():
+        if n not in got or got[n] is None:
+            continue
+        a = acc.setdefault(group(n), [0.0, 0.0, 0.0])
+        a[0] += float((got[n].double().cpu() - g).pow(2).sum())
+        a[1] += float((g32[n].double() - g).pow(2).sum())
+        a[2] += float(g.pow(2).sum())
+    tot = [sum(a[i] for a in acc.values()) for i in range(3)]
+    print(f"-- {title}")
+    for k in sorted(acc):
+        e, e32 = (acc[k][0] / acc[k][2]) ** 0.5, (acc[k][1] / acc[k][2]) ** 0.5
+        print(f"   {k:28s} hip {e:.2e}   cpu-fp32 {e32:.2e}   ratio {e / max(e32, 1e-30):5.2f}")
+    e, e32 = (tot[0] / tot[2]) ** 0.5, (tot[1] / tot[2]) ** 0.5
+    print(f"   {'whole network':28s} hip {e:.2e}   cpu-fp32 {e32:.2e}   ratio {e / max(e32, 1e-30):5.2f}", flush=True)
+
+
+def main():
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["fuser"]["dropout"] = 0.0
+    g = torch.Generator().manual_seed(41)
+    torch.manual_seed(41)
+    model = build("dprt", cfg)
+    with torch.no_grad():                       # as tests/test_gpu_model.py::_build: non-trivial BN state and decoder weights
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.75)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+        for n, p in model.fuser.named_parameters():
+            p.add_(torch.randn(p.shape, generator=g) * 0.05)
+    sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+    batch = make_batch(cfg["model"]["inputs"], 4, seed=9)
+    labels = make_labels(4, seed=9)
+    w = cfg["train"]["loss_weights"]
+
+    def leafs(dtype):
+        return {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                    else (v.to(dtype) if v.is_floating_point() else v)) for k, v in sd64.items()}
+
+    def oracle(dtype, train):
+        sd = leafs(dtype)
+        b = {k: (v.to(dtype) if v.is_floating_point() else v) for k, v in batch.items()}
+        lab = [{k: (v.to(dtype) if v.is_floating_point() else v) for k, v in l.items()} for l in labels]
+        out = O.dprt_forward(sd, cfg, b, train=train)
+        loss, _ = O.loss_forward(out, lab, w)
+        loss.backward()
+        return float(loss), {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None}
+
+    model = model.to(DEV)
+    loss_fn = build_loss(cfg["train"])
+    dev_batch = {k: v.to(DEV) for k, v in batch.items()}
+    dev_labels = [{k: v.to(DEV) for k, v in l.items()} for l in labels]
+
+    def hip(train, compute="fp32", fused=True):
+        ops.conv_set_compute(compute)
+        model.train(train)
+        model.fuser.use_fused_train = fused
+        for l in model.fuser.mpfusion.values():
+            l.use_fused_train = fused
+        model.zero_grad(set_to_none=True)
+        out = model(dev_batch)
+        loss, _ = loss_fn(out, dev_labels)
+        loss.backward()
+        torch.cuda.synchronize()
+        ops.conv_set_compute("fp32")
+        return float(loss), {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    for train, title in ((True, "1. train-mode BatchNorm (batch statistics over 4 samples)"),
+                         (False, "2. frozen BatchNorm (eval-mode bodies under autograd, running statistics)")):
+        t0 = time.time()
+        l64, g64 = oracle(torch.float64, train)
+        l32, g32 = oracle(torch.float32, train)
+        print(f"== {title}: loss fp64 {l64:.6f} cpu-fp32 {l32:.6f}   (oracles {time.time() - t0:.0f} s)")
+        for name, kw in (("HIP default (fp32 MFMA, fused decoder)", {}),
+                         ("HIP conv GEMMs as 3 x bf16 split products (forward / data gradient)", dict(compute="bf16x3")),
+                         ("HIP eager decoder (torch ops + dpft_xattn_* kernels)", dict(fused=False))):
+            try:
+                lh, gh = hip(train, **kw)
+                table(f"{name}: loss {lh:.6f}", gh, g32, g64)
+            except Exception as e:          # noqa: BLE001
+                print(f"-- {name}: FAILED {type(e).__name__}: {e}")
+        # two HIP runs against each other: the run-to-run (atomics / split order) floor of this comparison
+        _, ga = hip(train)
+        _, gb = hip(train)
+        num = sum(float((ga[n].double() - gb[n].double()).pow(2).sum()) for n in ga)
+        den = sum(float(gb[n].double().pow(2).sum()) for n in ga)
+        print(f"   HIP run-to-run whole-network rel-L2: {(num / den) ** 0.5:.2e}")
+        del g64, g32
+
+    # ---- 3. the decoder alone, on identical fp32 pyramids ---------------------------------------------------------
+    print("== 3. decoder alone on identical fp32 pyramids (the HIP forward's own features)")
+    model.train(True)
+    model.fuser.use_fused_train = True
+    for l in model.fuser.mpfusion.values():
+        l.use_fused_train = True
+    with torch.no_grad():
+        feats = model._encode_views(dev_batch)
+    inputs = cfg["model"]["inputs"]
+    host_feats = {i: [t.detach().cpu() for t in feats[i].values()] for i in inputs}
+    shapes = [batch[f"{i}_shape"][:, :2] for i in inputs]
+    projs = [(batch[f"label_to_{i}_t"], batch[f"label_to_{i}_p"]) for i in inputs]
+    q = cfg["model"]["querent"]
+
+    def oracle_decoder(dtype):
+        sd = {k: v for k, v in leafs(dtype).items() if k.startswith("fuser.")}
+        lv = [[t.to(dtype).clone().requires_grad_(True) for t in host_feats[i]] for i in inputs]
+        c0 = O.querent(4, q["resolution"], q["minimum"], q["maximum"], dtype)
+        pr = [(t.to(dtype), p.to(dtype)) for t, p in projs]
+        out = O.impfusion(lv, shapes, pr, c0, sd, "fuser", cfg["model"]["fuser"])
+        lab = [{k: (v.to(dtype) if v.is_floating_point() else v) for k, v in l.items()} for l in labels]
+        loss, _ = O.loss_forward(out, lab, w)
+        loss.backward()
+        gr = {k: v.grad for k, v in sd.items() if v.grad is not None}
+        for vi, i in enumerate(inputs):
+            for li, t in enumerate(lv[vi]):
+                gr[f"pyramid.{i}.{li}"] = t.grad
+        return float(loss), gr
+    l64, g64 = oracle_decoder(torch.float64)
+    l32, g32 = oracle_decoder(torch.float32)
+    lv = {i: [t.detach().clone().requires_grad_(True) for t in feats[i].values()] for i in inputs}
+    from collections import OrderedDict
+    fd = [OrderedDict((k, t) for k, t in zip(feats[i].keys(), lv[i])) for i in inputs]
+    model.zero_grad(set_to_none=True)
+    out = model.fuser(batch=fd, shape=[dev_batch[f"{i}_shape"][:, :2] for i in inputs],
+                      projection=model._get_projetions(inputs, dev_batch), out=model.querent(dev_batch))
+    loss, _ = loss_fn(out, dev_labels)
+    loss.backward()
+    gh = {n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None and n.startswith("fuser.")}
+    for i in inputs:
+        for li, t in enumerate(lv[i]):
+            gh[f"pyramid.{i}.{li}"] = t.grad.detach().clone()
+
+    def grp(n):
+        return n if n.startswith("pyramid.") else "fuser parameters"
+    acc = {}
+    for n, gg in g64.items():
+        a = acc.setdefault(grp(n), [0.0, 0.0, 0.0])
+        a[0] += float((gh[n].double().cpu() - gg).pow(2).sum()); a[1] += float((g32[n].double() - gg).pow(2).sum()); a[2] += float(gg.pow(2).sum())
+    print(f"   loss fp64 {l64:.6f} cpu-fp32 {l32:.6f} hip {float(loss):.6f}")
+    for k in sorted(acc):
+        e, e32 = (acc[k][0] / acc[k][2]) ** 0.5, (acc[k][1] / acc[k][2]) ** 0.5
+        print(f"   {k:28s} hip {e:.2e}   cpu-fp32 {e32:.2e}   ratio {e / max(e32, 1e-30):5.2f}")
+
+    # ---- 4. reference points: pixel error and floor() flips ------------------------------------------------------------
+    print("== 4. reference points of the first iteration (querent centres), error vs fp64 in pixels of the finest level")
+    from dpft_amd.models.fusers import train_fused as tf
+    flags = model.fuser.transformation_flags(model._get_projetions(inputs, dev_batch))
+    proj = tf._Proj(model._get_projetions(inputs, dev_batch), [dev_batch[f"{i}_shape"][:, :2] for i in inputs], flags)
+    c0 = model.querent(dev_batch)["center"]
+    refs_hip = tf.reference_points(proj, c0).cpu().double()
+    for vi, i in enumerate(inputs):
+        r64 = O.reference_points(c0.cpu().double(), projs[vi][0].double(), projs[vi][1].double(), shapes[vi])
+        r32 = O.reference_points(c0.cpu().float(), projs[vi][0].float(), projs[vi][1].float(), shapes[vi]).double()
+        H, W = host_feats[i][0].shape[1:3]
+        scale = torch.tensor([W, H], dtype=torch.float64)
+        eh, e3 = ((refs_hip[vi] - r64) * scale).abs(), ((r32 - r64) * scale).abs()
+        inner = ((r64 > 0) & (r64 < 1)).all(-1)
+        fh = ((torch.floor(refs_hip[vi] * scale - 0.5) != torch.floor(r64 * scale - 0.5)).any(-1) & inner).double().mean()
+        f3 = ((torch.floor(r32 * scale - 0.5) != torch.floor(r64 * scale - 0.5)).any(-1) & inner).double().mean()
+        print(f"   {i:12s} level0 {H}x{W}: max |err| hip {float(eh.max()):.2e} px  cpu-fp32 {float(e3.max()):.2e} px   "
+              f"mean hip {float(eh.mean()):.2e}  cpu-fp32 {float(e3.mean()):.2e}   floor flips hip {float(fh):.2e}  cpu-fp32 {float(f3):.2e}")
+
+
+if __name__ == "__main__":
+    main()
