@@ -2386,6 +2386,26 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     return rc;
 }
 
+// C-ABI face of the launch plan's fused data gradients (kernel-level parity: tests/test_gpu_conv_table.py)
+extern "C" int dpft_conv2d_nhwc_dgrad_bn_reduce_f32(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx,
+                                                    int32_t accumulate, const float* res_src, const float* res_out,
+                                                    const uint8_t* res_mask8, const float* bn_y, const float* bn_block,
+                                                    const uint8_t* bn_mask8, int32_t bn_self_mask, float* sums,
+                                                    int32_t* applied, void* workspace, dpft_stream_t stream) {
+    DPFT_REQUIRE(bn_y && bn_block && sums && applied, "conv dgrad_bn_reduce: null BatchNorm argument");
+    DPFT_REQUIRE((bn_mask8 != nullptr) != (bn_self_mask != 0), "conv dgrad_bn_reduce: exactly one of bn_mask8 / bn_self_mask");
+    dpft::BnReduceFuse f{bn_y, bn_block, bn_mask8, bn_self_mask, sums, false};
+    int rc;
+    if (res_src) {
+        DPFT_REQUIRE(!accumulate && res_out, "conv dgrad_bn_reduce: the residual form needs res_out and does not accumulate");
+        rc = dpft::conv_dgrad_residual(d, dy, w_t, dx, res_src, res_out, workspace, stream, &f, res_mask8);
+    } else {
+        rc = dpft::conv_dgrad_fused(d, dy, w_t, dx, accumulate, workspace, stream, &f);
+    }
+    *applied = f.applied ? 1 : 0;
+    return rc;
+}
+
 extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,
                                           const float* pro_bn, int32_t pro_relu, float* dw,
                                           void* workspace, dpft_stream_t stream) {

@@ -91,6 +91,7 @@ SIGNATURES = {
     "dpft_conv2d_nhwc_fwd_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_fwd_bnact_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_dgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P]),
+    "dpft_conv2d_nhwc_dgrad_bn_reduce_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_wgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P, _P]),
     "dpft_conv2d_nhwc_wgrad_bias_f32": (_I, [_P, _P, _P, _P, _P, _P, _P]),
     "dpft_weight_transpose_f32": (_I, [_P, _P, _I, _I, _I, _P]),

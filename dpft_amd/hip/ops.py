@@ -123,6 +123,23 @@ def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
     return out
 
 
+def conv_dgrad_bn_reduce(cv: Conv, dy, w_t, bn_y, bn_block, sums, bn_mask8=None, residual=None, out=None, accumulate=False):
+    """The launch plan's fused data gradient (dpft_conv2d_nhwc_dgrad_bn_reduce_f32): dx, and -- when the launch could carry
+    it (returned flag) -- the BatchNorm-backward sums of the layer whose dout dx is added into ``sums`` [2][C].
+    ``bn_mask8`` None = the ReLU sits directly behind that BatchNorm (mask = bn(bn_y) > 0).
+    ``residual`` = (res_src, block_out, res_mask8 or None): dx += res_src under the block output's ReLU mask."""
+    if out is None:
+        out = torch.empty((cv.B, cv.H, cv.W, cv.C), dtype=torch.float32, device=dy.device)
+        accumulate = False
+    ws = workspace(cv.ws_bytes, dy.device)
+    applied = C.c_int32(0)
+    rs, ro, rm = residual if residual is not None else (None, None, None)
+    lib.call("dpft_conv2d_nhwc_dgrad_bn_reduce_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate),
+             ptr(rs), ptr(ro), ptr(rm), ptr(bn_y), ptr(bn_block), ptr(bn_mask8), int(bn_mask8 is None), ptr(sums),
+             C.addressof(applied), ptr(ws), stream())
+    return out, bool(applied.value)
+
+
 def conv_wgrad(cv: Conv, x, dy, pro=None, out=None):
     """dw physical [K][kh][kw][C] (returned as a (K,kh,kw,C) tensor).  ``out``: write into this buffer (same physical
     layout, e.g. a DP bucket view) instead of a fresh tensor."""

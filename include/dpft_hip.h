@@ -104,6 +104,23 @@ int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* desc, const float* x, c
 int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,
                                float* dx, int32_t accumulate, void* workspace,
                                dpft_stream_t stream);
+
+/* Data gradient with the FIRST PASS of a BatchNorm backward in its epilogue -- the form the ResNet launch plan
+ * (dpft_resnet_backward_stage) runs: the tensor this call writes, dx (B,H,W,C), is the `dout` of a BatchNorm layer
+ * whose input bn_y has the same shape and whose BN block (mean, gamma*invstd, beta, invstd) is bn_block [4][C];
+ * with d = dx under that layer's ReLU mask (bn_mask8: one byte per 4 channels, bit e = element e passed; or
+ * bn_self_mask: mask = bn(bn_y) > 0) the launch adds  sums[0][c] += sum_pixels d,  sums[1][c] += sum_pixels d * xhat,
+ * xhat = (bn_y - mean) * invstd  -- what dpft_bn_bwd_reduce_f32 computes in a pass of its own.  sums [2][C] must be
+ * zero (or hold a running total).  *applied = 1 when the launch carried the reduction; 0 when the problem takes a path
+ * that cannot (split-K, thin channels, a strided 1x1 whose parity classes leave pixels untouched): sums is then
+ * untouched and the caller runs the separate pass.
+ * res_src != NULL: the bottleneck's identity branch folded in as well, dx = dgrad(dy) + (mask ? res_src : 0) with the
+ * mask from res_mask8 (bytes) or res_out > 0 (the block output; always required for the split-K form); stride 1 only. */
+int dpft_conv2d_nhwc_dgrad_bn_reduce_f32(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx,
+                                         int32_t accumulate, const float* res_src, const float* res_out,
+                                         const uint8_t* res_mask8, const float* bn_y, const float* bn_block,
+                                         const uint8_t* bn_mask8, int32_t bn_self_mask, float* sums,
+                                         int32_t* applied, void* workspace, dpft_stream_t stream);
 /* dw[K][kh][kw][C] = sum_pixels dy (x) act(x); same optional prologue on x as forward.
  * dw is overwritten. */
 int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,

@@ -90,3 +90,68 @@ def test_bench_step_conv_problem_vs_fp64(shape, kinds):
         _close((acc - base).permute(0, 3, 1, 2), xa.grad, "dgrad accumulate", atol_scale=1e-4)
     print(shape, sorted(kinds), {k_: f"{v:.1e}" for k_, v in errs.items()})
     assert all(v < 2e-6 for v in errs.values()), errs            # fp32-roundoff class (the fp32 MFMA is an exact fmaf chain)
+
+
+def _body_dgrad_rows():
+    """dgrad rows of the table that are ResNet-body convs (the plan runs them with a BatchNorm-backward reduction in the
+    epilogue): C % 64 == 0 and K % 64 == 0."""
+    return [(k, kinds) for k, kinds in ROWS if "dgrad" in kinds and k[3] % 64 == 0 and k[4] % 64 == 0]
+
+
+@pytest.mark.parametrize("shape,kinds", _body_dgrad_rows(), ids=["x".join(str(v) for v in k) for k, _ in _body_dgrad_rows()])
+def test_bench_step_dgrad_with_bn_reduce_epilogue_vs_fp64(shape, kinds):
+    """the fp32 data gradient + BatchNorm-backward-reduce epilogue (and, for stride-1 1x1 convs, the
+    identity-branch ReLU backward folded into the same epilogue) at the bench step's shapes -- the form
+    dpft_resnet_backward_stage runs -- vs fp64: dx, and sums = (sum d, sum d * xhat) of d = dx under the ReLU mask, for both
+    mask sources (byte mask of a block output / bn(y) > 0).  Where the launch cannot carry the reduction (split-K) the
+    flag says so and sums stays untouched."""
+    from dpft_amd.hip import ops
+    B, H, W, C, K, k, s = shape
+    pad = k // 2
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    g = torch.Generator().manual_seed(sum(v * (i + 5) for i, v in enumerate(shape)) % 9973)
+    w = (torch.randn(K, C, k, k, generator=g) / (C * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    cv = ops.conv_problem(B, H, W, C, K, k, k, s, pad)
+    dy = torch.randn(B, cv.OH, cv.OW, K, generator=g)
+    dx_ref = torch.nn.grad.conv2d_input((B, C, H, W), w.double(), dy.double().permute(0, 3, 1, 2), stride=s, padding=pad) \
+        .permute(0, 2, 3, 1).contiguous()
+    bn_y = torch.randn(B, H, W, C, generator=g) * 1.5 + 0.3
+    mean, invstd = torch.randn(C, generator=g) * 0.4, torch.rand(C, generator=g) + 0.5
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    block = torch.stack((mean, gamma * invstd, beta, invstd)).contiguous()
+    xhat = (bn_y.double() - mean.double()) * invstd.double()
+    wt = ops.weight_transpose(w.to(DEV).permute(0, 2, 3, 1))
+    cases = [("self-mask", None, None)]
+    mask_bits = torch.rand(B, H, W, C, generator=g) > 0.4
+    packed = (mask_bits.view(B, H, W, C // 4, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8)).sum(-1) \
+        .to(torch.uint8).contiguous()
+    cases.append(("byte mask", packed, None))
+    if s == 1 and k == 1:                                   # conv1 of a bottleneck: identity branch in the same epilogue
+        res_src = torch.randn(B, H, W, C, generator=g)
+        block_out = torch.where(torch.rand(B, H, W, C, generator=g) > 0.5, torch.rand(B, H, W, C, generator=g) + 0.1,
+                                torch.zeros(B, H, W, C))
+        rm = ((block_out > 0).view(B, H, W, C // 4, 4).to(torch.uint8) * torch.tensor([1, 2, 4, 8], dtype=torch.uint8)).sum(-1) \
+            .to(torch.uint8).contiguous()
+        cases.append(("byte mask + identity branch", packed, (res_src, block_out, rm)))
+    for name, m8, res in cases:
+        ref = dx_ref if res is None else dx_ref + torch.where(res[1] > 0, res[0].double(), torch.zeros((), dtype=torch.float64))
+        mask = mask_bits if m8 is not None else ((xhat * gamma.double() + beta.double()) > 0)
+        # self-mask elements whose bn(y) is within fp32 round-off of zero may flip: leave them out of the reference sums
+        sure = torch.ones_like(mask) if m8 is not None else ((xhat * gamma.double() + beta.double()).abs() > 1e-5)
+        d = torch.where(mask, ref, torch.zeros((), dtype=torch.float64))
+        s_ref = torch.stack((d.sum((0, 1, 2)), (d * xhat).sum((0, 1, 2))))
+        slack = torch.stack(((ref.abs() * ~sure).sum((0, 1, 2)), (ref.abs() * xhat.abs() * ~sure).sum((0, 1, 2))))
+        sums = torch.zeros(2, C, device=DEV)
+        rg = None if res is None else (res[0].to(DEV), res[1].to(DEV), res[2].to(DEV))
+        dx, applied = ops.conv_dgrad_bn_reduce(cv, dy.to(DEV), wt, bn_y.to(DEV), block.to(DEV), sums,
+                                               bn_mask8=None if m8 is None else m8.to(DEV), residual=rg)
+        e = _close(dx, ref, f"dgrad [{name}]")
+        assert e < 2e-6, (name, e)
+        if applied:
+            got = sums.double().cpu()
+            scale = torch.stack((d.abs().sum((0, 1, 2)), (d * xhat).abs().sum((0, 1, 2))))      # cancellation-aware bound
+            err = ((got - s_ref).abs() - slack).clamp_min(0) / scale.clamp_min(1e-30)
+            assert float(err.max()) < 2e-6, (name, float(err.max()))
+        else:
+            assert float(sums.abs().max()) == 0.0, name
+        print(shape, name, "applied" if applied else "not carried (split-K / classes)", f"dx {e:.1e}")
