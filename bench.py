@@ -393,6 +393,10 @@ def main():
 
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
     fwd_mean, fwd_std = trainer.inference_time(data, warmup=10, reps=args.latency_reps)
+    # single-frame latency (what a "low inference time" claim is about, README.md:16 of the reference; its own protocol
+    # times a batch): the same protocol on batch 1
+    data1 = {k: v[:1].contiguous() for k, v in data.items()}
+    fwd1_mean, fwd1_std = trainer.inference_time(data1, warmup=10, reps=max(20, args.latency_reps // 3))
 
     # ---- HBM roofline of the deformable fusion decoder (SURVEY 8d "Roofline B") -------------------------
     # unit of work = one IMPFusion.forward (eval); algorithmic bytes = every cross-attention call streams its
@@ -502,6 +506,7 @@ def main():
                                      "f32x3": "experimental: fp32 conv operands as three bf16 terms, six term products "
                                               "on the bf16 matrix cores, fp32 accumulation"}[args.dtype]},
             "fwd_ms_per_frame": fwd_mean / B, "fwd_ms_per_batch": fwd_mean, "fwd_ms_std": fwd_std,
+            "fwd_ms_batch1": fwd1_mean, "fwd_ms_batch1_std": fwd1_std,
             "fwd_protocol": f"10 warm-up + {args.latency_reps} event-timed eval forwards of one batch (evaluator.py:109-125)",
             "step_definition": "zero_grad, forward, Hungarian set loss, backward, bucketed all-reduce, AdamW; the per-step "
                                "eval_fn of the reference's loop (trainer.py:134-136) is not part of the timed step",
@@ -519,7 +524,8 @@ def main():
                                 "note": "views and the camera's weight-gradient stream sit on probed, distinct hardware queues "
                                         "(dpft_stream_set); collectives: " + {"side": "in order on the camera's weight-gradient stream",
                                                                             "front": "in order on the last view's stream",
-                                                                            "pg": "the process group's own stream"}.get(
+                                                                            "pg": "the process group's own stream",
+                                                                            "own": "a dedicated stream"}.get(
                                             trainer.comm_placement, trainer.comm_placement)},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),

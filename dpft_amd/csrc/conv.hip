@@ -1858,7 +1858,11 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps) {
     // unsplit (tools/r03_tile_ab.sh), but over the whole step 128 / 192 / 256 are within run-to-run noise (conv time 28.2 /
     // 27.9 / 28.0 ms): the threshold stays at one workgroup per CU.
     static const int split_below = getenv("DPFT_SPLIT_BELOW") ? atoi(getenv("DPFT_SPLIT_BELOW")) : kNumCU;
-    if (nwg < split_below && ksteps >= 8) {
+    // (round 4) 200 ... 255 tiles with a SHALLOW reduction (<= 32 K-steps: the 1x1 convs of camera layer 4, 232 tiles)
+    // stay unsplit: the split's slab round trip + reduction launch cost more than the idle tenth of the chip
+    // (tools/r03_tile_ab.sh: 16x29 2048->512 forward 53.7 -> 36.9 us, 512->2048 data gradient 55.1 -> 40.1 us)
+    const bool shallow_nearly_full = nwg >= 200 && ksteps <= 32;
+    if (nwg < split_below && ksteps >= 8 && !shallow_nearly_full) {
         int s = (int)((kNumCU * 2 + nwg - 1) / nwg);
         s = s > 16 ? 16 : s;
         while (s > 1 && ksteps / s < 4) --s;

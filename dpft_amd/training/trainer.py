@@ -96,7 +96,9 @@ class DataParallelTrainer:
         # all-reduce kernel of N > 1 ranks would hold up the data-gradient chain for its whole duration.  "side" (default)
         # enqueues them, in order, on the camera's weight-gradient stream: the one chain with slack (6.5 ms of GEMMs in a 19 ms
         # backward) and the producer of most of every camera bucket; "front" = the last view's stream.  Forced one-rank
-        # collectives (tools/r03_comm_ab.sh): side 29.2, pg 29.4, front 31.7 ms against 28.7 ms plain.
+        # collectives (tools/r03_comm_ab.sh): side 29.2, pg 29.4, front 31.7 ms against 28.7 ms plain.  "own" = a dedicated
+        # stream.  All of this was chosen on ONE rank, where the all-reduce moves no bytes: with N > 1 the choice is an open
+        # question that tools/scale.sh sweeps (side | pg | own) -- DESIGN.md section 6 says what to expect.
         self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "side")
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         # epoch loop (trainer.py:21-47,64-67): epochs, schedule, logging frequency (None | 'step' | 'epoch')
@@ -130,11 +132,16 @@ class DataParallelTrainer:
         self.model.train()
         if self.collective and self.reducer.comm_stream is None and self.comm_placement != "pg" and self.device.type == "cuda" \
                 and dist.get_backend() == "nccl":
-            views = self.model.__dict__.get("_view_streams")
-            if views:
-                first = self.model.backbones[self.model.inputs[0]]
-                self.reducer.comm_stream = views[-1] if self.comm_placement == "front" or first.side_stream is None \
-                    else first.side_stream
+            if self.comm_placement == "own":
+                # a stream of its own: never joined by a backward stage, unlike the weight-gradient stream; the
+                # runtime maps it onto one of the 4 hardware queues, where it is in order with whatever else sits there
+                self.reducer.comm_stream = torch.cuda.Stream(self.device)
+            else:
+                views = self.model.__dict__.get("_view_streams")
+                if views:
+                    first = self.model.backbones[self.model.inputs[0]]
+                    self.reducer.comm_stream = views[-1] if self.comm_placement == "front" or first.side_stream is None \
+                        else first.side_stream
         self.reducer.reset()                               # zero_grad (grads live in the buckets)
         g = self.model.__dict__.get("_graphed_fuser")
         if g is not None:

@@ -1274,3 +1274,69 @@ def test_full_size_frozen_bn_gradients_at_fp32_roundoff():
     e, e32 = (tot[0] / tot[2]) ** 0.5, (tot[1] / tot[2]) ** 0.5
     print(f"full-size frozen-BN whole-network gradient rel-L2: hip {e:.2e}  fp32 oracle {e32:.2e}")
     assert e < max(1e-3, 2 * e32), (e, e32)
+
+
+def test_config1_full_resolution_camera_frame_eval_matches_oracle():
+    """BASELINE.json configs[0] at ITS shapes: kradar_camera_mono.json, ResNet-101, one un-resized
+    1 x 720 x 1280 camera frame (998 120 pyramid tokens, SURVEY 8d / App. A last row) -- conv shapes 360x640 ... 23x40 that
+    no other test and not the bench table reaches -- eval forward through the HIP path vs the oracle in the reference's fp32
+    arithmetic: 1e-4, bit-exact argmax(class)."""
+    from dpft_amd.configs import load_config
+    from dpft_amd.synthetic import make_batch
+    from oracle import dprt_oracle as O
+    g = torch.Generator().manual_seed(77)
+    cfg = copy.deepcopy(load_config("kradar_camera_mono"))
+    assert cfg["model"]["backbones"]["camera_mono"]["name"] == "ResNet101"
+    model = _build(cfg, g)
+    sd = {k: v.float() if v.is_floating_point() else v for k, v in state_dict_f64(model).items()}
+    batch = make_batch(cfg["model"]["inputs"], 1, seed=5, shapes={"camera_mono": (720, 1280, 3)})
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref, feats = O.dprt_forward(sd, cfg, batch, train=False, return_features=True)
+    assert sum(int(t.shape[1] * t.shape[2]) for t in feats["camera_mono"].values()) == 998120
+    model = model.to(DEV).eval()
+    with torch.no_grad():
+        out = model({k: v.to(DEV) for k, v in batch.items()})
+    assert model.fuser.__dict__.get("_fused_decoder"), "fused inference decoder was not used"
+    for k in out:
+        close(out[k], ref[k], rtol=1e-4, atol_scale=1e-4, what=f"config 1 full-resolution eval out {k}")
+    assert torch.equal(out["class"].argmax(-1).cpu(), ref["class"].argmax(-1))
+
+
+def test_train_step_takes_the_fused_decoder_kernels(monkeypatch):
+    """MLFusion keeps torch-op branches (nn.MultiheadAttention / nn.Linear) for configurations the
+    fused training kernels do not cover; a silent fall onto them would pass every parity test and only show up as a slow
+    step.  For the shipped configs the step must run sa_train / xf_train / hd_train: the three fused autograd Functions are
+    entered (4 iterations each, forward and backward) and none of the eager module branches is."""
+    from dpft_amd.models import build
+    from dpft_amd.models.fusers import train_fused as tf
+    from dpft_amd.models.fusers.mpfusion import MLFusion
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.1)
+    counts = {}
+
+    def count(cls, name):
+        orig = getattr(cls, name)
+
+        def wrapped(*a, **k):
+            counts[(cls.__name__, name)] = counts.get((cls.__name__, name), 0) + 1
+            return orig(*a, **k)
+        monkeypatch.setattr(cls, name, staticmethod(wrapped) if isinstance(cls.__dict__.get(name), staticmethod) else wrapped)
+    for fn in (tf.SelfAttnBlocksFn, tf.XattnFfnBlocksFn, tf.HeadBlockFn):
+        count(fn, "forward")
+        count(fn, "backward")
+    for name in ("forward_self_attn", "forward_cross_attn", "forward_ffn"):
+        count(MLFusion, name)
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=9, shapes=SHAPES, device=DEV)
+    labels = make_labels(2, seed=9, device=DEV)
+    torch.manual_seed(0)
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+    tr.train_step(batch, labels)                       # eager launches of the fused kernels (no graph capture here)
+    it = cfg["model"]["fuser"]["i_iter"]
+    for fn in ("SelfAttnBlocksFn", "XattnFfnBlocksFn", "HeadBlockFn"):
+        assert counts.get((fn, "forward")) == it and counts.get((fn, "backward")) == it, (fn, counts)
+    assert not any(k[0] == "MLFusion" for k in counts), counts
+    for name in ("kradar_radar_bev", "kradar_camera_mono", "kradar_radar"):      # the other shipped view subsets qualify as well
+        m = build("dprt", view_config(name))
+        assert all(l.fused_blocks_supported() and tf.head_supported(l, h) for l, h in zip(m.fuser.mpfusion.values(), m.fuser.heads)), name
