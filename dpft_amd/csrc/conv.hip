@@ -47,6 +47,7 @@ constexpr int BKP = 64;       // wgrad vector path: pixels per step
 // are halved at the load (the out-of-range marker 0x80000000 >> 1 still lies beyond any tensor), the 4 values are
 // widened to fp32 registers -- everything downstream (BN + ReLU prologue, LDS formats, MFMA) is unchanged.
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 widen_bf16x4(u32x2 v) {
     return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
                  __uint_as_float(v[1] & 0xffff0000u)};
@@ -83,6 +84,9 @@ struct IgemmArgs {
     const float* pro;      // producer BN block [4][C] = mean, scale, beta, invstd (or null)
     float* stats;     // [mtiles][2][N] or null
     float* partial;   // split-K: [splits][M][N] or null
+    int* sk_ticket;   // split-K fix-up (round 4): one zeroed ticket per output tile; the workgroup that draws the last one
+                      // sums the partial tiles in split order and runs the normal epilogue -- no reduction launch.  null = the
+                      // caller reduces `partial` with a kernel of its own
     int B, H, W, C;   // A-source tensor
     int OH, OW, N;    // output tensor
     int kh, kw, stride, pad;
@@ -158,6 +162,96 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     const int wm = wave / WGN, wn = wave % WGN;
     const int rbase = m0 + wm * RB * 32 + 4 * (lane >> 5);
     __syncthreads();  // LDS operand tiles are dead now
+    // ---- split-K fix-up (IgemmArgs::sk_ticket) -------------------------------------------------------------------------
+    // Every split workgroup writes its partial tile to the slab with agent-scope (write-through, sc1) stores, waits for
+    // their acknowledgement and takes a ticket of its output tile; the last one reads all partial tiles back with
+    // agent-scope loads, sums them in split order (the order of splitk_reduce_kernel: the result does not depend on which
+    // workgroup ends up last), puts the sums back into its accumulator registers and falls through to the epilogue of an
+    // unsplit launch -- bias, residual, accumulate, BatchNorm tile statistics, the fused BatchNorm-backward reduction.
+    // No fences (a release fence writes the whole L2 of the XCD back), no spinning (nobody waits for anybody).
+    const bool fix = a.partial != nullptr && a.sk_ticket != nullptr;
+    if (fix) {
+        constexpr int FLDC = BN + 4, FC4 = BN / 4, FITER = BM * FC4 / NT;
+        float* Fs = smem;
+        if (own)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * RB * 32 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    Fs[row * FLDC + wn * CB * 32 + cb * 32 + (lane & 31)] = acc[rb][cb][r];
+                }
+        __syncthreads();
+        const unsigned slab_bytes = (unsigned)a.M * (unsigned)a.N * 4u;
+        __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(a.partial, 0, (int)(slab_bytes * (unsigned)a.splits), 0x00020000);
+#pragma unroll
+        for (int it = 0; it < FITER; ++it) {
+            const int idx = tid + it * NT;
+            const int row = idx / FC4, c4 = idx - row * FC4;
+            if (m0 + row < a.M && n0 + c4 * 4 < a.N) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&Fs[row * FLDC + c4 * 4]);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), prs,
+                                                       (int)(((unsigned)(m0 + row) * (unsigned)a.N + n0 + c4 * 4) * 4u),
+                                                       (int)(slab_bytes * (unsigned)split), 16);      // aux 16 = sc1
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);
+        int* ticket = a.sk_ticket + mt * a.ntiles + n0 / BN;
+        if (tid == 0) *flag = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        const bool is_last = *flag == a.splits - 1;
+        __syncthreads();      // everybody has read the flag before the sums overwrite it
+        if (!is_last) return;
+        // (formal release / acquire fences around the ticket -- buffer_wbl2 / buffer_inv -- were tried when a model-level test
+        // moved: results identical to the last digit, i.e. the sc1 stores / loads already give the ordering)
+        if (tid == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left clean for the next launch
+        constexpr int FCH = FITER < 8 ? FITER : 8;      // tile chunks in flight per thread
+        static_assert(FITER % FCH == 0, "fix-up chunking");
+#pragma unroll 1
+        for (int it0 = 0; it0 < FITER; it0 += FCH) {
+            f32x4 sum[FCH];
+            int voff[FCH];
+#pragma unroll
+            for (int u = 0; u < FCH; ++u) {
+                const int idx = tid + (it0 + u) * NT;
+                const int row = idx / FC4, c4 = idx - row * FC4;
+                const bool ok = m0 + row < a.M && n0 + c4 * 4 < a.N;
+                voff[u] = ok ? (int)(((unsigned)(m0 + row) * (unsigned)a.N + n0 + c4 * 4) * 4u) : -1;      // -1: out of range -> 0
+                sum[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, voff[u], 0, 16));
+            }
+            for (int k = 1; k < a.splits; ++k) {
+                f32x4 t[FCH];
+#pragma unroll
+                for (int u = 0; u < FCH; ++u)
+                    t[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, voff[u], (int)(slab_bytes * (unsigned)k), 16));
+#pragma unroll
+                for (int u = 0; u < FCH; ++u) sum[u] += t[u];
+            }
+#pragma unroll
+            for (int u = 0; u < FCH; ++u) {
+                const int idx = tid + (it0 + u) * NT;
+                const int row = idx / FC4, c4 = idx - row * FC4;
+                *reinterpret_cast<f32x4*>(&Fs[row * FLDC + c4 * 4]) = sum[u];
+            }
+        }
+        __syncthreads();
+        if (own)
+#pragma unroll
+        for (int cb = 0; cb < CB; ++cb)
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = wm * RB * 32 + rb * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    acc[rb][cb][r] = Fs[row * FLDC + wn * CB * 32 + cb * 32 + (lane & 31)];
+                }
+        __syncthreads();      // the statistics / staging below reuse the same LDS
+    }
+    const bool part = a.partial != nullptr && !fix;      // this launch leaves partial tiles for a reduction kernel
     if (a.stats != nullptr || a.bnf_acc != nullptr) {
         // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
         float* red = smem;               // [WGM][BN]
@@ -240,17 +334,17 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 Cs[row * LDC + wn * CB * 32 + cb * 32 + (lane & 31)] = acc[rb][cb][r];
             }
     __syncthreads();
-    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.M * a.N : a.y;
-    const bool add_bias = (a.bias != nullptr) && (a.partial == nullptr);
-    const bool accum = a.accumulate && (a.partial == nullptr);
-    const bool y16 = a.y16 && (a.partial == nullptr);      // split-K partials stay fp32
+    float* __restrict__ out = part ? a.partial + (size_t)split * a.M * a.N : a.y;
+    const bool add_bias = (a.bias != nullptr) && !part;
+    const bool accum = a.accumulate && !part;
+    const bool y16 = a.y16 && !part;      // split-K partials stay fp32
     if ((a.N & 3) == 0) {
         constexpr int C4 = BN / 4;
         constexpr int ITER = BM * C4 / NT;
         static_assert(BM * C4 % NT == 0, "tile / thread count");
         f32x4 old[ITER];
         // operands of the fused BatchNorm-backward reduction: requested here, consumed in the store loop below
-        const bool bnr_pre = (a.bnr_sums != nullptr) && (a.partial == nullptr);
+        const bool bnr_pre = (a.bnr_sums != nullptr) && !part;
         f32x4 bnr_yv[ITER];
         unsigned bnr_mk[ITER];
         if (bnr_pre) {
@@ -267,8 +361,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 }
             }
         }
-        const bool resid = (a.res_src != nullptr) && (a.partial == nullptr);
-        const bool obn = (a.obn != nullptr) && (a.partial == nullptr);
+        const bool resid = (a.res_src != nullptr) && !part;
+        const bool obn = (a.obn != nullptr) && !part;
         const bool oadd = obn && a.oadd != nullptr;
         if (accum || resid || oadd) {
 #pragma unroll
@@ -299,7 +393,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         }
         // fused BatchNorm-backward reduction (see IgemmArgs::bnr_*): a thread owns ONE 4-channel chunk (NT % C4 == 0)
         static_assert(NT % C4 == 0, "a thread's channel chunk must not depend on the pass");
-        const bool bnr = (a.bnr_sums != nullptr) && (a.partial == nullptr);
+        const bool bnr = (a.bnr_sums != nullptr) && !part;
         f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f}, bmu = bs0, bis = bs0, bsc = bs0, bbe = bs0;
         const int bc = n0 + (tid % C4) * 4;
         if (bnr && bc < a.N) {
@@ -382,7 +476,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 if (add_bias) v += a.bias[n0 + c];
                 const size_t off = out_pixel(a, m0 + row) * a.N + n0 + c;
                 float* o = out + off;
-                if (a.res_src != nullptr && a.partial == nullptr) v += a.res_mask[off] > 0.f ? a.res_src[off] : 0.f;
+                if (a.res_src != nullptr && !part) v += a.res_mask[off] > 0.f ? a.res_src[off] : 0.f;
                 else if (accum) v += *o;
                 *o = v;
             }
@@ -1806,6 +1900,18 @@ struct TileChoice {
     bool vec;
 };
 
+// Workspace layout (round 4): [ticket header: kWsHeader bytes][split-K partial slabs].  The header holds one int per output
+// tile of a split-K launch (IgemmArgs::sk_ticket); it must be ZERO when a buffer is first handed to the library
+// (dpft_conv2d_workspace_init) and every launch leaves it zero again.
+constexpr size_t kWsHeader = 16384;
+constexpr int kWsTickets = (int)(kWsHeader / sizeof(int));
+static inline float* ws_slabs(void* workspace) { return workspace ? reinterpret_cast<float*>((char*)workspace + kWsHeader) : nullptr; }
+// in-kernel split-K fix-up instead of a reduction launch (DPFT_SK_FIXUP=0: the separate reduction kernels, A/B switch)
+static bool sk_fixup_ok(const IgemmArgs& a, int splits, int kind) {      // kind: 1 forward, 2 data gradient, 4 residual data gradient
+    static const int on = getenv("DPFT_SK_FIXUP") == nullptr ? 7 : atoi(getenv("DPFT_SK_FIXUP"));
+    return (on & kind) && splits > 1 && (a.N & 3) == 0 && a.sub_step <= 1 && (int64_t)splits * a.M * a.N * 4 < (1ll << 31);
+}
+
 static TileChoice choose_tile(int M, int N, int C, int ksteps) {
     TileChoice t;
     t.vec = (C % BKV) == 0;
@@ -1923,6 +2029,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     a.splits = t.splits;
     a.ksteps_per_split = cdiv(a.ksteps, a.splits);
     const int nwg = a.mtiles * a.ntiles * a.splits;
+    DPFT_REQUIRE(!a.sk_ticket || a.mtiles * a.ntiles <= kWsTickets, "conv: %d output tiles exceed the split-K ticket header", a.mtiles * a.ntiles);
     dim3 grid(nwg), block(256);
     if (nonlin) {
         if constexpr (DGRAD) {
@@ -2025,6 +2132,7 @@ static int thin_wgrad(const dpft_conv_desc* d, const float* x, const float* dy, 
     handled = false;
     if (bias_done) *bias_done = false;
     if (!workspace) return DPFT_OK;
+    workspace = ws_slabs(workspace);      // the slabs start behind the ticket header
     if (conv16_matches(d)) {
         handled = true;
         static const bool tiled = getenv("DPFT_WGRAD16_TILED") == nullptr || atoi(getenv("DPFT_WGRAD16_TILED")) != 0;      // A/B switch
@@ -2144,7 +2252,14 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
         const int64_t ms = std::max<int64_t>(1, std::min<int64_t>(512, (64ll << 20) / wbytes));
         best = std::max<int64_t>(best, ms * wbytes);
     }
-    return best;
+    return best + (int64_t)kWsHeader;
+}
+
+extern "C" int64_t dpft_conv2d_workspace_header_bytes(void) { return (int64_t)kWsHeader; }
+
+extern "C" int dpft_conv2d_workspace_init(void* workspace, dpft_stream_t stream) {
+    DPFT_REQUIRE(workspace, "conv2d_workspace_init: null workspace");
+    return dpft::zero_fill(workspace, kWsHeader, stream);
 }
 
 extern "C" int dpft_conv_set_compute(int32_t mode) {
@@ -2194,10 +2309,13 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (d->act16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors
     DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 64 == 0 (C=%d)", d->C);
+    bool fixup = false;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
-        a.partial = (float*)workspace;
-        a.stats = nullptr;
+        a.partial = ws_slabs(workspace);
+        fixup = sk_fixup_ok(a, t.splits, 1);
+        if (fixup) a.sk_ticket = reinterpret_cast<int*>(workspace);      // the last split workgroup of a tile runs the whole epilogue
+        else a.stats = nullptr;
     } else if (fuse && fuse->acc && fuse->slab && stats && !bias && !d->act16 && t.vec && (a.N & 3) == 0 &&
                cdiv(a.M, t.bm) <= fuse->slab) {
         // deterministic form: the slab stays, one ticket per column tile (the zeroed accumulator region holds them: 2 K >= tiles)
@@ -2214,7 +2332,7 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     }
     rc = launch_igemm<false>(a, t, pro, st);
     if (rc) return rc;
-    if (t.splits > 1) {
+    if (t.splits > 1 && !fixup) {
         const int64_t MN = (int64_t)a.M * a.N;
         if (stats && !bias && (a.N % 64) == 0 && t.bm <= 128) {      // reduce + per-tile (mean, M2) in one launch
             hipLaunchKernelGGL(splitk_reduce_stats_kernel, dim3(cdiv(a.M, t.bm), a.N / 64), dim3(256), 0, st, a.partial, y,
@@ -2336,16 +2454,20 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
     }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (d->act16) t.splits = 1;
+    bool fixup = false;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
-        a.partial = (float*)workspace;
-    } else if (fuse_ok) {
+        a.partial = ws_slabs(workspace);
+        fixup = sk_fixup_ok(a, t.splits, 2);
+        if (fixup) a.sk_ticket = reinterpret_cast<int*>(workspace);
+    }
+    if ((t.splits == 1 || fixup) && fuse_ok) {      // (with the fix-up the last split workgroup of a tile runs the unsplit epilogue)
         set_bnr(a, fuse);
         fuse->applied = true;
     }
     rc = launch_igemm<true>(a, t, false, st);
     if (rc) return rc;
-    if (t.splits > 1) {
+    if (t.splits > 1 && !fixup) {
         const int64_t MN = (int64_t)a.M * a.N;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(cdiv(MN, 1024)), dim3(256), 0, st, a.partial, (const float*)nullptr, dx, MN, a.N, t.splits, accumulate);
         rc = check_launch("conv dgrad split-K reduce");
@@ -2372,16 +2494,20 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     if (res_mask8 && (a.N & 3) == 0) a.res_mask8 = res_mask8;      // (the split-K reduction and the scalar tail read res_mask)
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
     if (d->act16) t.splits = 1;
+    bool fixup = false;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
-        a.partial = (float*)workspace;
-    } else if (fuse && fuse->sums && (a.N & 3) == 0) {
+        a.partial = ws_slabs(workspace);
+        fixup = sk_fixup_ok(a, t.splits, 4);
+        if (fixup) a.sk_ticket = reinterpret_cast<int*>(workspace);
+    }
+    if ((t.splits == 1 || fixup) && fuse && fuse->sums && (a.N & 3) == 0) {
         set_bnr(a, fuse);
         fuse->applied = true;
     }
     rc = launch_igemm<true>(a, t, false, st);
     if (rc) return rc;
-    if (t.splits > 1) {
+    if (t.splits > 1 && !fixup) {
         const int64_t MN = (int64_t)a.M * a.N;
         hipLaunchKernelGGL(splitk_reduce_residual_kernel, dim3(cdiv(MN, 256)), dim3(256), 0, st, a.partial, res_src,
                            res_mask, dx, MN, t.splits);
@@ -2490,7 +2616,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
     if (splits > 1 && !workspace) splits = 1;
     a.splits = splits;
     a.psteps_per_split = cdiv(a.psteps, splits);
-    a.partial = splits > 1 ? (float*)workspace : nullptr;
+    a.partial = splits > 1 ? ws_slabs(workspace) : nullptr;
     const int nwg = (int)(tiles * splits);
     dim3 grid(nwg), block(256);
     static const int wpipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;

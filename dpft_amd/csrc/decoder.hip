@@ -503,7 +503,19 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     int t_flag = 0;
     if (!a.refs) {
         const int hf = view == 0 ? a.flag[0] : view == 1 ? a.flag[1] : view == 2 ? a.flag[2] : a.flag[3];
-        t_flag = hf < 0 ? dev_flags(a.y3)[view] : hf;
+        if (hf < 0) {
+            // left to the device: every wave evaluates it for itself (B * 16 floats, one load + a ballot -- round 4: no
+            // launch in front of the first cross-attention is left to do it); block 0 of the view leaves it where the
+            // head blocks of the later launches look for it
+            const float* Tv = view == 0 ? a.T[0] : view == 1 ? a.T[1] : view == 2 ? a.T[2] : a.T[3];
+            bool nz = false;
+            if (Tv)
+                for (int i = lane; i < a.B * 16; i += 64) nz |= Tv[i] != 0.f;
+            t_flag = __ballot(nz) != 0ull ? 1 : 0;
+            if (blockIdx.x == 0 && tid == 0) dev_flags(a.y3)[view] = t_flag;
+        } else {
+            t_flag = hf;
+        }
     }
     const float* __restrict__ img = a.pi[view] + PI_K2;
     // stage the view's weights (the row's own loads are issued first so that their latency hides behind this)
@@ -832,21 +844,6 @@ __global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs s
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float hs[4][2][64];
     const int bid = blockIdx.x;
-    if (composed == 2 && bid == (int)gridDim.x - 1) {      // first launch, flags left to the device: one extra block
-        if (threadIdx.x < 64) {                            // one wave, one ballot per view: no LDS, no barrier
-            const float* const Ts[4] = {ha.T[0], ha.T[1], ha.T[2], ha.T[3]};
-#pragma unroll
-            for (int v = 0; v < 4; ++v) {
-                if (v >= ha.V) break;
-                bool nz = false;
-                if (Ts[v])
-                    for (int i = threadIdx.x; i < ha.B * 16; i += 64) nz |= Ts[v][i] != 0.f;
-                const bool any = __ballot(nz) != 0ull;
-                if (threadIdx.x == 0) dev_flags(ha.y3)[v] = any ? 1 : 0;
-            }
-        }
-        return;
-    }
     if (bid < n_score) {
         if (composed == 1) scores_block<true>(sa, sm, bid);
         else scores_block<false>(sa, sm, bid);
@@ -938,7 +935,6 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     memset(&ha, 0, sizeof(ha));
     memset(&sa, 0, sizeof(sa));
     { const char* e = getenv("DPFT_DEC_DBG"); xa.dbg = e ? atoi(e) : 0; sa.stamps = ha.stamps = xa.dbg & 1024; }
-    bool device_flags = false;
     for (int v = 0; v < V; ++v) {
         const dpft_pyramid* pyr = d->pyr + v;
         const int P = d->n_points[v];
@@ -956,9 +952,8 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
         xa.prow[v] = ha.prow[v] = d->p_rows[v]; xa.flag[v] = ha.flag[v] = d->has_t[v];
         DPFT_REQUIRE(xa.Pm[v] && xa.shape[v] && (xa.T[v] || d->has_t[v] <= 0) && xa.prow[v] >= 3,
                      "decoder_forward: projection inputs of view %d missing", v);
-        if (d->has_t[v] < 0) device_flags = true;
     }
-    // has_t < 0: `transformation.any()` is evaluated on the device by an extra block of the first launch (dev_flags)
+    // has_t < 0: `transformation.any()` is evaluated on the device by the first cross-attention kernel (dev_flags)
     xa.attn = attn; xa.pos = d->pos; xa.y3 = y3; xa.B = B; xa.Q = Q; xa.V = V;
     ha.y3 = y3; ha.B = B; ha.Q = Q; ha.V = V; ha.ncls = d->num_classes;
     ha.size = d->size; ha.angle = d->angle; ha.cls = d->cls;
@@ -989,10 +984,14 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
             ha.center = last ? d->center : cbuf[(it - 1) & 1];
             ha.refs_out = last ? nullptr : refs;
         }
-        const bool eval_flags = first && device_flags;
-        hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head) + (eval_flags ? 1 : 0)), dim3(256),
-                           after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? (eval_flags ? 2 : 0) : 1);
-        RC(check_launch("decoder_scores_head"));
+        // iteration 0: the self-attention input is the learned query table -- its attention output is a constant of the
+        // weights; with d->attn0 (dpft_decoder_attn0_f32, made when the weights are packed) the launch disappears
+        const bool skip = first && d->attn0 != nullptr;
+        if (!skip) {
+            hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score + (first ? 0 : n_head)), dim3(256),
+                               after_last ? 0 : lds1, (hipStream_t)stream, sa, ha, n_score, first ? 0 : 1);
+            RC(check_launch("decoder_scores_head"));
+        }
         if (!first) {
             query = ha.query_out;
             center = ha.center;
@@ -1000,6 +999,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
         if (after_last) break;
         // ---- cross attention + FFN of iteration `it` ----
         xa.query = query; xa.qstride = first ? 0 : (long)Q * DC; xa.Bsa = sa.Bsa;
+        xa.attn = skip ? d->attn0 : attn;
         xa.refs = first ? nullptr : refs;
         xa.prev_center = center;
         xa.part = it + 1 < d->iters ? part : nullptr;
@@ -1007,6 +1007,26 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
         RC(check_launch("decoder_xattn"));
     }
     return DPFT_OK;
+}
+
+// Attention output of iteration 0 for ONE batch element, (V,Q,16): input = the learned query table + the query embedding,
+// i.e. a function of the weights alone (mpfusion.py:700-703: `query = self.query` for every sample).  Made once per weight
+// version next to the packed blobs; dpft_decoder_fwd.attn0 then replaces the first launch of every forward.
+extern "C" int dpft_decoder_attn0_f32(const float* packed_views, const float* pos, int32_t Q, int32_t V, float* attn0,
+                                      dpft_stream_t stream) {
+    DPFT_REQUIRE(packed_views && pos && attn0 && Q >= 1 && V >= 1 && V <= 4, "decoder_attn0: bad arguments");
+    ScoreArgs sa;
+    HeadArgs ha;
+    memset(&sa, 0, sizeof(sa));
+    memset(&ha, 0, sizeof(ha));
+    for (int v = 0; v < V; ++v) sa.pi[v] = packed_views + (size_t)v * pi_floats(Q);      // iteration 0's blobs
+    sa.pos = pos; sa.attn = attn0; sa.B = 1; sa.Bsa = 1; sa.Q = Q; sa.V = V;
+    sa.nchunk = cdiv(Q, QC);
+    const size_t lds1 = (4 * (size_t)(Q + NS) + SC_W + 2 * QC + 4 * QC * NS) * sizeof(float);
+    DPFT_REQUIRE(lds1 <= 62 * 1024, "decoder_attn0: %d queries do not fit the LDS of the score kernel", Q);
+    const int n_score = sa.nchunk * DM * V;
+    hipLaunchKernelGGL(decoder_scores_head_kernel, dim3(n_score), dim3(256), lds1, (hipStream_t)stream, sa, ha, n_score, 0);
+    return check_launch("decoder_attn0");
 }
 
 extern "C" int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V) {

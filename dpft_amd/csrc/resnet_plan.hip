@@ -385,6 +385,9 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
     void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
     const bool tr = train != 0;
     p->frozen = train == 2;
+    // split-K ticket headers of both workspaces (conv.hip: kWsHeader): zero once per arena use, every conv leaves them zero
+    RC(dpft_conv2d_workspace_init(ws, st));
+    RC(dpft_conv2d_workspace_init((char*)arena + (p->arena_bytes - p->ws_bytes - 128), st));
     if (!tr || p->frozen) RC(eval_bn_blocks(p, T, A, st));
     const float* xa = x;
     if (p->adj.w >= 0) {

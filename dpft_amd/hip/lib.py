@@ -69,7 +69,8 @@ class DecoderFwd(C.Structure):
                 ("pyr", C.c_void_p), ("query0", C.c_void_p), ("pos", C.c_void_p), ("center0", C.c_void_p),
                 ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
                 ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("work", C.c_void_p),
-                ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p)]
+                ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p),
+                ("attn0", C.c_void_p)]
 
 
 class OuterSpec(C.Structure):
@@ -85,6 +86,8 @@ SIGNATURES = {
     "dpft_version": (_I, []),
     "dpft_last_error": (C.c_char_p, []),
     "dpft_conv2d_workspace_bytes": (_L, [_DESC]),
+    "dpft_conv2d_workspace_header_bytes": (_L, []),
+    "dpft_conv2d_workspace_init": (_I, [_P, _P]),
     "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
     "dpft_conv_set_compute": (_I, [_I]),
     "dpft_conv_get_compute": (_I, []),
@@ -135,6 +138,7 @@ SIGNATURES = {
     "dpft_xattn_ffn_train_fwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _I, _I, _P]),
     "dpft_xattn_ffn_train_bwd_f32": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _F, _P, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "dpft_decoder_forward_f32": (_I, [C.POINTER(DecoderFwd), _P]),
+    "dpft_decoder_attn0_f32": (_I, [_P, _P, _I, _I, _P, _P]),
     "dpft_pack_targets_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dpft_match_cost_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _I, _I, _I, _I, _P]),

@@ -50,7 +50,9 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     buf = _ws_cache.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = torch.empty(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
+        # zeros: the buffer starts with the split-K ticket header (include/dpft_hip.h: must be zero at first use; the
+        # convolutions leave it zero)
+        buf = torch.zeros(int(nbytes * 1.25) + 1024, dtype=torch.uint8, device=device)
         _ws_cache[key] = buf
     return buf
 

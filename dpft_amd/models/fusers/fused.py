@@ -3,6 +3,7 @@ structs from an ``IMPFusion`` module and runs 2*i_iter + 1 kernels instead of ~7
 from __future__ import annotations
 
 import ctypes as C
+import os
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
 
@@ -89,6 +90,14 @@ class FusedDecoder:
             assert red.is_contiguous() and red.dtype == torch.float32
             lib.call("dpft_decoder_pack_head_f32", red.data_ptr(), C.byref(hw), V, head.num_classes,
                      self.packed_heads.data_ptr() + it * nh * 4, stream())
+        # iteration 0's self-attention output depends on the weights alone (its input is the learned query table): made
+        # here, once per weight version, instead of by the first launch of every forward (DPFT_DEC_ATTN0=0: A/B switch)
+        self.attn0 = None
+        if os.environ.get("DPFT_DEC_ATTN0", "1") != "0":
+            self.attn0 = torch.empty(V * f.n_queries * 16, dtype=torch.float32, device=dev)
+            lib.call("dpft_decoder_attn0_f32", self.packed_views.data_ptr(), pos.data_ptr(), f.n_queries, V,
+                     self.attn0.data_ptr(), stream())
+        d.attn0 = None if self.attn0 is None else self.attn0.data_ptr()
         d.V, d.iters, d.Q, d.num_classes = V, I, f.n_queries, f.heads[0].num_classes
         for v in range(V):
             d.n_points[v] = f.n_points[v]

@@ -61,8 +61,15 @@ typedef struct dpft_conv_desc {
                               *    Needs C % 64 == 0 and K % 64 == 0; the pointers are still declared const float*.  */
 } dpft_conv_desc;
 
-/* bytes of workspace dpft_conv2d_* may need for this problem (split-K partials); may be 0 */
+/* bytes of workspace dpft_conv2d_* may need for this problem: a ticket header + split-K partial slabs.
+ * Contract (round 4): the first dpft_conv2d_workspace_header_bytes() bytes of a workspace buffer must be ZERO when the
+ * buffer is first handed to the library (dpft_conv2d_workspace_init zero-fills them on `stream`); every call leaves
+ * them zero again, so one initialisation per buffer is enough.  The header holds one ticket per output tile of a
+ * split-K launch: the workgroup that draws a tile's last ticket sums the partial tiles in split order and runs the
+ * whole epilogue -- there is no separate reduction launch.  Calls that share a workspace must be stream-ordered. */
 int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d);
+int64_t dpft_conv2d_workspace_header_bytes(void);
+int dpft_conv2d_workspace_init(void* workspace, dpft_stream_t stream);
 /* number of M-tiles the forward kernel uses for its fused BN-statistics epilogue
  * (rows of the `stats` buffer: stats is [mtiles][2][K] floats = per-tile mean and M2);
  * *tile_rows receives the tile height so the caller can recover per-tile counts. */
@@ -365,7 +372,13 @@ typedef struct dpft_decoder_fwd {
                                             device (no host read-back of the matrices) */
     float* work;
     float *center, *size, *angle, *cls;
+    const float* attn0;                  /* (V,Q,16) from dpft_decoder_attn0_f32, or NULL: the attention output of iteration 0
+                                            (a constant of the weights) -- with it a forward is 2 * iters launches, not + 1 */
 } dpft_decoder_fwd;
+/* iteration 0's self-attention output for one batch element -- its input is the learned query table (mpfusion.py:700-703),
+ * so it depends on the weights only; call again after every weight change, like the pack functions */
+int dpft_decoder_attn0_f32(const float* packed_views, const float* pos, int32_t Q, int32_t V, float* attn0,
+                           dpft_stream_t stream);
 int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V);
 /* measurement aid: with DPFT_DEC_DBG=1024 in the environment the decoder kernels stamp a 100 MHz clock at their phase
  * boundaries; copies 2 kernels x 2048 blocks x 8 slots of uint64 (last launches) to dst (tools/decoder_stamps.py) */

@@ -883,7 +883,7 @@ def test_conv_bf16_activation_storage(B, H, W, Cin, K, k, stride):
     dy = torch.randn(B, d.OH, d.OW, K, generator=g).bfloat16().to(dev)
     tr = C.c_int32(0)
     tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(d), C.byref(tr)))
-    ws = torch.empty(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (64 << 20), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (64 << 20), dtype=torch.uint8, device=dev)      # (zero ticket header: include/dpft_hip.h)
     ops.conv_set_compute("bf16")
     try:
         y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device=dev)
@@ -973,7 +973,7 @@ def test_conv_bf16_native_operands(B, H, W, Cin, K, k, stride):
     wt = w.permute(3, 1, 2, 0).contiguous()          # [C][kh][kw][K]: the data gradient's operand
     tr = C.c_int32(0)
     tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(d), C.byref(tr)))
-    ws = torch.empty(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (64 << 20), dtype=torch.uint8, device=dev)
+    ws = torch.zeros(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (64 << 20), dtype=torch.uint8, device=dev)      # (zero ticket header: include/dpft_hip.h)
     ops.conv_set_compute("bf16")
     try:
         y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device=dev)
@@ -1113,3 +1113,38 @@ def test_pack_targets_kernel_matches_torch_packing(monkeypatch):
     assert got[4] == ref[4] == 7
     for g, r in zip(got[:4], ref[:4]):
         assert g.dtype == r.dtype and torch.equal(g, r)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(4, 16, 7, 256, 256, 3, 1), (4, 8, 4, 512, 2048, 1, 1), (4, 3, 7, 1024, 256, 1, 1), (4, 16, 29, 512, 512, 3, 1)])
+def test_splitk_fixup_is_repeatable_and_leaves_the_ticket_header_clean(shape):
+    """Round 4: split-K convs finish inside the launch (the workgroup with a tile's last ticket sums the partial tiles in
+    split order and runs the unsplit epilogue).  Whichever workgroup ends up last, the result is the same bits: 40 runs of
+    forward (+ BatchNorm tile statistics), data gradient and accumulating data gradient on one workspace are bit-identical,
+    the forward equals fp64 to fp32 round-off, and the workspace's ticket header is all zero afterwards."""
+    import ctypes as C
+    ops = _ops()
+    from dpft_amd.hip.lib import lib
+    B, H, W, Cin, K, k, s = shape
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w = (torch.randn(K, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last)
+    cv = ops.conv_problem(B, H, W, Cin, K, k, k, s, k // 2)
+    xg, wg = x.to(DEV), w.to(DEV).permute(0, 2, 3, 1)
+    yref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double(), None, stride=s, padding=k // 2)
+    y0, st0 = ops.conv_fwd(cv, xg, wg, want_stats=True)
+    close(y0.permute(0, 3, 1, 2), yref, what="split-K forward")
+    dy = torch.randn(B, cv.OH, cv.OW, K, generator=g).to(DEV)
+    wt = ops.weight_transpose(wg)
+    dx0 = ops.conv_dgrad(cv, dy, wt)
+    base = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+    acc0 = ops.conv_dgrad(cv, dy, wt, out=base.clone(), accumulate=True)
+    for _ in range(40):
+        y, st = ops.conv_fwd(cv, xg, wg, want_stats=True)
+        assert torch.equal(y, y0) and torch.equal(st, st0)
+        assert torch.equal(ops.conv_dgrad(cv, dy, wt), dx0)
+        assert torch.equal(ops.conv_dgrad(cv, dy, wt, out=base.clone(), accumulate=True), acc0)
+    ws = ops.workspace(cv.ws_bytes, xg.device)
+    hdr = int(lib.dpft_conv2d_workspace_header_bytes())
+    torch.cuda.synchronize()
+    assert hdr > 0 and int(ws[:hdr].count_nonzero()) == 0

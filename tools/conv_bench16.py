@@ -24,7 +24,7 @@ def run(spec, mode, reps=20, check=True):
     w32 = w.cuda()
     wt32 = ops.weight_transpose(w32)
     wq, wtq = (w32.bfloat16(), wt32.bfloat16()) if mode == 2 else (w32, wt32)
-    ws = torch.empty(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16), dtype=torch.uint8, device="cuda")
+    ws = torch.zeros(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16), dtype=torch.uint8, device="cuda")
     y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device="cuda")
     dx = torch.empty(B, H, W, Cc, dtype=torch.bfloat16, device="cuda")
     dw = torch.empty(K, k, k, Cc, dtype=torch.float32, device="cuda")

@@ -8,7 +8,7 @@
 --decoder: the second accounting of `roofline_decoder`: the SUM of the fused inference decoder's kernel
 durations per forward (forwards = decoder_xattn launches / iterations; weight-pack kernels, which only run when a
 parameter changed, are listed but not counted), priced against the SURVEY 8d bytes at 8 TB/s.  The bench line's
-event-timed figure includes the gaps between the 9 launches and excludes nothing; this one is kernels only.
+event-timed figure includes the gaps between the launches (8 since round 4) and excludes nothing; this one is kernels only.
 
 Kernel time of the conv family per step = sum of TotalDurationNs of every kernel a dpft_conv2d_nhwc_* call launches
 (main loops AND the split-K / slab reductions they need) / steps.  frac = algorithmic flops / that time / peak (157.3 TF)."""
