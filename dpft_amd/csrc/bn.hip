@@ -288,6 +288,98 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_kernel(const float* _
     }
 }
 
+// The same backward, tiled (round 4).  The gather form above recomputes relu(bn(y)) of a 3 x 3 window for each of the <= 4
+// windows an element belongs to -- 37 loads and ~330 vector instructions per 4 channels (139 us on the camera's 4 x 256 x
+// 455 x 64 stem output, 800 us at batch 8 in the mixed-precision step).  Here a workgroup owns 8 x 16 elements x 32
+// channels: (1) relu(bn(y)) of the 11 x 19 pixels its 5 x 9 windows cover goes to LDS once (one load per element + halo),
+// the windows' dout with it; (2) one thread per (window, 4 channels) finds the first arg-max in scan order; (3) one thread
+// per owned element sums the dout of the windows that chose it, in the order of the gather form -- bit-identical results.
+constexpr int PB_TH = 4, PB_TW = 8, PB_CQ = 8;                              // windows owned per tile (rows, cols), channel quads
+constexpr int PB_RH = 2 * PB_TH + 3, PB_RW = 2 * PB_TW + 3;                 // pixels staged
+constexpr int PB_WH = PB_TH + 1, PB_WW = PB_TW + 1;                         // windows evaluated
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_bwd_tiled_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                                         const float* __restrict__ dout, float* __restrict__ dz,
+                                                                         int B, int H, int W, int K4, int PH, int PW, int tiles_w,
+                                                                         int tiles_h) {
+    DPFT_SETPRIO_BN();
+    __shared__ f32x4 act[PB_RH * PB_RW][PB_CQ];          // relu(bn(y)), -1 outside the image
+    __shared__ f32x4 dwin[PB_WH * PB_WW][PB_CQ];         // dout of the windows (0 outside the pooled map)
+    __shared__ unsigned arg[PB_WH * PB_WW][PB_CQ];       // first arg-max (0..8) of each window, one byte per channel
+    const int K = K4 * 4, tid = threadIdx.x;
+    int t = blockIdx.x;
+    const int tw = t % tiles_w; t /= tiles_w;
+    const int th = t % tiles_h; t /= tiles_h;
+    const int cq0 = (t % (K4 / PB_CQ)) * PB_CQ;
+    const int b = t / (K4 / PB_CQ);
+    const int ph0 = th * PB_TH, pw0 = tw * PB_TW;
+    const int h0 = 2 * ph0 - 1, w0 = 2 * pw0 - 1;        // first staged pixel
+    for (int i = tid; i < PB_RH * PB_RW * PB_CQ; i += 256) {
+        const int q = i % PB_CQ, px = i / PB_CQ;
+        const int r = px / PB_RW, c = px - r * PB_RW;
+        const int h = h0 + r, w = w0 + c;
+        f32x4 v = {-1.f, -1.f, -1.f, -1.f};
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+            v = bn_apply4(reinterpret_cast<const f32x4*>(y)[(((int64_t)b * H + h) * W + w) * K4 + cq0 + q], bnp, K, (cq0 + q) * 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        act[px][q] = v;
+    }
+    for (int i = tid; i < PB_WH * PB_WW * PB_CQ; i += 256) {
+        const int q = i % PB_CQ, wi = i / PB_CQ;
+        const int ph = ph0 + wi / PB_WW, pw = pw0 + wi % PB_WW;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (ph < PH && pw < PW) d = ldv4<T>(dout, (((int64_t)b * PH + ph) * PW + pw) * K4 + cq0 + q);
+        dwin[wi][q] = d;
+    }
+    __syncthreads();
+    for (int i = tid; i < PB_WH * PB_WW * PB_CQ; i += 256) {
+        const int q = i % PB_CQ, wi = i / PB_CQ;
+        const int wr = wi / PB_WW, wc = wi - wr * PB_WW;
+        f32x4 best = {-1.f, -1.f, -1.f, -1.f};
+        unsigned bi = 0xffffffffu;                      // 0xff per channel: no valid pixel (cannot happen for a real window)
+#pragma unroll
+        for (int di = 0; di < 3; ++di)
+#pragma unroll
+            for (int dj = 0; dj < 3; ++dj) {
+                const f32x4 v = act[(2 * wr + di) * PB_RW + 2 * wc + dj][q];      // window (ph, pw) starts at pixel (2 ph - 1, 2 pw - 1)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    if (v[e] > best[e]) {                // outside pixels hold -1: never chosen, as the gather form skips them
+                        best[e] = v[e];
+                        bi = (bi & ~(0xffu << (8 * e))) | ((unsigned)(di * 3 + dj) << (8 * e));
+                    }
+            }
+        arg[wi][q] = bi;
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * PB_TH * 2 * PB_TW * PB_CQ; i += 256) {
+        const int q = i % PB_CQ, px = i / PB_CQ;
+        const int r = px / (2 * PB_TW), c = px - r * (2 * PB_TW);
+        const int h = 2 * ph0 + r, w = 2 * pw0 + c;
+        if (h >= H || w >= W) continue;
+        const f32x4 a0 = act[(r + 1) * PB_RW + c + 1][q];
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        const int ph_hi = (h + 1) >> 1, pw_hi = (w + 1) >> 1;
+        for (int ph = ph_hi - 1; ph <= ph_hi; ++ph) {
+            if (ph < 0 || ph >= PH || h < 2 * ph - 1 || h > 2 * ph + 1) continue;
+            for (int pw = pw_hi - 1; pw <= pw_hi; ++pw) {
+                if (pw < 0 || pw >= PW || w < 2 * pw - 1 || w > 2 * pw + 1) continue;
+                const int wi = (ph - ph0) * PB_WW + (pw - pw0);
+                const unsigned me = (unsigned)((h - (ph * 2 - 1)) * 3 + (w - (pw * 2 - 1)));
+                const unsigned bi = arg[wi][q];
+                const f32x4 d = dwin[wi][q];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] += (((bi >> (8 * e)) & 0xffu) == me) ? d[e] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] = a0[e] > 0.f ? g[e] : 0.f;
+        reinterpret_cast<f32x4*>(dz)[(((int64_t)b * H + h) * W + w) * K4 + cq0 + q] = g;
+    }
+}
+
 // BN backward pass 1: sums[0][k] += sum dz, sums[1][k] += sum dz*xhat
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ y, const float* __restrict__ dout,
@@ -638,6 +730,20 @@ int dpft::bn_relu_maxpool_bwd_any(const float* y, const float* bnp, const float*
                                   int32_t W, int32_t K, int32_t PH, int32_t PW, bool dout16, dpft_stream_t stream) {
     DPFT_REQUIRE(y && bnp && dout && dact && K % 4 == 0, "bn_relu_maxpool_bwd: bad arguments");
     const int64_t total = (int64_t)B * H * W * (K / 4);
+    static const bool tiled = getenv("DPFT_POOL_BWD_TILED") == nullptr || atoi(getenv("DPFT_POOL_BWD_TILED")) != 0;      // A/B switch
+    const int K4 = K / 4;
+    if (tiled && K4 % PB_CQ == 0 && PH == (H - 1) / 2 + 1 && PW == (W - 1) / 2 + 1) {      // 3 x 3 / stride 2 / pad 1 geometry
+        const int tiles_h = cdiv(H, 2 * PB_TH), tiles_w = cdiv(W, 2 * PB_TW);
+        const int64_t nb = (int64_t)B * (K4 / PB_CQ) * tiles_h * tiles_w;
+        DPFT_REQUIRE(nb < (1ll << 31), "bn_relu_maxpool_bwd: too many tiles");
+        if (dout16)
+            hipLaunchKernelGGL(bn_relu_maxpool_bwd_tiled_kernel<__bf16>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, y, bnp,
+                               dout, dact, B, H, W, K4, PH, PW, tiles_w, tiles_h);
+        else
+            hipLaunchKernelGGL(bn_relu_maxpool_bwd_tiled_kernel<float>, dim3((unsigned)nb), dim3(256), 0, (hipStream_t)stream, y, bnp,
+                               dout, dact, B, H, W, K4, PH, PW, tiles_w, tiles_h);
+        return check_launch("bn_relu_maxpool_bwd (tiled)");
+    }
     if (dout16)
         hipLaunchKernelGGL(bn_relu_maxpool_bwd_kernel<__bf16>, dim3(ew_blocks(total)), dim3(256), 0, (hipStream_t)stream, y,
                            bnp, dout, dact, B, H, W, K / 4, PH, PW);

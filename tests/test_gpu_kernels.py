@@ -206,7 +206,7 @@ def test_bn_train_forward_backward(shape):
     close(ops.bn_act(yg, bnp_e, relu=False), ref_e, what="bn eval")
 
 
-@pytest.mark.parametrize("shape", [(2, 19, 27, 64), (1, 8, 8, 64), (2, 37, 54, 64)])
+@pytest.mark.parametrize("shape", [(2, 19, 27, 64), (1, 8, 8, 64), (2, 37, 54, 64), (1, 65, 90, 64), (2, 128, 33, 64), (1, 7, 5, 128)])
 def test_bn_relu_maxpool(shape):
     ops = _ops()
     g = torch.Generator().manual_seed(7)
