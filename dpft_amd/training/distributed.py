@@ -64,6 +64,14 @@ class GradBucketReducer:
             self._avg_op = False
             self.collective_op = "sum"
         self.comm_stream = None      # optional torch stream the collectives are enqueued on (set by the trainer)
+        # Round 4: called as on_bucket_final(bucket index) on the stream where a bucket's FINAL gradients are available
+        # (behind its collective, or -- one rank -- behind its producers): the trainer steps the optimizer for that
+        # bucket's parameters there, so the update overlaps the rest of the backward.  `opt_stream` (one rank, optional):
+        # the stream to do that on instead of the firing stream (the camera's weight-gradient stream: off the critical chain)
+        self.on_bucket_final = None
+        self.opt_stream = None
+        self.opt_from = None         # raw handle of the stream whose buckets move to opt_stream
+        self._opt_streams = {}       # streams that carried such updates since reset(): joined by finish()
         self.average = average
         self.comm_dtype = comm_dtype if comm_dtype not in (None, torch.float32) else None
         self.params = [p for p in params if p.requires_grad]
@@ -100,6 +108,8 @@ class GradBucketReducer:
         for bi, b in enumerate(self.buckets):
             for p in b["params"]:
                 self._index[id(p)] = bi
+        self._bucket_index = {id(b["flat"]): bi for bi, b in enumerate(self.buckets)}
+        self._in_finish = False
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         self._pending: List = []
         self.reset()
@@ -166,6 +176,7 @@ class GradBucketReducer:
             for p in b["params"]:
                 p.grad = b["views"][id(p)]
         self._pending = []
+        self._opt_streams = {}
 
     def grad_sink(self, p: torch.nn.Parameter, g: torch.Tensor):
         """Direct hand-over from a hand-scheduled backward (bypasses autograd accumulation)."""
@@ -231,9 +242,35 @@ class GradBucketReducer:
         if b["ready"] == len(b["params"]) and not b["fired"]:
             self._fire(b)
 
+    def _final(self, b, st=None):
+        """The bucket's gradients are final on stream ``st`` (None: the current one)."""
+        if self.on_bucket_final is None or self._in_finish:
+            return
+        bi = self._bucket_index[id(b["flat"])]
+        if st is None or not b["flat"].is_cuda:
+            self.on_bucket_final(bi)
+            return
+        with torch.cuda.stream(st):
+            self.on_bucket_final(bi)
+        self._opt_streams[st.cuda_stream] = st
+
     def _fire(self, b):
         b["fired"] = True
         comm = self.comm_stream if b["flat"].is_cuda else None
+        if not self.collective:
+            # one rank, no exchange: the gradients are final as soon as every producer stream has passed this point
+            if self.on_bucket_final is not None and not self._in_finish and b["flat"].is_cuda:
+                cur = torch.cuda.current_stream(b["flat"].device)
+                # (only buckets finished on `opt_from` -- the main stream, the critical chain -- move; a view's own stream
+                # is idle once its backward is through)
+                tgt = self.opt_stream if (self.opt_stream is not None and cur.cuda_stream == self.opt_from) else cur
+                for sid, st in b["streams"].items():
+                    if sid != tgt.cuda_stream:
+                        tgt.wait_stream(st)
+                if cur.cuda_stream != tgt.cuda_stream and cur.cuda_stream not in b["streams"]:
+                    tgt.wait_stream(cur)
+                self._final(b, tgt)
+            return
         if b["flat"].is_cuda and self.collective and comm is None:     # single process: finish() joins the streams
             # The process group's stream orders itself behind the CURRENT stream only, so the current stream has to wait for
             # the other producers of this bucket.  That stalls a compute chain at every bucket boundary (the main stream
@@ -277,6 +314,7 @@ class GradBucketReducer:
                     dist.all_reduce(wire, op=op, group=self.group, async_op=False)
                     if b["stage"] is not None:
                         b["flat"].copy_(b["stage"])
+                    self._final(b)                                    # (on the communication stream, behind the collective)
                     self._pending.append((comm.record_event(), None))
 
     def seen_ids(self):
@@ -288,14 +326,23 @@ class GradBucketReducer:
 
     def finish(self):
         """Flush buckets whose parameters did not all receive gradients, then wait for every collective."""
-        for b in self.buckets:
-            if not b["fired"]:
-                # a parameter announced as overwritten whose producer did not run this step (a backward that was not
-                # reached, a partially used view) still holds the PREVIOUS step's gradient: reset() skipped it
-                for p in b["params"]:
-                    if id(p) in self._overwritten and id(p) not in b["seen"]:
-                        b["views"][id(p)].zero_()
-                self._fire(b)
+        self._in_finish = True           # buckets flushed here (parameters without a gradient) are left to optimizer.step()
+        try:
+            for b in self.buckets:
+                if not b["fired"]:
+                    # a parameter announced as overwritten whose producer did not run this step (a backward that was not
+                    # reached, a partially used view) still holds the PREVIOUS step's gradient: reset() skipped it
+                    for p in b["params"]:
+                        if id(p) in self._overwritten and id(p) not in b["seen"]:
+                            b["views"][id(p)].zero_()
+                    self._fire(b)
+        finally:
+            self._in_finish = False
+        if self.arena.is_cuda and self._opt_streams:
+            cur = torch.cuda.current_stream(self.arena.device)
+            for sid, st in self._opt_streams.items():      # early optimizer launches: whatever follows sees the new weights
+                if sid != cur.cuda_stream:
+                    cur.wait_stream(st)
         if self.arena.is_cuda:
             # Gradients are written straight into the buckets by kernels on several streams (view encoders, their weight-
             # gradient streams, replayed graphs) and no AccumulateGrad node runs for them, so the autograd engine has no

@@ -25,6 +25,17 @@ class FusedAdamW(torch.optim.Optimizer):
         self._tables = None
         self._step = 0                 # launches so far; a tensor's own count is _step - skipped[t]
         self._restore = False          # self.state was replaced by load_state_dict: re-seed the flat buffers from it
+        # Segments (round 4): the DP reducer's buckets.  A bucket whose gradients are final (all produced, all-reduced) can
+        # be stepped at once, on the stream that finished it, while the backward goes on elsewhere -- step_segment();
+        # step() then only launches what is left.  Rows of the chunk table are ordered by segment for that.
+        self._segments = None          # list of lists of parameters (a parameter not listed belongs to the trailing segment)
+        self._round_open = False       # a step_segment() of the current step has already advanced _step
+        self._done = set()             # (table index, segment index) launched in the current step
+
+    def attach_segments(self, param_lists):
+        """Declare the segments (lists of parameters, e.g. GradBucketReducer buckets) step_segment() may be called with."""
+        self._segments = [list(ps) for ps in param_lists]
+        self._tables = None            # rebuilt (row order) at the next step
 
     @staticmethod
     def _layout(t: torch.Tensor):
@@ -80,7 +91,17 @@ class FusedAdamW(torch.optim.Optimizer):
                 v = torch.zeros(total, dtype=torch.float32, device=dev)
                 skip_host = [0] * len(ps)
             rows, off = [], 0
+            seg_of = {}
+            if self._segments is not None:
+                for si, sp in enumerate(self._segments):
+                    for q in sp:
+                        seg_of[id(q)] = si
+            n_seg = (len(self._segments) if self._segments is not None else 0) + 1      # + the trailing segment
+            seg_rows = [[] for _ in range(n_seg)]
+            seg_tensors = [[] for _ in range(n_seg)]
             for ti, p in enumerate(ps):
+                rows = seg_rows[seg_of.get(id(p), n_seg - 1)]
+                seg_tensors[seg_of.get(id(p), n_seg - 1)].append(ti)
                 mv, vv = self._flat_view(m, off, p), self._flat_view(v, off, p)
                 if not keep:
                     st = self.state.get(p, {})
@@ -101,6 +122,10 @@ class FusedAdamW(torch.optim.Optimizer):
                         rows.append((pp + 4 * c0, gp + 4 * c0, m.data_ptr() + 4 * (off + c0),
                                      v.data_ptr() + 4 * (off + c0), n, ti))
                 off += p.numel()
+            seg_range, rows = [], []
+            for sr in seg_rows:                                         # rows of a segment are contiguous in the table
+                seg_range.append((len(rows), len(sr)))
+                rows += sr
             if not keep:
                 skipped = torch.tensor(skip_host, dtype=torch.int32).to(dev)
             arr = np.zeros(len(rows), dtype=np.dtype([("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"),
@@ -110,7 +135,8 @@ class FusedAdamW(torch.optim.Optimizer):
             chunks = torch.from_numpy(arr.view(np.uint8).copy()).to(dev)
             active = torch.ones(len(ps), dtype=torch.int32, device=dev)
             tables.append(dict(params=ps, ptrs=self._ptrs(ps), m=m, v=v, skipped=skipped, chunks=chunks,
-                               n_chunks=len(rows), active=active, active_host=None))
+                               n_chunks=len(rows), active=active, active_host=None, seg_range=seg_range,
+                               seg_tensors=seg_tensors))
         self._tables = tables
         self._restore = False
 
@@ -118,21 +144,66 @@ class FusedAdamW(torch.optim.Optimizer):
         """ids of parameters that received a gradient this step (others are skipped like ``grad is None``)."""
         self._active_ids = active_ids
 
+    CHUNK_BYTES = 40
+
+    def _launch(self, group, t, first: int, count: int):
+        if count <= 0:
+            return
+        b1, b2 = group["betas"]
+        import ctypes as C
+        lib.call("dpft_adamw_f32", C.c_void_p(t["chunks"].data_ptr() + first * self.CHUNK_BYTES), count, ptr(t["active"]),
+                 ptr(t["skipped"]),
+                 float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                 self._step, stream())
+
+    @torch.no_grad()
+    def step_segment(self, si: int) -> bool:
+        """Update the parameters of segment ``si`` NOW, on the current stream (their gradients are final there).  Returns
+        False -- and leaves the segment to step() -- when the tables are stale or a tensor of the segment sat the previous
+        step out (its `active` flag on the device would have to change first).  The step count advances once per step."""
+        if self._segments is None or self._restore or self._tables is None:
+            return False
+        if any(self._ptrs(t["params"]) != t["ptrs"] for t in self._tables):
+            return False
+        todo = []
+        for gi, (group, t) in enumerate(zip(self.param_groups, self._tables)):
+            first, count = t["seg_range"][si]
+            if count == 0 or (gi, si) in self._done:
+                continue
+            host = t["active_host"]
+            if host is None or any(host[ti] != 1 for ti in t["seg_tensors"][si]):
+                return False
+            todo.append((gi, group, t, first, count))
+        if not self._round_open:
+            self._step += 1
+            self._round_open = True
+        for gi, group, t, first, count in todo:
+            self._launch(group, t, first, count)
+            self._done.add((gi, si))
+        return True
+
     @torch.no_grad()
     def step(self, closure=None):
         if self._restore or self._tables is None or any(self._ptrs(t["params"]) != t["ptrs"] for t in self._tables):
+            assert not self._round_open, "FusedAdamW: gradients moved between step_segment() and step()"
             self._build()
-        self._step += 1
+        if not self._round_open:
+            self._step += 1
         ids = getattr(self, "_active_ids", None)
-        for group, t in zip(self.param_groups, self._tables):
+        for gi, (group, t) in enumerate(zip(self.param_groups, self._tables)):
             host = [int(p.grad is not None and (ids is None or id(p) in ids)) for p in t["params"]]
             if host != t["active_host"]:
+                # (tensors of segments already stepped in this round were all active, before and now: their flags do not move)
                 t["active"].copy_(torch.tensor(host, dtype=torch.int32))
                 t["active_host"] = host
-            b1, b2 = group["betas"]
-            lib.call("dpft_adamw_f32", ptr(t["chunks"]), t["n_chunks"], ptr(t["active"]), ptr(t["skipped"]),
-                     float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                     self._step, stream())
+            if not any(g == gi for g, _ in self._done):
+                self._launch(group, t, 0, t["n_chunks"])                # nothing stepped early: the one launch of before
+            else:
+                for si, (first, count) in enumerate(t["seg_range"]):
+                    if (gi, si) not in self._done:
+                        self._launch(group, t, first, count)
+        self._round_open = False
+        self._done.clear()
         note_weights_changed()                             # in-place through raw pointers: no _version bump
         return None
 

@@ -135,3 +135,93 @@ def test_epoch_loop_trains_validates_and_checkpoints(tmp_path):
     more = tr2.train(train_loader, None, start_epoch=epoch + 1, timestamp=stamp, dst=str(tmp_path), sampler=sampler)
     assert [os.path.basename(p) for p in more] == ["20250101-000000-000_checkpoint_0002.pt"]
     assert abs(tr2.optimizer.param_groups[0]["lr"] - 1e-3 * 0.125) < 1e-12
+
+
+@pytest.mark.gpu
+def test_fused_adamw_segment_steps_equal_the_single_launch():
+    """Round 4: FusedAdamW.step_segment() -- the DP buckets stepped one by one as their gradients become final -- followed by
+    step() for the rest is the SAME update as one step() over everything: parameters, both moments and the per-parameter
+    step counts bit-identical over 5 steps, including a tensor that sits a step out (its segment then falls back to
+    step()) and a parameter that belongs to no segment."""
+    from dpft_amd.training.optimizer import FusedAdamW
+    g = torch.Generator().manual_seed(3)
+    shapes = [(64, 32, 3, 3), (64,), (64,), (128, 64, 1, 1), (128,), (1000, 16), (7,), (33, 5)]
+
+    def make():
+        ps = []
+        for sh in shapes:
+            t = torch.randn(sh, generator=torch.Generator().manual_seed(len(ps) + 1))
+            if len(sh) == 4:
+                t = t.contiguous(memory_format=torch.channels_last)
+            ps.append(torch.nn.Parameter(t.cuda()))
+        return ps
+    pa, pb = make(), make()
+    oa, ob = FusedAdamW(pa, lr=1e-3), FusedAdamW(pb, lr=1e-3)
+    ob.attach_segments([pb[0:3], pb[3:5], pb[5:7]])          # pb[7] belongs to no segment
+    for step in range(5):
+        grads = [torch.randn(sh, generator=g) for sh in shapes]
+        for ps in (pa, pb):
+            for i, (p, gr) in enumerate(zip(ps, grads)):
+                gr = gr.contiguous(memory_format=torch.channels_last) if gr.dim() == 4 else gr
+                p.grad = None if (step == 2 and i == 4) else (gr.cuda() if p.grad is None else p.grad.copy_(gr.cuda()))
+        oa.step()
+        early = [ob.step_segment(si) for si in (2, 0, 1)] if step > 0 else []      # (the first step builds the tables)
+        ob.step()
+        if step in (1, 4):
+            assert all(early), early
+        if step in (2, 3):
+            assert early == [False, False, False], early     # a gradient tensor appeared / disappeared: the tables are stale, step() rebuilds
+    for a, b in zip(pa, pb):
+        assert torch.equal(a, b)
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for i in sa:
+        assert float(sa[i]["step"]) == float(sb[i]["step"]), (i, sa[i]["step"], sb[i]["step"])
+        assert torch.equal(sa[i]["exp_avg"], sb[i]["exp_avg"]) and torch.equal(sa[i]["exp_avg_sq"], sb[i]["exp_avg_sq"])
+    assert float(sa[4]["step"]) == 4.0 and float(sa[0]["step"]) == 5.0
+
+
+@pytest.mark.gpu
+def test_trainer_steps_buckets_early_and_trains_like_the_single_launch(monkeypatch):
+    """The trainer's use of it: buckets are stepped as they become final (one rank: on the camera's weight-gradient stream),
+    the losses of 6 steps follow the single-launch trainer's (run-to-run differences of the decoder's gradient atomics
+    aside), every parameter moved."""
+    import copy
+    from dpft_amd.configs import load_config
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    cfg["model"]["fuser"]["dropout"] = 0.0
+    shapes = {"camera_mono": (96, 160, 3), "radar_bev": (64, 43, 6), "radar_front": (37, 43, 6)}
+    dev = torch.device("cuda")
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=5, shapes=shapes, device=dev)
+    labels = make_labels(2, seed=5, device=dev)
+    losses, early = {}, {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("DPFT_EARLY_ADAMW", mode)
+        torch.manual_seed(0)
+        tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
+        assert tr.early_adamw == (mode == "1")
+        tr.enable_graphs(batch)
+        before = {k: v.detach().clone() for k, v in tr.model.named_parameters()}
+        n_early = [0]
+        if mode == "1":
+            orig = tr.optimizer.step_segment
+            def counted(si, orig=orig):
+                ok = orig(si)
+                n_early[0] += int(ok)
+                return ok
+            tr.reducer.on_bucket_final = counted
+        losses[mode] = [float(tr.train_step(batch, labels)[0]) for _ in range(6)]
+        torch.cuda.synchronize()
+        early[mode] = n_early[0]
+        moved = [k for k, v in tr.model.named_parameters() if v.grad is not None and float(v.grad.abs().max()) > 0
+                 and not torch.equal(v.detach(), before[k])]
+        assert len(moved) > 200
+        if mode == "1":
+            assert tr.reducer.opt_stream is not None and early["1"] >= 5 * 3, early      # most buckets of steps 2..6
+    assert losses["0"][0] == pytest.approx(losses["1"][0], rel=1e-5)
+    for a, b in zip(losses["0"], losses["1"]):
+        assert a == pytest.approx(b, rel=2e-2), (losses["0"], losses["1"])
+    assert losses["1"][-1] < losses["1"][0]
