@@ -449,6 +449,7 @@ struct XattnArgs {
     int B, Q, V, Bsa;
     long qstride;
     int dbg;
+    int* zero_tickets;          // first launch of a forward with a fused last launch: block (x, 0) clears ticket x
 };
 
 // reference point of one view: cartesian center -> (optional T + spherical) -> projection P -> normalised, clamped
@@ -488,10 +489,133 @@ __device__ __forceinline__ float mish_fast(float x) {
     return x * (t * __builtin_amdgcn_rcpf(t + 2.f));
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// K3: view reduction + heads + next reference points, one wave per (b, q)
+// ---------------------------------------------------------------------------------------------------------
+struct HeadArgs {
+    const float* y3;            // (V,B,Q,16)
+    const float* ph;            // packed head blob
+    const float* prev_center;   // (B,Q,3)
+    const float* T[4];
+    const float* Pm[4];
+    const int64_t* shape[4];
+    int prow[4], flag[4];
+    float* query_out;           // (B,Q,16)
+    float *center, *size, *angle, *cls;
+    float* refs_out;            // (V,B,Q,2) reference points of the NEW center, or NULL (last iteration)
+    int B, Q, V, ncls, stamps;
+};
+
+// `hsw`: 128 floats of LDS scratch of this wave.  SC1: y3 was written by OTHER workgroups of the SAME launch (the fused last
+// launch, below) -- read with agent-scope loads.
+template <bool SC1>
+__device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, int bq, int hid) {
+    const int lane = threadIdx.x & 63;
+    if (bq >= a.B * a.Q) return;
+    stamp(a.stamps, 0, 1024 + hid, 0);
+    const int b = bq / a.Q;
+    const int c = lane & 15, v2 = lane >> 4;
+    // transformation.any() of view `lane` (device-side form): requested now, used at the very end of the block
+    int t_flag = 0;
+    if (a.refs_out && lane < a.V) {
+        const int hf = lane == 0 ? a.flag[0] : lane == 1 ? a.flag[1] : lane == 2 ? a.flag[2] : a.flag[3];
+        t_flag = hf < 0 ? dev_flags(a.y3)[lane] : hf;
+    }
+    const float* ph = a.ph;
+    float yv = 0.f;
+    if (v2 < a.V) {
+        const float* src = a.y3 + ((size_t)v2 * a.B * a.Q + bq) * DC + c;
+        yv = SC1 ? __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *src;
+    }
+    // !SC1: all weights of the wave (input-independent, L2) are requested BEFORE the first use of y3, which was written by
+    // other XCDs a moment ago: one memory round trip for the whole block instead of one per MLP layer (112 registers).
+    // SC1 (tail of the cross-attention kernel, 80-register budget): one 16-float weight set at a time.
+    float wr[SC1 ? 1 : 4][DC], wh[SC1 ? 1 : 3][DC];
+    if constexpr (!SC1) {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int k = 0; k < DC; ++k) wr[v][k] = v < a.V ? ph[PH_RED_WT + (v * DC + k) * DC + c] : 0.f;
+#pragma unroll
+        for (int l = 0; l < 3; ++l)
+#pragma unroll
+            for (int k = 0; k < DC; ++k) wh[l][k] = ph[PH_W + (l * DC + k) * 64 + lane];
+    }
+    auto load_wh = [&](int l) {
+        if constexpr (SC1) {
+#pragma unroll
+            for (int k = 0; k < DC; ++k) wh[0][k] = ph[PH_W + (l * DC + k) * 64 + lane];
+        }
+    };
+    // view reduction: queries.view(B,N,C*V) is channel-major / view-minor (mpfusion.py:436-438)
+    float x = 0.f;
+#pragma unroll
+    for (int v = 0; v < 4; ++v) {
+        if constexpr (SC1) {
+            if (v >= a.V) break;
+#pragma unroll
+            for (int k = 0; k < DC; ++k) wr[0][k] = ph[PH_RED_WT + (v * DC + k) * DC + c];
+        }
+#pragma unroll
+        for (int k = 0; k < DC; ++k) x = fmaf(wr[SC1 ? 0 : v][k], rdlane(yv, v * 16 + k), x);
+        if constexpr (SC1) asm volatile("" ::: "memory");
+    }
+    if (lane < 16) a.query_out[(size_t)bq * DC + lane] = x;
+    stamp(a.stamps, 0, 1024 + hid, 1);
+    // heads (heads/detection.py:252-275): branch g = lane / 16 (center, size, angle, class), row o = lane % 16
+    const int g = lane >> 4, o = lane & 15;
+    float t = 0.f;
+    load_wh(0);
+#pragma unroll
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[0][k], rdlane(x, k), t);
+    hsw[lane] = fmaxf(t, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    t = 0.f;
+    load_wh(1);
+#pragma unroll
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[SC1 ? 0 : 1][k], hsw[g * 16 + k], t);
+    hsw[64 + lane] = fmaxf(t, 0.f);
+    __builtin_amdgcn_wave_barrier();
+    t = 0.f;
+    load_wh(2);
+#pragma unroll
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[SC1 ? 0 : 2][k], hsw[64 + g * 16 + k], t);
+    const int nout = g == 0 ? 3 : (g == 1 ? 3 : (g == 2 ? 2 : a.ncls));
+    float cen = 0.f;
+    if (o < nout) {
+        if (g == 0) { cen = t + a.prev_center[bq * 3 + o]; a.center[bq * 3 + o] = cen; }
+        else if (g == 1) a.size[bq * 3 + o] = fmaxf(t, 0.f);
+        else if (g == 2) a.angle[bq * 2 + o] = tanhf(t);
+        else a.cls[bq * a.ncls + o] = t;
+    }
+    stamp(a.stamps, 0, 1024 + hid, 2);
+    if (a.refs_out) {       // reference points of the new center for the next iteration: lane = view
+        const float cx = rdlane(cen, 0), cy = rdlane(cen, 1), cz = rdlane(cen, 2);
+        if (lane < a.V) {
+            float u, vv;
+            reference_point(cx, cy, cz, t_flag, a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
+                            a.Pm[lane] + (size_t)b * a.prow[lane] * 4, (float)a.shape[lane][b * 2 + 0],
+                            (float)a.shape[lane][b * 2 + 1], u, vv);
+            *reinterpret_cast<f32x2*>(a.refs_out + ((size_t)lane * a.B * a.Q + bq) * 2) = f32x2{u, vv};
+        }
+    }
+    stamp(a.stamps, 0, 1024 + hid, 3);
+}
+
+
+__device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)[2][64], int hid) {
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    reduce_head_rows<false>(a, &hs[wave][0][0], hid * 4 + wave, hid);
+}
+
 constexpr int XW_FLOATS = 384;      // per-wave scratch: wq float4[64] | addr uint2[64] (low bits: dw, dh, level); small vectors reuse wq
 
-template <int R>
-__global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
+// LAST (round 4): the final iteration's launch also runs the view reduction + detection heads of its rows -- the three
+// view blocks of a query group take a ticket when their y3 rows are out (agent-scope stores), whoever draws the last one
+// runs reduce_head_rows for the group's R queries.  The forward's trailing head launch disappears.  `tickets`: one int per
+// blockIdx.x, zeroed by the FIRST cross-attention launch of the forward (a.zero_tickets).
+template <int R, bool LAST>
+__device__ __forceinline__ void xattn_body(const XattnArgs& a, const HeadArgs* hap, int* tickets) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ __attribute__((aligned(16))) int lvl_tab[DPFT_MAX_LEVELS][4];      // ptr lo, ptr hi, H, W
     const int tid = threadIdx.x, lane = tid & 63;
@@ -556,8 +680,16 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
                         a.Pm[view] + (size_t)b * a.prow[view] * 4, (float)a.shape[view][b * 2 + 0],
                         (float)a.shape[view][b * 2 + 1], rx, ry);
     }
+    if (a.zero_tickets && blockIdx.y == 0 && tid == 0) a.zero_tickets[blockIdx.x] = 0;
     __syncthreads();
-    if (!live) return;
+    if (!live) {
+        if constexpr (LAST) {      // (waves without a row still take part in the ticket hand-over of their block)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            __syncthreads();
+        }
+        return;
+    }
     stamp(son, 1, sblk, 1);
     float* ws = sm + K2_FLOATS + wave * XW_FLOATS;
     f32x4* wq = reinterpret_cast<f32x4*>(ws);
@@ -724,6 +856,16 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
         f = slices4_sum(f) + sm[K2_F2B + c];
         y3 = layernorm16(f + y2, sm[K2_N3W + c], sm[K2_N3B + c]);
     }
+    if constexpr (LAST) {
+        if (lane < 16) __hip_atomic_store(a.y3 + ((size_t)view * a.B * a.Q + bq) * DC + lane, y3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(sm);      // the staged weights are dead: every wave of the block is past its FFN
+        if (tid == 0) *flag = __hip_atomic_fetch_add(tickets + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*flag == a.V - 1) reduce_head_rows<true>(*hap, ws, bq, blockIdx.x);
+        return;
+    }
     if (lane < 16) a.y3[((size_t)view * a.B * a.Q + bq) * DC + lane] = y3;
     stamp(son, 1, sblk, 4);
     if (a.part) {       // this view's share of the next layer's q/k/v rows of every target view (lane = output)
@@ -747,93 +889,13 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
     stamp(son, 1, sblk, 5);
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// K3: view reduction + heads + next reference points, one wave per (b, q)
-// ---------------------------------------------------------------------------------------------------------
-struct HeadArgs {
-    const float* y3;            // (V,B,Q,16)
-    const float* ph;            // packed head blob
-    const float* prev_center;   // (B,Q,3)
-    const float* T[4];
-    const float* Pm[4];
-    const int64_t* shape[4];
-    int prow[4], flag[4];
-    float* query_out;           // (B,Q,16)
-    float *center, *size, *angle, *cls;
-    float* refs_out;            // (V,B,Q,2) reference points of the NEW center, or NULL (last iteration)
-    int B, Q, V, ncls, stamps;
-};
-
-__device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)[2][64], int hid) {
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int bq = hid * 4 + wave;
-    if (bq >= a.B * a.Q) return;
-    stamp(a.stamps, 0, 1024 + hid, 0);
-    const int b = bq / a.Q;
-    const int c = lane & 15, v2 = lane >> 4;
-    // transformation.any() of view `lane` (device-side form): requested now, used at the very end of the block
-    int t_flag = 0;
-    if (a.refs_out && lane < a.V) {
-        const int hf = lane == 0 ? a.flag[0] : lane == 1 ? a.flag[1] : lane == 2 ? a.flag[2] : a.flag[3];
-        t_flag = hf < 0 ? dev_flags(a.y3)[lane] : hf;
-    }
-    const float* ph = a.ph;
-    const float yv = v2 < a.V ? a.y3[((size_t)v2 * a.B * a.Q + bq) * DC + c] : 0.f;
-    // all weights of the wave (input-independent, L2) are requested BEFORE the first use of y3, which was written by
-    // other XCDs a moment ago: one memory round trip for the whole block instead of one per MLP layer
-    float wr[4][DC], wh[3][DC];
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int k = 0; k < DC; ++k) wr[v][k] = v < a.V ? ph[PH_RED_WT + (v * DC + k) * DC + c] : 0.f;
-#pragma unroll
-    for (int l = 0; l < 3; ++l)
-#pragma unroll
-        for (int k = 0; k < DC; ++k) wh[l][k] = ph[PH_W + (l * DC + k) * 64 + lane];
-    // view reduction: queries.view(B,N,C*V) is channel-major / view-minor (mpfusion.py:436-438)
-    float x = 0.f;
-#pragma unroll
-    for (int v = 0; v < 4; ++v)
-#pragma unroll
-        for (int k = 0; k < DC; ++k) x = fmaf(wr[v][k], rdlane(yv, v * 16 + k), x);
-    if (lane < 16) a.query_out[(size_t)bq * DC + lane] = x;
-    stamp(a.stamps, 0, 1024 + hid, 1);
-    // heads (heads/detection.py:252-275): branch g = lane / 16 (center, size, angle, class), row o = lane % 16
-    const int g = lane >> 4, o = lane & 15;
-    float t = 0.f;
-#pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(wh[0][k], rdlane(x, k), t);
-    hs[wave][0][lane] = fmaxf(t, 0.f);
-    __builtin_amdgcn_wave_barrier();
-    t = 0.f;
-#pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(wh[1][k], hs[wave][0][g * 16 + k], t);
-    hs[wave][1][lane] = fmaxf(t, 0.f);
-    __builtin_amdgcn_wave_barrier();
-    t = 0.f;
-#pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(wh[2][k], hs[wave][1][g * 16 + k], t);
-    const int nout = g == 0 ? 3 : (g == 1 ? 3 : (g == 2 ? 2 : a.ncls));
-    float cen = 0.f;
-    if (o < nout) {
-        if (g == 0) { cen = t + a.prev_center[bq * 3 + o]; a.center[bq * 3 + o] = cen; }
-        else if (g == 1) a.size[bq * 3 + o] = fmaxf(t, 0.f);
-        else if (g == 2) a.angle[bq * 2 + o] = tanhf(t);
-        else a.cls[bq * a.ncls + o] = t;
-    }
-    stamp(a.stamps, 0, 1024 + hid, 2);
-    if (a.refs_out) {       // reference points of the new center for the next iteration: lane = view
-        const float cx = rdlane(cen, 0), cy = rdlane(cen, 1), cz = rdlane(cen, 2);
-        if (lane < a.V) {
-            float u, vv;
-            reference_point(cx, cy, cz, t_flag, a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
-                            a.Pm[lane] + (size_t)b * a.prow[lane] * 4, (float)a.shape[lane][b * 2 + 0],
-                            (float)a.shape[lane][b * 2 + 1], u, vv);
-            *reinterpret_cast<f32x2*>(a.refs_out + ((size_t)lane * a.B * a.Q + bq) * 2) = f32x2{u, vv};
-        }
-    }
-    stamp(a.stamps, 0, 1024 + hid, 3);
+template <int R>
+__global__ __launch_bounds__(R * 64, 6) void decoder_xattn_kernel(XattnArgs a) {
+    xattn_body<R, false>(a, nullptr, nullptr);
+}
+template <int R>
+__global__ __launch_bounds__(R * 64, 6) void decoder_xattn_last_kernel(XattnArgs a, HeadArgs ha, int* tickets) {
+    xattn_body<R, true>(a, &ha, tickets);
 }
 
 
@@ -928,6 +990,9 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
     float* cbuf[2] = {y3 + (size_t)V * nq * DC, y3 + (size_t)V * nq * DC + nq * 3};
     float* refs = cbuf[1] + nq * 3;
     float* part = refs + (size_t)V * nq * 2;
+    int* tickets = reinterpret_cast<int*>(part + (size_t)2 * V * V * nq * 32);      // behind `part` (dpft_decoder_work_floats)
+    static const bool fuse_last = getenv("DPFT_DEC_FUSE_LAST") == nullptr || atoi(getenv("DPFT_DEC_FUSE_LAST")) != 0;      // A/B switch
+    const int nxb = cdiv((int64_t)nq, XR);
     XattnArgs xa;
     HeadArgs ha;
     ScoreArgs sa;
@@ -997,13 +1062,26 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
             center = ha.center;
         }
         if (after_last) break;
+        const bool last_it = it + 1 == d->iters;
         // ---- cross attention + FFN of iteration `it` ----
         xa.query = query; xa.qstride = first ? 0 : (long)Q * DC; xa.Bsa = sa.Bsa;
         xa.attn = skip ? d->attn0 : attn;
         xa.refs = first ? nullptr : refs;
         xa.prev_center = center;
         xa.part = it + 1 < d->iters ? part : nullptr;
-        hipLaunchKernelGGL(decoder_xattn_kernel<XR>, dim3(cdiv((int64_t)nq, XR), V), dim3(XR * 64), lds2, (hipStream_t)stream, xa);
+        xa.zero_tickets = (fuse_last && first && d->iters > 1) ? tickets : nullptr;
+        if (last_it && fuse_last && d->iters > 1) {
+            // the heads of the last iteration ride in this launch (decoder_xattn_last_kernel): no trailing launch
+            ha.ph = d->packed_heads + (size_t)it * PH_FLOATS;
+            ha.prev_center = center;
+            ha.query_out = qbuf[it & 1];
+            ha.center = d->center;
+            ha.refs_out = nullptr;
+            hipLaunchKernelGGL(decoder_xattn_last_kernel<XR>, dim3(nxb, V), dim3(XR * 64), lds2, (hipStream_t)stream, xa, ha, tickets);
+            RC(check_launch("decoder_xattn (+ heads)"));
+            break;
+        }
+        hipLaunchKernelGGL(decoder_xattn_kernel<XR>, dim3(nxb, V), dim3(XR * 64), lds2, (hipStream_t)stream, xa);
         RC(check_launch("decoder_xattn"));
     }
     return DPFT_OK;
@@ -1031,7 +1109,8 @@ extern "C" int dpft_decoder_attn0_f32(const float* packed_views, const float* po
 
 extern "C" int64_t dpft_decoder_work_floats(int32_t B, int32_t Q, int32_t V) {
     const int64_t nq = (int64_t)B * Q;
-    return 2 * nq * DC + 2 * (int64_t)V * nq * DC + 2 * nq * 3 + (int64_t)V * nq * 2 + (int64_t)V * V * nq * 64 + 64;      // part: 2 x V*V*nq*8*4
+    return 2 * nq * DC + 2 * (int64_t)V * nq * DC + 2 * nq * 3 + (int64_t)V * nq * 2 + (int64_t)V * V * nq * 64 + 64      // part: 2 x V*V*nq*8*4
+           + cdiv(nq, (int64_t)XR) + 16;                                                                                    // tickets of the fused last launch
 }
 
 // debug: copy the phase stamps of the last launches (2 kernels x 2048 blocks x 8 slots of uint64) to host memory
