@@ -508,7 +508,9 @@ struct HeadArgs {
 
 // `hsw`: 128 floats of LDS scratch of this wave.  SC1: y3 was written by OTHER workgroups of the SAME launch (the fused last
 // launch, below) -- read with agent-scope loads.
-template <bool SC1>
+constexpr int DEC_SH_BLOCKS = 5;      // resident 256-thread blocks per CU decoder_scores_head_kernel's register budget is sized for
+// STAGED: one 16-float weight set in registers at a time (~20 registers instead of 112; one more L2 round trip per set)
+template <bool SC1, bool STAGED = SC1>
 __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, int bq, int hid) {
     const int lane = threadIdx.x & 63;
     if (bq >= a.B * a.Q) return;
@@ -530,8 +532,8 @@ __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, 
     // !SC1: all weights of the wave (input-independent, L2) are requested BEFORE the first use of y3, which was written by
     // other XCDs a moment ago: one memory round trip for the whole block instead of one per MLP layer (112 registers).
     // SC1 (tail of the cross-attention kernel, 80-register budget): one 16-float weight set at a time.
-    float wr[SC1 ? 1 : 4][DC], wh[SC1 ? 1 : 3][DC];
-    if constexpr (!SC1) {
+    float wr[STAGED ? 1 : 4][DC], wh[STAGED ? 1 : 3][DC];
+    if constexpr (!STAGED) {
 #pragma unroll
         for (int v = 0; v < 4; ++v)
 #pragma unroll
@@ -542,7 +544,7 @@ __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, 
             for (int k = 0; k < DC; ++k) wh[l][k] = ph[PH_W + (l * DC + k) * 64 + lane];
     }
     auto load_wh = [&](int l) {
-        if constexpr (SC1) {
+        if constexpr (STAGED) {
 #pragma unroll
             for (int k = 0; k < DC; ++k) wh[0][k] = ph[PH_W + (l * DC + k) * 64 + lane];
         }
@@ -551,14 +553,14 @@ __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, 
     float x = 0.f;
 #pragma unroll
     for (int v = 0; v < 4; ++v) {
-        if constexpr (SC1) {
+        if constexpr (STAGED) {
             if (v >= a.V) break;
 #pragma unroll
             for (int k = 0; k < DC; ++k) wr[0][k] = ph[PH_RED_WT + (v * DC + k) * DC + c];
         }
 #pragma unroll
-        for (int k = 0; k < DC; ++k) x = fmaf(wr[SC1 ? 0 : v][k], rdlane(yv, v * 16 + k), x);
-        if constexpr (SC1) asm volatile("" ::: "memory");
+        for (int k = 0; k < DC; ++k) x = fmaf(wr[STAGED ? 0 : v][k], rdlane(yv, v * 16 + k), x);
+        if constexpr (STAGED) asm volatile("" ::: "memory");
     }
     if (lane < 16) a.query_out[(size_t)bq * DC + lane] = x;
     stamp(a.stamps, 0, 1024 + hid, 1);
@@ -573,13 +575,13 @@ __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, 
     t = 0.f;
     load_wh(1);
 #pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(wh[SC1 ? 0 : 1][k], hsw[g * 16 + k], t);
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[STAGED ? 0 : 1][k], hsw[g * 16 + k], t);
     hsw[64 + lane] = fmaxf(t, 0.f);
     __builtin_amdgcn_wave_barrier();
     t = 0.f;
     load_wh(2);
 #pragma unroll
-    for (int k = 0; k < DC; ++k) t = fmaf(wh[SC1 ? 0 : 2][k], hsw[64 + g * 16 + k], t);
+    for (int k = 0; k < DC; ++k) t = fmaf(wh[STAGED ? 0 : 2][k], hsw[64 + g * 16 + k], t);
     const int nout = g == 0 ? 3 : (g == 1 ? 3 : (g == 2 ? 2 : a.ncls));
     float cen = 0.f;
     if (o < nout) {
@@ -605,7 +607,7 @@ __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, 
 
 __device__ __forceinline__ void reduce_head_block(const HeadArgs& a, float (*hs)[2][64], int hid) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    reduce_head_rows<false>(a, &hs[wave][0][0], hid * 4 + wave, hid);
+    reduce_head_rows<false, DEC_SH_BLOCKS >= 5>(a, &hs[wave][0][0], hid * 4 + wave, hid);
 }
 
 constexpr int XW_FLOATS = 384;      // per-wave scratch: wq float4[64] | addr uint2[64] (low bits: dw, dh, level); small vectors reuse wq
@@ -902,10 +904,13 @@ __global__ __launch_bounds__(R * 64, 6) void decoder_xattn_last_kernel(XattnArgs
 // One launch = the score blocks of iteration it (blocks [0, n_score)) + the reduction / head blocks of iteration it-1
 // (blocks [n_score, ...)): both only depend on the previous cross-attention kernel, so the head MLPs' latency chain
 // hides behind the scores instead of sitting between two kernel boundaries.
-__global__ __launch_bounds__(256, 4) void decoder_scores_head_kernel(ScoreArgs sa, HeadArgs ha, int n_score, int composed) {
+__global__ __launch_bounds__(256, DEC_SH_BLOCKS) void decoder_scores_head_kernel(ScoreArgs sa, HeadArgs ha, int n_score, int composed) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     __shared__ float hs[4][2][64];
-    const int bid = blockIdx.x;
+    // head blocks FIRST (round 4): their latency chain (first touch of y3, three dependent MLP layers) starts with the launch
+    // and hides behind the score blocks; dispatched last they were the kernel's tail (13.3 us for 8.5 us of score blocks)
+    const int n_head_blocks = (int)gridDim.x - n_score;
+    const int bid = (int)blockIdx.x < n_head_blocks ? n_score + (int)blockIdx.x : (int)blockIdx.x - n_head_blocks;
     if (bid < n_score) {
         if (composed == 1) scores_block<true>(sa, sm, bid);
         else scores_block<false>(sa, sm, bid);

@@ -1148,3 +1148,48 @@ def test_splitk_fixup_is_repeatable_and_leaves_the_ticket_header_clean(shape):
     hdr = int(lib.dpft_conv2d_workspace_header_bytes())
     torch.cuda.synchronize()
     assert hdr > 0 and int(ws[:hdr].count_nonzero()) == 0
+
+
+@pytest.mark.gpu
+def test_splitk_fixup_holds_under_concurrent_streams():
+    """The hand-over of the split-K fix-up (agent-scope stores of the partial tiles, a ticket, agent-scope loads by the last
+    workgroup -- no fences) with other work on the device: three streams run split-K convolutions back to back on their own
+    workspaces while a fourth streams 1 GiB copies through HBM and L2; every one of 3 x 150 results is bit-equal to the
+    result computed alone."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    shapes = [(4, 16, 7, 256, 256, 3, 1), (4, 8, 4, 512, 2048, 1, 1), (4, 16, 29, 512, 512, 3, 1)]
+    jobs = []
+    for B, H, W, Cin, K, k, s in shapes:
+        x = torch.randn(B, H, W, Cin, generator=g).to(DEV)
+        w = (torch.randn(K, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5).contiguous(memory_format=torch.channels_last).to(DEV)
+        cv = ops.conv_problem(B, H, W, Cin, K, k, k, s, k // 2)
+        wg = w.permute(0, 2, 3, 1)
+        y0, st0 = ops.conv_fwd(cv, x, wg, want_stats=True)
+        dy = torch.randn(B, cv.OH, cv.OW, K, generator=g).to(DEV)
+        wt = ops.weight_transpose(wg)
+        dx0 = ops.conv_dgrad(cv, dy, wt)
+        jobs.append((cv, x, wg, dy, wt, y0.clone(), st0.clone(), dx0.clone()))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in jobs]
+    hog_stream = torch.cuda.Stream()
+    a, b = torch.empty(1 << 28, device=DEV), torch.empty(1 << 28, device=DEV)
+    bad = []
+    for it in range(150):
+        with torch.cuda.stream(hog_stream):
+            b.copy_(a)
+        outs = []
+        for st, (cv, x, wg, dy, wt, y0, s0, dx0) in zip(streams, jobs):
+            with torch.cuda.stream(st):
+                y, s_ = ops.conv_fwd(cv, x, wg, want_stats=True)
+                dx = ops.conv_dgrad(cv, dy, wt)
+                outs.append((y, s_, dx))
+        if it % 10 == 9:
+            torch.cuda.synchronize()
+        for ji, ((y, s_, dx), job) in enumerate(zip(outs, jobs)):
+            for st in streams:
+                st.synchronize()
+            if not (torch.equal(y, job[5]) and torch.equal(s_, job[6]) and torch.equal(dx, job[7])):
+                bad.append((it, ji))
+    torch.cuda.synchronize()
+    assert not bad, bad[:10]

@@ -60,7 +60,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             agg[n][0] += float(r["Counter_Value"]); agg[n][1] += 1
     draw[c] = {k: {"sum_kb": v[0], "launches": v[1], "kb_per_launch": v[0] / max(v[1], 1)} for k, v in agg.items()}
 try:
-    fwds = draw["FETCH_SIZE"]["void dpft::decoder_xattn_kernel<7>"]["launches"] / 4.0
+    fwds = sum(v["launches"] for k, v in draw["FETCH_SIZE"].items() if "decoder_xattn" in k) / 4.0
     fetch = 2.0 * 1024 * sum(v["sum_kb"] for v in draw["FETCH_SIZE"].values()) / fwds
     write = 1024 * sum(v["sum_kb"] for v in draw["WRITE_SIZE"].values()) / fwds
     dout = {"method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, --kernel-trace only) over tools/decoder_only.py (REPS=5 + 3 warm-up forwards of the fused inference decoder at B=4); counter unit KB; FETCH_SIZE doubled (gfx950 note; uncalibrated for the 16-byte gathers, i.e. an upper estimate), WRITE_SIZE uncorrected",

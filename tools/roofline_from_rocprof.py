@@ -32,7 +32,7 @@ def decoder_main(argv):
     mb = float(argv[2]) if len(argv) > 2 else 555.917472          # kradar, B=4
     rows = list(csv.DictReader(open(path)))
     kern = {re.sub(r"\(.*", "", r["Name"]): (int(r["Calls"]), float(r["TotalDurationNs"])) for r in rows}
-    xattn = [v for k, v in kern.items() if "decoder_xattn_kernel" in k]
+    xattn = [v for k, v in kern.items() if "decoder_xattn" in k]      # (+ decoder_xattn_last_kernel: the final iteration with the heads)
     fwds = sum(c for c, _ in xattn) / iters
     counted = {k: v for k, v in kern.items() if "decoder_" in k and "pack" not in k}
     total_ns = sum(ns for _, ns in counted.values())
