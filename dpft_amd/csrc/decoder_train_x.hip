@@ -270,6 +270,10 @@ __device__ __forceinline__ void xf_forward_row(const XfArgs& a, int view, int bq
     }
 }
 
+// Backward: 5 waves per SIMD (96 VGPRs + 26 spilled): the 4 800 rows of a call at B = 4 (1 200 blocks) are then resident
+// TOGETHER on 256 CUs x 20 waves; at 4 per SIMD (123 VGPRs) 176 blocks ran as a second round: 226 -> 215 us.  The forward
+// loses with the same budget (35.4 -> 37.2 us) and keeps 4.
+constexpr int XF_WAVES = 5;
 // grid (ceil(B*Q / 4), V), 4 waves (= 4 rows of one view) per block
 __global__ __launch_bounds__(256) void xf_train_fwd_kernel(XfArgs a) {
     __shared__ float sm[4][16 + NOA + 32];
@@ -290,7 +294,7 @@ __global__ __launch_bounds__(256) void xf_train_fwd_kernel(XfArgs a) {
 }
 
 template <bool SAVED>
-__global__ __launch_bounds__(256) void xf_train_bwd_kernel(XfArgs a) {
+__global__ __launch_bounds__(256, XF_WAVES) void xf_train_bwd_kernel(XfArgs a) {
     __shared__ __attribute__((aligned(16))) float sm[4][16 + NOA + 32 + NOA + 32 + 32 + 128 + 128 + 32];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bq = blockIdx.x * 4 + wv, view = blockIdx.y;
