@@ -434,8 +434,8 @@ def main():
                "frac": dec_bytes / t_dec / 8.0e12, "traffic": dec_traffic, "traffic_is": "HBM bytes per forward (counters)",
                "traffic_source": dec_src, "decoder_fwd_us": t_dec * 1e6,
                "algorithmic_mb": dec_bytes / 1e6, "kernel": "decoder_scores_head + decoder_xattn "
-               f"({2 * fcfg['i_iter']} launches per forward; iteration 0's self-attention output, a constant of the "
-               "weights, is made when the weights are packed)",
+               f"({2 * fcfg['i_iter'] - 1} launches per forward: iteration 0's self-attention output, a constant of the "
+               "weights, is made when the weights are packed; the last iteration's heads ride in its cross-attention launch)",
                "note": "frac prices the measured time against the time 8 TB/s needs for the ALGORITHMIC bytes of SURVEY 8d "
                        "(every cross-attention call streaming its pyramid once); the sample-then-project kernels touch far "
                        "fewer HBM bytes (traffic), they are bound by L2 line requests and kernel-boundary latency",
