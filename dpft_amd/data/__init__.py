@@ -4,3 +4,4 @@ from dpft_amd.data.loader import PrefetchLoader, ShardedSampler, listed_collatin
 from dpft_amd.data.preprocess import GpuPreprocessor, resized_output_size                        # noqa: F401
 from dpft_amd.data.synthetic_raw import SyntheticRawDataset                                      # noqa: F401
 from dpft_amd.data.radar_projection import doppler_raster, radar_projection                      # noqa: F401
+from dpft_amd.data.kradar import KRadarFolderDataset, initialize_kradar                       # noqa: F401

