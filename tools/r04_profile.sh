@@ -126,5 +126,5 @@ cd /root/repo
 DPFT_CONV_TABLE=$OUT/r04_conv_table_fp32.txt timeout 900 python bench.py > $OUT/r04_bench.json 2> $OUT/r04_bench.err
 # (9) loader-in-the-loop rate, frozen-BN / train-mode gradient probe
 timeout 600 python tools/loader_rate.py > $OUT/r04_loader_rate.json 2> $OUT/r04_loader_rate.err
-timeout 900 python tools/grad_gap_probe.py > $OUT/r04_grad_gap_probe.txt 2> /dev/null
+timeout 900 python tools/grad_gap_probe.py > $OUT/r04_grad_gap_probe_rerun.txt 2> /dev/null      # (profiles/r04_grad_gap_probe.txt also holds the four-other-seeds runs)
 tail -2 $OUT/r04_serial.log; grep "ms/step" $OUT/r04_plain.log; grep decoder_fwd $OUT/r04_decoder.log; head -c 600 $OUT/r04_roofline_from_rocprof.json
