@@ -41,7 +41,7 @@
 
 namespace dpft {
 
-__global__ void pack_view_kernel(dpft_decoder_view s, int n_off, int n_att, float* __restrict__ d) {
+__device__ __forceinline__ void pack_view_body(const dpft_decoder_view& s, int n_off, int n_att, float* __restrict__ d) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PV_FLOATS; i += gridDim.x * blockDim.x) {
         float v = 0.f;
         int r;
@@ -71,6 +71,24 @@ __global__ void pack_view_kernel(dpft_decoder_view s, int n_off, int n_att, floa
         else if (i < PV_N3_B) v = s.norm3_w[i - PV_N3_W];
         else v = s.norm3_b[i - PV_N3_B];
         d[i] = v;
+    }
+}
+
+__global__ void pack_view_kernel(dpft_decoder_view s, int n_off, int n_att, float* __restrict__ d) { pack_view_body(s, n_off, n_att, d); }
+
+// all views of a layer in one launch (blockIdx.y = view): the training decoder packed its three views with three launches
+// per layer and forward (round 4)
+struct PackViews {
+    dpft_decoder_view v[4];
+    int n_off[4], n_att[4];
+    float* d[4];
+};
+__global__ void pack_views_kernel(PackViews p) {
+    switch (blockIdx.y) {      // constant indices: the argument struct stays in the kernarg segment
+        case 0: pack_view_body(p.v[0], p.n_off[0], p.n_att[0], p.d[0]); break;
+        case 1: pack_view_body(p.v[1], p.n_off[1], p.n_att[1], p.d[1]); break;
+        case 2: pack_view_body(p.v[2], p.n_off[2], p.n_att[2], p.d[2]); break;
+        default: pack_view_body(p.v[3], p.n_off[3], p.n_att[3], p.d[3]); break;
     }
 }
 
@@ -937,6 +955,26 @@ extern "C" int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t
     hipLaunchKernelGGL(pack_view_kernel, dim3(cdiv(PV_FLOATS, 256)), dim3(256), 0, (hipStream_t)stream, *view,
                        DM * L * P * 2, DM * L * P, packed);
     return check_launch("decoder_pack_view");
+}
+
+extern "C" int dpft_decoder_pack_views_f32(const dpft_decoder_view* views, int32_t V, const int32_t* L, const int32_t* P,
+                                           float* packed, dpft_stream_t stream) {
+    DPFT_REQUIRE(views && L && P && packed && V >= 1 && V <= 4, "decoder_pack_views: bad arguments");
+    PackViews pv;
+    memset(&pv, 0, sizeof(pv));
+    for (int v = 0; v < V; ++v) {
+        DPFT_REQUIRE(L[v] >= 1 && L[v] <= DPFT_MAX_LEVELS && P[v] >= 1 && P[v] <= 4 && L[v] * P[v] * DM * 3 <= NOA,
+                     "decoder_pack_views: L=%d, P=%d exceed the fused kernel's budget (P <= 4, L*P <= 20)", L[v], P[v]);
+        const float* const* f = reinterpret_cast<const float* const*>(views + v);
+        for (size_t i = 0; i < sizeof(dpft_decoder_view) / sizeof(float*); ++i)
+            DPFT_REQUIRE(f[i], "decoder_pack_views: view %d parameter pointer %d is null", v, (int)i);
+        pv.v[v] = views[v];
+        pv.n_off[v] = DM * L[v] * P[v] * 2;
+        pv.n_att[v] = DM * L[v] * P[v];
+        pv.d[v] = packed + (size_t)v * PV_FLOATS;
+    }
+    hipLaunchKernelGGL(pack_views_kernel, dim3(cdiv(PV_FLOATS, 256), V), dim3(256), 0, (hipStream_t)stream, pv);
+    return check_launch("decoder_pack_views");
 }
 
 extern "C" int dpft_decoder_pack_head_f32(const float* red_w, const float* const* head_w, int32_t V, int32_t num_classes,

@@ -123,6 +123,7 @@ SIGNATURES = {
     "dpft_decoder_packed_infer_floats": (_L, [_I]),
     "dpft_decoder_pack_infer_f32": (_I, [C.POINTER(DecoderView), _I, _I, _P, _P, _I, _I, _P, _P, _I, _P, _P]),
     "dpft_decoder_pack_view_f32": (_I, [C.POINTER(DecoderView), _I, _I, _P, _P]),
+    "dpft_decoder_pack_views_f32": (_I, [_P, _I, _P, _P, _P, _P]),
     "dpft_decoder_pack_head_f32": (_I, [_P, C.POINTER(C.c_void_p * 12), _I, _I, _P, _P]),
     "dpft_decoder_work_floats": (_L, [_I, _I, _I]),
     "dpft_debug_decoder_stamps": (_I, [_P]),

@@ -151,8 +151,8 @@ def _pack_views(params: List[torch.Tensor], V: int, n_levels, n_points, dev):
     views = (DecoderView * V)()
     for v in range(V):
         views[v] = DecoderView(*[t.data_ptr() for t in params[22 * v:22 * v + 22]])
-        lib.call("dpft_decoder_pack_view_f32", C.byref(views[v]), n_levels[v], n_points[v],
-                 packed.data_ptr() + v * nv * 4, stream())
+    lib.call("dpft_decoder_pack_views_f32", C.cast(views, C.c_void_p), V, C.cast((C.c_int32 * V)(*n_levels), C.c_void_p),
+             C.cast((C.c_int32 * V)(*n_points), C.c_void_p), packed.data_ptr(), stream())      # one launch for the V views
     return packed, views
 
 

@@ -339,6 +339,9 @@ int64_t dpft_decoder_packed_head_floats(void);   /* floats per packed reduction+
 /* packed <- one MLFusion's parameters (L levels, P points of its MSDeformAttn) */
 int dpft_decoder_pack_view_f32(const dpft_decoder_view* view, int32_t L, int32_t P, float* packed,
                                dpft_stream_t stream);
+/* the same for all V views of a layer in one launch; packed = V consecutive blobs */
+int dpft_decoder_pack_views_f32(const dpft_decoder_view* views, int32_t V, const int32_t* L, const int32_t* P, float* packed,
+                                dpft_stream_t stream);
 /* inference decoder's blob of one MLFusion = view `view_index` of one MPFusion layer: per-head in_proj rows with
  * 1/sqrt(d)*log2(e) folded into q, the offsets / logits matrix in the lanes' sample-slot order, the LDS image of the
  * cross-attention kernel, the input-independent part of the self-attention's q / k / v rows over pos (Q,16) =
