@@ -552,7 +552,11 @@ __global__ __launch_bounds__(256) void sa_train_bwd_kv_kernel(SaArgs a) {
     }
 }
 
-static int pick_qw(int B, int Q, int V) {
+static int pick_qw(int B, int Q, int V, int which = 0) {      // which: 0 forward, 1 backward (queries), 2 backward (keys / values)
+    static const int env[3] = {getenv("DPFT_SA_QW_FWD") ? atoi(getenv("DPFT_SA_QW_FWD")) : 0,
+                               getenv("DPFT_SA_QW_BWD") ? atoi(getenv("DPFT_SA_QW_BWD")) : 0,
+                               getenv("DPFT_SA_KW") ? atoi(getenv("DPFT_SA_KW")) : 0};      // tuning aid
+    if (env[which] >= 1 && env[which] <= 8 && env[which] != 7) return env[which];
     const int tiles = std::max(1, kNumCU / (V * B));
     int qw = std::min(8, std::max(1, cdiv(cdiv(Q, tiles), 4)));
     if (qw == 7) qw = 8;
@@ -633,12 +637,13 @@ extern "C" int dpft_selfattn_train_bwd_f32(const dpft_sa_params* params, int32_t
     a.dy1 = dy1; a.lse = const_cast<float*>(lse); a.attn = const_cast<float*>(attn); a.zhat = const_cast<float*>(zhat);
     a.rstd = const_cast<float*>(rstd); a.dx = dx; a.dxp = dxp;
     a.dA = scratch; a.delta = scratch + (size_t)V * B * Q * TC;
-    const int qw = pick_qw(B, Q, V), qt = 4 * qw;
+    int qw = pick_qw(B, Q, V, 1), qt = 4 * qw;
     const size_t lds_q = ((size_t)Q * 32 + 48 * 16 + 48 + 6 * qt * TC + qt * TH + std::max(2 * qt * TC, 0)) * sizeof(float);
     DPFT_REQUIRE(lds_q <= 160 * 1024, "selfattn_train_bwd: %d queries do not fit the LDS", Q);
     SA_DISPATCH(sa_train_bwd_q_kernel, qw, dim3(cdiv(Q, qt), V, B), lds_q, stream, a);
     rc = check_launch("selfattn_train_bwd_q");
     if (rc) return rc;
+    qw = pick_qw(B, Q, V, 2); qt = 4 * qw;
     const size_t lds_kv = ((size_t)Q * 48 + 48 * 16 + 48 + 6 * qt * TC) * sizeof(float);
     DPFT_REQUIRE(lds_kv <= 160 * 1024, "selfattn_train_bwd: %d queries do not fit the LDS", Q);
     SA_DISPATCH(sa_train_bwd_kv_kernel, qw, dim3(cdiv(Q, qt), V, B), lds_kv, stream, a);
