@@ -1919,6 +1919,7 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps) {
         int bm, bn, sp;
         if (t.vec && sscanf(f, "%d,%d,%d", &bm, &bn, &sp) == 3) {
             t.bm = bm; t.bn = bn; t.splits = sp < 1 ? 1 : sp;
+            while (t.splits > 1 && ksteps / t.splits < 2) --t.splits;      // every split keeps at least one pipelined K-step
             return t;
         }
     }

@@ -657,3 +657,129 @@ extern "C" int dpft_rows_outer_f32(const float* rows, int32_t G, int32_t R, int3
                        (int64_t)R * W, sp, out, out_gstride);
     return dpft::check_launch("rows_outer");
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dpft_memops: up to DPFT_MEMOPS_MAX device-to-device copies / zero fills in ONE launch (the small per-step input copies
+// of a replayed decoder graph, the clears of a gradient reducer, the static-address input copies of the launch plans).
+// The host glue used the runtime's blit kernels for these (one launch per tensor).
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dpft {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct MemOps {
+    int n;
+    int first_block[DPFT_MEMOPS_MAX + 1];      // blocks [first_block[i], first_block[i + 1]) work on op i
+    dpft_memop op[DPFT_MEMOPS_MAX];
+};
+constexpr int MEMOP_BLOCK_BYTES = 256 * 16 * 8;      // 8 sixteen-byte accesses per thread
+
+__global__ __launch_bounds__(256) void memops_kernel(MemOps m) {
+    int i = 0;
+    while (i + 1 < m.n && (int)blockIdx.x >= m.first_block[i + 1]) ++i;
+    const dpft_memop o = m.op[i];
+    const int nblk = m.first_block[i + 1] - m.first_block[i];
+    const int blk = blockIdx.x - m.first_block[i];
+    const bool vec = (((uintptr_t)o.dst | (uintptr_t)o.src) & 15) == 0;
+    if (vec) {
+        const uint64_t n16 = o.bytes >> 4;
+        u32x4* d = reinterpret_cast<u32x4*>(o.dst);
+        const u32x4* s = reinterpret_cast<const u32x4*>(o.src);
+        const u32x4 z = {0u, 0u, 0u, 0u};
+        for (uint64_t k = (uint64_t)blk * 256 + threadIdx.x; k < n16; k += (uint64_t)nblk * 256) d[k] = s ? s[k] : z;
+        const uint64_t done = n16 << 4;                      // tail: 4-byte words
+        unsigned* dt = reinterpret_cast<unsigned*>((char*)o.dst + done);
+        const unsigned* st_ = s ? reinterpret_cast<const unsigned*>((const char*)o.src + done) : nullptr;
+        if (blk == 0 && threadIdx.x < ((o.bytes - done) >> 2)) dt[threadIdx.x] = st_ ? st_[threadIdx.x] : 0u;
+    } else {
+        const uint64_t n4 = o.bytes >> 2;
+        unsigned* d = reinterpret_cast<unsigned*>(o.dst);
+        const unsigned* s = reinterpret_cast<const unsigned*>(o.src);
+        for (uint64_t k = (uint64_t)blk * 256 + threadIdx.x; k < n4; k += (uint64_t)nblk * 256) d[k] = s ? s[k] : 0u;
+    }
+}
+}  // namespace dpft
+
+extern "C" int dpft_memops(int32_t n, const dpft_memop* ops, dpft_stream_t stream) {
+    DPFT_REQUIRE(ops && n >= 1 && n <= DPFT_MEMOPS_MAX, "memops: 1..%d operations per call", DPFT_MEMOPS_MAX);
+    dpft::MemOps m;
+    m.n = n;
+    int blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        DPFT_REQUIRE(ops[i].dst && (ops[i].bytes & 3) == 0 && (((uintptr_t)ops[i].dst | (uintptr_t)ops[i].src) & 3) == 0,
+                     "memops: operation %d needs 4-byte aligned pointers and a size that is a multiple of 4", i);
+        m.op[i] = ops[i];
+        m.first_block[i] = blocks;
+        const uint64_t want = (ops[i].bytes + dpft::MEMOP_BLOCK_BYTES - 1) / dpft::MEMOP_BLOCK_BYTES;
+        blocks += (int)std::max<uint64_t>(1, std::min<uint64_t>(want, 2048));
+    }
+    m.first_block[n] = blocks;
+    hipLaunchKernelGGL(dpft::memops_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, m);
+    return dpft::check_launch("memops");
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dpft_sum_leading_f32: dst[i] (+)= sum_s sum_l src_s[l * inner + i], i < inner -- the leading-axis sums of the training
+// decoder's backward (gradients of a tensor broadcast over views / batch elements / replicas, and of a parameter used by
+// several blocks) in ONE launch with a fixed summation order (sources in table order, leading index ascending).
+// Replaces Tensor.sum(...) + the autograd engine's add chains.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace dpft {
+struct SumSrcs {
+    int n;
+    dpft_sum_src s[DPFT_SUM_SRCS_MAX];
+};
+__global__ __launch_bounds__(256) void sum_leading_kernel(SumSrcs t, int64_t inner4, float* __restrict__ dst, int accumulate) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= inner4) return;
+    f32x4 acc = accumulate ? reinterpret_cast<const f32x4*>(dst)[i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < t.n; ++k) {
+        const f32x4* __restrict__ p = reinterpret_cast<const f32x4*>(t.s[k].src) + i;
+        const int nl = t.s[k].n_lead;
+        int l = 0;
+        for (; l + 4 <= nl; l += 4) {      // four loads in flight, added in order
+            const f32x4 a = p[(int64_t)l * inner4], b = p[(int64_t)(l + 1) * inner4], c = p[(int64_t)(l + 2) * inner4],
+                        d = p[(int64_t)(l + 3) * inner4];
+            acc += a; acc += b; acc += c; acc += d;
+        }
+        for (; l < nl; ++l) acc += p[(int64_t)l * inner4];
+    }
+    reinterpret_cast<f32x4*>(dst)[i] = acc;
+}
+}  // namespace dpft
+
+extern "C" int dpft_sum_leading_f32(int32_t n_src, const dpft_sum_src* srcs, int64_t inner, float* dst, int32_t accumulate,
+                                    dpft_stream_t stream) {
+    DPFT_REQUIRE(srcs && dst && n_src >= 1 && n_src <= DPFT_SUM_SRCS_MAX, "sum_leading: 1..%d sources per call", DPFT_SUM_SRCS_MAX);
+    DPFT_REQUIRE(inner > 0 && (inner & 3) == 0 && ((uintptr_t)dst & 15) == 0, "sum_leading: inner %% 4 == 0, 16-byte aligned tensors");
+    dpft::SumSrcs t;
+    t.n = n_src;
+    for (int i = 0; i < n_src; ++i) {
+        DPFT_REQUIRE(srcs[i].src && srcs[i].n_lead >= 1 && ((uintptr_t)srcs[i].src & 15) == 0, "sum_leading: bad source %d", i);
+        t.s[i] = srcs[i];
+    }
+    const int64_t inner4 = inner / 4;
+    hipLaunchKernelGGL(dpft::sum_leading_kernel, dim3((unsigned)((inner4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, t, inner4,
+                       dst, accumulate);
+    return dpft::check_launch("sum_leading");
+}
+
+
+// dropout seed of the training decoder (train_fused.py advance_seed): snap = state; state += increment -- one launch
+// (captured in the forward graph) instead of a clone and an add
+namespace dpft {
+__global__ void seed_advance_kernel(long long* __restrict__ state, long long* __restrict__ snap, long long inc) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const long long v = *state;
+        *snap = v;
+        *state = v + inc;
+    }
+}
+}  // namespace dpft
+
+extern "C" int dpft_seed_advance(int64_t* state, int64_t* snap, int64_t increment, dpft_stream_t stream) {
+    DPFT_REQUIRE(state && snap, "seed_advance: null tensor");
+    hipLaunchKernelGGL(dpft::seed_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)state, (long long*)snap,
+                       (long long)increment);
+    return dpft::check_launch("seed_advance");
+}

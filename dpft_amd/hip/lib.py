@@ -73,6 +73,14 @@ class DecoderFwd(C.Structure):
                 ("attn0", C.c_void_p)]
 
 
+class MemOp(C.Structure):
+    _fields_ = [("dst", C.c_void_p), ("src", C.c_void_p), ("bytes", C.c_uint64)]
+
+
+class SumSrc(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("n_lead", C.c_int32)]
+
+
 class OuterSpec(C.Structure):
     _fields_ = [("col_a", C.c_int32), ("n_a", C.c_int32), ("col_b", C.c_int32), ("n_b", C.c_int32), ("out_off", C.c_int64)]
 
@@ -157,6 +165,9 @@ SIGNATURES = {
     "dpft_profile_overhead_ms": (_F, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
     "dpft_rows_outer_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _L, _P]),
+    "dpft_memops": (_I, [_I, _P, _P]),
+    "dpft_seed_advance": (_I, [_P, _P, _L, _P]),
+    "dpft_sum_leading_f32": (_I, [_I, _P, _L, _P, _I, _P]),
     "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
     "dpft_resnet_plan_create": (_L, [C.POINTER(ResnetDesc)]),
     "dpft_resnet_plan_destroy": (None, [_L]),

@@ -57,6 +57,68 @@ def workspace(nbytes: int, device) -> Optional[torch.Tensor]:
     return buf
 
 
+MEMOPS_MAX = 16
+SUM_SRCS_MAX = 16
+
+
+def memops(pairs) -> None:
+    """[(dst, src | None), ...] contiguous same-dtype device tensors: all copies (src None = zero fill) in ceil(n / 16)
+    launches on the current stream (dpft_memops) -- the glue's replacement for per-tensor Tensor.copy_ / zero_ calls."""
+    from dpft_amd.hip.lib import MemOp
+    todo = []
+    for dst, src in pairs:
+        if dst.numel() == 0:
+            continue
+        nbytes = dst.numel() * dst.element_size()
+        if not dst.is_contiguous() or nbytes % 4 or (src is not None and (not src.is_contiguous() or src.dtype != dst.dtype or
+                                                                         src.numel() != dst.numel() or src.device != dst.device)):
+            dst.copy_(src) if src is not None else dst.zero_()      # layouts the kernel does not take (never on the step's path)
+            continue
+        todo.append((dst.data_ptr(), 0 if src is None else src.data_ptr(), nbytes))
+    for i in range(0, len(todo), MEMOPS_MAX):
+        chunk = todo[i:i + MEMOPS_MAX]
+        arr = (MemOp * len(chunk))(*[MemOp(d, s or None, n) for d, s, n in chunk])
+        lib.call("dpft_memops", len(chunk), C.cast(arr, C.c_void_p), stream())
+
+
+def sum_leading(srcs, inner_shape, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out (+)= sum over every source's leading axes: each source is a contiguous fp32 tensor whose trailing dimensions are
+    ``inner_shape``; one launch (dpft_sum_leading_f32), fixed order.  Up to 16 sources."""
+    from dpft_amd.hip.lib import SumSrc
+    inner = 1
+    for d in inner_shape:
+        inner *= int(d)
+    srcs = [t if t.is_contiguous() else t.contiguous() for t in srcs]
+    if out is None:
+        out = torch.empty(tuple(inner_shape), dtype=torch.float32, device=srcs[0].device)
+        accumulate = False
+    arr = (SumSrc * len(srcs))(*[SumSrc(t.data_ptr(), t.numel() // inner) for t in srcs])
+    lib.call("dpft_sum_leading_f32", len(srcs), C.cast(arr, C.c_void_p), inner, ptr(out), int(accumulate), stream())
+    return out
+
+
+# Gradient sinks: a producer of an activation that wants its gradient at a FIXED address (the backbone's launch plan replays
+# captured backward stages that read their output gradients from static buffers) registers that buffer here; the consumer's
+# backward (the FPN's lateral data gradients) then writes the gradient straight into it instead of a fresh tensor that the
+# producer would have to copy (12 device copies, 225 MB per step on kradar.json).  Keyed by the activation's address.
+_grad_sinks = {}
+
+
+def register_grad_sink(activation: torch.Tensor, sink: torch.Tensor) -> None:
+    _grad_sinks[activation.data_ptr()] = sink
+
+
+def drop_grad_sink(activation: torch.Tensor) -> None:
+    _grad_sinks.pop(activation.data_ptr(), None)
+
+
+def grad_sink(activation: torch.Tensor) -> Optional[torch.Tensor]:
+    s = _grad_sinks.get(activation.data_ptr())
+    if s is None or s.shape != activation.shape or s.device != activation.device or s.dtype != activation.dtype:
+        return None
+    return s
+
+
 class Conv:
     """Geometry + cached descriptor/workspace size of one convolution problem."""
     __slots__ = ("desc", "ws_bytes", "tiles", "tile_rows", "B", "H", "W", "C", "K", "kh", "kw", "stride", "pad",

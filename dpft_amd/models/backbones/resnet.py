@@ -184,7 +184,7 @@ class _BodyFn(torch.autograd.Function):
             if plan.x_static is None or plan.x_static.shape != x.shape:
                 plan.x_static = torch.empty_like(x)
             if x.data_ptr() != plan.x_static.data_ptr():
-                plan.x_static.copy_(x)
+                ops.memops([(plan.x_static, x)])
                 x = plan.x_static
             arena = plan.arena
         else:
@@ -250,6 +250,14 @@ class _BodyFn(torch.autograd.Function):
         for off, shape in plan.outs:
             n = shape[0] * shape[1] * shape[2] * shape[3]
             outs.append(af[off:off + n].view(shape))
+        if need_grad and lease is not None:
+            # the captured backward stages read their output gradients from fixed addresses: offer those buffers to the
+            # consumers' backward (ops.grad_sink) so that the gradients are produced in place
+            for li, o in enumerate(outs):
+                sd = plan.dout_static.get(li)
+                if sd is None or sd.shape != o.shape:
+                    sd = plan.dout_static[li] = torch.empty_like(o)
+                ops.register_grad_sink(o, sd)
         if need_grad:
             ctx.state = dict(owner=owner, plan=plan, x=x, arena=arena, tables=t, keep=keep, weights=weights,
                              convs=convs, bns=bns, conv_g=conv_g, bn_g=bn_g, bn_b=bn_b, flat=flat, direct=direct,
@@ -269,6 +277,10 @@ class _BodyFn(torch.autograd.Function):
             lib.call("dpft_resnet_plan_set_side_stream", plan.handle, C.c_void_p(side.cuda_stream))
             plan.__dict__["_side"] = side.cuda_stream
         douts = list(douts) + [None] * (4 - len(douts))
+        if st["lease"] is not None:
+            af = st["arena"].view(torch.float32)
+            for off, shape in plan.outs:
+                ops.drop_grad_sink(af[off:off + 1])
         # stage -> parameters whose gradients are complete after that stage's call
         stage_params = {li: [] for li in range(body.n_layers)}
         for li in range(body.n_layers):
@@ -286,8 +298,8 @@ class _BodyFn(torch.autograd.Function):
                     sd = plan.dout_static.get(li)
                     if sd is None or sd.shape != d.shape:
                         sd = plan.dout_static[li] = torch.empty_like(d)
-                    if sd.data_ptr() != d.data_ptr():
-                        sd.copy_(d)
+                    if sd.data_ptr() != d.data_ptr():      # (not produced in place: see ops.grad_sink)
+                        ops.memops([(sd, d)])
                     d = sd
                 keep_alive.append(d)
             lib.call("dpft_resnet_backward_stage", plan.handle, li, ptr(st["x"]), C.byref(st["tables"]),

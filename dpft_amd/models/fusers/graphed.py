@@ -18,6 +18,8 @@ from typing import Dict, List, Optional
 import torch
 from torch import nn
 
+from dpft_amd.hip import ops
+
 
 # Other threads of the process (the RCCL watchdog of torch.distributed polls its events) must not invalidate a capture
 # in progress: only this thread's calls are checked.
@@ -37,7 +39,7 @@ class _FlatFuser(nn.Module):
         it = iter(tensors)
         views = [OrderedDict((k, next(it)) for k in keys) for keys in self.level_keys]
         n = len(self.level_keys)
-        shapes = [next(it) for _ in range(n)]
+        shapes = [next(it)[:, :2] for _ in range(n)]
         proj = [(next(it), next(it)) for _ in range(n)]
         out = self.fuser(batch=views, shape=shapes, projection=proj, out=OrderedDict(center=center0),
                          has_transformation=self.flags)
@@ -47,9 +49,8 @@ class _FlatFuser(nn.Module):
 class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g: "GraphedFuser", *inputs):
-        for s, a in zip(g.static_inputs, inputs[:len(g.static_inputs)]):
-            if s.data_ptr() != a.data_ptr():
-                s.copy_(a)
+        # this step's small inputs (shapes, projection matrices) into the graph's static buffers: one launch for all of them
+        ops.memops([(s, a) for s, a in zip(g.static_inputs, inputs[:len(g.static_inputs)]) if s.data_ptr() != a.data_ptr()])
         g.fwd_graph.replay()
         ctx.g = g
         g.last_inputs = inputs[1:1 + g.n_levels]            # this step's pyramid tensors (see backward_from)
@@ -130,7 +131,9 @@ class GraphedFuser:
         for i in self.inputs:
             static += [v.detach().clone().requires_grad_(True) for v in feats[i].values()]
         self.n_levels = len(static) - 1
-        static += [sample_batch[f"{i}_shape"][:, :2].clone() for i in self.inputs]
+        # (the whole (B, 3) shape rows: contiguous, so that a step's rows go in with the other small inputs; the fuser reads
+        # the first two columns)
+        static += [sample_batch[f"{i}_shape"].clone() for i in self.inputs]
         for t, p in proj:
             static += [t.detach().clone(), p.detach().clone()]
         model.train()
@@ -187,14 +190,13 @@ class GraphedFuser:
         args = [out["center"]]
         for i in self.inputs:
             args += list(features[i].values())
-        args += [shapes[i][:, :2] for i in self.inputs]
+        args += [shapes[i] for i in self.inputs]
         for t, p in projection:
             args += [t, p]
         if [tuple(a.shape) for a in args] != self.shapes:
             raise RuntimeError("graphed fuser called with shapes different from the captured ones")
         if not torch.is_grad_enabled():
-            for s_, a_ in zip(self.eval_inputs, args):
-                s_.copy_(a_)
+            ops.memops(list(zip(self.eval_inputs, args)))
             self.eval_graph.replay()
             c, s, a, k = (o.clone() for o in self.eval_outputs)
             return OrderedDict([("center", c), ("size", s), ("angle", a), ("class", k)])

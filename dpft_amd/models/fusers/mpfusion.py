@@ -119,13 +119,14 @@ class MPFusion(nn.Module):
         from dpft_amd.models.fusers import train_fused as _tf
         return self.use_fused_train and all(_tf.xf_supported(ml) for ml in self.ml_fusion_layers.values())
 
-    def forward_fused_blocks(self, query, batch, refs, pos2d, seed, salt: int):
-        """(V,B,Q,16) outputs of every view's MLFusion from the fused HIP training kernels; refs (V,B,Q,2)."""
+    def forward_fused_blocks(self, query, batch_views, refs, pos2d, seed, salt: int, batch=None):
+        """(V,B,Q,16) outputs of every view's MLFusion from the fused HIP training kernels; refs (V,B,Q,2).  ``query`` (B,Q,16),
+        or (Q,16) broadcast over ``batch`` elements; ``pos2d`` the (Q,16) table or a hub from ``train_fused.make_pos_hub``."""
         from dpft_amd.models.fusers import train_fused as _tf
         layers = list(self.ml_fusion_layers.values())
         p_drop = self.dropout if self.training else 0.0
-        y1 = _tf.self_attn_blocks(layers, query, pos2d, seed, salt, p_drop)
-        return _tf.xattn_ffn_blocks(layers, batch, y1, pos2d, refs, seed, salt, p_drop)
+        y1 = _tf.self_attn_blocks(layers, query, pos2d, seed, salt, p_drop, batch=batch)
+        return _tf.xattn_ffn_blocks(layers, batch_views, y1, pos2d, refs, seed, salt, p_drop)
 
     def forward(self, query, batch, reference_points, query_positions, pos2d=None, seed=None, salt: int = 0):
         layers = list(self.ml_fusion_layers.values())
@@ -231,25 +232,29 @@ class IMPFusion(nn.Module):
                 # would stall the host until every encoder has finished: 4 ms of the forward latency)
                 return fused(batch, shape, projection, out, has_transformation)
         flags = has_transformation if has_transformation is not None else self.transformation_flags(projection)
-        query = self.query.unsqueeze(0).repeat(B, 1, 1)
-        query_pos = self.query_embedding.weight.unsqueeze(0).repeat(B, 1, 1)
         pyramids = [make_pyramid_state(list(levels.values())) for levels in batch]
         seed = None
-        if query.is_cuda:
+        if self.query.is_cuda:
             from dpft_amd.models.fusers import train_fused as _tf
-            seed = _tf.advance_seed(query.device)
+            seed = _tf.advance_seed(self.query.device)
             layers = list(self.mpfusion.values())
             if self.use_fused_train and all(l.fused_blocks_supported() and _tf.head_supported(l, h)
                                             for l, h in zip(layers, self.heads)):
                 # every layer = 3 fused forward launches (self attention | cross attention + FFN | reduction +
                 # heads + next reference points) with hand-written backward kernels (train_fused.py)
                 proj = _tf._Proj(projection, shape, flags)
-                pos2d = self.query_embedding.weight
+                # query_embedding.weight is read by both blocks of every layer: its gradient is collected by one hub
+                # (one summation launch in the backward instead of a reduction per block + autograd's add chain); the
+                # learned query table goes in as it is -- the first layer broadcasts it over the batch itself
+                pos_hub = _tf.make_pos_hub(self.query_embedding.weight)
                 refs = _tf.reference_points(proj, out["center"])
+                query = self.query
                 for it, (layer, head) in enumerate(zip(layers, self.heads)):
-                    y3 = layer.forward_fused_blocks(query, pyramids, refs, pos2d, seed, it)
+                    y3 = layer.forward_fused_blocks(query, pyramids, refs, pos_hub, seed, it, batch=B)
                     query, out, refs = _tf.head_block(layer, head, proj, y3, out["center"], it + 1 < len(layers))
                 return out
+        query = self.query.unsqueeze(0).repeat(B, 1, 1)
+        query_pos = self.query_embedding.weight.unsqueeze(0).repeat(B, 1, 1)
         for it, (layer, head) in enumerate(zip(self.mpfusion.values(), self.heads)):
             reference_points = [
                 self.get_reference_points(out["center"][..., :3], p[0], p[1], s, f)

@@ -13,6 +13,7 @@ from typing import Dict, List
 
 import torch
 
+from dpft_amd.hip import ops
 from dpft_amd.hip.lib import DecoderView, HeadTrain, Pyramid, SaParams, lib, make_pyramid, stream
 
 _SA_SIZES = (768, 48, 256, 16, 16, 16)        # in_proj_weight, in_proj_bias, out_proj.weight, .bias, norm1.weight, .bias
@@ -24,9 +25,51 @@ def advance_seed(device: torch.device) -> torch.Tensor:
     st = _seed_state.get(device)
     if st is None:
         st = _seed_state[device] = torch.randint(0, 2 ** 62, (1,), dtype=torch.int64).to(device)
-    snap = st.clone()
-    st.add_(0x9E3779B97F4A7C15 & (2 ** 62 - 1))
+    snap = torch.empty_like(st)
+    lib.call("dpft_seed_advance", st.data_ptr(), snap.data_ptr(), 0x9E3779B97F4A7C15 & (2 ** 62 - 1), stream())      # snap = state; state += c
     return snap
+
+
+class PosState:
+    """The (Q,16) query-position table of one decoder forward: read by both blocks of every layer (8 uses on kradar.json).
+    The blocks take the detached table plus the hub's token and leave their un-reduced gradient buffers here; the hub's
+    backward, which autograd runs after the last of them, sums everything in ONE launch (ops.sum_leading, fixed order) --
+    instead of a reduction per block and the engine's chain of adds."""
+
+    def __init__(self, pos: torch.Tensor):
+        self.pos = pos.detach().contiguous()
+        self.parts: List[torch.Tensor] = []
+
+
+class _PosHubFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, state: PosState, pos):
+        ctx.state = state
+        ctx.set_materialize_grads(False)      # the token carries ordering only
+        return pos.new_empty(())
+
+    @staticmethod
+    def backward(ctx, gtoken):
+        parts, ctx.state.parts = ctx.state.parts, []
+        if not parts:
+            return None, None
+        g = None
+        for i in range(0, len(parts), ops.SUM_SRCS_MAX):
+            g = ops.sum_leading(parts[i:i + ops.SUM_SRCS_MAX], ctx.state.pos.shape, out=g, accumulate=g is not None)
+        return None, g
+
+
+def make_pos_hub(pos: torch.Tensor):
+    """-> (state, token) for ``self_attn_blocks`` / ``xattn_ffn_blocks`` in place of the table itself."""
+    state = PosState(pos)
+    return state, _PosHubFn.apply(state, pos)
+
+
+def _pos_args(pos):
+    """table | hub -> (table the kernels read, hub state | None, differentiable tensor threaded through autograd)"""
+    if isinstance(pos, tuple):
+        return pos[0].pos, pos[0], pos[1]
+    return pos, None, pos
 
 
 def sa_supported(ml) -> bool:
@@ -49,35 +92,39 @@ def _structs(tensors: List[torch.Tensor], V: int):
 
 class SelfAttnBlocksFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, pos, seed, salt: int, p_drop: float, *params):
+    def forward(ctx, x, pos_dep, seed, salt: int, p_drop: float, pos, hub, batch, *params):
+        # x (B,Q,16), or the (Q,16) table of a first layer, broadcast over `batch` elements (row stride 0);
+        # pos_dep: the table itself or a hub token (what autograd differentiates), pos: the table the kernels read
         V = len(params) // 6
-        if x.stride()[1:] != (16, 1):
+        if x.stride()[-2:] != (16, 1):
             x = x.contiguous()
         pos = pos.contiguous()
         params = [p if p.is_contiguous() else p.contiguous() for p in params]
-        B, Q, _ = x.shape
+        B, Q = (int(batch), x.shape[0]) if x.dim() == 2 else x.shape[:2]
+        xs0 = 0 if (x.dim() == 2 or B == 1) else x.stride(0)
         dev = x.device
         y1 = torch.empty((V, B, Q, 16), dtype=torch.float32, device=dev)
         attn, zhat = torch.empty_like(y1), torch.empty_like(y1)
         lse = torch.empty((V, B, Q, 8), dtype=torch.float32, device=dev)
         rstd = torch.empty((V, B, Q), dtype=torch.float32, device=dev)
         arr = _structs(params, V)
-        lib.call("dpft_selfattn_train_fwd_f32", C.cast(arr, C.c_void_p), V, x.data_ptr(), x.stride(0) if B > 1 else 0,
+        lib.call("dpft_selfattn_train_fwd_f32", C.cast(arr, C.c_void_p), V, x.data_ptr(), xs0,
                  pos.data_ptr(), float(p_drop), seed.data_ptr(), int(salt), y1.data_ptr(), lse.data_ptr(),
                  attn.data_ptr(), zhat.data_ptr(), rstd.data_ptr(), B, Q, stream())
         ctx.save_for_backward(x, pos, seed, lse, attn, zhat, rstd, *params)
-        ctx.meta = (V, int(salt), float(p_drop))
+        ctx.meta = (V, int(salt), float(p_drop), B, Q, xs0)
+        ctx.hub = hub
         return y1
 
     @staticmethod
     def backward(ctx, dy1):
         x, pos, seed, lse, attn, zhat, rstd, *params = ctx.saved_tensors
-        V, salt, p_drop = ctx.meta
-        B, Q, _ = x.shape
+        V, salt, p_drop, B, Q, xs0 = ctx.meta
         dev = x.device
         dy1 = dy1.contiguous()
         per_view = sum(_SA_SIZES)
-        flat = torch.zeros(V * per_view, dtype=torch.float32, device=dev)
+        flat = torch.empty(V * per_view, dtype=torch.float32, device=dev)
+        ops.memops([(flat, None)])
         grads, garr, off = [], (SaParams * V)(), 0
         for v in range(V):
             ptrs = []
@@ -90,17 +137,25 @@ class SelfAttnBlocksFn(torch.autograd.Function):
         dxp = torch.empty_like(dx)
         scratch = torch.empty(int(lib.dpft_selfattn_train_scratch_floats(B, Q, V)), dtype=torch.float32, device=dev)
         arr = _structs(params, V)
-        lib.call("dpft_selfattn_train_bwd_f32", C.cast(arr, C.c_void_p), V, x.data_ptr(), x.stride(0) if B > 1 else 0,
+        lib.call("dpft_selfattn_train_bwd_f32", C.cast(arr, C.c_void_p), V, x.data_ptr(), xs0,
                  pos.data_ptr(), p_drop, seed.data_ptr(), salt, dy1.data_ptr(), lse.data_ptr(), attn.data_ptr(),
                  zhat.data_ptr(), rstd.data_ptr(), C.cast(garr, C.c_void_p), dx.data_ptr(), dxp.data_ptr(),
                  scratch.data_ptr(), B, Q, stream())
-        return (dx.sum(0), dxp.sum((0, 1)), None, None, None, *grads)
+        gx = ops.sum_leading([dx], x.shape)                       # over the views (and the batch for a broadcast table)
+        if ctx.hub is not None:
+            ctx.hub.parts.append(dxp)                             # summed with the other blocks' shares by the hub
+            gpos = None
+        else:
+            gpos = ops.sum_leading([dxp], pos.shape)
+        return (gx, gpos, None, None, None, None, None, None, *grads)
 
 
-def self_attn_blocks(layers, x, pos, seed, salt: int, p_drop: float):
-    """y1 (V,B,Q,16) of the V MLFusion layers' self-attention blocks; x (B,Q,16), pos (Q,16)."""
+def self_attn_blocks(layers, x, pos, seed, salt: int, p_drop: float, batch=None):
+    """y1 (V,B,Q,16) of the V MLFusion layers' self-attention blocks; x (B,Q,16) -- or (Q,16), broadcast over ``batch``
+    elements --, pos (Q,16) or a hub (``make_pos_hub``)."""
     params = [t for ml in layers for t in sa_params(ml)]
-    return SelfAttnBlocksFn.apply(x, pos, seed, salt, p_drop, *params)
+    table, hub, dep = _pos_args(pos)
+    return SelfAttnBlocksFn.apply(x, dep, seed, salt, p_drop, table, hub, batch, *params)
 
 
 def _rows_outer(rows: torch.Tensor, specs, out_floats: int) -> torch.Tensor:
@@ -158,7 +213,7 @@ def _pack_views(params: List[torch.Tensor], V: int, n_levels, n_points, dev):
 
 class XattnFfnBlocksFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, states, seed, salt: int, p_drop: float, n_points, y1, pos, refs, *rest):
+    def forward(ctx, states, seed, salt: int, p_drop: float, n_points, y1, pos_dep, refs, pos, hub, *rest):
         V = len(states)
         tokens, params = rest[:V], list(rest[V:])
         params = [p if p.is_contiguous() else p.contiguous() for p in params]
@@ -179,6 +234,7 @@ class XattnFfnBlocksFn(torch.autograd.Function):
                  seed.data_ptr(), int(salt), y3.data_ptr(), saved.data_ptr(), B, Q, stream())
         ctx.save_for_backward(y1, pos, refs, seed, packed, saved, *params)
         ctx.states, ctx.meta = states, (V, int(salt), float(p_drop), list(n_points), n_levels)
+        ctx.hub = hub
         return y3
 
     @staticmethod
@@ -240,7 +296,12 @@ class XattnFfnBlocksFn(torch.autograd.Function):
                       g_f1[v], col[v, X["DPRE"]:X["DOUT"]], g_f2[v], col[v, X["DF"]:X["DPRE"]],
                       col[v, X["G3"]:X["B3"]], col[v, X["B3"]:X["G2"]]]
         gtok = [None] * V                       # tokens carry ordering only (_PyramidHub ignores their gradient)
-        return (None, None, None, None, None, dy1, dqp.sum((0, 1)), dref, *gtok, *grads)
+        if ctx.hub is not None:
+            ctx.hub.parts.append(dqp)
+            gpos = None
+        else:
+            gpos = ops.sum_leading([dqp], pos.shape)
+        return (None, None, None, None, None, dy1, gpos, dref, None, None, *gtok, *grads)
 
 
 def xattn_ffn_blocks(layers, pyramids, y1, pos, refs, seed, salt: int, p_drop: float):
@@ -249,7 +310,8 @@ def xattn_ffn_blocks(layers, pyramids, y1, pos, refs, seed, salt: int, p_drop: f
     tokens = [p[1] for p in pyramids]
     params = [t for ml in layers for t in view_params(ml)]
     n_points = [ml.ms_deform_attn.n_points for ml in layers]
-    return XattnFfnBlocksFn.apply(states, seed, salt, p_drop, n_points, y1, pos, refs, *tokens, *params)
+    table, hub, dep = _pos_args(pos)
+    return XattnFfnBlocksFn.apply(states, seed, salt, p_drop, n_points, y1, dep, refs, table, hub, *tokens, *params)
 
 
 # ---------------------------------------------------------------------------------------------------------

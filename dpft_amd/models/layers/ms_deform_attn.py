@@ -69,7 +69,8 @@ class PyramidState:
             offs.append(total)
             total += (n + 63) // 64 * 64
         l0 = self.levels[0]
-        flat = torch.zeros(total, dtype=l0.dtype, device=l0.device)
+        flat = torch.empty(total, dtype=l0.dtype, device=l0.device)
+        ops.memops([(flat, None)])      # (these buffers only exist on the device path: the HIP kernels add into them)
         n = len(shapes)
         self.grads = [flat[offs[i]:offs[i] + sizes[i]].view(shapes[i]) for i in range(n)]
         if with_replicas:
@@ -93,7 +94,7 @@ class PyramidState:
         if self.rep is not None and self.grads is not None:
             for g, r in zip(self.grads, self.rep):
                 if r is not None:
-                    g.add_(r.sum(0))
+                    ops.sum_leading([r], g.shape, out=g, accumulate=True)      # g += sum of the replicas, one launch
         self.rep = None
 
 
@@ -103,7 +104,7 @@ class _PyramidHub(Function):
         ctx.state = state
         ctx.n = len(levels)
         ctx.set_materialize_grads(False)      # the token carries ordering only: its consumers return no gradient for it
-        return levels[0].new_zeros(())
+        return levels[0].new_empty(())      # (never read)
 
     @staticmethod
     def backward(ctx, gtoken):

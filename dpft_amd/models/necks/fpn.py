@@ -100,7 +100,7 @@ class _FPNFn(torch.autograd.Function):
             conv = fpn.inner_blocks[i][0]
             wgrad(ci[i], xs[i], g, conv)
             if ctx.x_needs[i]:
-                dxs[i] = ops.conv_dgrad(ci[i], g, wts[conv])
+                dxs[i] = ops.conv_dgrad(ci[i], g, wts[conv], out=ops.grad_sink(xs[i]))      # in place where the producer asked for it
             g_prev = g
         if direct is not None:
             direct.mark_ready_many(list(fpn.parameters()))

@@ -164,7 +164,10 @@ class GradBucketReducer:
 
     def reset(self):
         """Call before every backward: zero the buckets and point ``param.grad`` at the bucket views."""
-        if len(self._zero_spans) == 1 and self._zero_spans[0] == (0, self.arena.numel()):
+        if self.arena.is_cuda:      # all spans in one launch (dpft_memops)
+            from dpft_amd.hip import ops
+            ops.memops([(self.arena[a:b], None) for a, b in self._zero_spans])
+        elif len(self._zero_spans) == 1 and self._zero_spans[0] == (0, self.arena.numel()):
             self.arena.zero_()
         else:
             for a, b in self._zero_spans:

@@ -493,6 +493,38 @@ int dpft_rows_outer_f32(const float* rows, int32_t G, int32_t R, int32_t W, cons
                         int32_t n_specs, float* out, int64_t out_gstride, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Up to DPFT_MEMOPS_MAX device-to-device copies / zero fills (src == NULL) in ONE launch: the host glue's small per-step
+ * tensor copies and clears (static inputs of a replayed decoder graph, static-address plan inputs, reducer clears) -- the
+ * reference's counterparts are Tensor.copy_ / zero_ calls of its training loop (src/dprt/training/trainer.py:107-150).
+ * Pointers 4-byte aligned, sizes multiples of 4 bytes (16-byte accesses when both pointers allow); ops is a HOST array.
+ * ---------------------------------------------------------------------------------------- */
+#define DPFT_MEMOPS_MAX 16
+typedef struct dpft_memop {
+    void* dst;
+    const void* src;      /* NULL = zero fill */
+    uint64_t bytes;
+} dpft_memop;
+int dpft_memops(int32_t n, const dpft_memop* ops, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * dst[i] (+)= sum_s sum_{l < n_lead_s} src_s[l * inner + i], i < inner: leading-axis sums of the training decoder's backward in
+ * one launch, fixed summation order (table order, leading index ascending).  The reference's counterparts are the implicit
+ * sums of autograd (expand / repeat backward, gradient accumulation of a parameter with several uses:
+ * src/dprt/models/fusers/mpfusion.py:601-668 uses query_embedding.weight in every layer).  srcs is a HOST array.
+ * ---------------------------------------------------------------------------------------- */
+#define DPFT_SUM_SRCS_MAX 16
+typedef struct dpft_sum_src {
+    const float* src;
+    int32_t n_lead;
+} dpft_sum_src;
+int dpft_sum_leading_f32(int32_t n_src, const dpft_sum_src* srcs, int64_t inner, float* dst, int32_t accumulate,
+                         dpft_stream_t stream);
+
+/* Dropout seed of the fused training decoder: *snap = *state; *state += increment (one launch, capturable).  The reference
+ * draws its dropout masks from torch's generator (nn.Dropout in src/dprt/models/fusers/mpfusion.py:95-119). */
+int dpft_seed_advance(int64_t* state, int64_t* snap, int64_t increment, dpft_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Matcher cost helper: GIoU3D of yaw-only boxes, (B,N) predictions x (B,Mg) targets.
  * boxes are (x,y,z,l,w,h,yaw) rows of 7 floats; out (B,N,Mg).
  * ---------------------------------------------------------------------------------------- */
