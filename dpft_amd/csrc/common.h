@@ -102,6 +102,7 @@ bool profiling_active();      // conv.hip: true between dpft_profile_start / dpf
 // gradients (round 3, tools/plan_graph_check.py: never with a device sync around the graph launch, never in the
 // memset-free forward graphs); kernel nodes only is also what the decoder graphs consist of.
 int zero_fill(void* ptr, size_t bytes, dpft_stream_t stream);
+int bias_grad_ws(const float* dy, float* db, int64_t M, int32_t K, void* workspace, dpft_stream_t stream);
 
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();

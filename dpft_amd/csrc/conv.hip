@@ -1853,6 +1853,47 @@ __global__ void bias_grad_kernel(const float* __restrict__ dy, float* __restrict
     }
 }
 
+// The same column sums WITHOUT a cleared output and without atomics (round 4): every block leaves its K partial sums in a
+// slab of the conv workspace (agent-scope stores), takes a ticket, and the block that draws the last one adds the partials
+// in block order and writes db -- one launch, a fixed summation order.  kBiasBlocks blocks at most.
+constexpr int kBiasBlocks = 256;
+__global__ __launch_bounds__(256) void bias_grad_slab_kernel(const float* __restrict__ dy, float* __restrict__ db, int64_t M, int K,
+                                                              float* __restrict__ slab, int* __restrict__ ticket) {
+    __shared__ float red[256];
+    __shared__ int last;
+    const int rpi = 256 / K;            // rows per iteration
+    const int c = threadIdx.x % K, r0 = threadIdx.x / K;
+    float s = 0.f;
+    if (r0 < rpi)
+        for (int64_t m = (int64_t)blockIdx.x * rpi + r0; m < M; m += (int64_t)gridDim.x * rpi)
+            s += dy[m * K + c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float t = 0.f;
+        for (int i = 0; i < rpi; ++i) t += red[threadIdx.x + i * K];
+        __hip_atomic_store(slab + (size_t)blockIdx.x * K + threadIdx.x, t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+    __syncthreads();
+    if (!last) return;
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left clean
+    float t = 0.f;
+    if (r0 < rpi)
+        for (int b = r0; b < (int)gridDim.x; b += rpi)
+            t += __hip_atomic_load(slab + (size_t)b * K + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    red[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < K) {
+        float u = 0.f;
+        for (int i = 0; i < rpi; ++i) u += red[threadIdx.x + i * K];
+        db[threadIdx.x] = u;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // optional per-launch instrumentation (bench.py roofline): HIP events on the launch stream
 // ---------------------------------------------------------------------------------------------
@@ -2253,6 +2294,7 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
         const int64_t ms = std::max<int64_t>(1, std::min<int64_t>(512, (64ll << 20) / wbytes));
         best = std::max<int64_t>(best, ms * wbytes);
     }
+    best = std::max<int64_t>(best, (int64_t)kBiasBlocks * std::min(d->K, 256) * 4);      // bias_grad_slab_kernel's partial sums
     return best + (int64_t)kWsHeader;
 }
 
@@ -2742,6 +2784,18 @@ extern "C" int dpft_bias_grad_f32(const float* dy, float* db, int64_t M, int32_t
     return check_launch("bias_grad");
 }
 
+// bias gradient behind a weight gradient on the same stream: the conv workspace is free again (ticket header zero, slabs
+// consumed) -- the slab form above; without a workspace the cleared-output + atomics form
+int dpft::bias_grad_ws(const float* dy, float* db, int64_t M, int32_t K, void* workspace, dpft_stream_t stream) {
+    static const bool slab_on = getenv("DPFT_BIAS_SLAB") == nullptr || atoi(getenv("DPFT_BIAS_SLAB")) != 0;      // A/B switch
+    if (!workspace || !slab_on || K > 256 || K <= 0) return dpft_bias_grad_f32(dy, db, M, K, stream);
+    const int rpi = 256 / K;
+    const int blocks = (int)std::min<int64_t>(kBiasBlocks, (M + rpi - 1) / rpi);
+    hipLaunchKernelGGL(bias_grad_slab_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, db, M, (int)K, ws_slabs(workspace),
+                       reinterpret_cast<int*>(workspace));
+    return check_launch("bias_grad (slab)");
+}
+
 // Weight gradient AND bias gradient of a conv with bias (the FPN's convs): one pass over dy where the weight-gradient kernel
 // has dy at hand (3x3 16 -> 16, thin 1x1 -> 16), the two separate launches otherwise.  Same results either way.
 extern "C" int dpft_conv2d_nhwc_wgrad_bias_f32(const dpft_conv_desc* d, const float* x, const float* dy, float* dw, float* db,
@@ -2758,11 +2812,11 @@ extern "C" int dpft_conv2d_nhwc_wgrad_bias_f32(const dpft_conv_desc* d, const fl
         rc = dpft::thin_wgrad(d, x, dy, dw, workspace, (hipStream_t)stream, handled, db, &bias_done);
         if (rc) return rc;
         if (handled && bias_done) return DPFT_OK;
-        if (handled) return dpft_bias_grad_f32(dy, db, (int64_t)d->B * d->OH * d->OW, d->K, stream);
+        if (handled) return dpft::bias_grad_ws(dy, db, (int64_t)d->B * d->OH * d->OW, d->K, workspace, stream);
     }
     rc = dpft_conv2d_nhwc_wgrad_f32(d, x, dy, nullptr, 0, dw, workspace, stream);
     if (rc) return rc;
-    return dpft_bias_grad_f32(dy, db, (int64_t)d->B * d->OH * d->OW, d->K, stream);
+    return dpft::bias_grad_ws(dy, db, (int64_t)d->B * d->OH * d->OW, d->K, workspace, stream);
 }
 
 static float g_prof_overhead_ms = 0.f;      // elapsed time of an EMPTY event bracket (subtracted from every record)

@@ -461,6 +461,7 @@ struct XattnArgs {
     const float* T[4];          // (B,4,4)
     const float* Pm[4];         // (B,prow,4)
     const int64_t* shape[4];    // (B,2) = H, W
+    int sstride;                // int64 elements between shape rows
     int prow[4], flag[4], P[4];
     float* y3;                  // (V,B,Q,16)
     float* part;                // (V targets,B,Q,V sources,64) next layer's partial q/k/v rows, or NULL (last layer)
@@ -517,6 +518,7 @@ struct HeadArgs {
     const float* T[4];
     const float* Pm[4];
     const int64_t* shape[4];
+    int sstride;
     int prow[4], flag[4];
     float* query_out;           // (B,Q,16)
     float *center, *size, *angle, *cls;
@@ -614,8 +616,8 @@ __device__ __forceinline__ void reduce_head_rows(const HeadArgs& a, float* hsw, 
         if (lane < a.V) {
             float u, vv;
             reference_point(cx, cy, cz, t_flag, a.T[lane] ? a.T[lane] + (size_t)b * 16 : nullptr,
-                            a.Pm[lane] + (size_t)b * a.prow[lane] * 4, (float)a.shape[lane][b * 2 + 0],
-                            (float)a.shape[lane][b * 2 + 1], u, vv);
+                            a.Pm[lane] + (size_t)b * a.prow[lane] * 4, (float)a.shape[lane][b * a.sstride + 0],
+                            (float)a.shape[lane][b * a.sstride + 1], u, vv);
             *reinterpret_cast<f32x2*>(a.refs_out + ((size_t)lane * a.B * a.Q + bq) * 2) = f32x2{u, vv};
         }
     }
@@ -697,8 +699,8 @@ __device__ __forceinline__ void xattn_body(const XattnArgs& a, const HeadArgs* h
     } else {
         const float* pc = a.prev_center + (size_t)bqc * 3;
         reference_point(pc[0], pc[1], pc[2], t_flag, a.T[view] ? a.T[view] + (size_t)b * 16 : nullptr,
-                        a.Pm[view] + (size_t)b * a.prow[view] * 4, (float)a.shape[view][b * 2 + 0],
-                        (float)a.shape[view][b * 2 + 1], rx, ry);
+                        a.Pm[view] + (size_t)b * a.prow[view] * 4, (float)a.shape[view][b * a.sstride + 0],
+                        (float)a.shape[view][b * a.sstride + 1], rx, ry);
     }
     if (a.zero_tickets && blockIdx.y == 0 && tid == 0) a.zero_tickets[blockIdx.x] = 0;
     __syncthreads();
@@ -1062,6 +1064,7 @@ extern "C" int dpft_decoder_forward_f32(const dpft_decoder_fwd* d, dpft_stream_t
                      "decoder_forward: projection inputs of view %d missing", v);
     }
     // has_t < 0: `transformation.any()` is evaluated on the device by the first cross-attention kernel (dev_flags)
+    xa.sstride = ha.sstride = d->shape_stride > 0 ? d->shape_stride : 2;
     xa.attn = attn; xa.pos = d->pos; xa.y3 = y3; xa.B = B; xa.Q = Q; xa.V = V;
     ha.y3 = y3; ha.B = B; ha.Q = Q; ha.V = V; ha.ncls = d->num_classes;
     ha.size = d->size; ha.angle = d->angle; ha.cls = d->cls;

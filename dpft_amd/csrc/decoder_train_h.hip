@@ -30,6 +30,7 @@ struct HdArgs {
     const float* T[4];
     const float* Pm[4];
     const int64_t* shape[4];
+    int sstride;                 // int64 elements between shape rows
     int prow[4], flag[4];
     float *x, *center, *size, *angle, *cls, *refs;                   // forward outputs (refs may be null)
     const float *dx, *dcenter, *dsize, *dangle, *dcls, *drefs;      // backward inputs (any may be null)
@@ -175,8 +176,8 @@ __global__ __launch_bounds__(256) void hd_train_fwd_kernel(HdArgs a) {
     if (a.refs != nullptr && lane < a.V) {
         const int v = lane;
         const RefPoint rp = ref_point<false>(cs[0], cs[1], cs[2], a.flag[v], a.T[v] ? a.T[v] + (size_t)b * 16 : nullptr,
-                                             a.Pm[v] + (size_t)b * a.prow[v] * 4, (float)a.shape[v][b * 2 + 0],
-                                             (float)a.shape[v][b * 2 + 1], 0.f, 0.f, nullptr);
+                                             a.Pm[v] + (size_t)b * a.prow[v] * 4, (float)a.shape[v][b * a.sstride + 0],
+                                             (float)a.shape[v][b * a.sstride + 1], 0.f, 0.f, nullptr);
         float* r = a.refs + (((size_t)v * a.B * a.Q) + bq) * 2;
         r[0] = rp.u;
         r[1] = rp.v;
@@ -212,7 +213,7 @@ __global__ __launch_bounds__(256) void hd_train_bwd_kernel(HdArgs a) {
         const float* dr = a.drefs + ((size_t)v * nq + bq) * 2;
         float dc[3];
         ref_point<true>(cs[0], cs[1], cs[2], a.flag[v], a.T[v] ? a.T[v] + (size_t)b * 16 : nullptr,
-                        a.Pm[v] + (size_t)b * a.prow[v] * 4, (float)a.shape[v][b * 2 + 0], (float)a.shape[v][b * 2 + 1],
+                        a.Pm[v] + (size_t)b * a.prow[v] * 4, (float)a.shape[v][b * a.sstride + 0], (float)a.shape[v][b * a.sstride + 1],
                         dr[0], dr[1], dc);
         dcv[v * 3 + 0] = dc[0]; dcv[v * 3 + 1] = dc[1]; dcv[v * 3 + 2] = dc[2];
     }
@@ -301,6 +302,7 @@ static int hd_fill(HdArgs& a, const dpft_head_train* h, int B, int Q, int V, boo
         a.T[v] = h->T[v]; a.Pm[v] = h->P[v]; a.shape[v] = h->shape[v]; a.prow[v] = h->p_rows[v]; a.flag[v] = h->has_t[v];
     }
     a.B = B; a.Q = Q; a.V = V; a.ncls = h->num_classes;
+    a.sstride = h->shape_stride > 0 ? h->shape_stride : 2;
     return DPFT_OK;
 }
 

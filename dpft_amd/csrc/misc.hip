@@ -297,6 +297,11 @@ struct LossArgs {
     const int32_t* counts;
     const float* gout;          // (5) upstream gradient of the batch-reduced terms (backward)
     float* losses;              // (5) accumulated (caller zero-fills)            (forward)
+    // forward, one launch without a cleared output (dpft_set_loss_fwd_total_f32): per-block partial sums + a ticket; the last
+    // block adds them in block order, writes losses[5] and total = sum_k sel[k] * losses[k]
+    float* slab;                // [ticket (8 floats)][blocks][8] or null
+    const float* sel;
+    float* total;
     float *dcls, *dcenter, *dsize, *dangle;                                     // (backward)
     float w[5];
     float alpha;
@@ -386,7 +391,32 @@ __global__ __launch_bounds__(256) void set_loss_kernel(LossArgs a) {
             if (lane == 0) red[k][wv] = v;
         }
         __syncthreads();
-        if (threadIdx.x < 5) atomicAdd(a.losses + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+        if (a.slab == nullptr) {
+            if (threadIdx.x < 5) atomicAdd(a.losses + threadIdx.x, red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3]);
+            return;
+        }
+        __shared__ int last;
+        __shared__ float tot[5];
+        if (threadIdx.x < 5)
+            __hip_atomic_store(a.slab + 8 + (size_t)blockIdx.x * 8 + threadIdx.x,
+                               red[threadIdx.x][0] + red[threadIdx.x][1] + red[threadIdx.x][2] + red[threadIdx.x][3], __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* ticket = reinterpret_cast<int*>(a.slab);
+        if (threadIdx.x == 0) last = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (int)gridDim.x - 1;
+        __syncthreads();
+        if (!last) return;
+        if (threadIdx.x == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left clean
+        if (threadIdx.x < 5) {
+            float t = 0.f;
+            for (int b = 0; b < (int)gridDim.x; ++b)
+                t += __hip_atomic_load(a.slab + 8 + (size_t)b * 8 + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.losses[threadIdx.x] = t;
+            tot[threadIdx.x] = a.sel ? t * a.sel[threadIdx.x] : 0.f;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0 && a.total) *a.total = tot[0] + tot[1] + tot[2] + tot[3] + tot[4];
     }
 }
 
@@ -502,6 +532,22 @@ extern "C" int dpft_set_loss_fwd_f32(const float* cls, const float* center, cons
     DPFT_REQUIRE(hipMemsetAsync(losses5, 0, 5 * sizeof(float), (hipStream_t)stream) == hipSuccess, "set_loss_fwd: memset failed");
     hipLaunchKernelGGL(set_loss_kernel<false>, dim3(cdiv((int64_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, a);
     return check_launch("set_loss_fwd");
+}
+
+extern "C" int64_t dpft_set_loss_scratch_floats(int32_t B, int32_t N) { return 8 + 8 * (int64_t)cdiv((int64_t)B * N, 256); }
+
+extern "C" int dpft_set_loss_fwd_total_f32(const float* cls, const float* center, const float* size, const float* angle,
+                                           const float* gt_box, const float* gt_onehot, const int32_t* match,
+                                           const int32_t* counts, const float* weights5, float alpha, const float* sel,
+                                           float* scratch, float* losses5, float* total, int32_t B, int32_t N, int32_t Mmax,
+                                           int32_t C, dpft_stream_t stream) {
+    LossArgs a;
+    int rc = loss_fill(a, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, B, N, Mmax, C);
+    if (rc) return rc;
+    DPFT_REQUIRE(losses5 && scratch && sel && total, "set_loss_fwd_total: null tensor");
+    a.losses = losses5; a.slab = scratch; a.sel = sel; a.total = total;
+    hipLaunchKernelGGL(set_loss_kernel<false>, dim3(cdiv((int64_t)B * N, 256)), dim3(256), 0, (hipStream_t)stream, a);
+    return check_launch("set_loss_fwd_total");
 }
 
 extern "C" int dpft_set_loss_bwd_f32(const float* cls, const float* center, const float* size, const float* angle,
@@ -782,4 +828,58 @@ extern "C" int dpft_seed_advance(int64_t* state, int64_t* snap, int64_t incremen
     hipLaunchKernelGGL(dpft::seed_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (long long*)state, (long long*)snap,
                        (long long)increment);
     return dpft::check_launch("seed_advance");
+}
+
+
+// *ptrs[i] += increment for up to DPFT_I64_PTRS_MAX int64 scalars in one launch (BatchNorm's num_batches_tracked counters of
+// a backbone: torch._foreach_add_ took a vendor multi-tensor kernel per step and encoder)
+namespace dpft {
+struct I64Ptrs {
+    long long* p[DPFT_I64_PTRS_MAX];
+};
+__global__ void i64_add_many_kernel(I64Ptrs t, int n, long long inc) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) *t.p[i] += inc;
+}
+}  // namespace dpft
+
+extern "C" int dpft_i64_add_many(int32_t n, int64_t* const* ptrs, int64_t increment, dpft_stream_t stream) {
+    DPFT_REQUIRE(ptrs && n >= 1 && n <= DPFT_I64_PTRS_MAX, "i64_add_many: 1..%d pointers per call", DPFT_I64_PTRS_MAX);
+    dpft::I64Ptrs t;
+    for (int i = 0; i < n; ++i) {
+        DPFT_REQUIRE(ptrs[i] && ((uintptr_t)ptrs[i] & 7) == 0, "i64_add_many: pointer %d null or not 8-byte aligned", i);
+        t.p[i] = (long long*)ptrs[i];
+    }
+    hipLaunchKernelGGL(dpft::i64_add_many_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, t, n, (long long)increment);
+    return dpft::check_launch("i64_add_many");
+}
+
+
+// dst_i[k] += src_i[k] for n (dst, src, bytes) entries of a DEVICE-resident table, one block per entry: the captured
+// decoder backward adds its parameter gradients into the data-parallel buckets (static addresses: the table is written
+// once after the capture) -- was torch._foreach_add_ (five vendor multi-tensor launches per replay)
+namespace dpft {
+__global__ __launch_bounds__(256) void add_many_kernel(const dpft_memop* __restrict__ table) {
+    const dpft_memop o = table[blockIdx.x];
+    float* __restrict__ d = reinterpret_cast<float*>(o.dst);
+    const float* __restrict__ s = reinterpret_cast<const float*>(o.src);
+    const uint64_t n = o.bytes >> 2;
+    if (((((uintptr_t)d) | ((uintptr_t)s)) & 15) == 0) {
+        const uint64_t n4 = n >> 2;
+        for (uint64_t k = threadIdx.x; k < n4; k += 256) {
+            f32x4 v = reinterpret_cast<f32x4*>(d)[k];
+            v += reinterpret_cast<const f32x4*>(s)[k];
+            reinterpret_cast<f32x4*>(d)[k] = v;
+        }
+        for (uint64_t k = (n4 << 2) + threadIdx.x; k < n; k += 256) d[k] += s[k];
+    } else {
+        for (uint64_t k = threadIdx.x; k < n; k += 256) d[k] += s[k];
+    }
+}
+}  // namespace dpft
+
+extern "C" int dpft_add_many_f32(int32_t n, const dpft_memop* table_device, dpft_stream_t stream) {
+    DPFT_REQUIRE(table_device && n >= 1, "add_many: empty table");
+    hipLaunchKernelGGL(dpft::add_many_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, table_device);
+    return dpft::check_launch("add_many");
 }

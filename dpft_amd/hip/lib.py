@@ -60,7 +60,7 @@ class HeadTrain(C.Structure):
                 ("cls", C.c_void_p), ("refs", C.c_void_p),
                 ("dx", C.c_void_p), ("dcenter", C.c_void_p), ("dsize", C.c_void_p), ("dangle", C.c_void_p),
                 ("dcls", C.c_void_p), ("drefs", C.c_void_p),
-                ("dy3", C.c_void_p), ("dcenter_prev", C.c_void_p), ("rows", C.c_void_p)]
+                ("dy3", C.c_void_p), ("dcenter_prev", C.c_void_p), ("rows", C.c_void_p), ("shape_stride", C.c_int32)]
 
 
 class DecoderFwd(C.Structure):
@@ -70,7 +70,7 @@ class DecoderFwd(C.Structure):
                 ("T", C.c_void_p * 4), ("P", C.c_void_p * 4), ("shape", C.c_void_p * 4),
                 ("p_rows", C.c_int32 * 4), ("has_t", C.c_int32 * 4), ("work", C.c_void_p),
                 ("center", C.c_void_p), ("size", C.c_void_p), ("angle", C.c_void_p), ("cls", C.c_void_p),
-                ("attn0", C.c_void_p)]
+                ("attn0", C.c_void_p), ("shape_stride", C.c_int32)]
 
 
 class MemOp(C.Structure):
@@ -151,6 +151,8 @@ SIGNATURES = {
     "dpft_pack_targets_f32": (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _P]),
     "dpft_match_cost_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _I, _I, _I, _I, _P]),
+    "dpft_set_loss_scratch_floats": (_L, [_I, _I]),
+    "dpft_set_loss_fwd_total_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dpft_set_loss_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, C.POINTER(_F * 5), _F, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "dpft_resize_bilinear_nhwc_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_resize_bilinear_nhwc_u8": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
@@ -166,6 +168,8 @@ SIGNATURES = {
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
     "dpft_rows_outer_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _L, _P]),
     "dpft_memops": (_I, [_I, _P, _P]),
+    "dpft_add_many_f32": (_I, [_I, _P, _P]),
+    "dpft_i64_add_many": (_I, [_I, _P, _L, _P]),
     "dpft_seed_advance": (_I, [_P, _P, _L, _P]),
     "dpft_sum_leading_f32": (_I, [_I, _P, _L, _P, _I, _P]),
     "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P]),

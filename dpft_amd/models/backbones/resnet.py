@@ -243,8 +243,14 @@ class _BodyFn(torch.autograd.Function):
             if sig is not None and all(wk.data_ptr() == c.weight.data_ptr() for wk, c in zip(weights, convs)):
                 owner.__dict__["_infer_tables"] = (sig, t, keep, weights)
         lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), mode, stream())
-        if train:
-            torch._foreach_add_([m.num_batches_tracked for m in bns], 1)
+        if train:      # num_batches_tracked += 1 of every BatchNorm: one launch per 256 counters
+            ptrs = tuple(m.num_batches_tracked.data_ptr() for m in bns)
+            cached = owner.__dict__.get("_nbt_ptrs")
+            if cached is None or cached[0] != ptrs:
+                cached = owner.__dict__["_nbt_ptrs"] = (ptrs, [(C.c_void_p * len(ptrs[i:i + 256]))(*ptrs[i:i + 256])
+                                                               for i in range(0, len(ptrs), 256)])
+            for arr in cached[1]:
+                lib.call("dpft_i64_add_many", len(arr), C.cast(arr, C.c_void_p), 1, stream())
         af = arena.view(torch.float32)
         outs = []
         for off, shape in plan.outs:
@@ -387,7 +393,7 @@ class BackboneBase(nn.Module):
         st["_plans"] = {}
         st["grad_direct"] = None
         st["side_stream"] = None
-        for k in ("_ordered", "_infer_tables", "_plist", "_direct_lease"):
+        for k in ("_ordered", "_infer_tables", "_plist", "_direct_lease", "_nbt_ptrs"):
             st.pop(k, None)
         return st
 

@@ -121,7 +121,11 @@ class FusedDecoder:
         pyrs = (Pyramid * V)()
         for v in range(V):
             pyrs[v] = make_pyramid(keep[v])
-        shapes = [s.to(torch.int64).contiguous() for s in shape]
+        strides = {s.stride(0) for s in shape if s.dtype == torch.int64 and s.dim() == 2 and s.stride(1) == 1 and s.shape[1] >= 2}
+        if len(strides) == 1 and all(s.dtype == torch.int64 and s.dim() == 2 and s.stride(1) == 1 for s in shape):
+            shapes, d.shape_stride = list(shape), strides.pop()      # the dataset's rows, read in place
+        else:
+            shapes, d.shape_stride = [s[:, :2].to(torch.int64).contiguous() for s in shape], 2
         Ts = [t.contiguous().float() for t, _ in projection]
         Ps = [p.contiguous().float() for _, p in projection]
         d.B = B

@@ -19,6 +19,7 @@ import torch
 from torch import nn
 
 from dpft_amd.hip import ops
+from dpft_amd.hip.lib import lib, stream
 
 
 # Other threads of the process (the RCCL watchdog of torch.distributed polls its events) must not invalidate a capture
@@ -158,6 +159,10 @@ class GraphedFuser:
             self.static_outputs = self.flat(*static)
         self.static_grad_outputs = [torch.zeros_like(o) for o in self.static_outputs]
         self.bwd_graph = torch.cuda.CUDAGraph()
+        # (dst, src, bytes) rows of the parameter-gradient additions: the addresses only exist once the capture has run, so
+        # the launch is captured against an empty DEVICE table that is filled right after
+        add_table = torch.empty((max(len(self.params), 1), 3), dtype=torch.int64, device=center0.device) if grad_direct is not None else None
+        add_rows = []
         with torch.enable_grad(), torch.cuda.graph(self.bwd_graph, capture_error_mode=CAPTURE_MODE):   # its own private pool (see module docstring)
             grads = torch.autograd.grad(self.static_outputs, diff_inputs, self.static_grad_outputs,
                                         allow_unused=True)
@@ -165,7 +170,17 @@ class GraphedFuser:
                 pairs = [(grad_direct.grad_buffer(p), t) for p, t in zip(self.params, grads[self.n_levels:]) if t is not None]
                 if any(v is None for v, _ in pairs):
                     raise RuntimeError("GraphedFuser: a decoder parameter is not owned by the gradient reducer")
-                torch._foreach_add_([v for v, _ in pairs], [t for _, t in pairs])
+                plain = [(v, t) for v, t in pairs if v.is_contiguous() and t.is_contiguous() and v.numel() == t.numel()
+                         and v.dtype == t.dtype == torch.float32]
+                other = [(v, t) for v, t in pairs if not any(v is pv for pv, _ in plain)]
+                if plain:      # one launch for all of them (dpft_add_many_f32)
+                    add_rows = [(v.data_ptr(), t.data_ptr(), 4 * v.numel()) for v, t in plain]
+                    lib.call("dpft_add_many_f32", len(add_rows), add_table.data_ptr(), stream())
+                if other:
+                    torch._foreach_add_([v for v, _ in other], [t for _, t in other])
+        if add_rows:
+            add_table[:len(add_rows)].copy_(torch.tensor(add_rows, dtype=torch.int64))
+        self._add_table = add_table
         self.static_grad_inputs = list(grads)
         self.params_with_grad = [p for p, t in zip(self.params, grads[self.n_levels:]) if t is not None]
         torch.cuda.synchronize()

@@ -343,13 +343,20 @@ class _Proj:
     def __init__(self, projection, shape, flags):
         self.T = [t.contiguous().float() for t, _ in projection]
         self.P = [p.contiguous().float() for _, p in projection]
-        self.shape = [s[:, :2].to(torch.int64).contiguous() for s in shape]
+        # (H, W) rows as int64: read in place from the dataset's (B, >= 2) int64 rows when every view has the same row stride
+        # (dpft_head_train.shape_stride), converted / compacted otherwise
+        strides = {s.stride(0) for s in shape if s.dtype == torch.int64 and s.dim() == 2 and s.stride(1) == 1 and s.shape[1] >= 2}
+        if len(strides) == 1 and all(s.dtype == torch.int64 and s.dim() == 2 and s.stride(1) == 1 for s in shape):
+            self.shape, self.shape_stride = list(shape), strides.pop()
+        else:
+            self.shape, self.shape_stride = [s[:, :2].to(torch.int64).contiguous() for s in shape], 2
         self.flags = [int(f) for f in flags]
 
     def fill(self, h: HeadTrain):
         for v in range(len(self.T)):
             h.T[v], h.P[v], h.shape[v] = self.T[v].data_ptr(), self.P[v].data_ptr(), self.shape[v].data_ptr()
             h.p_rows[v], h.has_t[v] = self.P[v].shape[1], self.flags[v]
+        h.shape_stride = self.shape_stride
 
 
 def reference_points(proj: _Proj, center: torch.Tensor) -> torch.Tensor:

@@ -189,6 +189,9 @@ def _pack_targets_hip(targets, counts, ncls, dev, Mmax):
     return gt_box, gt_onehot, gt_id, counts_t, Mmax
 
 
+_loss_scratch: Dict[torch.device, torch.Tensor] = {}      # ticket + partial sums of dpft_set_loss_fwd_total_f32 (zero between launches)
+
+
 class _SetLossFn(torch.autograd.Function):
     """dpft_set_loss_fwd/bwd_f32: the five batch-reduced, weighted criterion terms for fixed assignments."""
 
@@ -199,13 +202,18 @@ class _SetLossFn(torch.autograd.Function):
         B, N, ncls = cls.shape
         Mmax = gt_box.shape[1]
         losses = torch.empty(5, dtype=torch.float32, device=cls.device)
+        total = torch.empty((), dtype=torch.float32, device=cls.device)
         w = (C.c_float * 5)(*weights5)
-        lib.call("dpft_set_loss_fwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+        # one launch: the five terms (per-block partial sums added in block order by the last block) and the total of the
+        # configured ones -- instead of a cleared output + atomics + a dot product, and of select x5 / stack / sum in
+        # autograd, whose backward alone is a dozen tiny launches between the step's two host syncs
+        need = int(lib.dpft_set_loss_scratch_floats(B, N))
+        scratch = _loss_scratch.get(cls.device)
+        if scratch is None or scratch.numel() < need:
+            scratch = _loss_scratch[cls.device] = torch.zeros(max(need, 1024), dtype=torch.float32, device=cls.device)
+        lib.call("dpft_set_loss_fwd_total_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                  gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
-                 losses.data_ptr(), B, N, Mmax, ncls, stream())
-        # the total of the configured terms is taken here (one op) instead of select x5 / stack / sum in autograd, whose
-        # backward alone is a dozen tiny launches between the step's two host syncs
-        total = torch.dot(losses, sel)
+                 sel.data_ptr(), scratch.data_ptr(), losses.data_ptr(), total.data_ptr(), B, N, Mmax, ncls, stream())
         ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts, sel)
         ctx.meta = (weights5, float(alpha))
         ctx.mark_non_differentiable(losses)

@@ -377,6 +377,8 @@ typedef struct dpft_decoder_fwd {
     float *center, *size, *angle, *cls;
     const float* attn0;                  /* (V,Q,16) from dpft_decoder_attn0_f32, or NULL: the attention output of iteration 0
                                             (a constant of the weights) -- with it a forward is 2 * iters launches, not + 1 */
+    int32_t shape_stride;                /* int64 elements between the rows of shape[v]: 0 = 2 (contiguous (B,2)); 3 reads the
+                                            first two columns of the dataset's (B,3) X_shape rows in place */
 } dpft_decoder_fwd;
 /* iteration 0's self-attention output for one batch element -- its input is the learned query table (mpfusion.py:700-703),
  * so it depends on the weights only; call again after every weight change, like the pack functions */
@@ -473,6 +475,7 @@ typedef struct dpft_head_train {
     float* refs;                                   /* (V,B,Q,2) or NULL */
     const float *dx, *dcenter, *dsize, *dangle, *dcls, *drefs;   /* backward inputs, any may be NULL */
     float *dy3, *dcenter_prev, *rows;              /* backward outputs */
+    int32_t shape_stride;                          /* int64 elements between the rows of shape[v]; 0 = 2 */
 } dpft_head_train;
 int64_t dpft_head_train_row_floats(void);
 int dpft_head_train_fwd_f32(const dpft_head_train* h, int32_t B, int32_t Q, int32_t V, dpft_stream_t stream);
@@ -520,6 +523,17 @@ typedef struct dpft_sum_src {
 int dpft_sum_leading_f32(int32_t n_src, const dpft_sum_src* srcs, int64_t inner, float* dst, int32_t accumulate,
                          dpft_stream_t stream);
 
+/* dst_i[k] += src_i[k] (fp32) for the n entries of a DEVICE-resident dpft_memop table (bytes = 4 * elements), one launch:
+ * gradient accumulation of many small parameters (autograd's AccumulateGrad of the reference's training loop,
+ * src/dprt/training/trainer.py:134-141).  The table may be written after the launch has been CAPTURED in a hipGraph. */
+int dpft_add_many_f32(int32_t n, const dpft_memop* table_device, dpft_stream_t stream);
+
+/* *ptrs[i] += increment for n <= DPFT_I64_PTRS_MAX int64 device scalars in one launch (ptrs: HOST array): the
+ * num_batches_tracked counters a train-mode BatchNorm forward bumps (torch.nn.BatchNorm2d; the reference's backbones are
+ * torchvision ResNets, src/dprt/models/backbones/resnet.py:120-176). */
+#define DPFT_I64_PTRS_MAX 256
+int dpft_i64_add_many(int32_t n, int64_t* const* ptrs, int64_t increment, dpft_stream_t stream);
+
 /* Dropout seed of the fused training decoder: *snap = *state; *state += increment (one launch, capturable).  The reference
  * draws its dropout masks from torch's generator (nn.Dropout in src/dprt/models/fusers/mpfusion.py:95-119). */
 int dpft_seed_advance(int64_t* state, int64_t* snap, int64_t increment, dpft_stream_t stream);
@@ -558,6 +572,16 @@ int dpft_set_loss_fwd_f32(const float* cls, const float* center, const float* si
                           const float* gt_box, const float* gt_onehot, const int32_t* match,
                           const int32_t* counts, const float* weights5, float alpha, float* losses5,
                           int32_t B, int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
+/* The same forward in ONE launch without a cleared output, plus total = sum_k sel[k] * losses5[k] (sel: DEVICE, 5 floats -- the
+ * configured terms; the reference sums them in src/dprt/training/loss.py:556-562): per-block partial sums in `scratch`
+ * (dpft_set_loss_scratch_floats(B, N) floats, ZERO when first handed over, left zero), added in block order by the block that
+ * draws the last ticket. */
+int64_t dpft_set_loss_scratch_floats(int32_t B, int32_t N);
+int dpft_set_loss_fwd_total_f32(const float* cls, const float* center, const float* size, const float* angle,
+                                const float* gt_box, const float* gt_onehot, const int32_t* match,
+                                const int32_t* counts, const float* weights5, float alpha, const float* sel,
+                                float* scratch, float* losses5, float* total, int32_t B, int32_t N, int32_t Mmax,
+                                int32_t C, dpft_stream_t stream);
 int dpft_set_loss_bwd_f32(const float* cls, const float* center, const float* size, const float* angle,
                           const float* gt_box, const float* gt_onehot, const int32_t* match,
                           const int32_t* counts, const float* weights5, float alpha, const float* gout5,
