@@ -166,6 +166,8 @@ class GraphedFuser:
         with torch.enable_grad(), torch.cuda.graph(self.bwd_graph, capture_error_mode=CAPTURE_MODE):   # its own private pool (see module docstring)
             grads = torch.autograd.grad(self.static_outputs, diff_inputs, self.static_grad_outputs,
                                         allow_unused=True)
+            from dpft_amd.models.fusers import train_fused as _tf
+            _tf.join_forked()      # the weight-gradient branches of the capture end here
             if grad_direct is not None:
                 pairs = [(grad_direct.grad_buffer(p), t) for p, t in zip(self.params, grads[self.n_levels:]) if t is not None]
                 if any(v is None for v, _ in pairs):

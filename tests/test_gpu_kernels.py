@@ -1193,3 +1193,114 @@ def test_splitk_fixup_holds_under_concurrent_streams():
                 bad.append((it, ji))
     torch.cuda.synchronize()
     assert not bad, bad[:10]
+
+
+# ---- round 4: the host glue's own kernels (no vendor copy / fill / sum / add launches left on the training step) ----------
+def test_memops_copies_and_zero_fills_in_one_call():
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    a = torch.randn(1000003, generator=g).to(DEV); b = torch.empty_like(a)
+    c = torch.randn(77, generator=g).to(DEV); d = torch.ones(77, device=DEV)
+    e = torch.randn(13, generator=g).to(DEV)[1:]; f = torch.empty(12, device=DEV)       # 4-byte aligned source only
+    z = torch.ones(5000, device=DEV)
+    i64 = torch.arange(6, device=DEV).view(2, 3); j64 = torch.empty_like(i64)
+    ops.memops([(b, a), (d, c), (f, e), (z, None), (j64, i64)])
+    assert torch.equal(a, b) and torch.equal(c, d) and torch.equal(f, e) and float(z.abs().sum()) == 0 and torch.equal(i64, j64)
+    pairs = [(torch.empty(100 + i, device=DEV), torch.randn(100 + i, generator=g).to(DEV)) for i in range(40)]      # > 16: chunked
+    ops.memops(pairs)
+    assert all(torch.equal(x, y) for x, y in pairs)
+    with pytest.raises(Exception):
+        from dpft_amd.hip.lib import lib, stream
+        lib.call("dpft_memops", 17, None, stream())
+
+
+def test_sum_leading_matches_torch_and_is_repeatable():
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(3, 4, 400, 16, generator=g).to(DEV); y = torch.randn(12, 400, 16, generator=g).to(DEV)
+    close(ops.sum_leading([x], (4, 400, 16)), x.double().sum(0), what="sum over views")
+    o = ops.sum_leading([x, y], (400, 16))
+    close(o, x.double().sum((0, 1)) + y.double().sum(0), what="two sources, every leading axis")
+    assert torch.equal(o, ops.sum_leading([x, y], (400, 16)))                       # fixed order: bit-identical
+    acc = torch.randn(4, 5, 14, 16, generator=g).to(DEV); r = torch.randn(32, 4, 5, 14, 16, generator=g).to(DEV)
+    ref = acc.double() + r.double().sum(0)
+    ops.sum_leading([r], acc.shape, out=acc, accumulate=True)
+    close(acc, ref, what="replica fold (accumulate)")
+
+
+def test_seed_advance_counter_bump_and_add_many():
+    from dpft_amd.hip.lib import lib, stream
+    import ctypes as C
+    st = torch.tensor([12345], dtype=torch.int64, device=DEV); sn = torch.empty_like(st)
+    lib.call("dpft_seed_advance", st.data_ptr(), sn.data_ptr(), 7, stream())
+    assert int(sn) == 12345 and int(st) == 12352
+    cnt = [torch.tensor(i, dtype=torch.int64, device=DEV) for i in range(104)]
+    arr = (C.c_void_p * len(cnt))(*[t.data_ptr() for t in cnt])
+    lib.call("dpft_i64_add_many", len(cnt), C.cast(arr, C.c_void_p), 1, stream())
+    assert [int(t) for t in cnt] == [i + 1 for i in range(104)]
+    g = torch.Generator().manual_seed(13)
+    dst = [torch.randn(n, generator=g).to(DEV) for n in (16, 7680, 256, 3, 48)]
+    dst[3] = torch.randn(4, generator=g).to(DEV)[1:]                                # unaligned entry
+    src = [torch.randn(t.numel(), generator=g).to(DEV) for t in dst]
+    ref = [a.clone() + b for a, b in zip(dst, src)]
+    table = torch.tensor([(a.data_ptr(), b.data_ptr(), 4 * a.numel()) for a, b in zip(dst, src)], dtype=torch.int64).to(DEV)
+    lib.call("dpft_add_many_f32", len(dst), table.data_ptr(), stream())
+    assert all(torch.equal(a, r) for a, r in zip(dst, ref))
+
+
+@pytest.mark.parametrize("shape", [(4, 128, 228, 16), (2, 9, 11, 256), (1, 3, 7, 48)])
+def test_bias_gradient_behind_a_weight_gradient_needs_no_cleared_output(shape):
+    """dpft_conv2d_nhwc_wgrad_bias_f32's bias half: partial sums in the conv workspace + last-ticket block (no memset, no
+    atomics) -- exact column sums into a POISONED output, bit-identical from call to call, ticket header left zero."""
+    ops = _ops()
+    B, H, W, K = shape
+    g = torch.Generator().manual_seed(14)
+    x = torch.randn(B, H, W, 32, generator=g).to(DEV)
+    dy = torch.randn(B, H, W, K, generator=g).to(DEV)
+    cv = ops.conv_problem(B, H, W, 32, K, 1, 1, 1, 0)
+    outs = []
+    for _ in range(3):
+        dw = torch.empty(K, 1, 1, 32, device=DEV)
+        db = torch.full((K,), float("nan"), device=DEV)
+        ops.conv_wgrad_bias(cv, x, dy, out=dw, bias_out=db)
+        outs.append(db.clone())
+    close(outs[0], dy.double().sum((0, 1, 2)), what="bias gradient (slab form)")
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    ws = ops.workspace(cv.ws_bytes, x.device)
+    from dpft_amd.hip.lib import lib
+    assert int(ws[:int(lib.dpft_conv2d_workspace_header_bytes())].view(torch.int32).abs().sum()) == 0
+
+
+def test_set_loss_forward_with_total_equals_the_two_step_form():
+    """dpft_set_loss_fwd_total_f32 (one launch, block-ordered sums) vs dpft_set_loss_fwd_f32 (memset + atomics) + dot."""
+    import ctypes as C
+    from dpft_amd.hip.lib import lib, stream
+    g = torch.Generator().manual_seed(15)
+    B, N, Mmax, ncls = 4, 400, 6, 2
+    cls = torch.randn(B, N, ncls, generator=g).to(DEV); center = torch.randn(B, N, 3, generator=g).to(DEV)
+    size = torch.rand(B, N, 3, generator=g).to(DEV); angle = torch.randn(B, N, 2, generator=g).to(DEV)
+    gt_box = torch.randn(B, Mmax, 8, generator=g).to(DEV)
+    gt_onehot = torch.nn.functional.one_hot(torch.randint(0, ncls, (B, Mmax), generator=g), ncls).float().to(DEV)
+    counts = torch.tensor([6, 3, 0, 1], dtype=torch.int32)
+    match = torch.full((B, Mmax, 2), -1, dtype=torch.int32)
+    for b in range(B):
+        m = int(counts[b])
+        match[b, :m, 0] = torch.randperm(N, generator=g)[:m].int(); match[b, :m, 1] = torch.randperm(m, generator=g).int()
+    match, counts = match.to(DEV), counts.to(DEV)
+    w = (C.c_float * 5)(1.0, 2.0, 0.5, 0.25, 1.5)
+    sel = torch.tensor([1.0, 0.0, 1.0, 1.0, 1.0], device=DEV)
+    a5 = torch.empty(5, device=DEV)
+    lib.call("dpft_set_loss_fwd_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(), gt_box.data_ptr(),
+             gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), 0.75, a5.data_ptr(), B, N, Mmax, ncls, stream())
+    scratch = torch.zeros(int(lib.dpft_set_loss_scratch_floats(B, N)), device=DEV)
+    runs = []
+    for _ in range(2):
+        b5 = torch.full((5,), float("nan"), device=DEV); tot = torch.full((), float("nan"), device=DEV)
+        lib.call("dpft_set_loss_fwd_total_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(), gt_box.data_ptr(),
+                 gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), 0.75, sel.data_ptr(), scratch.data_ptr(),
+                 b5.data_ptr(), tot.data_ptr(), B, N, Mmax, ncls, stream())
+        runs.append((b5.clone(), tot.clone()))
+    close(runs[0][0], a5.double(), rtol=1e-5, what="five terms")
+    close(runs[0][1], (a5.double() * sel.double()).sum(), rtol=1e-5, what="total")
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])      # block order: repeatable
+    assert int(scratch[:8].view(torch.int32).abs().sum()) == 0                               # ticket left clean
