@@ -113,6 +113,7 @@ struct IgemmArgs {
     const float* oadd;
     int orelu;
     int ablate;       // tuning aid (DPFT_ABLATE): 1 no global loads, 2 no LDS stores, 4 no epilogue, 8 no MFMAs
+    int epf;          // host: the launch qualifies for the epilogue-operand prefetch (EpiPrefetch below)
     // Fused first pass of a BatchNorm backward (dpft::BnReduceFuse): the tensor this launch writes IS the `dout` of a
     // BatchNorm layer whose input y has the same shape; the epilogue adds sum(d) and sum(d * xhat) of its tile to
     // bnr_sums[2][N] (d = stored value under that layer's ReLU mask) -- the separate reduction pass over (y, dout), its
@@ -149,14 +150,44 @@ __device__ __forceinline__ size_t out_pixel(const IgemmArgs& a, int m) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Epilogue operands fetched DURING the main loop (igemm_pipe_kernel<..., EPF = true>, round 4).  The residual data gradient
+// of a bottleneck's conv1 (dx = conv_dgrad + masked identity gradient, with the next BatchNorm's backward reduction in its
+// epilogue) reads two more full-size tensors than it writes; all workgroups of a launch reach that epilogue together, so
+// its loads found an idle matrix pipe and its main loop an idle memory system (layer 3, fp32: ~40 us of MFMAs, then ~15 us
+// of streaming).  Here a thread's epilogue operands -- per 4-channel quad: the BatchNorm input `bnr_y`, the identity
+// gradient `res_src` and their two ReLU mask bytes -- are requested together with the first K-step's tile and simply are in
+// registers when the epilogue starts: one memory round trip instead of two per workgroup, and the loads no longer queue up
+// behind 900 workgroups that finish their MFMAs at the same moment.  Host side: only for the form with both byte masks, unsplit.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+// MODE 1: the residual form above (bnr_y, res_src, both mask bytes).  MODE 2: a plain data gradient that carries a BatchNorm-
+// backward reduction (conv2 / conv3 of a bottleneck): bnr_y, and the mask byte where that layer's ReLU mask is a byte mask.
+template <int ITER, bool H16, int MODE_>
+struct EpiPrefetch {
+    static constexpr int MODE = MODE_;
+    using Q = typename std::conditional<H16, u32x2_t, f32x4>::type;      // 4 channels as stored (bf16 / fp32), not widened:
+    Q y[ITER], g[MODE_ == 1 ? ITER : 1];                                  // a conversion would be a use of the load
+    unsigned mk[ITER], rm[MODE_ == 1 ? ITER : 1];
+};
+template <bool H16> __device__ __forceinline__ f32x4 pf_widen(f32x4 v) { return v; }
+template <bool H16> __device__ __forceinline__ f32x4 pf_widen(u32x2_t v) {
+    return f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16),
+                 __uint_as_float(v[1] & 0xffff0000u)};
+}
+template <typename PF> struct pf_mode { static constexpr int value = PF::MODE; };
+template <> struct pf_mode<std::nullptr_t> { static constexpr int value = 0; };
+
+// ---------------------------------------------------------------------------------------------
 // shared epilogue: store accumulators (+bias), optional split-K partial, optional BN tile stats
 // ---------------------------------------------------------------------------------------------
 // NT = threads of the workgroup: 256, or 512 for the K-split form of the vector kernel whose waves 4..7 have already
 // handed their accumulators to waves 0..3 -- they own no results here (`own`) but take part in the barriers and in the
 // LDS -> global store loops.
-template <int BM, int BN, int WGM, int WGN, int RB, int CB, int NT = 256>
+template <int BM, int BN, int WGM, int WGN, int RB, int CB, int NT = 256, typename PF = std::nullptr_t>
 __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[RB][CB], int m0,
-                                               int n0, int mt, int split, float* smem) {
+                                               int n0, int mt, int split, float* smem, PF* pf = nullptr) {
+    constexpr bool HAS_PF = !std::is_same<PF, std::nullptr_t>::value;      // operands already requested (EpiPrefetch)
+    constexpr int PFM = pf_mode<PF>::value;                                // 0 | 1 residual form | 2 reduction only
     const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3;
     const bool own = NT == 256 || tid < 256;
     const int wm = wave / WGN, wn = wave % WGN;
@@ -169,7 +200,9 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
     // workgroup ends up last), puts the sums back into its accumulator registers and falls through to the epilogue of an
     // unsplit launch -- bias, residual, accumulate, BatchNorm tile statistics, the fused BatchNorm-backward reduction.
     // No fences (a release fence writes the whole L2 of the XCD back), no spinning (nobody waits for anybody).
-    const bool fix = a.partial != nullptr && a.sk_ticket != nullptr;
+    // (HAS_PF: the host launches that kernel only unsplit, without statistics / bias / accumulation / inference epilogue (mode 1:
+    // with both byte masks) -- the other forms are compiled out of it: half the registers and scalar state of the generic epilogue)
+    const bool fix = !HAS_PF && a.partial != nullptr && a.sk_ticket != nullptr;
     if (fix) {
         constexpr int FLDC = BN + 4, FC4 = BN / 4, FITER = BM * FC4 / NT;
         float* Fs = smem;
@@ -251,8 +284,8 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 }
         __syncthreads();      // the statistics / staging below reuse the same LDS
     }
-    const bool part = a.partial != nullptr && !fix;      // this launch leaves partial tiles for a reduction kernel
-    if (a.stats != nullptr || a.bnf_acc != nullptr) {
+    const bool part = !HAS_PF && a.partial != nullptr && !fix;      // this launch leaves partial tiles for a reduction kernel
+    if (!HAS_PF && (a.stats != nullptr || a.bnf_acc != nullptr)) {
         // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
         float* red = smem;               // [WGM][BN]
         float* smean = smem + WGM * BN;  // [BN]
@@ -335,19 +368,27 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             }
     __syncthreads();
     float* __restrict__ out = part ? a.partial + (size_t)split * a.M * a.N : a.y;
-    const bool add_bias = (a.bias != nullptr) && !part;
-    const bool accum = a.accumulate && !part;
+    const bool add_bias = !HAS_PF && (a.bias != nullptr) && !part;
+    const bool accum = !HAS_PF && a.accumulate && !part;
     const bool y16 = a.y16 && !part;      // split-K partials stay fp32
-    if ((a.N & 3) == 0) {
+    if (HAS_PF || (a.N & 3) == 0) {
         constexpr int C4 = BN / 4;
         constexpr int ITER = BM * C4 / NT;
         static_assert(BM * C4 % NT == 0, "tile / thread count");
         f32x4 old[ITER];
         // operands of the fused BatchNorm-backward reduction: requested here, consumed in the store loop below
-        const bool bnr_pre = (a.bnr_sums != nullptr) && !part;
+        const bool bnr_pre = HAS_PF || ((a.bnr_sums != nullptr) && !part);
         f32x4 bnr_yv[ITER];
         unsigned bnr_mk[ITER];
-        if (bnr_pre) {
+        if (bnr_pre && HAS_PF) {
+            if constexpr (HAS_PF) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    bnr_yv[it] = pf_widen<true>(pf->y[it]);
+                    bnr_mk[it] = (PFM == 1 || a.bnr_mask8) ? pf->mk[it] : 0u;
+                }
+            }
+        } else if (bnr_pre) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + it * NT;
@@ -361,10 +402,20 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 }
             }
         }
-        const bool resid = (a.res_src != nullptr) && !part;
-        const bool obn = (a.obn != nullptr) && !part;
+        const bool resid = PFM == 1 || (PFM == 0 && (a.res_src != nullptr) && !part);
+        const bool obn = !HAS_PF && (a.obn != nullptr) && !part;
         const bool oadd = obn && a.oadd != nullptr;
-        if (accum || resid || oadd) {
+        if (PFM == 1) {
+            if constexpr (PFM == 1) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) {
+                    const f32x4 g = pf_widen<true>(pf->g[it]);
+                    const unsigned mk = pf->rm[it];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) old[it][e] = ((mk >> e) & 1u) ? g[e] : 0.f;
+                }
+            }
+        } else if (accum || resid || oadd) {
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int idx = tid + it * NT;
@@ -393,13 +444,13 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         }
         // fused BatchNorm-backward reduction (see IgemmArgs::bnr_*): a thread owns ONE 4-channel chunk (NT % C4 == 0)
         static_assert(NT % C4 == 0, "a thread's channel chunk must not depend on the pass");
-        const bool bnr = (a.bnr_sums != nullptr) && !part;
+        const bool bnr = HAS_PF || ((a.bnr_sums != nullptr) && !part);
         f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f}, bmu = bs0, bis = bs0, bsc = bs0, bbe = bs0;
         const int bc = n0 + (tid % C4) * 4;
         if (bnr && bc < a.N) {
             bmu = *reinterpret_cast<const f32x4*>(a.bnr_bnp + bc);
             bis = *reinterpret_cast<const f32x4*>(a.bnr_bnp + 3 * a.N + bc);
-            if (a.bnr_self_mask) {
+            if (PFM != 1 && a.bnr_self_mask) {
                 bsc = *reinterpret_cast<const f32x4*>(a.bnr_bnp + a.N + bc);
                 bbe = *reinterpret_cast<const f32x4*>(a.bnr_bnp + 2 * a.N + bc);
             }
@@ -432,7 +483,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                         f32x4 d = v;
                         // bf16 storage: reduce what the stand-alone pass would read back, i.e. the rounded value
                         if (decltype(H16)::value) d = __builtin_convertvector(__builtin_convertvector(v, bf16x4s), f32x4);
-                        if (a.bnr_mask8) {
+                        if (PFM == 1 || a.bnr_mask8) {
                             const unsigned mk = bnr_mk[it];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) d[e] = ((mk >> e) & 1u) ? d[e] : 0.f;
@@ -482,7 +533,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             }
         }
     }
-    if (a.bnf_slab) {
+    if (!HAS_PF && a.bnf_slab) {
         // Deterministic BatchNorm finalize inside the forward conv: the workgroups of one COLUMN tile take tickets; whoever
         // draws the last one merges that tile's columns of the statistics slab with the arithmetic of bn_finalize_kernel
         // (bn.hip: 32 tile groups per channel, pivot = tile 0, groups summed in order) -- bit-identical to the separate
@@ -555,7 +606,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             }
         }
     }
-    if (a.bnf_acc != nullptr) {
+    if (!HAS_PF && a.bnf_acc != nullptr) {
         // Every tile has added its sums with device-scope atomics; an atomic is acknowledged (vmcnt) once it has been
         // performed at the coherence point, so "wait for mine, then take a ticket" orders them before the last ticket --
         // no release fence (nothing here publishes plain stores), the last workgroup reads the totals with device-scope
@@ -2089,6 +2140,15 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
             launch_lds(kernel, grid, block, lds, st, a);
         };
 #define PIPE16_LDS(BM_, BN_, PBK_) std::max((size_t)2 * (BM_ + BN_) * PBK_ * 2, (size_t)BM_ * (BN_ + 4) * 4 + (size_t)3 * BN_ * 4)
+        if constexpr (DGRAD) {      // epilogue operands requested with the first tile (EpiPrefetch; a.epf = its MODE)
+            bool took = true;
+            if (a.epf == 1 && t.bm == 128 && t.bn == 64) go16(igemm_pipe_kernel<128, 64, 2, 2, 64, true, false, true, 1>, 64, PIPE16_LDS(128, 64, 64));
+            else if (a.epf == 2 && t.bm == 128 && t.bn == 64) go16(igemm_pipe_kernel<128, 64, 2, 2, 64, true, false, true, 2>, 64, PIPE16_LDS(128, 64, 64));
+            else if (a.epf == 2 && t.bm == 64 && t.bn == 64 && a.C % 128 == 0) go16(igemm_pipe_kernel<64, 64, 2, 2, 128, true, false, true, 2>, 128, PIPE16_LDS(64, 64, 128));
+            else if (a.epf == 2 && t.bm == 64 && t.bn == 64) go16(igemm_pipe_kernel<64, 64, 2, 2, 64, true, false, true, 2>, 64, PIPE16_LDS(64, 64, 64));
+            else took = false;
+            if (took) return check_launch("conv igemm (pipelined, bf16 operands, epilogue prefetch)");
+        }
         if (t.bm == 128 && t.bn == 128) go16(igemm_pipe_kernel<128, 128, 2, 2, 64, DGRAD, false, true>, 64, PIPE16_LDS(128, 128, 64));
         else if (t.bm == 128 && t.bn == 64) go16(igemm_pipe_kernel<128, 64, 2, 2, 64, DGRAD, false, true>, 64, PIPE16_LDS(128, 64, 64));
         else if (a.C % 128 == 0) go16(igemm_pipe_kernel<64, 64, 2, 2, 128, DGRAD, false, true>, 128, PIPE16_LDS(64, 64, 128));
@@ -2113,6 +2173,15 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
         if (pro) go(igemm_pipe_kernel<BM_, BN_, 2, 2, PBK_, DGRAD, !DGRAD>, PBK_, PIPE_LDS(BM_, BN_, PBK_)); \
         else go(igemm_pipe_kernel<BM_, BN_, 2, 2, PBK_, DGRAD, false>, PBK_, PIPE_LDS(BM_, BN_, PBK_));      \
     } while (0)
+        if constexpr (DGRAD) {      // epilogue operands requested with the first tile (EpiPrefetch; a.epf = its MODE)
+            bool took = !pro;
+            if (pro) {}
+            else if (a.epf == 1 && t.bm == 128 && t.bn == 64) go(igemm_pipe_kernel<128, 64, 2, 2, 32, true, false, false, 1>, 32, PIPE_LDS(128, 64, 32));
+            else if (a.epf == 2 && t.bm == 128 && t.bn == 64) go(igemm_pipe_kernel<128, 64, 2, 2, 32, true, false, false, 2>, 32, PIPE_LDS(128, 64, 32));
+            else if (a.epf == 2 && t.bm == 64 && t.bn == 64 && !short_k) go(igemm_pipe_kernel<64, 64, 2, 2, 64, true, false, false, 2>, 64, PIPE_LDS(64, 64, 64));
+            else took = false;
+            if (took) return check_launch("conv igemm (pipelined, epilogue prefetch)");
+        }
         if (t.bm == 128 && t.bn == 128) LAUNCH_PIPE(128, 128, 32);
         else if (t.bm == 128 && t.bn == 64) LAUNCH_PIPE(128, 64, 32);
         else if (t.bm == 64 && t.bn == 128) LAUNCH_PIPE(64, 128, 32);
@@ -2508,6 +2577,11 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
         set_bnr(a, fuse);
         fuse->applied = true;
     }
+    // unsplit stride-1 launch that carries the reduction and nothing else in its epilogue: the reduction's operand (and mask
+    // byte) is requested with the first tile (EpiPrefetch mode 2; DPFT_EPF bit 1)
+    static const int epf_on = getenv("DPFT_EPF") == nullptr ? 3 : atoi(getenv("DPFT_EPF"));
+    if ((epf_on & 2) && t.splits == 1 && a.bnr_sums && !accumulate && d->stride == 1 && t.vec && (int64_t)a.M * a.N < (1ll << 29))
+        a.epf = 2;
     rc = launch_igemm<true>(a, t, false, st);
     if (rc) return rc;
     if (t.splits > 1 && !fixup) {
@@ -2547,6 +2621,15 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     if ((t.splits == 1 || fixup) && fuse && fuse->sums && (a.N & 3) == 0) {
         set_bnr(a, fuse);
         fuse->applied = true;
+    }
+    // the full form (identity gradient + next BatchNorm's reduction, both ReLU masks as bytes), unsplit, with enough rows to
+    // fill the chip with 128 x 64 tiles: its epilogue operands are fetched during the main loop (EpiPrefetch; the launcher
+    // takes the kernel when the operand types allow the pipelined path).  DPFT_EPF=0: the plain epilogue, A/B switch.
+    static const int epf_on = getenv("DPFT_EPF") == nullptr ? 3 : atoi(getenv("DPFT_EPF"));      // bit 0: this form, bit 1: mode 2
+    if ((epf_on & 1) && t.splits == 1 && a.bnr_sums && a.bnr_mask8 && a.res_mask8 && t.vec && (int64_t)a.M * a.N < (1ll << 29) &&
+        (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) >= kNumCU && getenv("DPFT_FORCE_TILE") == nullptr) {
+        a.epf = 1;
+        t.bm = 128; t.bn = 64;
     }
     rc = launch_igemm<true>(a, t, false, st);
     if (rc) return rc;

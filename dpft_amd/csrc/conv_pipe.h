@@ -44,9 +44,12 @@ __device__ __forceinline__ void static_for(Fn&& f) {
 // and one v_mfma_f32_32x32x16_bf16 (fp32 accumulation) per 32x32 block and group.  No arithmetic touches an operand on
 // its way to the matrix cores, so nothing but LDS-DMA feeds the stages (PRO is not available: the mixed-precision plan
 // materialises BatchNorm+ReLU outputs instead).
-template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO, bool B16 = false>
+// EPF: the epilogue's operands (residual data gradient with the fused BatchNorm-backward reduction, both byte masks) are
+// requested behind the MFMAs of selected K-steps (EpiPrefetch, conv.hip) instead of after the last one.
+template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO, bool B16 = false, int EPF = 0>
 __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     static_assert(!(B16 && PRO), "bf16 operands: no fused prologue");
+    static_assert(EPF == 0 || (DGRAD && !PRO), "epilogue prefetch: data gradients only");      // EPF = EpiPrefetch::MODE
     constexpr int EB = B16 ? 2 : 4;         // bytes per element
     constexpr int EPC = 16 / EB;            // elements per 16-byte chunk
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
@@ -228,6 +231,31 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // ---- epilogue-operand prefetch (EPF) ------------------------------------------------------------------------------
+    // Quads outside the tensor read the tile's first element instead (never used): no branch around a load.  The element
+    // offset is rebuilt at every use from an opaque copy of the thread index.
+    constexpr int EP_ITER = BM * (BN / 4) / 256;
+    using PFT = EpiPrefetch<EP_ITER, B16, EPF>;
+    PFT pf;
+    auto pf_op = [&](auto IT_, auto KIND_) __attribute__((always_inline)) {
+        if constexpr (EPF != 0) {
+            constexpr int it = decltype(IT_)::value, kind = decltype(KIND_)::value;
+            constexpr int C4 = BN / 4;
+            int t = tid;
+            asm volatile("" : "+v"(t));
+            const int idx = t + it * 256;
+            const int row = idx / C4, c4 = idx - row * C4;
+            const bool ok = m0 + row < a.M && n0 + c4 * 4 < a.N;
+            const unsigned el = ok ? (unsigned)(m0 + row) * (unsigned)a.N + (unsigned)(n0 + c4 * 4)      // (stride-1 data gradient: output pixel = row)
+                                   : (unsigned)m0 * (unsigned)a.N + (unsigned)n0;
+            using Q = typename PFT::Q;
+            if constexpr (kind == 0) pf.y[it] = *reinterpret_cast<const Q*>(reinterpret_cast<const char*>(a.bnr_y) + (size_t)el * EB);
+            else if constexpr (kind == 1) { if constexpr (EPF == 1) pf.g[it] = *reinterpret_cast<const Q*>(reinterpret_cast<const char*>(a.res_src) + (size_t)el * EB); }
+            else if constexpr (kind == 2) { if (EPF == 1 || a.bnr_mask8) pf.mk[it] = a.bnr_mask8[el >> 2]; }
+            else { if constexpr (EPF == 1) pf.rm[it] = a.res_mask8[el >> 2]; }
+        }
+    };
+
     // fragment read addresses: lane l reads row l % 32 of a 32-row block, K-group kg, half h = l / 32 -> chunk 2 * kg + h
     const int fkey = (CH == 16) ? (lane & 15) : ((lane >> 1) & 7);
     const int h = lane >> 5;
@@ -256,7 +284,7 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     static_assert(NOPS <= SLOTS, "more loads than MFMA slots");
     static_assert(!PRO || (AP % LASTG == 0 && QPG >= 1 && QPG <= MPG), "prologue schedule");
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    auto step = [&](auto STG, auto MORE) {
+    auto step = [&](auto STG, auto MORE) __attribute__((always_inline)) {
         constexpr int stg = decltype(STG)::value;
         constexpr bool more = decltype(MORE)::value;
         using OTHER = std::integral_constant<int, (stg ^ 1)>;
@@ -313,6 +341,17 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
         if constexpr (PRO) static_for<AP>([&](auto I) { consume(S0{}, I); });
         advance();
     }
+    if constexpr (EPF != 0) {
+        // All of the thread's epilogue operands are requested here, with the first tile: one memory round trip (the first
+        // fence's) serves both, and the epilogue starts with its operands in registers.  (Tried: groups of 16 requests behind
+        // the MFMAs of later K-steps with a fence that lets the newest 16 fly -- the register allocator gave a second request
+        // site of a group its own destination registers and copied, 240 VGPRs instead of 200, and the isolated kernel time
+        // did not move; with everything up front it went from 61 to 54 us on the layer-3 fp32 problem, 69 -> 40 us in bf16.)
+        static_for<EP_ITER * 4>([&](auto O) {
+            constexpr int o = decltype(O)::value;
+            pf_op(std::integral_constant<int, o / 4>{}, std::integral_constant<int, o % 4>{});
+        });
+    }
     fence();
     int s_ = 0;
     for (; s_ + 2 < nsteps; s_ += 2) {
@@ -328,7 +367,8 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     } else if (nsteps - s_ == 1) {
         step(S0{}, F{});
     }
-    igemm_epilogue<BM, BN, WGM, WGN, RB, CB, 256>(a, acc, m0, n0, mt, split, smem);
+    if constexpr (EPF != 0) igemm_epilogue<BM, BN, WGM, WGN, RB, CB, 256, PFT>(a, acc, m0, n0, mt, split, smem, &pf);
+    else igemm_epilogue<BM, BN, WGM, WGN, RB, CB, 256>(a, acc, m0, n0, mt, split, smem);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

@@ -658,7 +658,10 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
         if (nextb && fuse_on)
             fn = BnReduceFuse{A + nextb->y3, A + nextb->p3, (const unsigned char*)(A + nextb->mask), 0, sums.buf[sums.cur], false};
         // identity branch dz = dout * (out > 0) folded into the epilogue of the conv1 data gradient
-        RC(conv_dgrad_residual(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, gp, A + b.out, ws, st, nextb ? &fn : nullptr, a16 ? nullptr : m8));
+        // (the byte mask also in bf16 storage: reading the block output back for `out > 0` was a third full-size operand of
+        // this epilogue; DPFT_RES_MASK8_A16=0 = that form, A/B switch)
+        static const bool m8_a16 = getenv("DPFT_RES_MASK8_A16") == nullptr || atoi(getenv("DPFT_RES_MASK8_A16")) != 0;
+        RC(conv_dgrad_residual(&b.c1.d, dyv[cur], wt + b.c1.wt, dx, gp, A + b.out, ws, st, nextb ? &fn : nullptr, (a16 && !m8_a16) ? nullptr : m8));
     }
     if (next_reduced) *next_reduced = fn.applied;
     cur ^= 1;
