@@ -180,7 +180,7 @@ class DataParallelTrainer:
             dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
             local, stepped = (bool(v) for v in flag.tolist())
         else:
-            stepped = local = float(loss) > 0              # trainer.py:131 (host sync, as in the reference; compared on the host)
+            stepped = local = float(loss.detach()) > 0              # trainer.py:131 (host sync, as in the reference; compared on the host)
         if stepped:
             if not local:
                 loss = sum(v.sum() for v in output.values()) * 0.0

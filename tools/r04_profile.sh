@@ -128,3 +128,8 @@ DPFT_CONV_TABLE=$OUT/r04_conv_table_fp32.txt timeout 900 python bench.py > $OUT/
 timeout 600 python tools/loader_rate.py > $OUT/r04_loader_rate.json 2> $OUT/r04_loader_rate.err
 timeout 900 python tools/grad_gap_probe.py > $OUT/r04_grad_gap_probe_rerun.txt 2> /dev/null      # (profiles/r04_grad_gap_probe.txt also holds the four-other-seeds runs)
 tail -2 $OUT/r04_serial.log; grep "ms/step" $OUT/r04_plain.log; grep decoder_fwd $OUT/r04_decoder.log; head -c 600 $OUT/r04_roofline_from_rocprof.json
+# (10) vendor / ATen kernels inside one steady-state step (the whole-run statistics above also count the set-up copies and fills)
+bash /root/repo/tools/step_vendor_rows.sh > $OUT/r04_step_vendor_rows.txt 2>&1
+# (11) the loader rate again with the sample files read from disk (KRadarFolderDataset over a generated folder tree)
+FILES=1 timeout 600 python /root/repo/tools/loader_rate.py > /dev/null 2>&1      # (first run on a fresh box: the tree is written, the workers' imports are cold -- 134 vs 152 samples/s)
+FILES=1 timeout 600 python /root/repo/tools/loader_rate.py > $OUT/r04_loader_rate_files.json 2>> $OUT/r04_loader_rate.err

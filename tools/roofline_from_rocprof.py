@@ -74,7 +74,9 @@ def main():
            "algorithmic_gflop_per_step": gflop,
            "conv_family_tflops_main_only": gflop / ms["conv_main"], "conv_family_tflops": gflop / conv,
            "peak_tflops": peak, "frac_main_only": gflop / ms["conv_main"] / peak, "frac": gflop / conv / peak,
-           "total_kernel_ms_per_step": round(sum(ms.values()), 3)}
+           "total_kernel_ms_per_step": round(sum(ms.values()), 3),
+           "note_vendor_aten": "whole-run launches / steps: contains the set-up copies and fills (parameter flattening, bucket / arena "
+                               "initialisation, warm-up); inside one steady-state step: profiles/r04_step_vendor_rows.txt (tools/step_vendor_rows.sh)"}
     print(json.dumps(out, indent=1))
 
 
