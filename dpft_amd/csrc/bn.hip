@@ -200,6 +200,75 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
     }
 }
 
+// bf16 storage with 16-byte accesses (round 4): a lane handles 8 consecutive channels per access (the 4-channel form above
+// moves 8 bytes per lane and access; these passes are pure HBM streaming and ran at 2.8 TB/s), two accesses per tensor in
+// flight.  K % 8 == 0; same arithmetic per element as bn_act_kernel<__bf16>.
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void widen8(u32x4_t v, f32x4& lo, f32x4& hi) {
+    lo = f32x4{__uint_as_float(v[0] << 16), __uint_as_float(v[0] & 0xffff0000u), __uint_as_float(v[1] << 16), __uint_as_float(v[1] & 0xffff0000u)};
+    hi = f32x4{__uint_as_float(v[2] << 16), __uint_as_float(v[2] & 0xffff0000u), __uint_as_float(v[3] << 16), __uint_as_float(v[3] & 0xffff0000u)};
+}
+__device__ __forceinline__ u32x4_t narrow8(f32x4 lo, f32x4 hi) {
+    const bf16x4_t a = __builtin_convertvector(lo, bf16x4_t), b = __builtin_convertvector(hi, bf16x4_t);      // RNE, as stv4<__bf16>
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    const u32x2v ua = __builtin_bit_cast(u32x2v, a), ub = __builtin_bit_cast(u32x2v, b);
+    return u32x4_t{ua[0], ua[1], ub[0], ub[1]};
+}
+__device__ __forceinline__ unsigned relu_bits(f32x4 v) {
+    return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
+}
+__global__ __launch_bounds__(256) void bn_act16_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                        const float* __restrict__ res, const float* __restrict__ rbnp,
+                                                        int relu, float* __restrict__ out, float* __restrict__ out32,
+                                                        int64_t n8, int K8, unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
+    const int K = K8 * 8;
+    constexpr int U = 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const u32x4_t* __restrict__ y8 = reinterpret_cast<const u32x4_t*>(y);
+    const u32x4_t* __restrict__ r8 = reinterpret_cast<const u32x4_t*>(res);
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n8; i0 += U * stride) {
+        u32x4_t yv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n8) {
+                yv[u] = y8[i];
+                if (res) rv[u] = r8[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n8) break;
+            const int c = (int)(i % K8) * 8;
+            f32x4 v[2], r[2];
+            widen8(yv[u], v[0], v[1]);
+            if (res) widen8(rv[u], r[0], r[1]);
+            unsigned bits = 0;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                v[hh] = bn_apply4(v[hh], bnp, K, c + 4 * hh);
+                if (res) {
+                    if (rbnp) r[hh] = bn_apply4(r[hh], rbnp, K, c + 4 * hh);
+                    v[hh] += r[hh];
+                }
+                if (relu) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[hh][e] = fmaxf(v[hh][e], 0.f);
+                }
+                bits |= relu_bits(v[hh]) << (8 * hh);
+            }
+            reinterpret_cast<u32x4_t*>(out)[i] = narrow8(v[0], v[1]);
+            if (out32) {
+                reinterpret_cast<f32x4*>(out32)[2 * i] = v[0];
+                reinterpret_cast<f32x4*>(out32)[2 * i + 1] = v[1];
+            }
+            if (mask8) reinterpret_cast<unsigned short*>(mask8)[i] = (unsigned short)bits;      // one byte per 4 channels
+        }
+    }
+}
+
 // stem: maxpool3x3/s2/p1 of relu(bn(y)); one thread per (b,ph,pw,4 channels)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
@@ -533,6 +602,81 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// BN backward pass 2, bf16 storage with 16-byte accesses (see bn_act16_kernel); K % 8 == 0
+__global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const float* __restrict__ y, const float* __restrict__ dout,
+                                                              const float* __restrict__ outp, const float* __restrict__ mbnp,
+                                                              const float* __restrict__ bnp, const float* __restrict__ gamma,
+                                                              const float* __restrict__ sums, float* __restrict__ dy,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              int64_t n8, int K, float invM, float* __restrict__ zero_buf,
+                                                              int zero_n, const unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
+    const int K8 = K / 8;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < K; c += blockDim.x) {
+            if (dbeta) dbeta[c] = sums[c];
+            if (dgamma) dgamma[c] = sums[K + c];
+        }
+        for (int c = threadIdx.x; c < zero_n; c += blockDim.x) zero_buf[c] = 0.f;
+    }
+    constexpr int U = 2;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const u32x4_t* __restrict__ d8 = reinterpret_cast<const u32x4_t*>(dout);
+    const u32x4_t* __restrict__ y8 = reinterpret_cast<const u32x4_t*>(y);
+    const u32x4_t* __restrict__ o8 = reinterpret_cast<const u32x4_t*>(outp);
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n8; i0 += U * stride) {
+        u32x4_t dq[U], yq[U], oq[U];
+        unsigned mq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i < n8) {
+                dq[u] = d8[i];
+                yq[u] = y8[i];
+                if (mask8) mq[u] = reinterpret_cast<const unsigned short*>(mask8)[i];
+                else if (outp) oq[u] = o8[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = i0 + u * stride;
+            if (i >= n8) break;
+            const int c0 = (int)(i % K8) * 8;
+            f32x4 d[2], yv[2], o[2], r[2];
+            widen8(dq[u], d[0], d[1]);
+            widen8(yq[u], yv[0], yv[1]);
+            if (!mask8 && outp) widen8(oq[u], o[0], o[1]);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int c = c0 + 4 * hh;
+                if (mask8) {
+                    const unsigned mk = mq[u] >> (8 * hh);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[hh][e] = ((mk >> e) & 1u) ? d[hh][e] : 0.f;
+                } else if (outp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[hh][e] = o[hh][e] > 0.f ? d[hh][e] : 0.f;
+                } else if (mbnp) {
+                    const f32x4 a = bn_apply4(yv[hh], mbnp, K, c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) d[hh][e] = a[e] > 0.f ? d[hh][e] : 0.f;
+                }
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+                const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c);
+                const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
+                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float xh = (yv[hh][e] - mu[e]) * is[e];
+                    r[hh][e] = ga[e] * is[e] * (d[hh][e] - s0[e] * invM - xh * s1[e] * invM);
+                }
+            }
+            reinterpret_cast<u32x4_t*>(dy)[i] = narrow8(r[0], r[1]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void relu_bwd_kernel(const float* __restrict__ dout, const float* __restrict__ outp,
                                                         float* __restrict__ dz, int64_t n) {
     const int64_t n4 = n / 4;
@@ -692,7 +836,12 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
     DPFT_REQUIRE(y && bnp && out && M > 0 && K > 0 && K % 4 == 0, "bn_act: bad arguments (K=%d)", K);
     DPFT_REQUIRE(res || !res_bnp, "bn_act: res_bnp without res");
     const int64_t n4 = M * K / 4;
-    if (act16)
+    static const bool wide16 = getenv("DPFT_BN_WIDE16") == nullptr || atoi(getenv("DPFT_BN_WIDE16")) != 0;      // A/B switch
+    if (act16 && wide16 && K % 8 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)res & 15) == 0 &&
+        ((uintptr_t)mask8 & 1) == 0)
+        hipLaunchKernelGGL(bn_act16_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
+                           out32, n4 / 2, K / 8, mask8);
+    else if (act16)
         hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
                            res_bnp, relu, out, out32, n4, K / 4, mask8);
     else
@@ -808,7 +957,12 @@ int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* o
     // frozen (running-statistics) BatchNorm: mean and variance do not depend on the batch, so dy = gamma invstd d -- the
     // batch form with its two mean terms weighted by 1/M = 0; dgamma = sum d xhat and dbeta = sum d are the same sums
     const float invM = frozen ? 0.f : 1.0f / (float)M;
-    if (act16)
+    static const bool wide16 = getenv("DPFT_BN_WIDE16") == nullptr || atoi(getenv("DPFT_BN_WIDE16")) != 0;      // A/B switch
+    if (act16 && wide16 && K % 8 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
+        ((uintptr_t)out & 15) == 0 && ((uintptr_t)mask8 & 1) == 0)
+        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
+                           gamma, sums, dy, dgamma, dbeta, n4 / 2, K, invM, zero_buf, (int)zero_n, mask8);
+    else if (act16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
                            mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
     else

@@ -1304,3 +1304,27 @@ def test_set_loss_forward_with_total_equals_the_two_step_form():
     close(runs[0][1], (a5.double() * sel.double()).sum(), rtol=1e-5, what="total")
     assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])      # block order: repeatable
     assert int(scratch[:8].view(torch.int32).abs().sum()) == 0                               # ticket left clean
+
+
+def test_bf16_batchnorm_passes_with_16_byte_accesses_equal_the_8_byte_form(tmp_path):
+    """bn_act16_kernel / bn_bwd_apply16_kernel (8 channels per access, round 4) vs the 4-channel bf16 kernels
+    (DPFT_BN_WIDE16=0): the same arithmetic per element -- the forward features of a bf16 ResNet-50 plan are BIT-equal and so
+    are all gradients of the last block (before the first atomics-ordered reduction can differ); the rest agrees to the
+    run-to-run spread of identical programs."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for wide in ("0", "1"):
+        f = str(tmp_path / f"w{wide}.pt")
+        env = dict(os.environ, DPFT_BN_WIDE16=wide, DPFT_ACT16="2")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "backbone_grad_dump.py"), f, "resnet50", "2,96,160", "bf16"],
+                           env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[wide] = torch.load(f)
+    a, b = outs["0"], outs["1"]
+    for k in a["feats"]:
+        assert torch.equal(a["feats"][k], b["feats"][k]), k
+    err = {n: float((a["grads"][n].double() - b["grads"][n].double()).norm() / (a["grads"][n].double().norm() + 1e-30)) for n in a["grads"]}
+    last = {n: e for n, e in err.items() if n.startswith("body.layer4.2.conv3") or n.startswith("body.layer4.2.bn3")}
+    assert last and all(e == 0.0 for e in last.values()), last
+    assert all(e < 0.3 for e in err.values()), max(err.items(), key=lambda kv: kv[1])
