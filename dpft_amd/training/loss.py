@@ -13,6 +13,7 @@ B per-sample ``C.cpu()`` syncs (assigner.py:135) are one padded device->host cop
 """
 from __future__ import annotations
 
+import os
 from typing import Any, Dict, List, Tuple
 
 import numpy as np
@@ -192,28 +193,34 @@ def _pack_targets_hip(targets, counts, ncls, dev, Mmax):
 _loss_scratch: Dict[torch.device, torch.Tensor] = {}      # ticket + partial sums of dpft_set_loss_fwd_total_f32 (zero between launches)
 
 
+def _set_loss_launch(cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel):
+    """(losses5, total) of dpft_set_loss_fwd_total_f32 -- shared by the autograd Function and the trainer's direct chain."""
+    import ctypes as C
+    from dpft_amd.hip.lib import lib, stream
+    B, N, ncls = cls.shape
+    Mmax = gt_box.shape[1]
+    losses = torch.empty(5, dtype=torch.float32, device=cls.device)
+    total = torch.empty((), dtype=torch.float32, device=cls.device)
+    w = (C.c_float * 5)(*weights5)
+    # one launch: the five terms (per-block partial sums added in block order by the last block) and the total of the
+    # configured ones -- instead of a cleared output + atomics + a dot product, and of select x5 / stack / sum in
+    # autograd, whose backward alone is a dozen tiny launches between the step's two host syncs
+    need = int(lib.dpft_set_loss_scratch_floats(B, N))
+    scratch = _loss_scratch.get(cls.device)
+    if scratch is None or scratch.numel() < need:
+        scratch = _loss_scratch[cls.device] = torch.zeros(max(need, 1024), dtype=torch.float32, device=cls.device)
+    lib.call("dpft_set_loss_fwd_total_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+             gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
+             sel.data_ptr(), scratch.data_ptr(), losses.data_ptr(), total.data_ptr(), B, N, Mmax, ncls, stream())
+    return losses, total
+
+
 class _SetLossFn(torch.autograd.Function):
     """dpft_set_loss_fwd/bwd_f32: the five batch-reduced, weighted criterion terms for fixed assignments."""
 
     @staticmethod
     def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel):
-        import ctypes as C
-        from dpft_amd.hip.lib import lib, stream
-        B, N, ncls = cls.shape
-        Mmax = gt_box.shape[1]
-        losses = torch.empty(5, dtype=torch.float32, device=cls.device)
-        total = torch.empty((), dtype=torch.float32, device=cls.device)
-        w = (C.c_float * 5)(*weights5)
-        # one launch: the five terms (per-block partial sums added in block order by the last block) and the total of the
-        # configured ones -- instead of a cleared output + atomics + a dot product, and of select x5 / stack / sum in
-        # autograd, whose backward alone is a dozen tiny launches between the step's two host syncs
-        need = int(lib.dpft_set_loss_scratch_floats(B, N))
-        scratch = _loss_scratch.get(cls.device)
-        if scratch is None or scratch.numel() < need:
-            scratch = _loss_scratch[cls.device] = torch.zeros(max(need, 1024), dtype=torch.float32, device=cls.device)
-        lib.call("dpft_set_loss_fwd_total_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
-                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
-                 sel.data_ptr(), scratch.data_ptr(), losses.data_ptr(), total.data_ptr(), B, N, Mmax, ncls, stream())
+        losses, total = _set_loss_launch(cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel)
         ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts, sel)
         ctx.meta = (weights5, float(alpha))
         ctx.mark_non_differentiable(losses)
@@ -302,14 +309,22 @@ class Loss(nn.modules.loss._Loss):
         if pin is None or pin.numel() < n_pack:
             pin = self.__dict__["_pin_i32"] = torch.empty(max(n_pack, 4096), dtype=torch.int32).pin_memory()
         packed = pin.numpy()[:n_pack]                                # assignments | pair counts: ONE upload, from pinned memory
-        packed[:] = -1
-        match = packed[:B * Mmax * 2].reshape(B, Mmax, 2)
-        for b, m in enumerate(counts):
-            if m:
-                i, j = linear_sum_assignment(host[b, :, :m])
-                match[b, :len(i), 0], match[b, :len(i), 1] = i, j
-                counts[b] = len(i)           # min(N, m) assigned pairs
-        packed[B * Mmax * 2:] = counts
+        # the whole batch in one host call (dpft_lsap_batch_f32: scipy's algorithm restated in C, same pairs in the same order --
+        # tests/test_host.py holds it to scipy): this sits in the one window of the step in which the GPU waits for the host
+        if os.environ.get("DPFT_LSAP_C", "1") != "0":
+            cnt = np.asarray(counts, dtype=np.int32)
+            if lib.dpft_lsap_batch_f32(host.ctypes.data, B, N, Mmax, cnt.ctypes.data, packed.ctypes.data,
+                                       packed[B * Mmax * 2:].ctypes.data) != 0:
+                raise ValueError("assignment failed: " + lib.dpft_last_error().decode())      # (scipy raises ValueError as well)
+        else:      # A/B switch: scipy per sample
+            packed[:] = -1
+            match = packed[:B * Mmax * 2].reshape(B, Mmax, 2)
+            for b, m in enumerate(counts):
+                if m:
+                    i, j = linear_sum_assignment(host[b, :, :m])
+                    match[b, :len(i), 0], match[b, :len(i), 1] = i, j
+                    counts[b] = len(i)           # min(N, m) assigned pairs
+            packed[B * Mmax * 2:] = counts
         packed_t = torch.empty(n_pack, dtype=torch.int32, device=dev)
         packed_t.copy_(pin[:n_pack], non_blocking=True)      # (the pinned buffer is rewritten only after the next step's sync)
         match_t, counts_m = packed_t[:B * Mmax * 2].view(B, Mmax, 2), packed_t[B * Mmax * 2:]
@@ -320,8 +335,7 @@ class Loss(nn.modules.loss._Loss):
                                                        dtype=torch.float32, device=dev)
         losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel)
         self.__dict__["_last"] = (cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel, total)
-        terms = losses5.unbind(0)                                                            # views, for logging
-        batch_losses = {k: terms[self._TERMS.index(k)] for k in self.loss_weights}
+        batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}        # views, for logging
         return total, batch_losses
 
     def backward_into(self, total: torch.Tensor, dcenter, dsize, dangle, dcls) -> bool:

@@ -562,6 +562,16 @@ int dpft_match_cost_f32(const float* cls, const float* center, const float* size
                         dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * HOST function (no launch): the assignments of a batch, cost (B,N,Mmax) fp32 in host memory as dpft_match_cost_f32 wrote it,
+ * sample b restricted to its first counts[b] targets.  match (B,Mmax,2) int32 = (query, target) pairs by ascending query
+ * index, -1 padded; n_matched[b] = min(N, counts[b]).  = scipy.optimize.linear_sum_assignment per sample
+ * (src/dprt/training/loss.py:305 through the assigner; scipy is third-party: its published algorithm -- Crouse 2016, shortest
+ * augmenting paths, double precision -- restated in dpft_amd/csrc/cabi.cpp).  Non-finite or infeasible costs are an error.
+ * ---------------------------------------------------------------------------------------- */
+int dpft_lsap_batch_f32(const float* cost, int32_t B, int32_t N, int32_t Mmax, const int32_t* counts, int32_t* match,
+                        int32_t* n_matched);
+
+/* ------------------------------------------------------------------------------------------
  * SetCriterion + batch reduction 'mean' (src/dprt/training/loss.py:17-60 focal loss with the raw-logit p_t,
  * :176-373 criterion, :486-564 weighting / reduction) for given assignments.
  * losses5 = batch-reduced, weighted (total_class, object_class, center, size, angle); match (B,Mmax,2) int32 =

@@ -362,3 +362,53 @@ def test_scheduler_factory_matches_torch():
           "schedulers": [{"name": "ExponentialLR", "gamma": 0.5}, {"name": "ConstantLR", "factor": 0.1, "total_iters": 1}]}
     assert lrs(ch)[:3] == pytest.approx([0.1, 0.5, 0.25])
     assert seq["schedulers"][0]["name"] == "ConstantLR"      # the config is not consumed (the reference pops from it)
+
+
+def test_c_assignment_solver_returns_scipys_pairs_in_scipys_order():
+    """dpft_lsap_batch_f32 (host code of the matcher, dpft_amd/csrc/cabi.cpp) vs scipy.optimize.linear_sum_assignment -- the
+    call the reference makes per sample (training/loss.py:305): same pairs, same order, on random rectangular problems in both
+    orientations, with many and with heavy ties, empty samples, and the -1 padding; non-finite costs are refused."""
+    import numpy as np
+    from scipy.optimize import linear_sum_assignment
+    from dpft_amd.hip.lib import lib
+    rng = np.random.default_rng(0)
+
+    def run(cost, counts):
+        B, N, Mmax = cost.shape
+        match = np.empty((B, Mmax, 2), np.int32)
+        nm = np.empty(B, np.int32)
+        cnt = np.asarray(counts, np.int32)
+        return lib.dpft_lsap_batch_f32(cost.ctypes.data, B, N, Mmax, cnt.ctypes.data, match.ctypes.data, nm.ctypes.data), match, nm
+
+    for trial in range(1200):
+        B, N, Mmax = int(rng.integers(1, 5)), int(rng.integers(1, 40)), int(rng.integers(1, 12))
+        cost = rng.standard_normal((B, N, Mmax)).astype(np.float32)
+        if trial % 4 == 1:
+            cost = np.round(cost * 2) / 2
+        elif trial % 4 == 2:
+            cost = np.abs(cost) * 1e3
+        elif trial % 4 == 3:
+            cost[:] = rng.integers(0, 3, cost.shape)
+        counts = rng.integers(0, Mmax + 1, B)
+        rc, match, nm = run(cost, counts)
+        assert rc == 0
+        for b in range(B):
+            m = int(counts[b])
+            if m == 0:
+                assert nm[b] == 0 and (match[b] == -1).all()
+                continue
+            i, j = linear_sum_assignment(cost[b, :, :m])
+            k = len(i)
+            assert nm[b] == k and (match[b, :k, 0] == i).all() and (match[b, :k, 1] == j).all() and (match[b, k:] == -1).all(), (trial, b)
+    cost = rng.standard_normal((4, 400, 7)).astype(np.float32)          # the training step's shape
+    rc, match, nm = run(cost, [7, 3, 0, 1])
+    assert rc == 0 and list(nm) == [7, 3, 0, 1]
+    for b, m in enumerate([7, 3, 0, 1]):
+        if m:
+            i, j = linear_sum_assignment(cost[b, :, :m])
+            assert (match[b, :m, 0] == i).all() and (match[b, :m, 1] == j).all()
+    cost[1, 5, 2] = np.nan
+    assert run(cost, [7, 3, 0, 1])[0] != 0 and b"non-finite" in lib.dpft_last_error()
+    cost[1, 5, 2] = 0.0
+    cost[3, 7, 6] = np.inf                                               # beyond the sample's count: not looked at
+    assert run(cost, [7, 3, 0, 1])[0] == 0
