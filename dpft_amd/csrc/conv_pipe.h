@@ -29,15 +29,7 @@
 
 namespace dpft {
 
-template <typename Fn, int... I>
-__device__ __forceinline__ void static_for_impl(Fn&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant
-template <int N, typename Fn>
-__device__ __forceinline__ void static_for(Fn&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
+// (static_for: conv_core.h)
 
 // B16: BOTH operands are bf16 in memory (activations in bf16 storage, dpft_conv_desc.act16 = 2: the caller also passes
 // bf16 weights) -- the same kernel with 2-byte elements: a 16-byte chunk is 8 reduction indices, a K-group is 16 of them

@@ -15,7 +15,7 @@
 namespace dpft {
 
 struct ConvRef {
-    dpft_conv_desc d;
+    dpft_conv_desc d{};
     int w;  // index into the conv table
     size_t wt = 0;  // float offset (inside the wt region) of this conv's transposed weights during its stage's backward
     size_t w16 = 0; // act16 = 2: float offset (in the arena) of this conv's bf16 shadow weights [K][taps][C]
@@ -97,8 +97,7 @@ struct ResnetPlan {
 static size_t align64(size_t f) { return (f + 63) & ~(size_t)63; }
 
 static dpft_conv_desc mk(int B, int H, int W, int C, int K, int k, int s, int p) {
-    dpft_conv_desc d;
-    d.act16 = 0;
+    dpft_conv_desc d{};      // (zero: fp32 storage, no operand planes)
     d.B = B; d.H = H; d.W = W; d.C = C; d.K = K; d.kh = k; d.kw = k; d.stride = s; d.pad = p;
     d.OH = (H + 2 * p - k) / s + 1;
     d.OW = (W + 2 * p - k) / s + 1;

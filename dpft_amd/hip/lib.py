@@ -21,7 +21,8 @@ class HipLibraryError(RuntimeError):
 
 
 class ConvDesc(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "K", "kh", "kw", "stride", "pad", "OH", "OW", "act16")]
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "K", "kh", "kw", "stride", "pad", "OH", "OW", "act16")] + \
+               [("a_planes", C.c_void_p), ("w_planes", C.c_void_p)]
 
 
 class Pyramid(C.Structure):
@@ -96,6 +97,7 @@ SIGNATURES = {
     "dpft_conv2d_workspace_bytes": (_L, [_DESC]),
     "dpft_conv2d_workspace_header_bytes": (_L, []),
     "dpft_conv2d_workspace_init": (_I, [_P, _P]),
+    "dpft_split_planes_f32": (_I, [_P, _P, _L, _P]),
     "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
     "dpft_conv_set_compute": (_I, [_I]),
     "dpft_conv_get_compute": (_I, []),

@@ -152,17 +152,42 @@ def conv_problem(B, H, W, Cin, K, kh, kw, stride, pad) -> Conv:
     return c
 
 
-def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False, out=None):
+def split_planes(t: torch.Tensor) -> torch.Tensor:
+    """fp32 tensor -> its three bf16 planes, shape (3, *t.shape): t == planes.float().sum(0) exactly
+    (dpft_split_planes_f32; the operand format of the split convolution kernels, conv_x3.hip)."""
+    t = t.contiguous()
+    out = torch.empty((3,) + tuple(t.shape), dtype=torch.bfloat16, device=t.device)
+    lib.call("dpft_split_planes_f32", ptr(t), ptr(out), t.numel(), stream())
+    return out
+
+
+class _with_planes:
+    """Puts (a_planes, w_planes) into a cached problem's descriptor for the duration of one call."""
+
+    def __init__(self, cv, planes):
+        self.cv, self.planes = cv, planes
+
+    def __enter__(self):
+        if self.planes is not None:
+            self.cv.desc.a_planes, self.cv.desc.w_planes = ptr(self.planes[0]), ptr(self.planes[1])
+
+    def __exit__(self, *exc):
+        self.cv.desc.a_planes = self.cv.desc.w_planes = None
+
+
+def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False, out=None, planes=None):
     """x (B,H,W,C) contiguous; w physical [K][kh][kw][C]. pro = (bn_block[4][C], relu) or None.
-    Returns y (B,OH,OW,K) and the per-tile stats tensor (or None).  ``out``: write y into this buffer."""
+    Returns y (B,OH,OW,K) and the per-tile stats tensor (or None).  ``out``: write y into this buffer.
+    ``planes`` = (split_planes(x), split_planes(w)): the GEMM reads these instead (bf16 matrix cores, fp32-grade result)."""
     y = out if out is not None else torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
     if out is not None and (tuple(out.shape) != (cv.B, cv.OH, cv.OW, cv.K) or not out.is_contiguous() or out.dtype != torch.float32):
         raise ValueError("conv_fwd: the output buffer does not match the problem")
     stats = torch.empty((cv.tiles, 2, cv.K), dtype=torch.float32, device=x.device) if want_stats else None
     ws = workspace(cv.ws_bytes, x.device)
     pb, prelu = (pro[0], int(pro[1])) if pro is not None else (None, 0)
-    lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(pb), prelu,
-             ptr(y), ptr(stats), ptr(ws), stream())
+    with _with_planes(cv, planes):
+        lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(pb), prelu,
+                 ptr(y), ptr(stats), ptr(ws), stream())
     return y, stats
 
 
@@ -176,18 +201,20 @@ def conv_fwd_bnact(cv: Conv, x, w, out_bn, relu=True, residual=None):
     return y
 
 
-def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False):
-    """dx (B,H,W,C); w_t physical [C][kh][kw][K]."""
+def conv_dgrad(cv: Conv, dy, w_t, out=None, accumulate=False, planes=None):
+    """dx (B,H,W,C); w_t physical [C][kh][kw][K].  ``planes`` = (split_planes(dy), split_planes(w_t))."""
     if out is None:
         out = torch.empty((cv.B, cv.H, cv.W, cv.C), dtype=torch.float32, device=dy.device)
         accumulate = False
     ws = workspace(cv.ws_bytes, dy.device)
-    lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate), ptr(ws),
-             stream())
+    with _with_planes(cv, planes):
+        lib.call("dpft_conv2d_nhwc_dgrad_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate), ptr(ws),
+                 stream())
     return out
 
 
-def conv_dgrad_bn_reduce(cv: Conv, dy, w_t, bn_y, bn_block, sums, bn_mask8=None, residual=None, out=None, accumulate=False):
+def conv_dgrad_bn_reduce(cv: Conv, dy, w_t, bn_y, bn_block, sums, bn_mask8=None, residual=None, out=None, accumulate=False,
+                         planes=None):
     """The launch plan's fused data gradient (dpft_conv2d_nhwc_dgrad_bn_reduce_f32): dx, and -- when the launch could carry
     it (returned flag) -- the BatchNorm-backward sums of the layer whose dout dx is added into ``sums`` [2][C].
     ``bn_mask8`` None = the ReLU sits directly behind that BatchNorm (mask = bn(bn_y) > 0).
@@ -198,9 +225,10 @@ def conv_dgrad_bn_reduce(cv: Conv, dy, w_t, bn_y, bn_block, sums, bn_mask8=None,
     ws = workspace(cv.ws_bytes, dy.device)
     applied = C.c_int32(0)
     rs, ro, rm = residual if residual is not None else (None, None, None)
-    lib.call("dpft_conv2d_nhwc_dgrad_bn_reduce_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate),
-             ptr(rs), ptr(ro), ptr(rm), ptr(bn_y), ptr(bn_block), ptr(bn_mask8), int(bn_mask8 is None), ptr(sums),
-             C.addressof(applied), ptr(ws), stream())
+    with _with_planes(cv, planes):
+        lib.call("dpft_conv2d_nhwc_dgrad_bn_reduce_f32", C.byref(cv.desc), ptr(dy), ptr(w_t), ptr(out), int(accumulate),
+                 ptr(rs), ptr(ro), ptr(rm), ptr(bn_y), ptr(bn_block), ptr(bn_mask8), int(bn_mask8 is None), ptr(sums),
+                 C.addressof(applied), ptr(ws), stream())
     return out, bool(applied.value)
 
 

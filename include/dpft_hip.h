@@ -59,6 +59,15 @@ typedef struct dpft_conv_desc {
                               *    4 channels = 8 bytes per loader lane, BatchNorm statistics still from the fp32
                               *    accumulators); weights, weight gradients, BN blocks and statistics stay fp32.
                               *    Needs C % 64 == 0 and K % 64 == 0; the pointers are still declared const float*.  */
+    /* Round 5: the GEMM operands as THREE bf16 PLANES (dpft_split_planes_f32: an fp32 value is exactly the sum of three bf16
+     * terms; plane p of element e at base + 2 (p E + e) bytes, E = the tensor's element count).  When BOTH are given and the
+     * problem takes the C % 64 == 0 path without an operand prologue, the forward / data-gradient GEMM reads its operands
+     * from them and multiplies on the bf16 matrix cores (six term products, fp32 accumulation: fp32-grade results at a
+     * multiple of the fp32 MFMA rate, dpft_amd/csrc/conv_x3.hip).  a_planes = planes of the A operand (x of the forward,
+     * dy of the data gradient), w_planes = planes of the weight tensor passed as w / w_t.  The fp32 tensors are still
+     * required (fallback paths, epilogues).  NULL = fp32 operands (zero-initialise the descriptor). */
+    const void* a_planes;
+    const void* w_planes;
 } dpft_conv_desc;
 
 /* bytes of workspace dpft_conv2d_* may need for this problem: a ticket header + split-K partial slabs.
@@ -70,6 +79,9 @@ typedef struct dpft_conv_desc {
 int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d);
 int64_t dpft_conv2d_workspace_header_bytes(void);
 int dpft_conv2d_workspace_init(void* workspace, dpft_stream_t stream);
+/* fp32 tensor of n elements (n % 4 == 0) -> three bf16 planes [3][n]: plane 0 = RNE bf16 of the value, plane 1 = RNE bf16 of
+ * what plane 0 left, plane 2 = the (exact) rest.  src = plane0 + plane1 + plane2 exactly. */
+int dpft_split_planes_f32(const float* src, void* planes, int64_t n, dpft_stream_t stream);
 /* number of M-tiles the forward kernel uses for its fused BN-statistics epilogue
  * (rows of the `stats` buffer: stats is [mtiles][2][K] floats = per-tile mean and M2);
  * *tile_rows receives the tile height so the caller can recover per-tile counts. */

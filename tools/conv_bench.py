@@ -19,11 +19,15 @@ def run(spec, reps=20, pro=True, stats=True):
     dy = torch.randn(B, cv.OH, cv.OW, K, device="cuda")
     bnp = torch.stack((torch.zeros(C), torch.ones(C), torch.zeros(C), torch.ones(C))).cuda() if (pro and C % 32 == 0) else None
     wt = ops.weight_transpose(w)
+    planes = os.environ.get("PLANES") == "1" and C % 64 == 0 and kind != "wgrad"      # operands as three bf16 planes (conv_x3.hip)
+    if planes:
+        xp, wp, dyp, wtp = ops.split_planes(x), ops.split_planes(w), ops.split_planes(dy), ops.split_planes(wt)
+        bnp = None
     def go():
         if kind == "fwd":
-            ops.conv_fwd(cv, x, w, pro=(bnp, True) if bnp is not None else None, want_stats=stats)
+            ops.conv_fwd(cv, x, w, pro=(bnp, True) if bnp is not None else None, want_stats=stats, planes=(xp, wp) if planes else None)
         elif kind == "dgrad":
-            ops.conv_dgrad(cv, dy, wt)
+            ops.conv_dgrad(cv, dy, wt, planes=(dyp, wtp) if planes else None)
         else:
             ops.conv_wgrad(cv, x, dy, pro=(bnp, True) if bnp is not None else None)
     for _ in range(3):
