@@ -45,6 +45,9 @@ def parse():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "f32x3"],
                     help="f32 = the reference's arithmetic (BASELINE metric, default); bf16 = mixed precision of "
                          "BASELINE.json configs[4]: bf16 operands / fp32 accumulation in the conv GEMMs")
+    ap.add_argument("--no-split", action="store_true",
+                    help="f32 only: v_mfma_f32_32x32x2_f32 everywhere (default: the big multi-tap conv GEMMs run as 3 x bf16 split "
+                         "products on the bf16 matrix cores -- fp32 in, fp32 out, dpft_conv_set_split)")
     ap.add_argument("--no-graphs", action="store_true", help="do not replay the decoder from hipGraphs")
     ap.add_argument("--bucket-mb", type=float, default=None, help="gradient bucket size (default 25 MiB)")
     ap.add_argument("--comm-dtype", default=None, choices=[None, "fp32", "bf16"], help="wire format of the gradient all-reduce")
@@ -252,6 +255,8 @@ def main():
         cfg["computing"]["conv_compute"] = "bf16x3"
     torch.manual_seed(cfg["computing"]["seed"])
     model = build("dprt", cfg)
+    if args.no_split:
+        ops.conv_set_split(False)
     trainer = DataParallelTrainer(model, cfg, device, bucket_mb=args.bucket_mb, comm_dtype=args.comm_dtype,
                                   force_collectives=args.force_collectives)
     inputs = cfg["model"]["inputs"]
@@ -338,7 +343,6 @@ def main():
         # two more views of the same launch log: FLOP-weighted mean of the per-shape rates (SURVEY 8d wording), and
         # the camera encoder alone (94 % of the FLOPs; the radar encoders' tiny GEMMs are launch-bound and, in the
         # real step, hidden behind the camera on their own streams -- in this serialized step they count in full)
-        flop_weighted = sum(v[0] * (v[0] / v[1]) for v in shapes.values()) / max(tot_f, 1.0)
         cam_w = {910, 455, 228, 114, 57, 29}          # widths of the camera feature maps (input of the conv)
         cam = [v for key, v in shapes.items() if key[3] in cam_w]
         cam_f, cam_t = sum(v[0] for v in cam), sum(v[1] for v in cam)
@@ -347,7 +351,7 @@ def main():
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for name in ("r04_conv_traffic_pmc.json", "r03_conv_traffic_pmc.json", "r02_conv_traffic_pmc.json"):
+        for name in ("r05_conv_traffic_pmc.json", "r04_conv_traffic_pmc.json", "r03_conv_traffic_pmc.json"):
             if os.path.exists(os.path.join(prof_dir, name)):
                 with open(os.path.join(prof_dir, name)) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -356,7 +360,14 @@ def main():
         # mixed precision: priced against the dense bf16 MFMA peak (2.5 PF) -- the kernels are then bound by their operand
         # path (global loads -> LDS -> fragments, two barriers per 64-deep K-step), not by the matrix pipe
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
-        family = {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)", "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
+        split = args.dtype == "f32" and ops.conv_get_split()
+        # share of the conv flops that ran as split products: forward / stride-1 data gradient of multi-tap filters, >= 2 GFLOP,
+        # C % 64 == 0 (conv.hip: choose_tile) -- shape key = kind, B, H, W, C, K, k, s
+        split_f = sum(v[0] for key, v in shapes.items()
+                      if key[0] in ("fwd", "dgrad") and key[6] > 1 and key[4] % 64 == 0 and (key[0] == "fwd" or key[7] == 1)
+                      and v[0] / max(v[2], 1) >= 2e9) if split else 0.0
+        family = {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" + ("; multi-tap filters >= 2 GFLOP: 3 x bf16 split, six v_mfma_f32_32x32x16_bf16 "
+                         "term products per fp32 product, fp32 accumulation (conv_x3.hip)" if split else ""), "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
                   "f32x3": "3 x bf16 split products on the bf16 MFMA, fp32 accumulation"}[args.dtype]
         # (round 3: the data-gradient launches also carry the BatchNorm-backward reduction of the layer they feed; its
         # time is inside their brackets although it is not conv work)
@@ -381,14 +392,23 @@ def main():
                 "timing": "HIP events around every conv call of one serialized step, on the launch stream (raw bracket time)",
                 "frac_main_kernels_only": tot_f / tot_t / 1e12 / peak,
                 "event_bracket_overhead_us": 1e6 * ovh,
-                "rocprof_summary": ("profiles/r03_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py)"
-                                    if args.dtype == "f32" and B == 4 else None),
+                "rocprof_summary": ("profiles/r05_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py -> "
+                                    "profiles/r05_roofline_from_rocprof.json)" if args.dtype == "f32" and B == 4 else None),
+                "precision": ("fp32 (3 x bf16 split, 6 products) on the multi-tap conv GEMMs >= 2 GFLOP, fp32 MFMA elsewhere: fp32 tensors "
+                              "in and out, error vs fp64 below the fp32 MFMA path's on every conv of the step "
+                              "(tests/test_gpu_conv_table.py)" if split else
+                              {"f32": "fp32 MFMA", "bf16": "bf16 operands, fp32 accumulation", "f32x3": "3 x bf16 split"}[args.dtype]),
+                "split_share_of_conv_flops": (split_f / tot_f) if tot_f > 0 else None,
+                "split_peak_tflops": PEAK_BF16_MFMA_TFLOPS / 6.0,
+                "frac_of_split_peak": tot_f / raw_t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                "frac_note": "frac prices ALL conv flops of the step against the fp32 MFMA peak (157.3 TF), whichever pipe ran them; "
+                             "frac_of_split_peak prices the same flops against 2500 / 6 = 416.7 TF, what six bf16 term products per "
+                             "fp32 product could deliver",
                 "peak_note": "157.3 TF = 2.4 GHz nominal; under sustained fp32 MFMA load the chip clocks ~2.16 GHz "
                              "(64-cycle MFMA measured at 71 nominal cycles, tools/probes/mfma_valu_overlap.hip), i.e. ~142 TF "
                              "is what the matrix pipe delivers; frac is priced against the nominal peak",
                 "per_kind_tflops": {k: v[0] / (v[1] + ovh * v[2]) / 1e12 for k, v in per_kind.items()},
-                "frac_flop_weighted": flop_weighted / 1e12 / peak,
-                "frac_camera_encoder": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
+                "conv_frac_camera_only": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
                 "camera_encoder_share_of_conv_time": (cam_t / tot_t) if tot_t > 0 else None}
 
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
@@ -423,7 +443,7 @@ def main():
         dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
         # counter traffic of the decoder kernels (tools/r03_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
         dec_traffic, dec_src = None, None
-        for pname in ("r04_decoder_traffic_pmc.json", "r03_decoder_traffic_pmc.json", "r02_decoder_traffic_pmc.json"):
+        for pname in ("r05_decoder_traffic_pmc.json", "r04_decoder_traffic_pmc.json", "r03_decoder_traffic_pmc.json"):
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)
             if os.path.exists(pmc):
                 with open(pmc) as f:
@@ -442,7 +462,7 @@ def main():
                "timing": f"{reps} back-to-back dpft_decoder_forward_f32 calls between two HIP events on the launch stream"}
         # second accounting: the SUM of the decoder kernels' durations per forward in the committed rocprofv3
         # summary (tools/roofline_from_rocprof.py --decoder) -- a constant read from profiles/, named in the line
-        for pname in ("r04_decoder_roofline_from_rocprof.json",):
+        for pname in ("r05_decoder_roofline_from_rocprof.json", "r04_decoder_roofline_from_rocprof.json"):
             pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)
             if os.path.exists(pj) and args.dtype == "f32" and B == 4:
                 with open(pj) as f:
@@ -450,6 +470,7 @@ def main():
                 dec["rocprof_kernel_sum_us"] = rj.get("kernel_sum_us_per_forward")
                 dec["frac_rocprof_kernel_sum"] = rj.get("frac")
                 dec["rocprof_summary"] = "profiles/" + pname + " <- " + str(rj.get("source"))
+                break
         # ---- training decoder (forward + backward graphs of the fusion decoder, SURVEY 8d "Backward") ----------------
         # unit = one IMPFusion forward + backward at B: bytes_fwd + bytes_bwd, bytes_bwd = bytes_fwd + the gradient
         # pyramids written once.  Timed as `reps` replays of the trainer's captured forward and backward graphs
@@ -485,6 +506,14 @@ def main():
                                    "and backward hipGraphs, dropout on)",
                          "timing": f"{tr_reps} replays of the captured forward + backward graphs between two HIP events"}
 
+    if rank == 0 and roof is not None:      # the other kernels' fractions inside the record the driver parses
+        if dec is not None:
+            roof["decoder_frac"] = dec["frac"]
+            roof["decoder_kernel_sum_frac"] = dec.get("frac_rocprof_kernel_sum")
+            roof["decoder_fwd_us"] = dec["decoder_fwd_us"]
+        if dec_train is not None:
+            roof["decoder_train_frac"] = dec_train["frac"]
+            roof["decoder_train_fwd_bwd_us"] = dec_train["decoder_train_fwd_bwd_us"]
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(args)
@@ -500,7 +529,10 @@ def main():
                                    "(camera 512x910x3 ResNet-101, radar BEV 256x107x6 + front 37x107x6 ResNet-50, "
                                    "FPN->16ch, IMPFusion 4 it x 3 views, Hungarian set loss, AdamW)",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "precision": {"f32": "fp32 (reference arithmetic)",
+                       "precision": {"f32": "fp32 (reference arithmetic; fp32 tensors and fp32 results everywhere)" +
+                                            ("" if args.no_split else ": the big multi-tap conv GEMMs form each fp32 product from six exact bf16 "
+                                             "term products on the bf16 matrix cores (3 x bf16 split, fp32 accumulation), the rest runs on "
+                                             "the fp32 MFMA"),
                                      "bf16": "mixed (BASELINE.json configs[4]): bf16 operands / fp32 accumulation in the conv GEMMs; "
                                              "activations of the large (camera) encoder bodies stored as bf16 in HBM, BatchNorm "
                                              "statistics / accumulators / master weights / decoder / loss / AdamW fp32",

@@ -96,6 +96,7 @@ struct TransposeBatch {      // [K][taps][C] -> [C][taps][K] of up to MAX weight
     }
 };
 int weight_transpose_batch(const TransposeBatch& tb, dpft_stream_t stream);
+int conv_mode_key();          // conv.hip: compute mode + split switch (what tile selection depends on)
 bool profiling_active();      // conv.hip: true between dpft_profile_start / dpft_profile_stop
 // zero `bytes` (multiple of 4) of device memory with a KERNEL (conv.hip).  hipMemsetAsync becomes a memset node when the
 // call is captured into a hipGraph, and replayed backward stages with memset nodes intermittently produced garbage

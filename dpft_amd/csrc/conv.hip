@@ -1365,6 +1365,7 @@ namespace dpft {
 struct TileChoice {
     int bm, bn, splits;
     bool vec;
+    bool x3 = false;      // chosen for the 3 x bf16 split kernels (compute mode 2, multi-tap filters)
 };
 
 // Workspace layout (round 4): [ticket header: kWsHeader bytes][split-K partial slabs].  The header holds one int per output
@@ -1387,6 +1388,16 @@ static int initial_compute_mode() {      // DPFT_CONV_COMPUTE=fp32|bf16|bf16x3 p
     return !strcmp(e, "bf16") ? 1 : (!strcmp(e, "bf16x3") ? 2 : 0);
 }
 static int g_conv_bf16 = initial_compute_mode();
+// fp32 mode: the big multi-tap GEMMs (3x3 / 7x7 filters over C % 64 == 0 channels, >= 2 GFLOP) run as 3 x bf16 split products on
+// the bf16 matrix cores (conv_x3.hip) -- fp32 operands, fp32 results, error against fp64 BELOW the fp32 MFMA's on every
+// shape of the step (tests/test_gpu_conv_table.py).  dpft_conv_set_split(0) / DPFT_CONV_SPLIT=0: fp32 MFMA everywhere.
+static int g_conv_split = getenv("DPFT_CONV_SPLIT") ? atoi(getenv("DPFT_CONV_SPLIT")) != 0 : 1;
+static int g_split_override = -1;      // workspace sizing: both answers
+int conv_mode_key();
+static bool split_on() {
+    if (g_split_override >= 0) return g_split_override != 0;
+    return g_conv_bf16 == 2 || (g_conv_bf16 == 0 && g_conv_split);
+}
 
 // `taps` = kh * kw of the problem (1 = unknown / not asked): in compute mode 2 the filters with more than one tap -- the
 // deep reductions -- take the 3 x bf16 split kernels (conv_x3.hip), whose best tiles differ: their operand stream
@@ -1395,23 +1406,20 @@ static int g_conv_bf16 = initial_compute_mode();
 static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
     TileChoice t;
     t.vec = (C % BKV) == 0;
-    if (g_conv_bf16 == 2 && taps > 1 && t.vec && getenv("DPFT_FORCE_TILE") == nullptr) {
+    t.x3 = false;
+    // (only where the GEMM is big enough to be bound by the matrix pipe: the latency-sized problems of the radar encoders
+    // measured 2x SLOWER on the 128-row tiles, profiles/r05_x3_table.txt)
+    if (split_on() && taps > 1 && t.vec && getenv("DPFT_FORCE_TILE") == nullptr &&
+        2.0 * M * N * (double)ksteps * BKV >= 2e9) {
+        t.x3 = true;
         if (N >= 128) {
             t.bm = 128; t.bn = 128;
             const int64_t nwg = (int64_t)cdiv(M, 128) * cdiv(N, 128);
-            int sp = (int)((kNumCU * 15 / 16 + nwg - 1) / nwg);      // ~240 workgroups
-            sp = std::max(1, std::min(sp, 8));
+            int sp = (int)std::max<int64_t>(1, std::min<int64_t>(8, kNumCU / nwg));      // at most one workgroup per CU: one round
             while (sp > 1 && ksteps / sp < 4) --sp;
-            if (nwg >= kNumCU * 3 / 4) sp = 1;
             t.splits = sp;
         } else {
             t.bm = 64; t.bn = 64; t.splits = 1;
-            const int64_t nwg = (int64_t)cdiv(M, 64) * cdiv(N, 64);
-            if (nwg < kNumCU && ksteps >= 8) {
-                int sp = (int)std::min<int64_t>(16, (kNumCU * 2 + nwg - 1) / nwg);
-                while (sp > 1 && ksteps / sp < 4) --sp;
-                t.splits = sp;
-            }
         }
         return t;
     }
@@ -1563,7 +1571,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     a.x3 = a.w3 = nullptr;
     // fp32 results from the bf16 matrix cores (compute mode 2, conv_x3.hip): three-term split of both operands, six MFMAs
     static const bool x3_all = getenv("DPFT_X3_ALL") != nullptr && atoi(getenv("DPFT_X3_ALL")) != 0;      // tuning aid: 1x1 convs too
-    if (t.vec && g_conv_bf16 == 2 && (a.kh * a.kw > 1 || x3_all) && !a.x16 && !a.y16 && !a.w16 && (!pro || a.pro_relu) &&
+    if (t.vec && (t.x3 || (g_conv_bf16 == 2 && (x3_all || getenv("DPFT_FORCE_TILE")))) && g_conv_bf16 != 1 && !a.x16 && !a.y16 && !a.w16 && (!pro || a.pro_relu) &&
         ((t.bm == 128 && (t.bn == 128 || t.bn == 64)) || (t.bm == 64 && t.bn == 64)))
         return launch_igemm_x3(a, t.bm, t.bn, DGRAD, pro, st);
     // fp32, linear taps: the software-pipelined kernel (conv_pipe.h) -- LDS-DMA operands, one barrier per K-step.
@@ -1757,16 +1765,15 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
     int64_t best = 0;
     if (conv16_matches(d)) best = std::max<int64_t>(best, (int64_t)conv16_wgrad_blocks(d) * 2320 * 4);      // (+ bias column sums)
     if (d->kh == 1 && d->kw == 1 && d->K <= 16 && d->C <= 8) best = std::max<int64_t>(best, (int64_t)kNumCU * 2 * d->K * (d->C + 1) * 4);
-    const int mode_now = g_conv_bf16;
-    for (int mode : {0, 2}) {      // whichever compute mode the launches will run in (the split mode picks its own splits)
-        g_conv_bf16 = mode;
+    for (int mode : {0, 1}) {      // with or without the split kernels, whichever the launches will run with (they pick their own splits)
+        g_split_override = mode;
         for (int dg = 0; dg < 2; ++dg) {
             IgemmArgs a; fill_igemm(a, d, dg != 0);
             TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->kh * d->kw);
             if (t.splits > 1) best = std::max<int64_t>(best, (int64_t)t.splits * a.M * a.N * 4);
         }
     }
-    g_conv_bf16 = mode_now;
+    g_split_override = -1;
     // wgrad: pixel-split partial slabs, at most min(512 splits, 64 MiB)
     {
         const int64_t wbytes = (int64_t)d->K * d->kh * d->kw * d->C * 4;
@@ -1796,10 +1803,19 @@ extern "C" int dpft_conv_set_compute(int32_t mode) {
 
 extern "C" int32_t dpft_conv_get_compute() { return dpft::g_conv_bf16; }
 
+extern "C" int dpft_conv_set_split(int32_t on) {
+    dpft::g_conv_split = on != 0;
+    return DPFT_OK;
+}
+
+extern "C" int32_t dpft_conv_get_split() { return dpft::g_conv_split; }
+
+int dpft::conv_mode_key() { return dpft::g_conv_bf16 * 2 + (dpft::g_conv_split ? 1 : 0); }
+
 extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows) {
     if (check_desc(d) != DPFT_OK) return -1;
     IgemmArgs a; fill_igemm(a, d, false);
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->kh * d->kw);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);      // (as conv_fwd_bnfinal asks)
     if (tile_rows) *tile_rows = t.bm;
     return cdiv(a.M, t.bm);
 }

@@ -64,6 +64,7 @@ struct ResnetPlan {
     // FrozenBatchNorm2d): the forward keeps the train path's tensors but normalises with the running statistics, the
     // backward's apply pass drops the batch-statistics terms (dy = gamma invstd d); set by the forward, read by the stages
     bool frozen = false;
+    int mode_key = 0;      // conv_mode_key() at build time: tile shapes (statistics tiles, workspace) depend on the compute mode
     // side stream of the weight-gradient GEMMs (they are off the critical path of the backward)
     hipStream_t side = nullptr;
     bool side_owned = true, side_set = false;      // side_set: side is valid (it may be the null stream)
@@ -120,6 +121,7 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     }
     ResnetPlan* p = new ResnetPlan();
     p->desc = *desc;
+    p->mode_key = conv_mode_key();
     size_t off = 0;
     auto take = [&](size_t floats) { size_t o = off; off += align64(floats); return o; };
     int nconv = 0, nbn = 0;
@@ -383,7 +385,7 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
     float* A = (float*)arena;
     void* ws = (char*)arena + (p->arena_bytes - 2 * p->ws_bytes - 256);
     const bool tr = train != 0;
-    p->frozen = train == 2;
+    p->frozen = train == 2;      // (what THIS forward's kernels use; the backward is told by its caller, see dpft_resnet_backward_stage)
     // split-K ticket headers of both workspaces (conv.hip: kWsHeader): zero once per arena use, every conv leaves them zero
     RC(dpft_conv2d_workspace_init(ws, st));
     RC(dpft_conv2d_workspace_init((char*)arena + (p->arena_bytes - p->ws_bytes - 128), st));
@@ -830,15 +832,21 @@ extern "C" int dpft_resnet_forward(int64_t h, const float* x, const dpft_resnet_
                                    int32_t train, dpft_stream_t st) {
     ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
     DPFT_REQUIRE(p && x && tables && arena, "resnet_forward: null argument");
+    DPFT_REQUIRE(conv_mode_key() == p->mode_key, "resnet_forward: the conv compute mode changed since the plan was built (rebuild the plan)");
     if (train != 1) return forward_impl(p, x, tables, arena, train, st);      // eval, frozen-BN: eager launches
     return run_graphed(p, -1, x, arena, nullptr, tables, st, [&]() { return forward_impl(p, x, tables, arena, train, st); });
 }
 
 extern "C" int dpft_resnet_backward_stage(int64_t h, int32_t stage, const float* x, const dpft_resnet_tables* tables,
-                                          void* arena, const float* dout, dpft_stream_t st) {
+                                          void* arena, const float* dout, int32_t frozen, dpft_stream_t st) {
     ResnetPlan* p = (ResnetPlan*)(intptr_t)h;
     DPFT_REQUIRE(p && x && tables && arena, "resnet_backward: null argument");
     DPFT_REQUIRE(stage >= 0 && stage < p->desc.n_layers, "resnet_backward: bad stage %d", stage);
+    DPFT_REQUIRE(conv_mode_key() == p->mode_key, "resnet_backward: the conv compute mode changed since the plan was built (rebuild the plan)");
+    // The BatchNorm mode of the forward this backward belongs to comes from the CALLER (the autograd node remembers it): plan
+    // state written by forward_impl would be stale after a replayed (graphed) train forward, which never runs forward_impl, and
+    // would flip under a pending backward when another forward of a different mode runs in between.
+    p->frozen = frozen != 0;
     if (p->frozen) return backward_stage_impl(p, stage, x, tables, arena, dout, st);
     return run_graphed(p, stage, x, arena, dout, tables, st,
                        [&]() { return backward_stage_impl(p, stage, x, tables, arena, dout, st); });

@@ -101,6 +101,8 @@ SIGNATURES = {
     "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
     "dpft_conv_set_compute": (_I, [_I]),
     "dpft_conv_get_compute": (_I, []),
+    "dpft_conv_set_split": (_I, [_I]),
+    "dpft_conv_get_split": (_I, []),
     "dpft_conv2d_nhwc_fwd_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_fwd_bnact_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P, _P, _P]),
     "dpft_conv2d_nhwc_dgrad_f32": (_I, [_DESC, _P, _P, _P, _I, _P, _P]),
@@ -180,7 +182,7 @@ SIGNATURES = {
     "dpft_resnet_plan_destroy": (None, [_L]),
     "dpft_resnet_plan_query": (_L, [_L, _I, _I]),
     "dpft_resnet_forward": (_I, [_L, _P, C.POINTER(ResnetTables), _P, _I, _P]),
-    "dpft_resnet_backward_stage": (_I, [_L, _I, _P, C.POINTER(ResnetTables), _P, _P, _P]),
+    "dpft_resnet_backward_stage": (_I, [_L, _I, _P, C.POINTER(ResnetTables), _P, _P, _I, _P]),
     "dpft_resnet_plan_set_side_stream": (_I, [_L, _P]),
     "dpft_resnet_plan_set_graph": (_I, [_L, _I]),
     "dpft_stream_set": (_I, [_P, _I, C.POINTER(C.c_void_p)]),

@@ -18,10 +18,22 @@ def conv_set_compute(mode: str) -> None:
     """"fp32" (the reference's arithmetic, default) or "bf16" (bf16 operands / fp32 accumulation in the forward and
     data-gradient GEMMs of the C % 64 == 0 convs; BASELINE.json configs[4])."""
     lib.call("dpft_conv_set_compute", {"fp32": 0, "bf16": 1, "bf16x3": 2}[mode])
+    _conv_cache.clear()      # tile shapes (statistics tiles, workspace) depend on the mode
 
 
 def conv_get_compute() -> str:
     return ("fp32", "bf16", "bf16x3")[int(lib.dpft_conv_get_compute())]
+
+
+def conv_set_split(on: bool) -> None:
+    """fp32 mode: big multi-tap GEMMs as 3 x bf16 split products on the bf16 matrix cores (default on; conv_x3.hip).
+    Changes tile shapes: cached problems are dropped."""
+    lib.call("dpft_conv_set_split", int(bool(on)))
+    _conv_cache.clear()
+
+
+def conv_get_split() -> bool:
+    return bool(lib.dpft_conv_get_split())
 
 
 def profile_start():
@@ -121,8 +133,7 @@ def grad_sink(activation: torch.Tensor) -> Optional[torch.Tensor]:
 
 class Conv:
     """Geometry + cached descriptor/workspace size of one convolution problem."""
-    __slots__ = ("desc", "ws_bytes", "tiles", "tile_rows", "B", "H", "W", "C", "K", "kh", "kw", "stride", "pad",
-                 "OH", "OW")
+    __slots__ = ("desc", "ws_bytes", "B", "H", "W", "C", "K", "kh", "kw", "stride", "pad", "OH", "OW")
 
     def __init__(self, B, H, W, Cin, K, kh, kw, stride, pad):
         self.desc = make_desc(B, H, W, Cin, K, kh, kw, stride, pad)
@@ -132,9 +143,18 @@ class Conv:
         self.ws_bytes = int(lib.dpft_conv2d_workspace_bytes(C.byref(self.desc)))
         if self.ws_bytes < 0:
             raise RuntimeError("bad conv descriptor: " + lib.dpft_last_error().decode())
+
+    # row tiles of the forward kernel's statistics epilogue: asked at every use -- the answer follows the compute mode
+    # (conv_set_compute / conv_set_split), and a problem object may outlive a mode change
+    @property
+    def tiles(self):
+        return int(lib.dpft_conv2d_stats_tiles(C.byref(self.desc), None))
+
+    @property
+    def tile_rows(self):
         tr = C.c_int32(0)
-        self.tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(self.desc), C.byref(tr)))
-        self.tile_rows = tr.value
+        lib.dpft_conv2d_stats_tiles(C.byref(self.desc), C.byref(tr))
+        return tr.value
 
     @property
     def M(self):

@@ -265,7 +265,7 @@ class _BodyFn(torch.autograd.Function):
                     sd = plan.dout_static[li] = torch.empty_like(o)
                 ops.register_grad_sink(o, sd)
         if need_grad:
-            ctx.state = dict(owner=owner, plan=plan, x=x, arena=arena, tables=t, keep=keep, weights=weights,
+            ctx.state = dict(owner=owner, plan=plan, x=x, arena=arena, tables=t, keep=keep, weights=weights, mode=mode,
                              convs=convs, bns=bns, conv_g=conv_g, bn_g=bn_g, bn_b=bn_b, flat=flat, direct=direct,
                              params=params, lease=lease)
             if direct is not None:
@@ -309,7 +309,7 @@ class _BodyFn(torch.autograd.Function):
                     d = sd
                 keep_alive.append(d)
             lib.call("dpft_resnet_backward_stage", plan.handle, li, ptr(st["x"]), C.byref(st["tables"]),
-                     ptr(st["arena"]), ptr(d), stream())
+                     ptr(st["arena"]), ptr(d), int(st["mode"] == 2), stream())
             if direct is not None:                       # this stage's gradients are in the DP buckets: release them
                 direct.mark_ready_many(stage_params[li])
         grads = {}
@@ -356,7 +356,7 @@ class BackboneBase(nn.Module):
         # 2 (default) = bf16 activations AND bf16 shadow weights, materialised BatchNorm+ReLU outputs, LDS-DMA bf16 GEMMs
         level = int(_os.environ.get("DPFT_ACT16", "2"))
         act16 = level if (_ops.conv_get_compute() == "bf16" and B * H * W >= self.ACT16_MIN_PIXELS) else 0
-        key = (B, H, W, act16)
+        key = (B, H, W, act16, _ops.conv_get_compute(), _ops.conv_get_split())      # tile shapes depend on the compute mode
         p = self._plans.get(key)
         if p is None:
             p = self._plans[key] = _Plan(self, B, H, W, act16)

@@ -98,6 +98,12 @@ int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows);
  * Returns DPFT_ERR_ARG for any other value. */
 int dpft_conv_set_compute(int32_t mode);
 int32_t dpft_conv_get_compute(void);
+/* fp32 compute mode only: run the big multi-tap GEMMs (3x3 / 7x7 filters, C % 64 == 0, >= 2 GFLOP) as 3 x bf16 split products
+ * on the bf16 matrix cores -- fp32 tensors in, fp32 results out, six exact term products per fp32 product accumulated in
+ * fp32 (dpft_amd/csrc/conv_x3.hip; error vs fp64 below the fp32 MFMA path's).  Default on (DPFT_CONV_SPLIT=0 presets off);
+ * off = v_mfma_f32_32x32x2_f32 everywhere.  Set before problems are sized: dpft_conv2d_stats_tiles depends on it. */
+int dpft_conv_set_split(int32_t on);
+int32_t dpft_conv_get_split(void);
 
 /* BN parameter block convention used across the library: bnp[4][K] floats =
  *   row 0 mean, row 1 scale = gamma*invstd, row 2 beta, row 3 invstd;   bn(v) = (v - mean)*scale + beta
@@ -248,10 +254,12 @@ int64_t dpft_resnet_plan_query(int64_t plan, int32_t what, int32_t idx);
 int dpft_resnet_forward(int64_t plan, const float* x, const dpft_resnet_tables* tables, void* arena,
                         int32_t train, dpft_stream_t stream);
 /* Backward of stage `stage` (call n_layers-1 ... 0 after a train forward; stage 0 also runs the
- * stem).  dout = external gradient of that stage's output (NULL = none). */
+ * stem).  dout = external gradient of that stage's output (NULL = none).  frozen = the BatchNorm mode of the forward this
+ * backward belongs to (1: it ran with train = 2, running statistics; 0: train = 1) -- the caller says it, the plan keeps
+ * no per-forward state. */
 int dpft_resnet_backward_stage(int64_t plan, int32_t stage, const float* x,
                                const dpft_resnet_tables* tables, void* arena, const float* dout,
-                               dpft_stream_t stream);
+                               int32_t frozen, dpft_stream_t stream);
 /* The stream the plan's weight-gradient GEMMs run on while the data-gradient chain continues on the caller's stream
  * (default: a stream the plan creates on first use).  Passing the caller's own stream keeps everything in order on it. */
 int dpft_resnet_plan_set_side_stream(int64_t plan, dpft_stream_t side);

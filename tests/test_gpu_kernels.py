@@ -131,7 +131,7 @@ def test_conv_bf16_operand_mode(case):
             dx = ops.conv_dgrad(cv, dy_nhwc, wt)
             dw = ops.conv_wgrad(cv, x.to(DEV), dy_nhwc, pro=(pro[0].to(DEV), True))
             res[mode] = (y.double().cpu().permute(0, 3, 1, 2), dx.double().cpu().permute(0, 3, 1, 2), stats,
-                         dw.double().cpu().permute(0, 3, 1, 2))
+                         dw.double().cpu().permute(0, 3, 1, 2), cv.tile_rows)
     finally:
         ops.conv_set_compute("fp32")
     rel = lambda a, b: float((a - b).norm() / b.norm())
@@ -150,7 +150,7 @@ def test_conv_bf16_operand_mode(case):
     assert e_w32 < 1e-5 and e_w16 < 6e-3, (e_w32, e_w16)             # (the 32 x 128-tiled problems, K <= 32, stay fp32)
     # tile statistics are computed from the bf16-mode output itself (consistent with what the BN backward will see)
     yb = res["bf16"][0].permute(0, 2, 3, 1).reshape(-1, K)
-    rows = cv.tile_rows
+    rows = res["bf16"][4]            # (the statistics tiles follow the compute mode)
     t0 = yb[:rows].float()
     close(res["bf16"][2][0, 0].cpu(), t0.mean(0), rtol=1e-4, atol_scale=1e-4, what="tile-0 mean in bf16 mode")
 

@@ -1096,6 +1096,52 @@ def test_replayed_encoder_plans_train_like_eager_launches(monkeypatch):
         assert g[i][1] < 1.5 * top, (i, g[i], top)
 
 
+def test_frozen_forward_between_graphed_train_steps_does_not_leak_its_batchnorm_mode(monkeypatch):
+    """the plan kept "frozen BatchNorm" as state written by forward_impl.  A train forward REPLAYED from its
+    hipGraph never runs forward_impl, so after one frozen pass (eval-mode body under autograd) the next train backward dropped
+    the batch-statistics terms -- silently wrong BatchNorm gradients.  The backward is told its mode by the caller now
+    (dpft_resnet_backward_stage: frozen).  A trainer with replayed plans takes three steps, then a frozen forward + backward,
+    then a fourth step; a fresh trainer with eager launches computes the same fourth step from the same parameters."""
+    import copy
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    data = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=SHAPES, device=DEV)
+    labels = make_labels(2, seed=3, device=DEV)
+    monkeypatch.setenv("DPFT_PLAN_GRAPHS", "2")
+    torch.manual_seed(3)
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+    for _ in range(3):
+        tr.train_step(data, labels)
+    assert any(p.graphed for i in tr.model.inputs for p in tr.model.backbones[i]._plans.values())
+    rs = {n: b.clone() for n, b in tr.model.named_buffers() if "running" in n}
+    tr.model.eval()
+    with torch.enable_grad():
+        o = tr.model(data)
+        sum(v.sum() for v in o.values()).backward()
+    tr.model.train()
+    for n, b in tr.model.named_buffers():      # a frozen pass leaves the running statistics alone
+        if n in rs:
+            assert torch.equal(b, rs[n]), n
+    torch.cuda.synchronize()
+    snap = copy.deepcopy(tr.model.state_dict())
+    loss_g, _ = tr.train_step(data, labels)
+    torch.cuda.synchronize()
+    grads_g = [b["flat"].double().clone() for b in tr.reducer.buckets]
+    monkeypatch.setenv("DPFT_PLAN_GRAPHS", "0")
+    tr2 = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+    tr2.model.load_state_dict(snap)
+    loss_e, _ = tr2.train_step(data, labels)
+    torch.cuda.synchronize()
+    grads_e = [b["flat"].double().clone() for b in tr2.reducer.buckets]
+    assert abs(float(loss_g) - float(loss_e)) < 1e-5 * abs(float(loss_e)), (float(loss_g), float(loss_e))
+    assert len(grads_g) == len(grads_e)
+    for a, b in zip(grads_g, grads_e):
+        # (atomics reorder sums between runs; a dropped mean term moves a backbone bucket by tens of percent)
+        assert float((a - b).norm()) < 5e-3 * float(b.norm()) + 1e-6, (float((a - b).norm()), float(b.norm()))
+
+
 def test_two_forwards_before_their_backwards_with_replayed_plans():
     """with plan graphs on, a plan's saved activations live in ONE persistent arena.  A second
     grad-enabled forward before the first one's backward (two batches per loss) must not overwrite them: it takes a fresh
