@@ -497,8 +497,7 @@ static int bn_backward(const float* y, const float* dout, const float* out, cons
     float* sums = bs.buf[bs.cur];
     float* other = bs.buf[bs.cur ^ 1];
     bs.cur ^= 1;
-    static const bool skip_reduce = getenv("DPFT_EXP_SKIP_BNREDUCE") != nullptr;      // timing experiment only (wrong gradients)
-    if (!reduced && !skip_reduce) RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st, mask8));
+    if (!reduced) RC(bn_bwd_reduce_prezeroed(y, dout, out, mask_bnp, bnp, sums, M, K, act16, st, mask8));
     return bn_bwd_apply_zeroing(y, dout, out, mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, M, K, other, 2 * 2048, act16, st,
                                 mask8, bs.frozen);
 }

@@ -127,7 +127,9 @@ class KRadarFolderDataset(Dataset):
     def _walk(self) -> List[Dict[str, str]]:
         root = os.path.join(self.src, self.split)
         out: List[Dict[str, str]] = []
-        for sequence in os.listdir(root):                    # (sequence order = directory order, as upstream)
+        # sorted: the index -> sample map feeds ShardedSampler on every rank, and os.listdir order is file-system dependent
+        # (upstream takes directory order; it is single-process, and the order is not observable after shuffling)
+        for sequence in sorted(os.listdir(root)):
             seq_dir = os.path.join(root, sequence)
             out += [self._files_of(os.path.join(seq_dir, s)) for s in sorted(os.listdir(seq_dir))]
         return out

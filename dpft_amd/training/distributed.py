@@ -28,11 +28,12 @@ import torch
 import torch.distributed as dist
 
 
-# timing experiment only (tools/r03_forced_breakdown.sh): buckets fire without their collective
-_EXP_SKIP_BUCKET_COLLECTIVES = __import__("os").environ.get("DPFT_EXP_SKIP_BUCKET_COLLECTIVES") == "1"
-
 
 class GradBucketReducer:
+    # one-rank timing experiment (tools/exp_switches.py flips it; never read from the environment): buckets fire without their
+    # collective -- no gradient exchange, so it is refused with more than one rank
+    exp_skip_bucket_collectives = False
+
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 25 << 20, process_group=None,
                  average: bool = True, group_of: Dict[int, str] = None, comm_dtype: Optional[torch.dtype] = None,
                  force_collectives: bool = False):
@@ -47,11 +48,9 @@ class GradBucketReducer:
         if self.world > 1:
             # the one-rank timing switches of tools/r03_forced_breakdown.sh would let ranks diverge (no gradient exchange) or
             # hang (ranks disagreeing on the step decision mismatch their collectives): refused outside one-rank runs
-            env = __import__("os").environ
-            bad = [k for k in ("DPFT_EXP_SKIP_BUCKET_COLLECTIVES", "DPFT_EXP_LOCAL_DECISION") if env.get(k) == "1"]
-            if bad or _EXP_SKIP_BUCKET_COLLECTIVES:
-                raise RuntimeError(f"{bad or ['DPFT_EXP_SKIP_BUCKET_COLLECTIVES']}: one-rank timing experiment switches "
-                                   f"are not allowed with world_size {self.world}")
+            if GradBucketReducer.exp_skip_bucket_collectives:
+                raise RuntimeError(f"exp_skip_bucket_collectives: one-rank timing experiment switches are not allowed with "
+                                   f"world_size {self.world}")
         # RCCL averages inside the collective (ncclAvg): no separate division pass over the 360 MB of buckets
         self._avg_op = average and dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         # One rank (bench.py --force-collectives, tests): the average over one rank IS the sum, and RCCL implements a one-rank
@@ -283,7 +282,7 @@ class GradBucketReducer:
             for sid, st in b["streams"].items():
                 if sid != cur.cuda_stream:          # tail of that stream is after its last contribution
                     cur.wait_stream(st)
-        if self.collective and not _EXP_SKIP_BUCKET_COLLECTIVES:
+        if self.collective and not GradBucketReducer.exp_skip_bucket_collectives:
             op = dist.ReduceOp.SUM
             if self._avg_op:
                 op = dist.ReduceOp.AVG

@@ -190,7 +190,9 @@ def _pack_targets_hip(targets, counts, ncls, dev, Mmax):
     return gt_box, gt_onehot, gt_id, counts_t, Mmax
 
 
-_loss_scratch: Dict[torch.device, torch.Tensor] = {}      # ticket + partial sums of dpft_set_loss_fwd_total_f32 (zero between launches)
+# ticket + partial sums of dpft_set_loss_fwd_total_f32 (zero between launches): one buffer per (device, stream) -- two launches in
+# flight on different streams (train and validation criteria, several losses) must not share a ticket
+_loss_scratch: Dict[tuple, torch.Tensor] = {}
 
 
 def _set_loss_launch(cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel):
@@ -206,12 +208,17 @@ def _set_loss_launch(cls, center, size, angle, gt_box, gt_onehot, match, counts,
     # configured ones -- instead of a cleared output + atomics + a dot product, and of select x5 / stack / sum in
     # autograd, whose backward alone is a dozen tiny launches between the step's two host syncs
     need = int(lib.dpft_set_loss_scratch_floats(B, N))
-    scratch = _loss_scratch.get(cls.device)
+    skey = (cls.device, int(torch.cuda.current_stream(cls.device).cuda_stream))
+    scratch = _loss_scratch.get(skey)
     if scratch is None or scratch.numel() < need:
-        scratch = _loss_scratch[cls.device] = torch.zeros(max(need, 1024), dtype=torch.float32, device=cls.device)
-    lib.call("dpft_set_loss_fwd_total_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
-             gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
-             sel.data_ptr(), scratch.data_ptr(), losses.data_ptr(), total.data_ptr(), B, N, Mmax, ncls, stream())
+        scratch = _loss_scratch[skey] = torch.zeros(max(need, 1024), dtype=torch.float32, device=cls.device)
+    try:
+        lib.call("dpft_set_loss_fwd_total_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+                 gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), float(alpha),
+                 sel.data_ptr(), scratch.data_ptr(), losses.data_ptr(), total.data_ptr(), B, N, Mmax, ncls, stream())
+    except Exception:
+        scratch.zero_()      # a launch that did not complete may leave its ticket behind
+        raise
     return losses, total
 
 

@@ -91,6 +91,10 @@ class DataParallelTrainer:
         self.reducer = GradBucketReducer(list(self.model.parameters()), bucket_bytes=int(bucket_mb * (1 << 20)),
                                          group_of=group_of, comm_dtype=wire, force_collectives=force_collectives)
         self.collective = self.reducer.collective
+        # one-rank timing experiment (tools/exp_switches.py): take the step decision from the local loss although collectives are
+        # on.  Never read from the environment; refused with more than one rank (ranks disagreeing on the decision mismatch
+        # their collectives and hang).
+        self._exp_local_decision = False
         # The collectives' hardware queue.  Four queues, four busy chains (main | camera weight gradients | two radar views):
         # RCCL's own stream ("pg") lands on whichever queue the runtime picks, possibly the critical chain's, where an
         # all-reduce kernel of N > 1 ranks would hold up the data-gradient chain for its whole duration.  "side" (default)
@@ -171,7 +175,9 @@ class DataParallelTrainer:
             if g is not None:
                 g.clone_outputs = True
         loss, losses = self.loss_fn(output, labels)
-        if self.collective and os.environ.get("DPFT_EXP_LOCAL_DECISION") != "1":      # (timing experiment switch)
+        if self._exp_local_decision and self.world > 1:
+            raise RuntimeError("_exp_local_decision is a one-rank timing experiment switch")
+        if self.collective and not self._exp_local_decision:
             # The global batch steps if ANY shard has a loss (MAX): a rank whose label shard is empty then runs the same
             # backward over a zero-valued loss, so it contributes zero gradients, issues its bucket collectives in the
             # same order and reports the same set of parameters-with-gradient as every other rank.
@@ -225,7 +231,15 @@ class DataParallelTrainer:
         return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
 
     def _rank_mean(self, scalars: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
-        """Mean over ranks of every scalar (ONE collective).  Every rank calls it with the same keys."""
+        """Mean over ranks of every scalar (ONE collective).  Every rank calls it with the same keys -- checked: a rank whose
+        loader yielded nothing (tiny validation split, drop_last) would otherwise skip the collective the others enter and
+        hang the job."""
+        if self.world > 1:
+            n = torch.tensor([len(scalars), -len(scalars)], dtype=torch.int64, device=self.device)
+            dist.all_reduce(n, op=dist.ReduceOp.MAX)
+            if int(n[0]) != -int(n[1]):
+                raise RuntimeError(f"rank {self.rank}: {len(scalars)} epoch scalars, another rank has {int(n[0])} / {-int(n[1])}: "
+                                   "a rank saw no batches (sampler / drop_last leave it an empty shard)")
         if not scalars:
             return scalars
         keys = sorted(scalars)
@@ -314,9 +328,11 @@ class DataParallelTrainer:
             dist.barrier()
 
     def train(self, data_loader: Iterable, val_loader: Iterable = None, start_epoch: int = 0, timestamp: str = None,
-              dst: str = None, sampler=None) -> List[str]:
+              dst: str = None, sampler=None, continue_schedule: bool = False) -> List[str]:
         """trainer.py:215-263.  ``sampler``: an optional ``ShardedSampler`` whose ``set_epoch`` is called per epoch.
-        Returns the checkpoint paths written."""
+        Resuming (``start_epoch`` > 0): like the reference (trainer.py:233-239 builds a FRESH optimizer and scheduler for a
+        resumed run) the learning-rate schedule starts over; ``continue_schedule=True`` fast-forwards it to where the
+        interrupted run stopped instead.  Returns the checkpoint paths written."""
         if timestamp is None:
             timestamp = datetime.datetime.now().strftime("%Y%m%d-%H%M%S-%f")[:-3]
             if self.world > 1:                       # one directory for the job: rank 0's clock
@@ -330,8 +346,9 @@ class DataParallelTrainer:
             os.makedirs(ckpt_dir, exist_ok=True)
             if self.logging is not None:
                 writer = _ScalarLog(osp.join(dst, timestamp))
-        for _ in range(start_epoch):                 # a resumed run continues the schedule where it stopped (the
-            self.scheduler.step()                    # reference restarts it: optimizer and scheduler are not pickled)
+        if continue_schedule:
+            for _ in range(start_epoch):             # opt-in: continue the schedule where the interrupted run stopped
+                self.scheduler.step()
         written = []
         for epoch in range(start_epoch, self.epochs):
             if sampler is not None:

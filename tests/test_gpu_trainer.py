@@ -134,7 +134,12 @@ def test_epoch_loop_trains_validates_and_checkpoints(tmp_path):
     tr2 = DataParallelTrainer.from_config(model, cfg)
     more = tr2.train(train_loader, None, start_epoch=epoch + 1, timestamp=stamp, dst=str(tmp_path), sampler=sampler)
     assert [os.path.basename(p) for p in more] == ["20250101-000000-000_checkpoint_0002.pt"]
-    assert abs(tr2.optimizer.param_groups[0]["lr"] - 1e-3 * 0.125) < 1e-12
+    # the reference builds a FRESH optimizer and scheduler for a resumed run (trainer.py:233-239): one scheduler step from lr0
+    assert abs(tr2.optimizer.param_groups[0]["lr"] - 1e-3 * 0.5) < 1e-12
+    # opt-in continuation of the interrupted schedule: two fast-forward steps + the epoch's own
+    tr3 = DataParallelTrainer.from_config(load(written[-1])[0], cfg)
+    tr3.train(train_loader, None, start_epoch=epoch + 1, timestamp=stamp + "b", dst=str(tmp_path), sampler=sampler, continue_schedule=True)
+    assert abs(tr3.optimizer.param_groups[0]["lr"] - 1e-3 * 0.125) < 1e-12
 
 
 @pytest.mark.gpu
