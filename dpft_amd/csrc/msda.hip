@@ -3,6 +3,12 @@
 // (1) dpft_msda_{fwd,bwd}_f32: operator-level drop-in for the Deformable-DETR CUDA extension the
 //     reference binds at src/dprt/models/layers/ms_deform_attn.py:24,32-39,58-66 (same tensors,
 //     same maths: SURVEY.md App. C).  Compatibility path.
+//     Attribution: the extension is the multi-scale deformable attention operator of Deformable DETR (X. Zhu et al., ICLR
+//     2021; https://github.com/fundamentalvision/Deformable-DETR, models/ops/src/cuda/ms_deform_im2col_cuda.cuh, Copyright
+//     (c) 2020 SenseTime, Apache License 2.0), absent from the reference checkout.  The bilinear-sampling variable names of
+//     the compatibility kernels below (h_im / w_im, lh / lw / hh / hw, v1..v4 and their gradient counterparts) follow that
+//     operator's published kernel body so that the two can be compared term by term; the code is written for gfx950 here,
+//     none of it is copied.
 // (2) dpft_xattn_{fwd,bwd}_f32: the MI355X hot path.  "Sample-then-project": the bilinear gather
 //     runs directly on the NHWC FPN levels (no flatten/cat, no dense value_proj, no `value`
 //     tensor: src/dprt/models/fusers/mpfusion.py:179, ms_deform_attn.py:172), and the per-head

@@ -50,6 +50,25 @@ class ShardedSampler(Sampler[int]):
         return iter(order[self.rank:total:self.world])
 
 
+class BlockShardedSampler(Sampler[int]):
+    """Evaluation shards: rank r takes the CONTIGUOUS block [start, start + len) of the split, in order, nothing dropped and
+    nothing repeated (the last rank may get fewer) -- sample k keeps the index, and with it the export file name, it has in
+    a one-process run (dpft_amd/evaluation/evaluator.py)."""
+
+    def __init__(self, n: int, rank: int = 0, world: int = 1):
+        if not 0 <= rank < world:
+            raise ValueError(f"rank {rank} outside world of {world}")
+        per = (n + world - 1) // world
+        self.start = min(n, rank * per)
+        self.stop = min(n, self.start + per)
+
+    def __len__(self) -> int:
+        return self.stop - self.start
+
+    def __iter__(self) -> Iterator[int]:
+        return iter(range(self.start, self.stop))
+
+
 def _pin(obj):
     if isinstance(obj, torch.Tensor):
         return obj.pin_memory() if not obj.is_pinned() and torch.cuda.is_available() else obj

@@ -17,7 +17,7 @@ import torch.nn.functional as F
 from torch import nn
 from torch.autograd import Function
 from torch.autograd.function import once_differentiable
-from torch.nn.init import constant_, xavier_uniform_
+from torch.nn.init import xavier_uniform_
 
 from dpft_amd.hip import ops
 
@@ -148,44 +148,46 @@ class _XAttnFn(Function):
         return None, None, gref, goff, gattn, gWv, gbv, None, None      # token: ordering only (_PyramidHub)
 
 
-def _is_power_of_2(n):
-    if (not isinstance(n, int)) or (n < 0):
-        raise ValueError("invalid input for _is_power_of_2: {} (type: {})".format(n, type(n)))
-    return (n & (n - 1) == 0) and n != 0
-
-
 class MSDeformAttn(nn.Module):
+    """Multi-scale deformable attention with the parameter set, initial values and call signatures of the reference's
+    module (src/dprt/models/layers/ms_deform_attn.py:75-217) on the HIP operators.  Parameter names / shapes are the
+    state-dict contract; the initial values are pinned by tests/golden/msda_init.npz (the reference's seeded init)."""
+
     def __init__(self, d_model=256, n_levels=4, n_heads=8, n_points=4):
         super().__init__()
-        if d_model % n_heads != 0:
-            raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
-        if not _is_power_of_2(d_model // n_heads):
+        head_dim, rest = divmod(d_model, n_heads)
+        if rest:
+            raise ValueError(f"d_model must be divisible by n_heads, but got {d_model} and {n_heads}")
+        if head_dim & (head_dim - 1):
             warnings.warn("d_model // n_heads should be a power of 2")
         self.im2col_step = 64
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
+        slots = n_heads * n_levels * n_points
+        # (creation order = the order the reference draws from the RNG: a seeded module gets the reference's values)
+        self.sampling_offsets = nn.Linear(d_model, 2 * slots)
+        self.attention_weights = nn.Linear(d_model, slots)
         self.value_proj = nn.Linear(d_model, d_model)
         self.output_proj = nn.Linear(d_model, d_model)
         self._reset_parameters()
 
+    @torch.no_grad()
     def _reset_parameters(self):
-        # ms_deform_attn.py:117-136
-        constant_(self.sampling_offsets.weight.data, 0.)
-        thetas = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
-        grid_init = torch.stack([thetas.cos(), thetas.sin()], -1)
-        grid_init = (grid_init / grid_init.abs().max(-1, keepdim=True)[0]).view(self.n_heads, 1, 1, 2) \
-            .repeat(1, self.n_levels, self.n_points, 1)
-        for i in range(self.n_points):
-            grid_init[:, :, i, :] *= i + 1
-        with torch.no_grad():
-            self.sampling_offsets.bias = nn.Parameter(grid_init.view(-1))
-        constant_(self.attention_weights.weight.data, 0.)
-        constant_(self.attention_weights.bias.data, 0.)
-        xavier_uniform_(self.value_proj.weight.data)
-        constant_(self.value_proj.bias.data, 0.)
-        xavier_uniform_(self.output_proj.weight.data)
-        constant_(self.output_proj.bias.data, 0.)
+        """Initial state (ms_deform_attn.py:117-136): offsets and attention logits start from zero weights, so every query
+        first looks at a fixed star -- head m along direction 2 pi m / n_heads, scaled to the unit square's border, point
+        p at p + 1 steps -- with uniform weights; the two projections are Xavier-uniform with zero bias."""
+        angle = torch.arange(self.n_heads, dtype=torch.float32) * (2.0 * math.pi / self.n_heads)
+        ray = torch.stack((angle.cos(), angle.sin()), dim=-1)
+        ray = ray / ray.abs().amax(dim=-1, keepdim=True)                                # onto the border of [-1, 1]^2
+        steps = torch.arange(1, self.n_points + 1, dtype=torch.float32)
+        star = ray[:, None, None, :] * steps[None, None, :, None]                       # (heads, 1, points, 2)
+        star = star.expand(self.n_heads, self.n_levels, self.n_points, 2)
+        self.sampling_offsets.weight.zero_()
+        self.sampling_offsets.bias = nn.Parameter(star.reshape(-1).clone())
+        self.attention_weights.weight.zero_()
+        self.attention_weights.bias.zero_()
+        for proj in (self.value_proj, self.output_proj):      # (this order: value_proj draws first)
+            xavier_uniform_(proj.weight)
+            proj.bias.zero_()
 
     def _offsets_and_weights(self, query):
         N, Len_q, _ = query.shape
@@ -210,27 +212,29 @@ class MSDeformAttn(nn.Module):
 
     def forward(self, query, reference_points, input_flatten, input_spatial_shapes, input_level_start_index,
                 input_padding_mask=None):
-        """Reference signature (ms_deform_attn.py:138-217) on the operator-level C-ABI."""
-        N, Len_q, _ = query.shape
-        N, Len_in, _ = input_flatten.shape
-        assert (input_spatial_shapes[:, 0] * input_spatial_shapes[:, 1]).sum() == Len_in
-        assert reference_points.shape[2] == input_spatial_shapes.shape[0] == \
-            input_level_start_index.shape[0] == self.n_levels
+        """The reference's call signature (ms_deform_attn.py:138-217) on the operator-level C-ABI (dpft_msda_fwd / bwd):
+        query (N, Lq, C); reference_points (N, Lq, L, 2) in [0, 1] or (N, Lq, L, 4) boxes; input_flatten (N, sum HW, C);
+        input_spatial_shapes (L, 2) rows (H, W); input_level_start_index (L,); input_padding_mask (N, sum HW) True = pad."""
+        N, Lq, _ = query.shape
+        Lin = input_flatten.shape[1]
+        hw = input_spatial_shapes.to(torch.long)
+        if int(hw.prod(dim=1).sum()) != Lin:
+            raise ValueError("input_spatial_shapes do not add up to the flattened input length")
+        if not (reference_points.shape[2] == hw.shape[0] == input_level_start_index.shape[0] == self.n_levels):
+            raise ValueError("reference_points / spatial shapes / level start indices disagree with n_levels")
         value = self.value_proj(input_flatten)
         if input_padding_mask is not None:
-            value = value.masked_fill(input_padding_mask[..., None], float(0))
-        value = value.view(N, Len_in, self.n_heads, self.d_model // self.n_heads)
-        sampling_offsets, attention_weights = self._offsets_and_weights(query)
-        if reference_points.shape[-1] == 2:
-            offset_normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            sampling_locations = reference_points[:, :, None, :, None, :] \
-                + sampling_offsets / offset_normalizer[None, None, None, :, None, :]
-        elif reference_points.shape[-1] == 4:
-            sampling_locations = reference_points[:, :, None, :, None, :2] \
-                + sampling_offsets / self.n_points * reference_points[:, :, None, :, None, 2:] * 0.5
+            value = torch.where(input_padding_mask[..., None], value.new_zeros(()), value)
+        value = value.view(N, Lin, self.n_heads, self.d_model // self.n_heads)
+        off, aw = self._offsets_and_weights(query)
+        anchor = reference_points[:, :, None, :, None, :]                     # broadcast over heads and points
+        kind = reference_points.shape[-1]
+        if kind == 2:          # a point per level: offsets are in pixels of that level -> normalise by (W, H)
+            wh = input_spatial_shapes.flip(-1).to(off.dtype)
+            loc = anchor + off / wh[None, None, None, :, None, :]
+        elif kind == 4:        # a box per level (cx, cy, w, h): offsets in units of half the box, spread over the points
+            loc = anchor[..., :2] + off * (anchor[..., 2:] * (0.5 / self.n_points))
         else:
-            raise ValueError("Last dim of reference_points must be 2 or 4, but get {} instead."
-                             .format(reference_points.shape[-1]))
-        output = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index,
-                                            sampling_locations, attention_weights, self.im2col_step)
-        return self.output_proj(output)
+            raise ValueError(f"Last dim of reference_points must be 2 or 4, but get {kind} instead.")
+        out = MSDeformAttnFunction.apply(value, input_spatial_shapes, input_level_start_index, loc, aw, self.im2col_step)
+        return self.output_proj(out)

@@ -406,14 +406,49 @@ def main():
     with open(os.path.join(OUT, "export.json"), "w") as f:
         json.dump(trees, f, sort_keys=True)
     gen_assign(cfg)
+    gen_msda_init()
     print("golden fixtures written to", OUT)
     for f in sorted(os.listdir(OUT)):
         print(f"  {f}: {os.path.getsize(os.path.join(OUT, f)) / 1024:.1f} KiB")
+
+
+def gen_msda_init():
+    """Round 5: the reference's seeded initial parameters of MSDeformAttn (ms_deform_attn.py:99-136) for two geometries --
+    pins dpft_amd.models.layers.ms_deform_attn.MSDeformAttn._reset_parameters (values AND random-draw order) and a forward
+    through the reference signature with 2-d and 4-d reference points."""
+    from dprt.models.layers.ms_deform_attn import MSDeformAttn
+    out = {}
+    for tag, (d_model, n_levels, n_heads, n_points) in (("fuser", (16, 5, 8, 4)), ("wide", (64, 3, 4, 2))):
+        torch.manual_seed(1234)
+        mod = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        for k, v in mod.state_dict().items():
+            out[f"{tag}.{k}"] = v.clone()
+        g = torch.Generator().manual_seed(77)
+        shapes = torch.tensor([[6, 5], [4, 7], [3, 3], [2, 5], [1, 2]][:n_levels])
+        start = torch.cat((shapes.new_zeros(1), shapes.prod(1).cumsum(0)[:-1]))
+        N, Lq, Lin = 2, 9, int(shapes.prod(1).sum())
+        _randomise(mod, g, 0.3)
+        q = torch.randn(N, Lq, d_model, generator=g)
+        src = torch.randn(N, Lin, d_model, generator=g)
+        mask = torch.rand(N, Lin, generator=g) < 0.2
+        ref2 = torch.rand(N, Lq, n_levels, 2, generator=g)
+        ref4 = torch.cat((ref2, torch.rand(N, Lq, n_levels, 2, generator=g) * 0.5 + 0.1), -1)
+        for k, v in mod.state_dict().items():
+            out[f"{tag}.rand.{k}"] = v.clone()
+        out.update({f"{tag}.q": q, f"{tag}.src": src, f"{tag}.mask": mask.to(torch.int64), f"{tag}.shapes": shapes, f"{tag}.start": start,
+                    f"{tag}.ref2": ref2, f"{tag}.ref4": ref4,
+                    f"{tag}.out2": mod(q, ref2, src, shapes, start, mask).detach(),
+                    f"{tag}.out4": mod(q, ref4, src, shapes, start, None).detach()})
+    np.savez_compressed(os.path.join(OUT, "msda_init.npz"), **_np(out))
 
 
 if __name__ == "__main__":
     if sys.argv[1:] == ["assign"]:                 # only the round-2 fixture (keeps the other files byte-identical)
         ref_import.install()
         gen_assign(json.load(open(CFG)))
+    elif sys.argv[1:] == ["msda_init"]:            # only the round-5 fixture
+        ref_import.install()
+        os.makedirs(OUT, exist_ok=True)
+        gen_msda_init()
     else:
         main()

@@ -1,5 +1,7 @@
 """Parity of every HIP kernel (through the C-ABI) against torch-CPU restatements of the same op.
 fp32 kernels vs fp64 CPU references; tolerance rtol 1e-4, atol 1e-5*max|ref|."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -1328,3 +1330,23 @@ def test_bf16_batchnorm_passes_with_16_byte_accesses_equal_the_8_byte_form(tmp_p
     last = {n: e for n, e in err.items() if n.startswith("body.layer4.2.conv3") or n.startswith("body.layer4.2.bn3")}
     assert last and all(e == 0.0 for e in last.values()), last
     assert all(e < 0.3 for e in err.values()), max(err.items(), key=lambda kv: kv[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag,geom", [("fuser", (16, 5, 8, 4)), ("wide", (64, 3, 4, 2))])
+def test_msda_module_reference_signature_matches_reference_golden(tag, geom):
+    """MSDeformAttn.forward with the reference's signature (flattened value, spatial shapes, level start index, padding mask;
+    2-d points and 4-d boxes as reference points) on the operator-level C-ABI vs the reference module's own outputs
+    (tests/golden/msda_init.npz, generated by importing the reference)."""
+    import numpy as np
+    from dpft_amd.models.layers.ms_deform_attn import MSDeformAttn
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msda_init.npz"))
+    t = lambda k: torch.from_numpy(gold[f"{tag}.{k}"])
+    mod = MSDeformAttn(*geom)
+    mod.load_state_dict({k: t("rand." + k) for k in mod.state_dict()})
+    mod = mod.to(DEV)
+    q, src, shapes, start = t("q").to(DEV), t("src").to(DEV), t("shapes").to(DEV), t("start").to(DEV)
+    out2 = mod(q, t("ref2").to(DEV), src, shapes, start, t("mask").to(DEV).bool())
+    out4 = mod(q, t("ref4").to(DEV), src, shapes, start, None)
+    close(out2, t("out2"), rtol=1e-4, atol_scale=1e-5, what="reference-signature forward, 2-d reference points + padding mask")
+    close(out4, t("out4"), rtol=1e-4, atol_scale=1e-5, what="reference-signature forward, 4-d reference boxes")

@@ -143,6 +143,83 @@ def test_epoch_loop_trains_validates_and_checkpoints(tmp_path):
 
 
 @pytest.mark.gpu
+def test_data_parallel_evaluator_merges_rank_exports_into_the_one_process_tree(tmp_path):
+    """``DataParallelEvaluator.evaluate_one_epoch`` (= evaluator.py:138-177 per rank): metrics and the K-Radar export over a
+    7-sample split, once as one process and once as two ranks played one after the other (contiguous blocks, private export
+    roots, ``merge_rank_exports``).  The merged tree equals the one-process tree file for file, the metric sums agree, and a
+    checkpoint goes through ``evaluate`` (model load, epoch, inference time with a short protocol)."""
+    from dpft_amd.data import BlockShardedSampler
+    from dpft_amd.evaluation import DataParallelEvaluator, Metric, merge_rank_exports
+    from dpft_amd.evaluation.exporters.kradar import KRadarExporter
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    cfg = _config()
+    torch.manual_seed(5)
+    model = build("dprt", cfg).to(DEV).eval()
+    n, bs = 7, 2
+    samples = []
+    for k in range(n):
+        data = make_batch(cfg["model"]["inputs"], 1, seed=100 + k, shapes=SHAPES)
+        lab = make_labels(1, seed=200 + k)[0]
+        lab["description"] = torch.tensor([k % 8, k % 2, k % 7])
+        samples.append((data, lab))
+
+    def loader(sampler):
+        idx = list(sampler)
+        batches = []
+        for i in range(0, len(idx), bs):
+            chunk = [samples[j] for j in idx[i:i + bs]]
+            batches.append(({k: torch.cat([c[0][k] for c in chunk]) for k in chunk[0][0]}, [c[1] for c in chunk]))
+
+        class L(list):
+            pass
+        out = L(batches)
+        out.sampler = sampler
+        return out
+
+    ev = DataParallelEvaluator(metric=Metric(metrics={"mAP": "mAP3D", "mGIoU": "mGIoU3D"}), exporter=KRadarExporter(conf_thrs=[0.0, 0.5]),
+                               device=torch.device(DEV), logging="epoch")
+    one = tmp_path / "one"
+    m_one = ev.evaluate_one_epoch(0, model, loader(BlockShardedSampler(n, 0, 1)), None, str(one))
+    two = tmp_path / "two"
+    sums, steps = {}, 0
+    for r in range(2):
+        sampler = BlockShardedSampler(n, r, 2)
+        assert (sampler.start, len(sampler)) == ((0, 4), (4, 3))[r]
+        ld = loader(sampler)
+        m = ev.evaluate_one_epoch(0, model, ld, None, str(two), rank=r, world=2)      # (no process group: this rank's means)
+        for k, v in m.items():
+            sums[k] = sums.get(k, 0.0) + v * len(ld)
+        steps += len(ld)
+    assert sorted(os.listdir(two)) == ["_rank0", "_rank1"]
+    merge_rank_exports(str(two), 2)
+
+    def tree(root):
+        out = {}
+        for d, _, files in os.walk(root):
+            for f in files:
+                out[os.path.relpath(os.path.join(d, f), root)] = open(os.path.join(d, f)).read()
+        return out
+    t1, t2 = tree(str(one)), tree(str(two))
+    assert t1 and sorted(t1) == sorted(t2)
+    for k in t1:
+        assert t1[k] == t2[k], k
+    assert any(k.endswith("val.txt") for k in t1) and any("/preds/000006.txt" in k for k in t1)
+    # metric means are per STEP (evaluator.py:160-171), so they depend on the batch boundaries: 2+2+2+1 in one process,
+    # (2+2 | 2+1) as two ranks -- the same batches here, so the step-weighted mean of the rank means is the one-process mean
+    assert set(m_one) == {"mAP", "mGIoU"} and all(v == v for v in m_one.values())
+    for k in m_one:
+        assert abs(sums[k] / steps - m_one[k]) < 1e-6, (k, sums[k] / steps, m_one[k])
+    # a checkpoint through evaluate(): pickled module -> load -> epoch loop -> inference time
+    ck = tmp_path / "20250102-000000-000_checkpoint_0004.pt"
+    torch.save(model, str(ck))
+    ev.latency_reps, ev.latency_warmup = 6, 2                            # a short protocol for the test
+    res = ev.evaluate(str(ck), loader(BlockShardedSampler(n, 0, 1)), str(tmp_path / "full"))
+    assert abs(res["mAP"] - m_one["mAP"]) < 1e-6 and abs(res["mGIoU"] - m_one["mGIoU"]) < 1e-5
+    assert os.path.isdir(os.path.join(str(tmp_path / "full"), "20250102-000000-000", "exports", "kradar"))
+
+
+@pytest.mark.gpu
 def test_fused_adamw_segment_steps_equal_the_single_launch():
     """Round 4: FusedAdamW.step_segment() -- the DP buckets stepped one by one as their gradients become final -- followed by
     step() for the rest is the SAME update as one step() over everything: parameters, both moments and the per-parameter

@@ -325,3 +325,23 @@ def test_hungarian_and_loss_forward_match_reference_golden(golden, ci):
     total.backward()
     for k in out:
         close(leaf[k].grad, g[f"c{ci}_grad_{k}"], rtol=1e-5, atol_scale=1e-6)
+
+
+def test_msda_module_initial_parameters_equal_the_reference_seeded_init():
+    """tests/golden/msda_init.npz (oracle/gen_golden.py: gen_msda_init): the reference's MSDeformAttn built under
+    torch.manual_seed(1234).  The product module written in this repo's own form (VERDICT r4 housekeeping) must draw the same
+    random numbers in the same order and produce the same star pattern: every tensor bit for bit."""
+    import os
+    import numpy as np
+    import torch
+    from dpft_amd.models.layers.ms_deform_attn import MSDeformAttn
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "msda_init.npz"))
+    for tag, geom in (("fuser", (16, 5, 8, 4)), ("wide", (64, 3, 4, 2))):
+        torch.manual_seed(1234)
+        mod = MSDeformAttn(*geom)
+        sd = mod.state_dict()
+        keys = [k[len(tag) + 1:] for k in gold.files if k.startswith(tag + ".") and not k.startswith(tag + ".rand.")
+                and k[len(tag) + 1:] in sd]
+        assert sorted(keys) == sorted(sd.keys()), (keys, list(sd))
+        for k in keys:
+            assert torch.equal(sd[k], torch.from_numpy(gold[f"{tag}.{k}"])), (tag, k)
