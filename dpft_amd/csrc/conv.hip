@@ -1903,9 +1903,18 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
     DPFT_REQUIRE(x && w && y && out_bn, "conv fwd_bnact: null tensor");
     hipStream_t st = (hipStream_t)stream;
     IgemmArgs a; fill_igemm(a, d, false);
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);
     if (d->act16) t.splits = 1;
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
+    if (t.x3 && t.splits > 1 && (a.N & 3) == 0 && workspace && sk_fixup_ok(a, t.splits, 1)) {
+        // split kernels with a K split: the last workgroup of a tile runs the whole inference epilogue (in-launch fix-up)
+        ProfScope prof(0, d, st);
+        a.x = x; a.w = w; a.y = y;
+        a.partial = ws_slabs(workspace);
+        a.sk_ticket = reinterpret_cast<int*>(workspace);
+        a.obn = out_bn; a.oadd = residual; a.orelu = relu;
+        return launch_igemm<false>(a, t, false, st);
+    }
     if (!t.vec || t.splits > 1 || (a.N & 3) != 0 || conv16_matches(d)) {
         rc = dpft_conv2d_nhwc_fwd_f32(d, x, w, nullptr, nullptr, 0, y, nullptr, workspace, stream);
         if (rc) return rc;
