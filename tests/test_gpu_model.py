@@ -1142,6 +1142,46 @@ def test_frozen_forward_between_graphed_train_steps_does_not_leak_its_batchnorm_
         assert float((a - b).norm()) < 5e-3 * float(b.norm()) + 1e-6, (float((a - b).norm()), float(b.norm()))
 
 
+def test_200_replayed_steps_reproduce_the_eager_steps_bit_for_bit_in_the_loss(monkeypatch):
+    """tools/plan_graph_check.py as a stress test.  With a zero learning rate the parameters never
+    move, so every step computes the same forward: the loss of all 200 steps must be the SAME BITS, replayed or eager (the
+    forward has no atomics), and every step's gradient must sit at round-off distance from the eager run's (the backward's
+    atomic sums reorder).  This is the situation in which memset nodes inside the replayed plans corrupted gradients from
+    about the 7th replay on in round 3; the plans hold kernel nodes only since (tools/probes/graph_memset_probe.hip: the
+    corruption does not reproduce with an isolated graph)."""
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    cfg = small_config(dropout=0.0)
+    cfg["train"]["optimizer"]["lr"] = 0.0
+    shapes = {"camera_mono": (128, 224, 3), "radar_bev": (128, 43, 6), "radar_front": (37, 107, 6)}
+    data = make_batch(cfg["model"]["inputs"], 2, seed=7, shapes=shapes, device=DEV)
+    labels = make_labels(2, seed=3, device=DEV)
+    runs = {}
+    for mode, steps in (("0", 12), ("2", 200)):
+        monkeypatch.setenv("DPFT_PLAN_GRAPHS", mode)
+        torch.manual_seed(3)
+        tr = DataParallelTrainer(build("dprt", cfg), cfg, torch.device(DEV))
+        if mode == "2":
+            tr.enable_graphs(data)                      # the decoder's forward / backward graphs too
+        hist = []
+        for _ in range(steps):
+            loss, _ = tr.train_step(data, labels)
+            hist.append((float(loss), [float(b["flat"].double().norm()) for b in tr.reducer.buckets]))
+        torch.cuda.synchronize()
+        if mode == "2":
+            assert all(p.graphed for i in tr.model.inputs for p in tr.model.backbones[i]._plans.values())
+        runs[mode] = hist
+    l0 = runs["0"][0][0]
+    assert all(l == l0 for l, _ in runs["0"]), sorted({l for l, _ in runs["0"]})
+    bad = [(i, l) for i, (l, _) in enumerate(runs["2"]) if l != l0]
+    assert not bad, (l0, bad[:5])
+    ref = runs["0"][0][1]
+    for i, (_, norms) in enumerate(runs["2"]):
+        for j, (a, b) in enumerate(zip(norms, ref)):
+            assert abs(a - b) <= 1e-4 * b + 1e-9, (i, j, a, b)
+
+
 def test_two_forwards_before_their_backwards_with_replayed_plans():
     """with plan graphs on, a plan's saved activations live in ONE persistent arena.  A second
     grad-enabled forward before the first one's backward (two batches per loss) must not overwrite them: it takes a fresh
