@@ -33,6 +33,10 @@ class GradBucketReducer:
     # one-rank timing experiment (tools/exp_switches.py flips it; never read from the environment): buckets fire without their
     # collective -- no gradient exchange, so it is refused with more than one rank
     exp_skip_bucket_collectives = False
+    # one-rank cost-model experiment (tools/exp_switches.py --standin-collective): called with the wire tensor right behind each
+    # bucket's collective, on the stream the collective was enqueued on -- a stand-in for the CU / HBM footprint an N > 1
+    # all-reduce kernel would have there.  None in the product.
+    exp_after_collective = None
 
     def __init__(self, params: List[torch.nn.Parameter], bucket_bytes: int = 25 << 20, process_group=None,
                  average: bool = True, group_of: Dict[int, str] = None, comm_dtype: Optional[torch.dtype] = None,
@@ -295,6 +299,8 @@ class GradBucketReducer:
                     wire = b["stage"]
                     wire.copy_(b["flat"])                             # round to the wire dtype (RNE)
                 self._pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), b))
+                if GradBucketReducer.exp_after_collective is not None:
+                    GradBucketReducer.exp_after_collective(wire)
             else:
                 # a stream of OUR choosing (= a hardware queue of our choosing, DataParallelTrainer): a synchronous
                 # collective is enqueued on the current stream, so the exchange of a bucket -- scaling, wire rounding,
@@ -314,6 +320,8 @@ class GradBucketReducer:
                         wire = b["stage"]
                         wire.copy_(b["flat"])
                     dist.all_reduce(wire, op=op, group=self.group, async_op=False)
+                    if GradBucketReducer.exp_after_collective is not None:
+                        GradBucketReducer.exp_after_collective(wire)
                     if b["stage"] is not None:
                         b["flat"].copy_(b["stage"])
                     self._final(b)                                    # (on the communication stream, behind the collective)

@@ -95,15 +95,16 @@ class DataParallelTrainer:
         # on.  Never read from the environment; refused with more than one rank (ranks disagreeing on the decision mismatch
         # their collectives and hang).
         self._exp_local_decision = False
-        # The collectives' hardware queue.  Four queues, four busy chains (main | camera weight gradients | two radar views):
-        # RCCL's own stream ("pg") lands on whichever queue the runtime picks, possibly the critical chain's, where an
-        # all-reduce kernel of N > 1 ranks would hold up the data-gradient chain for its whole duration.  "side" (default)
-        # enqueues them, in order, on the camera's weight-gradient stream: the one chain with slack (6.5 ms of GEMMs in a 19 ms
-        # backward) and the producer of most of every camera bucket; "front" = the last view's stream.  Forced one-rank
-        # collectives (tools/r03_comm_ab.sh): side 29.2, pg 29.4, front 31.7 ms against 28.7 ms plain.  "own" = a dedicated
-        # stream.  All of this was chosen on ONE rank, where the all-reduce moves no bytes: with N > 1 the choice is an open
-        # question that tools/scale.sh sweeps (side | pg | own) -- DESIGN.md section 6 says what to expect.
-        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "side")
+        # The collectives' hardware queue.  Four queues, four busy chains (main | camera weight gradients | two radar views).
+        # "pg" (default since round 5) = the process group's own stream, "side" = in order on the camera's weight-gradient
+        # stream (the chain with slack and the producer of most camera buckets; the round-3 default, chosen with no-op
+        # one-rank collectives), "own" = a dedicated stream, "front" = the last view's stream.  Round 5 put a kernel with an
+        # 8-rank ring all-reduce's footprint behind every bucket collective (32 workgroups, the bucket read and written twice:
+        # tools/r05_comm_standin.sh, profiles/r05_comm_standin.txt): median step 26.1 / 26.1 ms and 0.09 ms exposed with "pg",
+        # 26.0 / 27.6 ms and 0.29 ms exposed with "side" (its stream is joined by the main chain at every stage boundary, so a
+        # slow collective there holds the data-gradient chain), 26.3 / 27.4 ms with "own"; plain step 25.4-25.6 ms.  Still one
+        # rank: tools/scale.sh sweeps the three on a multi-GPU node.
+        self.comm_placement = os.environ.get("DPFT_COMM_STREAM", "pg")
         self.optimizer = build_optimizer(name, self.model.parameters(), device=device, **opt)   # trainer.py:233
         # epoch loop (trainer.py:21-47,64-67): epochs, schedule, logging frequency (None | 'step' | 'epoch')
         self.epochs = int(train.get("epochs", 1))

@@ -1,6 +1,8 @@
 """One-rank timing experiments that produce WRONG training (no gradient exchange / a local step decision) -- kept out of the
 package and the library: this wrapper flips the two switches and then runs bench.py in-process.
-usage: python tools/exp_switches.py [--skip-bucket-collectives] [--local-decision] -- <bench.py arguments>
+usage: python tools/exp_switches.py [--skip-bucket-collectives] [--local-decision] [--standin-collective] -- <bench.py arguments>
+--standin-collective: behind every bucket's (one-rank, forced) collective a kernel with the footprint of an 8-rank ring
+all-reduce runs on the same stream (tools/probes/comm_standin.hip; STANDIN_BLOCKS=32, STANDIN_PASSES=2)
 (tools/r03_forced_breakdown.sh used DPFT_EXP_* environment variables for the same; those are gone.)"""
 import os
 import runpy
@@ -17,6 +19,24 @@ def main():
     from dpft_amd.training import distributed, trainer
     if "--skip-bucket-collectives" in mine:
         distributed.GradBucketReducer.exp_skip_bucket_collectives = True
+    if "--standin-collective" in mine:
+        import ctypes
+        import subprocess
+        import torch
+        so = os.path.join(ROOT, "tools", "probes", "bin", "libcomm_standin.so")
+        if not os.path.exists(so):
+            os.makedirs(os.path.dirname(so), exist_ok=True)
+            subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O2", "-shared", "-fPIC", "-o", so,
+                                   os.path.join(ROOT, "tools", "probes", "comm_standin.hip")])
+        lib = ctypes.CDLL(so)
+        lib.standin_launch.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+        blocks, passes = int(os.environ.get("STANDIN_BLOCKS", "32")), int(os.environ.get("STANDIN_PASSES", "2"))
+
+        def standin(wire):
+            rc = lib.standin_launch(wire.data_ptr(), wire.numel() * wire.element_size(), passes, blocks,
+                                    torch.cuda.current_stream(wire.device).cuda_stream)
+            assert rc == 0, rc
+        distributed.GradBucketReducer.exp_after_collective = staticmethod(standin)
     if "--local-decision" in mine:
         init = trainer.DataParallelTrainer.__init__
 
