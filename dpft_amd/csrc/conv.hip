@@ -718,21 +718,6 @@ __global__ void splitk_reduce_residual_kernel(const float* __restrict__ partial,
 // LDS holds [32 pixels][BMn] of dY and [32 pixels][BNc] of x; both fragments are ds_read_b32
 // (consecutive lanes -> consecutive channels, conflict free).
 // ---------------------------------------------------------------------------------------------
-struct WgradArgs {
-    const float* x;
-    const float* dy;
-    float* dw;        // [K][taps][C]
-    float* partial;   // [splits][K*taps*C] or null
-    const float* pro; // BN block [4][C] of the x operand or null
-    int B, H, W, C;   // input
-    int OH, OW, K;    // dy
-    int kh, kw, stride, pad;
-    int M;            // B*OH*OW pixels (reduction)
-    int ktiles, ctiles, taps, splits, psteps, psteps_per_split;
-    int pro_relu;
-    int J;            // generic path: taps*C
-    int x16, dy16;    // x / dy stored as bf16 (vector path only)
-};
 
 // BF16 = true (mixed-precision mode, square tiles): both operands are rounded to bf16 and TRANSPOSED on their
 // way into LDS ([channel][pixel], so that a lane finds the 8 consecutive reduction indices v_mfma_f32_32x32x16_bf16
@@ -2206,7 +2191,12 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         a.psteps = cdiv(a.M, pk);
         a.psteps_per_split = cdiv(a.psteps, splits);
         const size_t tbl = (size_t)a.psteps_per_split * pk * 4;      // per-workgroup input-pixel offset table
-        if (bmn == 128) {
+        static const bool wx3 = getenv("DPFT_WGRAD_X3") == nullptr || atoi(getenv("DPFT_WGRAD_X3")) != 0;      // A/B switch
+        if (bmn == 128 && wx3 && split_on() && a.taps > 1 && 2.0 * a.M * (double)d->K * a.J >= 2e9) {
+            // the big multi-tap weight gradients on the split kernels (conv_x3.hip), like their forward / data gradient
+            rc = launch_wgrad_x3(a, pro, grid, st);
+            if (rc) return rc;
+        } else if (bmn == 128) {
             const size_t lds = (size_t)2 * 32 * (128 + 128) * 4 + tbl;
             if (pro) launch_lds(wgrad_pipe_kernel<128, 128, 2, 2, 32, true>, grid, block, lds, st, a);
             else launch_lds(wgrad_pipe_kernel<128, 128, 2, 2, 32, false>, grid, block, lds, st, a);

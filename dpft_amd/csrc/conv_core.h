@@ -645,8 +645,26 @@ __device__ __forceinline__ void static_for(Fn&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+struct WgradArgs {
+    const float* x;
+    const float* dy;
+    float* dw;        // [K][taps][C]
+    float* partial;   // [splits][K*taps*C] or null
+    const float* pro; // BN block [4][C] of the x operand or null
+    int B, H, W, C;   // input
+    int OH, OW, K;    // dy
+    int kh, kw, stride, pad;
+    int M;            // B*OH*OW pixels (reduction)
+    int ktiles, ctiles, taps, splits, psteps, psteps_per_split;
+    int pro_relu;
+    int J;            // generic path: taps*C
+    int x16, dy16;    // x / dy stored as bf16 (vector path only)
+};
+
 // conv_x3.hip: the 3 x bf16 split main loop (fp32 results from the bf16 matrix cores); `a` prepared as for igemm_pipe_kernel
 int launch_igemm_x3(IgemmArgs& a, int bm, int bn, bool dgrad, bool pro, hipStream_t st);
 int split_planes(const float* src, void* dst, int64_t n, hipStream_t st);      // fp32 -> three bf16 planes
+// weight gradient on the split kernels: 128 x 128 tiles, 32 pixels per step; `a` as for wgrad_pipe_kernel<128, 128, 2, 2, 32, *>
+int launch_wgrad_x3(const WgradArgs& a, bool pro, dim3 grid, hipStream_t st);
 
 }  // namespace dpft

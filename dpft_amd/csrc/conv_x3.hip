@@ -769,6 +769,367 @@ int split_planes(const float* src, void* dst, int64_t n, hipStream_t st) {
     return check_launch("split_planes");
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weight gradient on the split kernels:  dW[n][tap][c] = sum over pixels p of dY[p][n] * act(x)[p @ tap][c].  Both operands are
+// pixel-major in memory, the reduction runs over pixels, and v_mfma_f32_32x32x16_bf16 wants 8 consecutive PIXELS of one channel
+// per lane: the planes are written pixel-major into LDS ([pixel][channel], a lane's quad = 4 channels of one pixel = 8 bytes per
+// plane, 16-byte chunks XOR-swizzled by the pixel) and read with ds_read_b64_tr_b16, which transposes on the way out -- the
+// layout and read addressing of wgrad_pipe16_kernel (conv_pipe.h), three planes deep.  Loader side as igemm_x3_kernel: register
+// route, split in placeable pieces behind the MFMAs, two register sets (loads two steps ahead); the input-pixel offsets of a
+// tap come from a per-workgroup LDS table (wgrad_pipe_kernel).  128 x 128 tile, 32 pixels per step.
+// PRO_: 0 none | 1 BatchNorm + ReLU of x | 2 the same with padding (taps that miss the image must stay zero).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int PRO_>
+__global__ __launch_bounds__(256) void wgrad_x3_kernel(WgradArgs a) {
+    constexpr bool PRO = PRO_ != 0, MASK = PRO_ == 2;
+    constexpr int BMn = 128, BNc = 128, WGM = 2, WGN = 2, PK = 32;
+    constexpr int RB = 2, CB = 2;
+    constexpr int YL = BMn / 4, XL = BNc / 4;              // lanes (4-channel quads) per pixel row
+    constexpr int YRW = 64 / YL, XRW = 64 / XL;            // pixel rows per wave instruction
+    constexpr int YRPP = 4 * YRW, XRPP = 4 * XRW;          // pixel rows per pass of the 4 waves
+    constexpr int YP = PK / YRPP, XP = PK / XRPP, NQ = YP + XP;
+    constexpr int Y_ROWB = BMn * 2, X_ROWB = BNc * 2;      // bytes per plane row (one pixel)
+    constexpr int Y_PLANE = PK * Y_ROWB, X_PLANE = PK * X_ROWB;
+    constexpr int Y_BYTES = 3 * Y_PLANE, X_BYTES = 3 * X_PLANE, STAGE = Y_BYTES + X_BYTES;
+    constexpr int NG = PK / 16;
+    extern __shared__ __attribute__((aligned(16))) float smem[];      // 2 stages | pixel-offset table ; epilogue staging
+    char* const lds = reinterpret_cast<char*>(smem);
+    typedef __attribute__((address_space(3))) char lds_char;
+    const unsigned lds_base = (unsigned)(size_t)(lds_char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+
+    const int nwg = a.ktiles * a.ctiles * a.taps * a.splits;
+    int bid = xcd_remap(blockIdx.x, nwg);
+    const int split = bid / (a.ktiles * a.ctiles * a.taps);
+    bid -= split * (a.ktiles * a.ctiles * a.taps);
+    const int tap = bid / (a.ktiles * a.ctiles);
+    bid -= tap * (a.ktiles * a.ctiles);
+    const int kt_ = bid / a.ctiles, ct_ = bid - kt_ * a.ctiles;
+    const int n0 = kt_ * BMn, c0 = ct_ * BNc;
+    const int r = tap / a.kw, s = tap - r * a.kw;
+
+    const int yr = YRW * wave + lane / YL, ych = lane % YL;      // this lane's pixel row within a pass / channel quad
+    const int xr = XRW * wave + lane / XL, xch = lane % XL;
+    const bool y_ok = (n0 + ych * 4) < a.K;
+    const bool x_ok = (c0 + xch * 4) < a.C;
+    f32x4 p_mu = {0.f, 0.f, 0.f, 0.f}, p_sc = {1.f, 1.f, 1.f, 1.f}, p_sh = {0.f, 0.f, 0.f, 0.f};
+    if (PRO && x_ok) {      // the reduction runs over pixels: a lane's four channels never change
+        p_mu = *reinterpret_cast<const f32x4*>(a.pro + c0 + xch * 4);
+        p_sc = *reinterpret_cast<const f32x4*>(a.pro + a.C + c0 + xch * 4);
+        p_sh = *reinterpret_cast<const f32x4*>(a.pro + 2 * a.C + c0 + xch * 4);
+    }
+    const int ohw = a.OH * a.OW;
+    constexpr unsigned OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, a.M * a.K * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * 4, 0x00020000);
+    unsigned y_voff[YP];
+#pragma unroll
+    for (int i = 0; i < YP; ++i) y_voff[i] = y_ok ? (unsigned)((YRPP * i + yr) * a.K + n0 + ych * 4) * 4u : OOB;
+    const int ps_begin = split * a.psteps_per_split;
+    const int ps_end = min(a.psteps, ps_begin + a.psteps_per_split);
+    const int nsteps = max(ps_end - ps_begin, 0);
+    unsigned* const tbl = reinterpret_cast<unsigned*>(lds + 2 * STAGE);
+    {      // input-pixel byte offsets of this workgroup's pixel range for its tap (or the out-of-range marker)
+        const int npix = nsteps * PK;
+        for (int idx = tid; idx < npix; idx += 256) {
+            const int p = ps_begin * PK + idx;
+            const int b = p / ohw;
+            const int rem = p - b * ohw;
+            const int oh = rem / a.OW, ow = rem - oh * a.OW;
+            const int hi = oh * a.stride - a.pad + r, wi = ow * a.stride - a.pad + s;
+            const bool v = p < a.M && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            tbl[idx] = v ? ((((unsigned)b * a.H + hi) * a.W + wi) * a.C) * 4u : OOB;
+        }
+    }
+    __syncthreads();
+    typedef __attribute__((address_space(3))) const unsigned lds_u32;
+    unsigned tbl_ad = lds_base + 2 * STAGE + xr * 4;      // LDS address of this lane's first row of the next tile to load
+    const unsigned x_lane = x_ok ? (unsigned)(c0 + xch * 4) * 4u : OOB;
+    int next_ps = ps_begin;
+    int so_y = 0;
+    unsigned xoffs[XP];
+    auto prep = [&]() {
+        so_y = __builtin_amdgcn_readfirstlane(next_ps * PK * a.K * 4);
+#pragma unroll
+        for (int i = 0; i < XP; ++i) xoffs[i] = *(lds_u32*)(size_t)(tbl_ad + (unsigned)(XRPP * i * 4)) + x_lane;
+        tbl_ad += PK * 4;
+        ++next_ps;
+    };
+    f32x4 rq[2][NQ];                    // quads 0 .. YP-1: dY rows, YP .. NQ-1: x rows
+    unsigned rx_bad[2] = {0, 0};        // bit i: x quad i of the set was loaded from outside the image (MASK)
+    auto load_quad = [&](auto SET, auto K) {
+        constexpr int set = decltype(SET)::value, k = decltype(K)::value;
+        if constexpr (k < YP) {
+            rq[set][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_y, (int)y_voff[k], so_y, 0));
+        } else {
+            constexpr int i = k - YP;
+            rq[set][k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_x, (int)xoffs[i], 0, 0));
+            if constexpr (MASK) rx_bad[set] = (rx_bad[set] & ~(1u << i)) | ((xoffs[i] >> 31) << i);
+        }
+    };
+    // LDS destination of a quad: pixel row (yr / xr + rows per pass * pass), 8 bytes at half (quad & 1) of chunk (quad / 2) ^ key,
+    // key = (pixel % 4) * 4 (wgrad_pipe16_kernel's swizzle; rows per pass are multiples of 4, so the key is the lane's)
+    const int yw_off = yr * Y_ROWB + ((((ych >> 1) ^ ((yr & 3) << 2)) << 4) | ((ych & 1) << 3));
+    const int xw_off = xr * X_ROWB + ((((xch >> 1) ^ ((xr & 3) << 2)) << 4) | ((xch & 1) << 3));
+    f32x4 cv;
+    u32x2 c1, c2, c3;
+    float rr0 = 0.f, rr1 = 0.f;
+    auto piece = [&](auto STG, auto K, auto ID) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value, k = decltype(K)::value, id = decltype(ID)::value;
+        constexpr bool bn = PRO && k >= YP;
+        if constexpr (id == 0 || id == 1) {
+            if constexpr (id == 0) cv = rq[stg][k];
+#pragma unroll
+            for (int e = 2 * id; e < 2 * id + 2; ++e) cv[e] = fmaxf(fmaf(cv[e] - p_mu[e], p_sc[e], p_sh[e]), 0.f);
+        } else if constexpr (id == 2) {
+            const unsigned keep = ~(unsigned)__builtin_amdgcn_sbfe(rx_bad[stg], k - YP, 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cv[e] = __uint_as_float(__float_as_uint(cv[e]) & keep);
+        } else if constexpr (id == 3 || id == 5) {
+            constexpr int h = (id - 3) / 2;
+            if constexpr (id == 3 && !bn) cv = rq[stg][k];
+            const float x = cv[2 * h], y = cv[2 * h + 1];
+            const unsigned q = cvt_pk_bf16(x, y);
+            c1[h] = q;
+            rr0 = x - __uint_as_float(q << 16);
+            rr1 = y - __uint_as_float(q & 0xffff0000u);
+        } else if constexpr (id == 4 || id == 6) {
+            constexpr int h = (id - 4) / 2;
+            const unsigned q = cvt_pk_bf16(rr0, rr1);
+            c2[h] = q;
+            c3[h] = cvt_pk_bf16(rr0 - __uint_as_float(q << 16), rr1 - __uint_as_float(q & 0xffff0000u));
+        } else {
+            constexpr int PL = k < YP ? Y_PLANE : X_PLANE;
+            char* dst = lds + stg * STAGE + (k < YP ? k * YRPP * Y_ROWB + 0 : Y_BYTES + (k - YP) * XRPP * X_ROWB) + (k < YP ? yw_off : xw_off);
+            *reinterpret_cast<u32x2*>(dst) = c1;
+            *reinterpret_cast<u32x2*>(dst + PL) = c2;
+            *reinterpret_cast<u32x2*>(dst + 2 * PL) = c3;
+        }
+    };
+    constexpr int NPY = 5, NPX = PRO ? (MASK ? 8 : 7) : 5, NPIECE = YP * NPY + XP * NPX;
+    auto piece_at = [&](auto STG, auto P_) __attribute__((always_inline)) {
+        constexpr int P = decltype(P_)::value;
+        if constexpr (P < YP * NPY) {
+            piece(STG, std::integral_constant<int, P / NPY>{}, std::integral_constant<int, 3 + P % NPY>{});
+        } else {
+            constexpr int k = YP + (P - YP * NPY) / NPX, o = (P - YP * NPY) % NPX;
+            constexpr int id = !PRO ? o + 3 : (MASK ? o : (o < 2 ? o : o + 1));
+            piece(STG, std::integral_constant<int, k>{}, std::integral_constant<int, id>{});
+        }
+    };
+    auto quad_done_at = [](int P) constexpr {
+        if (P < YP * NPY) return P % NPY == NPY - 1 ? P / NPY : -1;
+        return (P - YP * NPY) % NPX == NPX - 1 ? YP + (P - YP * NPY) / NPX : -1;
+    };
+
+    f32x16 acc[RB][CB], acl[RB][CB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) { acc[i][j][q] = 0.f; acl[i][j][q] = 0.f; }
+
+    // transpose-read addresses (wgrad_pipe16_kernel): supplier lane (group G = lane / 16, s = lane % 16) -> pixel (G / 2) * 8 + s / 4
+    // of the K-group, channel quad s % 4 of the 16 channels (G % 2) of a 32-channel block
+    unsigned y_ad[2][RB], x_ad[2][CB];
+    {
+        const int G = lane >> 4, sl = lane & 15, r2 = sl >> 2, q = sl & 3;
+        const int pix = (G >> 1) * 8 + r2;
+        const int key = r2 << 2;
+#pragma unroll
+        for (int st_ = 0; st_ < 2; ++st_) {
+#pragma unroll
+            for (int i = 0; i < RB; ++i) {
+                const int c = (wm * RB + i) * 4 + 2 * (G & 1) + (q >> 1);
+                y_ad[st_][i] = lds_base + st_ * STAGE + pix * Y_ROWB + ((c ^ key) << 4) + (q & 1) * 8;
+            }
+#pragma unroll
+            for (int j = 0; j < CB; ++j) {
+                const int c = (wn * CB + j) * 4 + 2 * (G & 1) + (q >> 1);
+                x_ad[st_][j] = lds_base + st_ * STAGE + Y_BYTES + pix * X_ROWB + ((c ^ key) << 4) + (q & 1) * 8;
+            }
+        }
+    }
+#pragma unroll
+    for (int st_ = 0; st_ < 2; ++st_) {
+#pragma unroll
+        for (int i = 0; i < RB; ++i) asm volatile("" : "+v"(y_ad[st_][i]));
+#pragma unroll
+        for (int j = 0; j < CB; ++j) asm volatile("" : "+v"(x_ad[st_][j]));
+    }
+
+    constexpr int MPG = 6 * RB * CB, SLOTS = NG * MPG;
+    constexpr int NRD = 3 * 2 * (RB + CB);      // transpose reads per K-group: 3 planes x 2 halves x (RB + CB)
+    typedef __attribute__((address_space(3))) const u32x2 lds_u32x2;
+    auto step = [&](auto STG, auto M1_, auto M2_) __attribute__((always_inline)) {
+        constexpr int stg = decltype(STG)::value;
+        constexpr bool m1 = decltype(M1_)::value, m2 = decltype(M2_)::value;
+        using OTHER = std::integral_constant<int, (stg ^ 1)>;
+        if constexpr (m2) prep();
+        u32x2 av[2][3][RB][2], bv[2][3][CB][2];
+        auto frag_one = [&](auto SET, auto G, auto R) {
+            constexpr int set = decltype(SET)::value, g = decltype(G)::value, rr = decltype(R)::value;
+            constexpr int p = rr / (2 * (RB + CB)), o = (rr % (2 * (RB + CB))) / 2, h = rr % 2;
+            if constexpr (o < RB) {
+                u32x2& dst = av[set][p][o][h];
+                const unsigned ad = y_ad[stg][o];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(p * Y_PLANE + (g * 16 + h * 4) * Y_ROWB));
+            } else {
+                u32x2& dst = bv[set][p][o - RB][h];
+                const unsigned ad = x_ad[stg][o - RB];
+                asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(ad), "n"(p * X_PLANE + (g * 16 + h * 4) * X_ROWB));
+            }
+        };
+        static_for<NRD>([&](auto R) { frag_one(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, R); });
+        __builtin_amdgcn_sched_barrier(0);
+        static_for<SLOTS>([&](auto S) {
+            constexpr int sl = decltype(S)::value;
+            constexpr int g = sl / MPG, w = sl % MPG, t = w / (RB * CB), ij = w % (RB * CB), i = ij / CB, j = ij % CB;
+            constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 0, 0, 1, 1, 2};
+            if constexpr (w == 0) {
+                // the K-group's fragments (issued a group earlier) have landed.  Inline-asm reads are invisible to the compiler's
+                // counters; the fragment registers are operands of the wait so that nothing that uses them can move in front of it
+                auto& A_ = av[g & 1];
+                auto& B_ = bv[g & 1];
+                asm volatile("s_waitcnt lgkmcnt(0)"
+                             : "+v"(A_[0][0][0]), "+v"(A_[0][0][1]), "+v"(A_[0][1][0]), "+v"(A_[0][1][1]), "+v"(A_[1][0][0]), "+v"(A_[1][0][1]),
+                               "+v"(A_[1][1][0]), "+v"(A_[1][1][1]), "+v"(A_[2][0][0]), "+v"(A_[2][0][1]), "+v"(A_[2][1][0]), "+v"(A_[2][1][1]),
+                               "+v"(B_[0][0][0]), "+v"(B_[0][0][1]), "+v"(B_[0][1][0]), "+v"(B_[0][1][1]), "+v"(B_[1][0][0]), "+v"(B_[1][0][1]),
+                               "+v"(B_[1][1][0]), "+v"(B_[1][1][1]), "+v"(B_[2][0][0]), "+v"(B_[2][0][1]), "+v"(B_[2][1][0]), "+v"(B_[2][1][1])
+                             :: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            constexpr int pa = t == 2 ? 0 : TA[t], pb = t == 2 ? 0 : TB[t];
+            const u32x4 fa = __builtin_shufflevector(av[g & 1][pa][i][0], av[g & 1][pa][i][1], 0, 1, 2, 3);
+            const u32x4 fb = __builtin_shufflevector(bv[g & 1][pb][j][0], bv[g & 1][pb][j][1], 0, 1, 2, 3);
+            if constexpr (t == 2)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acc[i][j], 0, 0, 0);
+            else
+                acl[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa), __builtin_bit_cast(bf16x8, fb), acl[i][j], 0, 0, 0);
+            if constexpr (g + 1 < NG) {
+                constexpr int r0 = w * NRD / MPG, r1 = (w + 1) * NRD / MPG;
+                static_for<r1 - r0>([&](auto R) {
+                    frag_one(std::integral_constant<int, ((g + 1) & 1)>{}, std::integral_constant<int, (g + 1 < NG ? g + 1 : 0)>{},
+                             std::integral_constant<int, r0 + decltype(R)::value>{});
+                });
+            }
+            if constexpr (m1) {
+                constexpr int p0 = sl * NPIECE / SLOTS, p1 = (sl + 1) * NPIECE / SLOTS;
+                static_for<p1 - p0>([&](auto Q) {
+                    constexpr int P = p0 + decltype(Q)::value;
+                    piece_at(OTHER{}, std::integral_constant<int, P>{});
+                    constexpr int done = quad_done_at(P);
+                    if constexpr (m2 && done >= 0) load_quad(OTHER{}, std::integral_constant<int, (done >= 0 ? done : 0)>{});
+                });
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    auto fence = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using T = std::true_type;
+    using F = std::false_type;
+    if (nsteps > 0) {      // tile 0 -> stage 0 (through set 0); tile 1 -> set 1, tile 2 -> set 0
+        prep();
+        static_for<NQ>([&](auto K) { load_quad(S0{}, K); });
+        static_for<NPIECE>([&](auto P) { piece_at(S0{}, P); });
+        if (nsteps > 1) {
+            prep();
+            static_for<NQ>([&](auto K) { load_quad(S1{}, K); });
+        }
+        if (nsteps > 2) {
+            prep();
+            static_for<NQ>([&](auto K) { load_quad(S0{}, K); });
+        }
+    }
+    fence();
+    int rem = nsteps;
+    for (; rem >= 5; rem -= 2) {
+        step(S0{}, T{}, T{});
+        fence();
+        step(S1{}, T{}, T{});
+        fence();
+    }
+    if (rem == 4) {
+        step(S0{}, T{}, T{});
+        fence();
+        step(S1{}, T{}, F{});
+        fence();
+        step(S0{}, T{}, F{});
+        fence();
+        step(S1{}, F{}, F{});
+    } else if (rem == 3) {
+        step(S0{}, T{}, F{});
+        fence();
+        step(S1{}, T{}, F{});
+        fence();
+        step(S0{}, F{}, F{});
+    } else if (rem == 2) {
+        step(S0{}, T{}, F{});
+        fence();
+        step(S1{}, F{}, F{});
+    } else if (rem == 1) {
+        step(S0{}, F{}, F{});
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
+#pragma unroll
+        for (int j = 0; j < CB; ++j) acc[i][j] += acl[i][j];
+    // epilogue: as wgrad_pipe_kernel (fp32 weight gradients / pixel-split partials)
+    float* __restrict__ out = a.partial ? a.partial + (size_t)split * a.K * a.taps * a.C : a.dw;
+    constexpr int RP = RB * 32;
+    constexpr int LDC = BNc + 4;
+    static_assert(RP * LDC * 4 <= 2 * STAGE, "wgrad epilogue staging does not fit the operand LDS");
+    float* Cs = smem;
+    for (int hh = 0; hh < WGM; ++hh) {
+        __syncthreads();
+        if (wm == hh) {
+#pragma unroll
+            for (int j = 0; j < CB; ++j)
+#pragma unroll
+                for (int i = 0; i < RB; ++i)
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) {
+                        const int row = i * 32 + (q & 3) + 8 * (q >> 2) + 4 * (lane >> 5);
+                        Cs[row * LDC + wn * CB * 32 + j * 32 + (lane & 31)] = acc[i][j][q];
+                    }
+        }
+        __syncthreads();
+        constexpr int C4 = BNc / 4;
+        for (int idx = tid; idx < RP * C4; idx += 256) {
+            const int row = idx / C4, c4 = idx - row * C4;
+            const int n = n0 + hh * RP + row, c = c0 + c4 * 4;
+            if (n < a.K && c < a.C)
+                *reinterpret_cast<f32x4*>(out + ((size_t)n * a.taps + tap) * a.C + c) = *reinterpret_cast<const f32x4*>(&Cs[row * LDC + c4 * 4]);
+        }
+    }
+}
+
+int launch_wgrad_x3(const WgradArgs& a, bool pro, dim3 grid, hipStream_t st) {
+    const size_t lds = (size_t)2 * 3 * 32 * (128 + 128) * 2 + (size_t)a.psteps_per_split * 32 * 4;
+    const bool padded = a.kh * a.kw > 1 || a.pad > 0;
+    auto go = [&](auto kernel) {
+        static size_t configured = 0;
+        if (lds > configured) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            configured = lds;
+        }
+        hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
+    };
+    if (pro && padded) go(wgrad_x3_kernel<2>);
+    else if (pro) go(wgrad_x3_kernel<1>);
+    else go(wgrad_x3_kernel<0>);
+    return check_launch("conv wgrad (3 x bf16 split)");
+}
+
 template <typename K>
 static void launch_x3(K kernel, dim3 grid, size_t lds, hipStream_t st, const IgemmArgs& args) {
     static size_t configured = 0;       // one static per kernel instantiation

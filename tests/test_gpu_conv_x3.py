@@ -75,7 +75,10 @@ def test_split_mode_error_not_above_the_fp32_mfma_paths(shape):
     g = torch.Generator().manual_seed(3)
     bn = torch.stack((torch.randn(C, generator=g) * 0.5, torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3, torch.ones(C)))
     xd = ((x.double() - bn[0].double()) * bn[1].double() + bn[2].double()).clamp_min(0)
-    yref_pro = F.conv2d(xd.permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=s, padding=pad).permute(0, 2, 3, 1)
+    w64 = w.double().permute(0, 3, 1, 2).clone().requires_grad_(True)
+    yp = F.conv2d(xd.permute(0, 3, 1, 2), w64, stride=s, padding=pad)
+    yp.backward(dy.double().permute(0, 3, 1, 2))
+    yref_pro, dwref_pro = yp.detach().permute(0, 2, 3, 1), w64.grad.permute(0, 2, 3, 1)
     xg, wg, dyg, bng = x.to(DEV), w.to(DEV), dy.to(DEV), bn.to(DEV)
     wt = ops.weight_transpose(wg)
     err = {}
@@ -92,12 +95,16 @@ def test_split_mode_error_not_above_the_fp32_mfma_paths(shape):
             assert float((bnp[0].double().cpu() - yr.mean(0)).abs().max()) < 1e-5 * float(yr.abs().max())
             if s == 1:
                 e["dgrad"] = _rel(ops.conv_dgrad(cv, dyg, wt), dxref)
+            e["wgrad+prologue"] = _rel(ops.conv_wgrad(cv, xg, dyg, pro=(bng, True)), dwref_pro)      # (wgrad_x3_kernel where K, C >= 128)
             err[split] = e
     finally:
         ops.conv_set_split(True)
     print(shape, {k_: (f"{err[False][k_]:.2e}", f"{err[True][k_]:.2e}") for k_ in err[True]})
     for k_ in err[True]:
-        assert err[True][k_] < 2e-6 and err[True][k_] <= err[False][k_] * 1.02 + 1e-9, (k_, err[False][k_], err[True][k_])
+        # (the weight gradient sums over pixel splits in both modes: partial slabs added in fp32 -- the split products cannot be
+        # better than that final sum, hence the looser factor there)
+        lim = 1.25 if k_.startswith("wgrad") else 1.02
+        assert err[True][k_] < 2e-6 and err[True][k_] <= err[False][k_] * lim + 1e-9, (k_, err[False][k_], err[True][k_])
 
 
 @pytest.mark.parametrize("shape", [(3, 33, 57, 256, 256, 3, 1), (4, 32, 57, 256, 256, 3, 1), (2, 64, 114, 128, 128, 3, 1), (4, 16, 29, 512, 512, 3, 1),
