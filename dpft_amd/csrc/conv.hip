@@ -2192,7 +2192,8 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         a.psteps_per_split = cdiv(a.psteps, splits);
         const size_t tbl = (size_t)a.psteps_per_split * pk * 4;      // per-workgroup input-pixel offset table
         static const bool wx3 = getenv("DPFT_WGRAD_X3") == nullptr || atoi(getenv("DPFT_WGRAD_X3")) != 0;      // A/B switch
-        if (bmn == 128 && wx3 && split_on() && a.taps > 1 && 2.0 * a.M * (double)d->K * a.J >= 2e9) {
+        static const bool wx3_1x1 = getenv("DPFT_WGRAD_X3_1X1") == nullptr || atoi(getenv("DPFT_WGRAD_X3_1X1")) != 0;      // A/B switch
+        if (bmn == 128 && wx3 && split_on() && (a.taps > 1 || wx3_1x1) && 2.0 * a.M * (double)d->K * a.J >= 2e9) {
             // the big multi-tap weight gradients on the split kernels (conv_x3.hip), like their forward / data gradient
             rc = launch_wgrad_x3(a, pro, grid, st);
             if (rc) return rc;

@@ -1,8 +1,8 @@
 cd /root/repo
 export PYTHONUNBUFFERED=1
 for i in 1 2; do
-DPFT_WGRAD_X3=0 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --latency-reps 5 2>/dev/null | grep "^{" | tail -n 1 > gpurun_out/wx_off_$i.json
-DPFT_WGRAD_X3=1 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --latency-reps 5 2>/dev/null | grep "^{" | tail -n 1 > gpurun_out/wx_on_$i.json
+DPFT_WGRAD_X3_1X1=0 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --latency-reps 5 2>/dev/null | grep "^{" | tail -n 1 > gpurun_out/wx_off_$i.json
+DPFT_WGRAD_X3_1X1=1 python bench.py --steps 40 --warmup 10 --no-cpu-baseline --latency-reps 5 2>/dev/null | grep "^{" | tail -n 1 > gpurun_out/wx_on_$i.json
 done
 python - <<'PY'
 import json
