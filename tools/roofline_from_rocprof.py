@@ -17,7 +17,7 @@ import json
 import re
 import sys
 
-MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "wgrad_pipe_kernel", "wgrad_pipe16_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
+MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "igemm_x3_kernel", "igemm_x3p_kernel", "wgrad_x3_kernel", "wgrad_pipe_kernel", "wgrad_pipe16_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
         "conv16_", "wgrad16_", "thin_wgrad", "wgrad_stem7_kernel", "conv1x1_to16_kernel", "wgrad1x1_")
 AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel", "zero_fill_kernel")
 GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", "pack_"),
