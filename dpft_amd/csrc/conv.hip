@@ -33,22 +33,15 @@ namespace dpft {
 // carries the divisions.
 // BF16 = true (mixed-precision mode, dpft_conv_set_compute): the operands are rounded to bf16 (RNE) when a tile is written
 // to LDS and multiplied with v_mfma_f32_32x32x16_bf16 (fp32 accumulation); tensors in memory stay fp32.
-// X3 = true (with BF16; experimental mode 2): every fp32 operand value is split into three bf16 terms a = a1 + a2 + a3
-// (each the RNE rounding of what the previous ones left: 3 x 8 = 24 mantissa bits) kept in three LDS planes, and a
-// product sum uses the six term products of weight >= 2^-16: a1b1 + a1b2 + a2b1 + a1b3 + a2b2 + a3b1, all exact in the
-// bf16 MFMA, accumulated in fp32 -- fp32-grade results from the matrix cores, which (unlike the fp32 MFMA) do not share
-// the vector ALUs (tools/probes/mfma_valu_overlap.hip): 6 x 32 instead of 8 x 64 cycles per 16 reduction indices.
+// (The three-term split of fp32 operands that this kernel carried as an experiment through rounds 1-4 is conv_x3.hip now.)
 // KS = 2: 512 threads per tile -- waves 4..7 mirror waves 0..3 on the ODD K-groups of every step and hand their
 // accumulators over through LDS at the end.  Same tile, same loads, same MFMA count, twice the waves per SIMD: the mid / late
 // layers launch < 2 workgroups per CU (456 tiles at layer 3) and run latency-bound -- two of these kernels side by side
 // finish in 1.55-1.68x the time of one (tools/occupancy_probe.py).
-template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false, bool X3 = false,
-          int KS = 1>
+template <int BM, int BN, int WGM, int WGN, bool DGRAD, bool PRO, bool LIN = true, bool BF16 = false, int KS = 1>
 __global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArgs a) {
-    static_assert(!X3 || BF16, "the split mode builds on the bf16 path");
-    static_assert(KS == 1 || (KS == 2 && !X3), "K-split form: two wave sets");
+    static_assert(KS == 1 || KS == 2, "K-split form: two wave sets");
     constexpr int NT = 64 * WGM * WGN * KS, ROWS = NT / 16;      // loader: 16 lanes x 16 bytes per row, ROWS rows per pass
-    constexpr int PLANE = (BM + BN) * LDKH;      // halfs per bf16 plane (split mode: 3 planes)
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
     constexpr int AP = BM / ROWS, BP = BN / ROWS;      // ROWS rows x 16 chunks (of 16 B) per loader pass
     static_assert(WGM * WGN == 4 && RB >= 1 && CB >= 1, "bad tile");
@@ -144,7 +137,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArg
     const __amdgpu_buffer_rsrc_t rsrc_a =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, a.B * a.H * a.W * a.C * (a.x16 ? 2 : 4), 0x00020000);
     const bool x16 = a.x16 != 0;
-    const bool raw_a = BF16 && !X3 && !PRO && x16;      // bf16 tensor -> bf16 LDS tile without arithmetic: copy the bits
+    const bool raw_a = BF16 && !PRO && x16;      // bf16 tensor -> bf16 LDS tile without arithmetic: copy the bits
     const __amdgpu_buffer_rsrc_t rsrc_b =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w), 0, a.N * a.Ktot * 4, 0x00020000);
     const int cpt = a.C / BKV;  // K-steps per filter tap
@@ -230,16 +223,8 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArg
         for (int i = 0; i < BP; ++i)
             rbv[sidx][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_b, (int)b_off[i], koff * 4, 0));
     };
-    auto store_bf16 = [&](__bf16* dst, f32x4 v) {      // one plane (rounded), or three planes (split)
-        const bf16x4 t1 = __builtin_convertvector(v, bf16x4);
-        *reinterpret_cast<bf16x4*>(dst) = t1;
-        if constexpr (X3) {
-            const f32x4 r1 = v - __builtin_convertvector(t1, f32x4);
-            const bf16x4 t2 = __builtin_convertvector(r1, bf16x4);
-            *reinterpret_cast<bf16x4*>(dst + PLANE) = t2;
-            const f32x4 r2 = r1 - __builtin_convertvector(t2, f32x4);
-            *reinterpret_cast<bf16x4*>(dst + 2 * PLANE) = __builtin_convertvector(r2, bf16x4);
-        }
+    auto store_bf16 = [&](__bf16* dst, f32x4 v) {      // rounded to bf16 (RNE)
+        *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(v, bf16x4);
     };
     const bool pro_mask = a.kh * a.kw > 1 || a.pad > 0;      // padding exists: BN(0) != 0 must be forced back to 0
     auto store_tile = [&](auto S) {
@@ -328,45 +313,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArg
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    // Split mode: six term products per 32x32 block and K-group.  Back-to-back MFMAs on ONE accumulator wait out the full
-    // MFMA latency (measured: the naive chain of six ran at 1/3 of the matrix rate), so the terms are issued term-major
-    // over the blocks of the wave and, where a wave owns fewer than four blocks, spread over three accumulator sets
-    // (by magnitude: a1b1 | a1b2 + a2b1 | a1b3 + a2b2 + a3b1 -- which also adds the small terms among themselves first).
-    constexpr int NSET = X3 ? ((RB * CB >= 4) ? 1 : 3) : 1;
-    f32x16 accx[NSET][RB][CB];
-    if constexpr (X3 && NSET > 1) {
-#pragma unroll
-        for (int q = 1; q < NSET; ++q)
-#pragma unroll
-            for (int i = 0; i < RB; ++i)
-#pragma unroll
-                for (int j = 0; j < CB; ++j)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) accx[q][i][j][r] = 0.f;
-    }
-    auto compute_x3 = [&]() {
-        constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 0, 0, 1, 1, 2}, TS[6] = {2, 1, 0, 2, 1, 2};
-#pragma unroll
-        for (int kg = 0; kg < BKV / 16; ++kg) {
-            bf16x8 af[3][RB], bf[3][CB];
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                for (int i = 0; i < RB; ++i) af[t][i] = *reinterpret_cast<const bf16x8*>(a_fragh + t * PLANE + i * 32 * LDKH + kg * 16);
-#pragma unroll
-                for (int j = 0; j < CB; ++j) bf[t][j] = *reinterpret_cast<const bf16x8*>(b_fragh + t * PLANE + j * 32 * LDKH + kg * 16);
-            }
-#pragma unroll
-            for (int t = 0; t < 6; ++t)
-#pragma unroll
-                for (int i = 0; i < RB; ++i)
-#pragma unroll
-                    for (int j = 0; j < CB; ++j) {
-                        f32x16& c = (NSET == 1 || TS[t] == 0) ? accp[0][i][j] : accx[NSET == 1 ? 0 : TS[t]][i][j];
-                        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[TA[t]][i], bf[TB[t]][j], c, 0, 0, 0);
-                    }
-        }
-    };
     auto compute_f32 = [&]() {
         f32x4 af[2][RB], bf[2][CB];
         auto frags = [&](int set, int kg) {
@@ -396,8 +342,7 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArg
     };
 
     auto compute = [&]() {
-        if constexpr (X3) compute_x3();
-        else if constexpr (BF16) compute_bf16();
+        if constexpr (BF16) compute_bf16();
         else compute_f32();
     };
 
@@ -432,12 +377,6 @@ __global__ __launch_bounds__(64 * WGM * WGN * KS) void igemm_vec_kernel(IgemmArg
         }
     }
     f32x16 (&acc)[RB][CB] = accp[0];
-    if constexpr (X3 && NSET > 1) {
-#pragma unroll
-        for (int i = 0; i < RB; ++i)
-#pragma unroll
-            for (int j = 0; j < CB; ++j) acc[i][j] += accx[1][i][j] + accx[2][i][j];
-    }
     if (NACC == 2) {
 #pragma unroll
         for (int i = 0; i < RB; ++i)
@@ -722,16 +661,15 @@ __global__ void splitk_reduce_residual_kernel(const float* __restrict__ partial,
 // BF16 = true (mixed-precision mode, square tiles): both operands are rounded to bf16 and TRANSPOSED on their
 // way into LDS ([channel][pixel], so that a lane finds the 8 consecutive reduction indices v_mfma_f32_32x32x16_bf16
 // wants); see store_tile.
-template <int BMn, int BNc, int WGM, int WGN, bool PRO, bool BF16 = false, bool X3 = false>
+template <int BMn, int BNc, int WGM, int WGN, bool PRO, bool BF16 = false>
 __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
-    static_assert(!X3 || (BF16 && BMn == 128), "split weight gradient: 128 x 128 tile, on top of the bf16 path");
     static_assert(!BF16 || (BMn == BNc && (BMn == 128 || BMn == 64)), "bf16 weight gradient: 128 x 128 and 64 x 64 tiles");
     constexpr int RB = BMn / WGM / 32, CB = BNc / WGN / 32;
     constexpr int YCH = BMn / 4, XCH = BNc / 4;        // float4 chunks per pixel row
     constexpr int YRP = 256 / YCH, XRP = 256 / XCH;    // pixel rows per pass
     constexpr int YP = BKP / YRP, XP = BKP / XRP;
     static_assert(WGM * WGN == 4 && YP >= 1 && XP >= 1, "bad wgrad tile");
-    constexpr int SMEM_FLOATS = X3 ? 3 * (BMn + BNc) * 76 / 2 : BKP * (BMn + BNc);      // split mode: three bf16 planes
+    constexpr int SMEM_FLOATS = BKP * (BMn + BNc);
     __shared__ __attribute__((aligned(16))) float smem[SMEM_FLOATS];
     float* Ys = smem;
     float* Xs = smem + BKP * BMn;
@@ -833,7 +771,6 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
     // conflicted because the lanes of a wave differ in the CHANNEL chunk, i.e. by whole rows).
     constexpr int WLD = BMn == 128 ? 76 : 72;      // 64 x 64 tile (16 channel chunks per pixel row): 36 words, order (e + ych / 4) % 4
     constexpr int RSH = BMn == 128 ? 3 : 2;
-    constexpr int WPLANE = (BMn + BNc) * WLD;      // halfs per plane (split mode)
     __bf16* Yh = reinterpret_cast<__bf16*>(smem);
     __bf16* Xh = Yh + BMn * WLD;
     auto rot4 = [](f32x4 v, int r) {      // v[(e + r) & 3] at position e, r per lane
@@ -849,15 +786,7 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
             typedef float f32x2_ __attribute__((ext_vector_type(2)));
             f32x2_ v = {a0[e], a1[e]};
             __bf16* dst = &T[(ch * 4 + ((e + r) & 3)) * WLD + rowp];
-            const bf16x2 t1 = __builtin_convertvector(v, bf16x2);
-            *reinterpret_cast<bf16x2*>(dst) = t1;
-            if constexpr (X3) {      // three-term split (see igemm_vec_kernel), planes WPLANE halfs apart
-                v -= __builtin_convertvector(t1, f32x2_);
-                const bf16x2 t2 = __builtin_convertvector(v, bf16x2);
-                *reinterpret_cast<bf16x2*>(dst + WPLANE) = t2;
-                v -= __builtin_convertvector(t2, f32x2_);
-                *reinterpret_cast<bf16x2*>(dst + 2 * WPLANE) = __builtin_convertvector(v, bf16x2);
-            }
+            *reinterpret_cast<bf16x2*>(dst) = __builtin_convertvector(v, bf16x2);
         }
     };
     auto pro4 = [&](f32x4 v, int i) {
@@ -923,27 +852,6 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
                 const bf16x4 lo = *reinterpret_cast<const bf16x4*>(q), hi = *reinterpret_cast<const bf16x4*>(q + 4);
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             };
-            if constexpr (X3) {      // six term products per block, term-major over the wave's four blocks
-                constexpr int TA[6] = {2, 1, 0, 1, 0, 0}, TB[6] = {0, 0, 0, 1, 1, 2};
-#pragma unroll
-                for (int kg = 0; kg < BKP / 16; ++kg) {
-                    bf16x8 ay3[3][RB], bx3[3][CB];
-#pragma unroll
-                    for (int t = 0; t < 3; ++t) {
-#pragma unroll
-                        for (int i = 0; i < RB; ++i) ay3[t][i] = frag8(yf + t * WPLANE + i * 32 * WLD + kg * 16);
-#pragma unroll
-                        for (int j = 0; j < CB; ++j) bx3[t][j] = frag8(xf + t * WPLANE + j * 32 * WLD + kg * 16);
-                    }
-#pragma unroll
-                    for (int t = 0; t < 6; ++t)
-#pragma unroll
-                        for (int i = 0; i < RB; ++i)
-#pragma unroll
-                            for (int j = 0; j < CB; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ay3[TA[t]][i], bx3[TB[t]][j], acc[i][j], 0, 0, 0);
-                }
-            }
             bf16x8 ay[2][RB], bx[2][CB];
             auto frags = [&](int set, int kg) {
 #pragma unroll
@@ -951,9 +859,9 @@ __global__ __launch_bounds__(256) void wgrad_vec_kernel(WgradArgs a) {
 #pragma unroll
                 for (int j = 0; j < CB; ++j) bx[set][j] = frag8(xf + j * 32 * WLD + kg * 16);
             };
-            if constexpr (!X3) frags(0, 0);
+            frags(0, 0);
 #pragma unroll
-            for (int kg = 0; kg < (X3 ? 0 : BKP / 16); ++kg) {
+            for (int kg = 0; kg < BKP / 16; ++kg) {
                 if (kg + 1 < BKP / 16) frags((kg + 1) & 1, kg + 1);
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -1609,19 +1517,15 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
 #define LAUNCH_VEC(BM_, BN_, WGM_, WGN_)                                                      \
     do {                                                                                      \
         constexpr size_t lds = (size_t)(BM_ + BN_) * LDK * sizeof(float);                     \
-        if (g_conv_bf16 == 2) {                                                               \
-            constexpr size_t lds3 = std::max(lds, (size_t)3 * (BM_ + BN_) * LDKH * 2);        \
-            if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true, true>, grid, block, lds3, st, a); \
-            else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true, true>, grid, block, lds3, st, a);      \
-        } else if (g_conv_bf16 && ks2) {                                                      \
+        if (g_conv_bf16 == 1 && ks2) {                                                        \
             if constexpr (DGRAD && BM_ == 64 && BN_ == 64)                                    \
-                launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, true, false, true, true, false, 2>, grid, block2, lds, st, a); \
-        } else if (g_conv_bf16) {                                                             \
+                launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, true, false, true, true, 2>, grid, block2, lds, st, a); \
+        } else if (g_conv_bf16 == 1) {                                                        \
             if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD, true, true>, grid, block, lds, st, a); \
             else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false, true, true>, grid, block, lds, st, a);      \
         } else if (ks2) {                                                                     \
             if constexpr (DGRAD && BM_ == 64 && BN_ == 64)                                    \
-                launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, true, false, true, false, false, 2>, grid, block2, lds, st, a); \
+                launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, true, false, true, false, 2>, grid, block2, lds, st, a); \
         } else if (pro) launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, !DGRAD>, grid, block, lds, st, a); \
         else launch_lds(igemm_vec_kernel<BM_, BN_, WGM_, WGN_, DGRAD, false>, grid, block, lds, st, a);      \
     } while (0)
@@ -2212,10 +2116,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \
         else hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, false>), grid, block, 0, st, a);     \
     } while (0)
-        if (bmn == 128 && g_conv_bf16 == 2) {      // split mode: 117 KB of LDS (three bf16 planes)
-            if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true, true>), grid, block, 0, st, a);
-            else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true, true>), grid, block, 0, st, a);
-        } else if (bmn == 128 && g_conv_bf16 == 1) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
+        if (bmn == 128 && g_conv_bf16 == 1) {      // mixed-precision mode (dpft_conv_set_compute): bf16 operands
             if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, true, true>), grid, block, 0, st, a);
             else hipLaunchKernelGGL((wgrad_vec_kernel<128, 128, 2, 2, false, true>), grid, block, 0, st, a);
         } else if (bmn == 64 && g_conv_bf16 == 1) {

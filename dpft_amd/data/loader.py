@@ -218,7 +218,26 @@ class PrefetchLoader:
         try:
             up = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
             ring = _PinnedRing(self.depth + 2) if up is not None else None      # queue depth + the one being filled + the one consumed
-            for inputs, targets in self.source:
+            # Slot reuse: a worker writes batch n + per_worker into the slot of its batch n.  The DataLoader hands a
+            # worker its next task when the main process TAKES a batch from it, batches arrive round-robin over the workers, and
+            # a worker runs `prefetch` tasks ahead: taking global batch i dispatches the task that overwrites the slot of batch
+            # i - (per_worker - prefetch) * workers.  Its upload must have completed by then -- waited for here (an event that
+            # old has long fired unless the upload stream is stalled; with one worker the distance is two batches).
+            upload_done: Dict[int, "torch.cuda.Event"] = {}
+            reuse = None
+            if self.slots is not None:
+                reuse = max(1, self.slots.per_worker - 2) * self.slots.n_workers
+            it, i = iter(self.source), -1
+            while True:
+                i += 1
+                if reuse is not None:
+                    old_ev = upload_done.pop(i - reuse, None)
+                    if old_ev is not None:
+                        old_ev.synchronize()
+                try:
+                    inputs, targets = next(it)
+                except StopIteration:
+                    break
                 if stop.is_set():
                     break
                 in_slot = self.slots is not None and isinstance(inputs, dict) and SlotCollate.KEY in inputs
@@ -240,6 +259,8 @@ class PrefetchLoader:
                     ev = torch.cuda.Event()
                     ev.record(up)
                 ring.done(slot, ev)
+                if in_slot:
+                    upload_done[i] = ev
                 q.put((batch, labels, ev, host))
         except BaseException as e:          # surface loader errors in the consumer thread
             q.put(e)
@@ -283,8 +304,15 @@ def load_listed(dataset: Dataset, config: Dict[str, Any], device="cpu", rank: in
     import os
     if torch.device(device).type == "cuda" and workers > 0 and len(dataset) > 0 and os.environ.get("DPFT_LOADER_SLOTS", "1") != "0":
         # the workers stack their batches straight into shared page-locked slots (SlotCollate); layout from the first sample
-        slots = SlotCollate(dataset[0][0], config["train"]["batch_size"], workers)
-        slots.register()
+        # (workers x 4 slots of one batch each in /dev/shm, page-locked: ~450 MB per rank for 16 workers on raw K-Radar frames.  A
+        # container with a small /dev/shm cannot hold that: fall back to the plain collate + the pinned staging ring)
+        try:
+            slots = SlotCollate(dataset[0][0], config["train"]["batch_size"], workers)
+            slots.register()
+        except (RuntimeError, OSError, MemoryError) as e:
+            import warnings
+            warnings.warn(f"shared batch slots unavailable ({e}); using the pinned staging ring (slower loader)")
+            slots = None
     dl = DataLoader(dataset, batch_size=config["train"]["batch_size"], sampler=sampler, num_workers=workers,
                     collate_fn=slots if slots is not None else listed_collating, drop_last=True, persistent_workers=False)
     return PrefetchLoader(dl, device, preprocessor, slots=slots), sampler
