@@ -411,6 +411,38 @@ def main():
                 "conv_frac_camera_only": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
                 "camera_encoder_share_of_conv_time": (cam_t / tot_t) if tot_t > 0 else None}
 
+    # ---- the step's host window: GPU time between the matcher's cost kernel and the start of the decoder's backward graph ------
+    # (the one place where the GPU waits for the host: read-back of the cost matrices, assignments, upload, criterion + gradient
+    # launches, graph launch).  Events recorded by wrapping the two call sites; median over 12 extra steps after the timed region.
+    loss_window_us = None
+    g_ = trainer.model.__dict__.get("_graphed_fuser")
+    if rank == 0 and world == 1 and not collective and g_ is not None and hasattr(trainer.loss_fn, "_to_host"):      # (one rank: the
+        # extra steps hold no collective another rank would have to join)
+        n_w = 12
+        ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(n_w)]
+        ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_w)]
+        cur = [0]
+        o_host, o_replay = trainer.loss_fn._to_host, g_.bwd_graph.replay
+
+        def _host(t):
+            ev_c[cur[0]].record()
+            return o_host(t)
+
+        def _replay():
+            ev_b[cur[0]].record()
+            return o_replay()
+        trainer.loss_fn._to_host, g_.bwd_graph.replay = _host, _replay
+        try:
+            for i in range(n_w):
+                cur[0] = i
+                trainer.train_step(data, labels)
+            torch.cuda.synchronize()
+            w = sorted(ev_c[i].elapsed_time(ev_b[i]) * 1e3 for i in range(n_w))
+            loss_window_us = w[n_w // 2]
+        except Exception:
+            loss_window_us = None
+        finally:
+            trainer.loss_fn._to_host, g_.bwd_graph.replay = o_host, o_replay
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
     fwd_mean, fwd_std = trainer.inference_time(data, warmup=10, reps=args.latency_reps)
     # single-frame latency (what a "low inference time" claim is about, README.md:16 of the reference; its own protocol
@@ -562,6 +594,9 @@ def main():
                                             trainer.comm_placement, trainer.comm_placement)},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
+            "loss_window_us": loss_window_us,
+            "loss_window_is": "median GPU time from the end of the matcher's cost kernel to the start of the decoder's backward graph "
+                              "(read-back, assignments, upload, criterion + gradient launches, graph launch), 12 steps after the timed region",
             "roofline": roof, "roofline_decoder": dec, "roofline_decoder_train": dec_train, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -32,6 +32,8 @@ extern "C" const char* dpft_last_error(void) { return dpft::g_err; }
 // 4 x (400 x <= 20) problems take a few microseconds here against ~25 us of call overhead each through scipy, inside the
 // one window of the training step in which the GPU waits for the host.
 // ---------------------------------------------------------------------------------------------------------------------
+#include <hip/hip_runtime.h>
+
 #include <algorithm>
 #include <cmath>
 #include <limits>
@@ -123,4 +125,34 @@ extern "C" int dpft_lsap_batch_f32(const float* cost, int32_t B, int32_t N, int3
         }
     }
     return DPFT_OK;
+}
+
+// The step's host window in ONE call (round 5): assignments of the batch (dpft_lsap_batch_f32) -> their upload from the caller's
+// page-locked buffer -> the criterion launch (dpft_set_loss_fwd_total_f32) -> optionally its gradient launch
+// (dpft_set_loss_bwd_f32 with d total / d term = sel) straight into the buffers the decoder's backward graph reads.  Between
+// the matcher's read-back and the backward graph the GPU has nothing to run: every Python statement there is step time
+// (tools/loss_window.py: 270 us of host work before, mostly tensor bookkeeping around four small calls).
+// cost: HOST (B, N, Mmax); counts_host (B,): targets per sample; packed_host: page-locked (B * Mmax * 2 + B,) int32 that
+// receives assignments | matched counts; packed_dev: its device twin (same layout).
+extern "C" int dpft_assign_loss_f32(const float* cost, const int32_t* counts_host, int32_t* packed_host, int32_t* packed_dev,
+                                    const float* cls, const float* center, const float* size, const float* angle,
+                                    const float* gt_box, const float* gt_onehot, const float* weights5, float alpha,
+                                    const float* sel, float* scratch, float* losses5, float* total, float* dcls, float* dcenter,
+                                    float* dsize, float* dangle, int32_t B, int32_t N, int32_t Mmax, int32_t C,
+                                    dpft_stream_t stream) {
+    DPFT_REQUIRE(cost && counts_host && packed_host && packed_dev, "assign_loss: null argument");
+    int rc = dpft_lsap_batch_f32(cost, B, N, Mmax, counts_host, packed_host, packed_host + (size_t)B * Mmax * 2);
+    if (rc) return rc;
+    const size_t bytes = ((size_t)B * Mmax * 2 + B) * sizeof(int32_t);
+    if (hipMemcpyAsync(packed_dev, packed_host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream) != hipSuccess) {
+        dpft::set_error("assign_loss: upload failed");
+        return DPFT_ERR_LAUNCH;
+    }
+    const int32_t* match = packed_dev;
+    const int32_t* matched = packed_dev + (size_t)B * Mmax * 2;
+    rc = dpft_set_loss_fwd_total_f32(cls, center, size, angle, gt_box, gt_onehot, match, matched, weights5, alpha, sel, scratch,
+                                     losses5, total, B, N, Mmax, C, stream);
+    if (rc || !dcls) return rc;
+    return dpft_set_loss_bwd_f32(cls, center, size, angle, gt_box, gt_onehot, match, matched, weights5, alpha, sel, dcls, dcenter,
+                                 dsize, dangle, B, N, Mmax, C, stream);
 }

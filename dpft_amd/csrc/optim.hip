@@ -17,12 +17,16 @@ struct AdamChunk {
 // `skipped[t]` = number of optimizer steps tensor t sat out (no gradient): its own step count is `step - skipped[t]`,
 // like the per-parameter `state["step"]` of torch.optim.AdamW.  Only inactive blocks write it (the block of a tensor's
 // first chunk), only active blocks read it, so there is no race inside a launch.
+// `gate` (round 5, may be null): the step's loss on the device.  The reference steps only `if loss > 0` (training/trainer.py:131);
+// the trainer launches backward and optimizer without reading the loss back, and a loss that is not positive closes the gate
+// here: every tensor sits the step out exactly as if it had no gradient.
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict__ chunks, const int32_t* __restrict__ active,
                                                      int32_t* __restrict__ skipped, int32_t step,
                                                      float lr, float beta1, float beta2, float eps, float decay,
-                                                     float step_size, float inv_sqrt_bc2) {
+                                                     float step_size, float inv_sqrt_bc2, const float* __restrict__ gate) {
     const AdamChunk c = chunks[blockIdx.x];
-    if (active && !active[c.tensor]) {             // parameters without a gradient are skipped (grad is None)
+    const bool closed = gate != nullptr && !(gate[0] > 0.f);
+    if (closed || (active && !active[c.tensor])) {             // parameters without a gradient are skipped (grad is None)
         if (skipped && c.m == nullptr && threadIdx.x == 0) skipped[c.tensor] += 1;   // marker row: one per tensor
         return;
     }
@@ -70,10 +74,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamChunk* __restrict_
 using namespace dpft;
 
 extern "C" int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, int32_t* skipped, float lr,
-                              float beta1, float beta2, float eps, float weight_decay, int32_t step, dpft_stream_t stream) {
+                              float beta1, float beta2, float eps, float weight_decay, int32_t step, const float* gate,
+                              dpft_stream_t stream) {
     DPFT_REQUIRE(chunks && n_chunks > 0 && step >= 1, "adamw: bad arguments");
     const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
     hipLaunchKernelGGL(adamw_kernel, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, (const AdamChunk*)chunks, active, skipped, step, lr,
-                       beta1, beta2, eps, (float)(1.0 - (double)lr * weight_decay), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)));
+                       beta1, beta2, eps, (float)(1.0 - (double)lr * weight_decay), (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), gate);
     return check_launch("adamw");
 }

@@ -173,11 +173,12 @@ SIGNATURES = {
     "dpft_rows_outer_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _L, _P]),
     "dpft_memops": (_I, [_I, _P, _P]),
     "dpft_lsap_batch_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
+    "dpft_assign_loss_f32": (_I, [_P] * 11 + [_F] + [_P] * 8 + [_I] * 4 + [_P]),
     "dpft_add_many_f32": (_I, [_I, _P, _P]),
     "dpft_i64_add_many": (_I, [_I, _P, _L, _P]),
     "dpft_seed_advance": (_I, [_P, _P, _L, _P]),
     "dpft_sum_leading_f32": (_I, [_I, _P, _L, _P, _I, _P]),
-    "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P]),
+    "dpft_adamw_f32": (_I, [_P, _I, _P, _P, _F, _F, _F, _F, _F, _I, _P, _P]),
     "dpft_resnet_plan_create": (_L, [C.POINTER(ResnetDesc)]),
     "dpft_resnet_plan_destroy": (None, [_L]),
     "dpft_resnet_plan_query": (_L, [_L, _I, _I]),

@@ -226,8 +226,10 @@ class _SetLossFn(torch.autograd.Function):
     """dpft_set_loss_fwd/bwd_f32: the five batch-reduced, weighted criterion terms for fixed assignments."""
 
     @staticmethod
-    def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel):
-        losses, total = _set_loss_launch(cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel)
+    def forward(ctx, cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel, pre=None):
+        # pre = (losses5, total) already computed by dpft_assign_loss_f32 (Loss.forward_fused): no launch here
+        losses, total = pre if pre is not None else \
+            _set_loss_launch(cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel)
         ctx.save_for_backward(cls, center, size, angle, gt_box, gt_onehot, match, counts, sel)
         ctx.meta = (weights5, float(alpha))
         ctx.mark_non_differentiable(losses)
@@ -248,7 +250,7 @@ class _SetLossFn(torch.autograd.Function):
                  gt_box.data_ptr(), gt_onehot.data_ptr(), match.data_ptr(), counts.data_ptr(), C.byref(w), alpha,
                  gout.data_ptr(), dcls.data_ptr(), dcenter.data_ptr(), dsize.data_ptr(), dangle.data_ptr(), B, N, Mmax,
                  ncls, stream())
-        return dcls, dcenter, dsize, dangle, None, None, None, None, None, None, None
+        return dcls, dcenter, dsize, dangle, None, None, None, None, None, None, None, None
 
 
 class Loss(nn.modules.loss._Loss):
@@ -299,6 +301,9 @@ class Loss(nn.modules.loss._Loss):
         B, N, ncls = cls.shape
         dev = cls.device
         counts = [int(t["gt_class"].shape[0]) if all(v.numel() for v in t.values()) else 0 for t in targets]
+        # host-known: whether this batch has any target.  Without one the loss is exactly 0 (below); with one it is positive (the
+        # focal term alone), so the trainer takes its `loss > 0` decision (trainer.py:131) from this flag instead of a read-back
+        self.__dict__["last_has_targets"] = max(counts) > 0
         if max(counts) == 0:
             zero = torch.zeros((), device=dev, dtype=cls.dtype, requires_grad=True)
             return zero * 1.0, {k: zero for k in self.loss_weights}
@@ -310,20 +315,64 @@ class Loss(nn.modules.loss._Loss):
             lib.call("dpft_match_cost_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                      gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
                      ncls, stream())
-        host = self._to_host(cost)                                                            # the one sync of the step
+        # (everything the host window needs is prepared BEFORE the sync, while the GPU still runs the cost kernel: after the
+        # read-back only the one C call is left)
         n_pack = B * Mmax * 2 + B
         pin = self.__dict__.get("_pin_i32")
         if pin is None or pin.numel() < n_pack:
             pin = self.__dict__["_pin_i32"] = torch.empty(max(n_pack, 4096), dtype=torch.int32).pin_memory()
         packed = pin.numpy()[:n_pack]                                # assignments | pair counts: ONE upload, from pinned memory
-        # the whole batch in one host call (dpft_lsap_batch_f32: scipy's algorithm restated in C, same pairs in the same order --
-        # tests/test_host.py holds it to scipy): this sits in the one window of the step in which the GPU waits for the host
-        if os.environ.get("DPFT_LSAP_C", "1") != "0":
+        weights5 = tuple(float(self.loss_weights.get(k, 0.0)) for k in self._TERMS)
+        sel = self.__dict__.get("_sel")
+        if sel is None or sel.device != dev:
+            sel = self.__dict__["_sel"] = torch.tensor([1.0 if k in self.loss_weights else 0.0 for k in self._TERMS],
+                                                       dtype=torch.float32, device=dev)
+        packed_t = torch.empty(n_pack, dtype=torch.int32, device=dev)
+        match_t, counts_m = packed_t[:B * Mmax * 2].view(B, Mmax, 2), packed_t[B * Mmax * 2:]
+        self.__dict__["_bwd_written"] = None
+        use_c = os.environ.get("DPFT_LSAP_C", "1") != "0"
+        if use_c:
             cnt = np.asarray(counts, dtype=np.int32)
-            if lib.dpft_lsap_batch_f32(host.ctypes.data, B, N, Mmax, cnt.ctypes.data, packed.ctypes.data,
-                                       packed[B * Mmax * 2:].ctypes.data) != 0:
-                raise ValueError("assignment failed: " + lib.dpft_last_error().decode())      # (scipy raises ValueError as well)
-        else:      # A/B switch: scipy per sample
+            losses5 = torch.empty(5, dtype=torch.float32, device=dev)
+            total = torch.empty((), dtype=torch.float32, device=dev)
+            need = int(lib.dpft_set_loss_scratch_floats(B, N))
+            st_ = stream()
+            skey = (dev, int(st_.value or 0))
+            scratch = _loss_scratch.get(skey)
+            if scratch is None or scratch.numel() < need:
+                scratch = _loss_scratch[skey] = torch.zeros(max(need, 1024), dtype=torch.float32, device=dev)
+            tg = self.__dict__.get("fused_grad_targets")            # (dcenter, dsize, dangle, dcls) or None
+            ok_t = tg is not None and all(t.shape == r.shape and t.is_contiguous() and t.dtype == torch.float32
+                                          for t, r in zip(tg, (center, size, angle, cls)))
+            w5 = (C.c_float * 5)(*weights5)
+            c_args = (cnt.ctypes.data, packed.ctypes.data, packed_t.data_ptr(),
+                      cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
+                      gt_box.data_ptr(), gt_onehot.data_ptr(), C.cast(w5, C.c_void_p), 0.75, sel.data_ptr(),
+                      scratch.data_ptr(), losses5.data_ptr(), total.data_ptr(),
+                      tg[3].data_ptr() if ok_t else None, tg[0].data_ptr() if ok_t else None,
+                      tg[1].data_ptr() if ok_t else None, tg[2].data_ptr() if ok_t else None,
+                      B, N, Mmax, ncls, st_)
+            assign_loss = lib.dpft_assign_loss_f32
+        host = self._to_host(cost)                                                            # the one sync of the step
+        if use_c:
+            # The whole host window in ONE C call (dpft_assign_loss_f32, csrc/cabi.cpp): the batch's assignments (scipy's algorithm
+            # restated in C, same pairs in the same order -- tests/test_host.py), their upload from the pinned buffer (rewritten only
+            # after the next step's sync), the criterion launch and -- when the trainer has named the buffers the decoder's backward
+            # graph reads (fused_grad_targets) -- the criterion's gradient launch.  This window is the one place of the step where
+            # the GPU waits for the host.
+            try:
+                rc = assign_loss(host.ctypes.data, *c_args)
+            except Exception:
+                scratch.zero_()
+                raise
+            if rc != 0:
+                scratch.zero_()      # a launch that did not complete may leave its ticket behind
+                raise ValueError("assignment / loss failed: " + lib.dpft_last_error().decode())      # (scipy raises ValueError as well)
+            if ok_t:
+                self.__dict__["_bwd_written"] = tuple(tg)
+            losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel,
+                                              (losses5, total))
+        else:      # A/B switch: scipy per sample, separate launches
             packed[:] = -1
             match = packed[:B * Mmax * 2].reshape(B, Mmax, 2)
             for b, m in enumerate(counts):
@@ -332,15 +381,8 @@ class Loss(nn.modules.loss._Loss):
                     match[b, :len(i), 0], match[b, :len(i), 1] = i, j
                     counts[b] = len(i)           # min(N, m) assigned pairs
             packed[B * Mmax * 2:] = counts
-        packed_t = torch.empty(n_pack, dtype=torch.int32, device=dev)
-        packed_t.copy_(pin[:n_pack], non_blocking=True)      # (the pinned buffer is rewritten only after the next step's sync)
-        match_t, counts_m = packed_t[:B * Mmax * 2].view(B, Mmax, 2), packed_t[B * Mmax * 2:]
-        weights5 = tuple(float(self.loss_weights.get(k, 0.0)) for k in self._TERMS)
-        sel = self.__dict__.get("_sel")
-        if sel is None or sel.device != dev:
-            sel = self.__dict__["_sel"] = torch.tensor([1.0 if k in self.loss_weights else 0.0 for k in self._TERMS],
-                                                       dtype=torch.float32, device=dev)
-        losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel)
+            packed_t.copy_(pin[:n_pack], non_blocking=True)
+            losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel)
         self.__dict__["_last"] = (cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel, total)
         batch_losses = {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}        # views, for logging
         return total, batch_losses
@@ -354,6 +396,9 @@ class Loss(nn.modules.loss._Loss):
         if last is None or last[-1] is not total:
             return False
         cls, center, size, angle, gt_box, gt_onehot, match, counts, weights5, alpha, sel, _ = last
+        written = self.__dict__.pop("_bwd_written", None)
+        if written is not None and all(a is b for a, b in zip(written, (dcenter, dsize, dangle, dcls))):
+            return True      # dpft_assign_loss_f32 launched the gradient kernel into exactly these buffers
         B, N, ncls = cls.shape
         w = (C.c_float * 5)(*weights5)
         for t, ref in ((dcenter, center), (dsize, size), (dangle, angle), (dcls, cls)):
@@ -366,6 +411,7 @@ class Loss(nn.modules.loss._Loss):
 
     def forward(self, inputs: Dict[str, torch.Tensor], targets: List[Dict[str, torch.Tensor]]):
         self.__dict__.pop("_last", None)
+        self.__dict__["last_has_targets"] = None      # (None = unknown: the eager path)
         if self._fused_ok(inputs):
             return self.forward_fused(inputs, targets)
         return self.forward_eager(inputs, targets)

@@ -140,6 +140,11 @@ class FusedAdamW(torch.optim.Optimizer):
         self._tables = tables
         self._restore = False
 
+    def set_gate(self, loss: "torch.Tensor" = None):
+        """Device-side `if loss > 0` (trainer.py:131) for the NEXT step(): a scalar tensor that stays on the device; the launch
+        updates nothing when it is not positive.  Consumed by step()."""
+        self._gate = loss
+
     def set_active(self, active_ids):
         """ids of parameters that received a gradient this step (others are skipped like ``grad is None``)."""
         self._active_ids = active_ids
@@ -154,7 +159,7 @@ class FusedAdamW(torch.optim.Optimizer):
         lib.call("dpft_adamw_f32", C.c_void_p(t["chunks"].data_ptr() + first * self.CHUNK_BYTES), count, ptr(t["active"]),
                  ptr(t["skipped"]),
                  float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                 self._step, stream())
+                 self._step, ptr(getattr(self, "_gate", None)), stream())
 
     @torch.no_grad()
     def step_segment(self, si: int) -> bool:
@@ -204,6 +209,7 @@ class FusedAdamW(torch.optim.Optimizer):
                         self._launch(group, t, first, count)
         self._round_open = False
         self._done.clear()
+        self._gate = None
         note_weights_changed()                             # in-place through raw pointers: no _version bump
         return None
 

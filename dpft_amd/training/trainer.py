@@ -175,7 +175,16 @@ class DataParallelTrainer:
         finally:
             if g is not None:
                 g.clone_outputs = True
+        if g is not None and g.last_inputs is not None and os.environ.get("DPFT_MANUAL_CHAIN", "1") != "0" \
+                and hasattr(self.loss_fn, "backward_into"):
+            # the buffers the decoder's backward graph reads its output gradients from: the loss call launches the criterion's
+            # gradient kernel into them itself (one C call for the whole host window, Loss.forward_fused)
+            go = g.static_grad_outputs
+            self.loss_fn.__dict__["fused_grad_targets"] = (go[0], go[1], go[2], go[3])
+        elif hasattr(self.loss_fn, "__dict__"):
+            self.loss_fn.__dict__["fused_grad_targets"] = None
         loss, losses = self.loss_fn(output, labels)
+        gate = None
         if self._exp_local_decision and self.world > 1:
             raise RuntimeError("_exp_local_decision is a one-rank timing experiment switch")
         if self.collective and not self._exp_local_decision:
@@ -187,7 +196,16 @@ class DataParallelTrainer:
             dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
             local, stepped = (bool(v) for v in flag.tolist())
         else:
-            stepped = local = float(loss.detach()) > 0              # trainer.py:131 (host sync, as in the reference; compared on the host)
+            # trainer.py:131 `if loss > 0`: the loss is exactly 0 when the batch has no target and positive otherwise (the focal term
+            # alone) -- the host knows which from the label dicts, so it launches backward and optimizer WITHOUT reading the loss
+            # back (the read-back was the second host sync inside the window in which the GPU waits for the host); the comparison
+            # itself is done on the device by the optimizer launch (FusedAdamW.set_gate: nothing is updated unless loss > 0).
+            known = getattr(self.loss_fn, "last_has_targets", None)
+            if known is not None and isinstance(self.optimizer, FusedAdamW):
+                stepped = local = bool(known)
+                gate = loss.detach()
+            else:
+                stepped = local = float(loss.detach()) > 0          # (eager loss / torch optimizer: compared on the host)
         if stepped:
             if not local:
                 loss = sum(v.sum() for v in output.values()) * 0.0
@@ -196,6 +214,7 @@ class DataParallelTrainer:
             self.reducer.finish()
             if isinstance(self.optimizer, FusedAdamW):
                 self.optimizer.set_active(self.reducer.seen_ids())
+                self.optimizer.set_gate(gate)
             self.optimizer.step()
         if with_metrics and self.eval_fn is not None:
             return loss.detach(), {k: v.detach() for k, v in losses.items()}, self.eval_fn(output, labels)

@@ -590,6 +590,16 @@ int dpft_match_cost_f32(const float* cls, const float* center, const float* size
  * ---------------------------------------------------------------------------------------- */
 int dpft_lsap_batch_f32(const float* cost, int32_t B, int32_t N, int32_t Mmax, const int32_t* counts, int32_t* match,
                         int32_t* n_matched);
+/* The host window of a training step in one call (round 5): dpft_lsap_batch_f32 on the read-back cost matrices -> upload of
+ * assignments | matched counts from the caller's page-locked `packed_host` into `packed_dev` (both (B * Mmax * 2 + B) int32) ->
+ * dpft_set_loss_fwd_total_f32 -> and, when dcls is not NULL, dpft_set_loss_bwd_f32 with d total / d term = sel straight into
+ * (dcls, dcenter, dsize, dangle).  Replaces training/loss.py:296-373 + the `loss.backward()` hop into the head outputs between the
+ * matcher's sync and the decoder's backward. */
+int dpft_assign_loss_f32(const float* cost_host, const int32_t* counts_host, int32_t* packed_host, int32_t* packed_dev,
+                         const float* cls, const float* center, const float* size, const float* angle, const float* gt_box,
+                         const float* gt_onehot, const float* weights5, float alpha, const float* sel, float* scratch,
+                         float* losses5, float* total, float* dcls, float* dcenter, float* dsize, float* dangle, int32_t B,
+                         int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SetCriterion + batch reduction 'mean' (src/dprt/training/loss.py:17-60 focal loss with the raw-logit p_t,
@@ -676,9 +686,12 @@ int dpft_radar_projection_f32(const float* tesseract, const float* doppler_raste
  * skipped (or NULL): device int32 per tensor, the number of steps the tensor sat out; its bias corrections use
  * step - skipped[t] (the per-parameter state["step"] of torch.optim.AdamW).  A row with m == NULL is the tensor's
  * "marker row": it carries no elements and advances skipped[t] when the tensor is inactive (one such row per tensor).
+ * gate (round 5, or NULL): device float, the step's loss -- the reference steps only `if loss > 0` (training/trainer.py:131);
+ * with a gate that is not positive every tensor sits the launch out as if it had no gradient, so the host need not read the
+ * loss back before it launches the backward and the optimizer.
  * ---------------------------------------------------------------------------------------- */
 int dpft_adamw_f32(const void* chunks, int32_t n_chunks, const int32_t* active, int32_t* skipped, float lr, float beta1,
-                   float beta2, float eps, float weight_decay, int32_t step, dpft_stream_t stream);
+                   float beta2, float eps, float weight_decay, int32_t step, const float* gate, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Measurement aid (bench.py `roofline`): while started, every dpft_conv2d_nhwc_* call is bracketed
