@@ -263,6 +263,45 @@ def test_fused_adamw_segment_steps_equal_the_single_launch():
 
 
 @pytest.mark.gpu
+def test_fused_adamw_gate_is_the_reference_loss_greater_zero_decision():
+    """Round 5: the trainer no longer reads the loss back for `if loss > 0: backward; optimizer.step()` (trainer.py:130-133); the
+    optimizer launch takes the loss as a device-side gate.  gate > 0: the same update as without a gate, bit for bit; gate == 0 (or
+    NaN): nothing moves -- parameters, moments -- and the per-parameter step counts do not advance (torch.optim.AdamW would not
+    have been called)."""
+    from dpft_amd.training.optimizer import FusedAdamW
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 32, 3, 3), (64,), (257,), (1000, 16)]
+
+    def make():
+        ps = [torch.nn.Parameter(torch.randn(s, generator=g).to(DEV)) for s in shapes]
+        return ps, FusedAdamW(ps, lr=1e-2, weight_decay=0.01)
+    g.manual_seed(11)
+    pa, oa = make()
+    g.manual_seed(11)
+    pb, ob = make()
+    grads = [[torch.randn(s, generator=g).to(DEV) for s in shapes] for _ in range(4)]
+    gates = [torch.tensor(2.5, device=DEV), torch.tensor(0.0, device=DEV), torch.tensor(float("nan"), device=DEV), torch.tensor(1e-30, device=DEV)]
+    for step, (gr, gate) in enumerate(zip(grads, gates)):
+        for p, q, t in zip(pa, pb, gr):
+            p.grad, q.grad = t.clone(), t.clone()
+        before = [q.detach().clone() for q in pb]
+        ob.set_gate(gate)
+        ob.step()
+        if step in (1, 2):                                  # closed gate: the reference skips backward AND step
+            for q, b0 in zip(pb, before):
+                assert torch.equal(q.detach(), b0)
+        else:
+            oa.step()                                       # the ungated optimizer only sees the steps that happened
+            for p, q in zip(pa, pb):
+                assert torch.equal(p.detach(), q.detach()), step
+    torch.cuda.synchronize()
+    sa, sb = oa.state_dict()["state"], ob.state_dict()["state"]
+    for k in sa:
+        assert float(sa[k]["step"]) == float(sb[k]["step"]) == 2.0
+        assert torch.equal(sa[k]["exp_avg"], sb[k]["exp_avg"]) and torch.equal(sa[k]["exp_avg_sq"], sb[k]["exp_avg_sq"])
+
+
+@pytest.mark.gpu
 def test_trainer_steps_buckets_early_and_trains_like_the_single_launch(monkeypatch):
     """The trainer's use of it: buckets are stepped as they become final (one rank: on the camera's weight-gradient stream),
     the losses of 6 steps follow the single-launch trainer's (run-to-run differences of the decoder's gradient atomics
