@@ -422,16 +422,13 @@ def main():
         ev_c = [torch.cuda.Event(enable_timing=True) for _ in range(n_w)]
         ev_b = [torch.cuda.Event(enable_timing=True) for _ in range(n_w)]
         cur = [0]
-        o_host, o_replay = trainer.loss_fn._to_host, g_.bwd_graph.replay
-
-        def _host(t):
-            ev_c[cur[0]].record()
-            return o_host(t)
+        o_replay = g_.bwd_graph.replay
 
         def _replay():
             ev_b[cur[0]].record()
             return o_replay()
-        trainer.loss_fn._to_host, g_.bwd_graph.replay = _host, _replay
+        trainer.loss_fn.__dict__["_cost_hook"] = lambda: ev_c[cur[0]].record()
+        g_.bwd_graph.replay = _replay
         try:
             for i in range(n_w):
                 cur[0] = i
@@ -442,7 +439,8 @@ def main():
         except Exception:
             loss_window_us = None
         finally:
-            trainer.loss_fn._to_host, g_.bwd_graph.replay = o_host, o_replay
+            trainer.loss_fn.__dict__.pop("_cost_hook", None)
+            g_.bwd_graph.replay = o_replay
     # ---- fwd ms/frame with the reference's latency protocol (evaluator.py:109-125) ----------------
     fwd_mean, fwd_std = trainer.inference_time(data, warmup=10, reps=args.latency_reps)
     # single-frame latency (what a "low inference time" claim is about, README.md:16 of the reference; its own protocol
@@ -596,7 +594,10 @@ def main():
             "loss": float(loss),
             "loss_window_us": loss_window_us,
             "loss_window_is": "median GPU time from the end of the matcher's cost kernel to the start of the decoder's backward graph "
-                              "(read-back, assignments, upload, criterion + gradient launches, graph launch), 12 steps after the timed region",
+                              "(assignment kernel -- one wavefront per sample, no host round trip --, criterion + gradient kernels; "
+                              "DPFT_LSAP_DEV=0: read-back, host assignments, upload instead), 12 steps after the timed region",
+            "loss_window_assignments": "device" if getattr(trainer.loss_fn, "assign_on_device", False)
+                                       and os.environ.get("DPFT_LSAP_DEV", "1") != "0" else "host",
             "roofline": roof, "roofline_decoder": dec, "roofline_decoder_train": dec_train, "cpu_baseline": cpu,
         }
         print(json.dumps(line))

@@ -174,6 +174,8 @@ SIGNATURES = {
     "dpft_memops": (_I, [_I, _P, _P]),
     "dpft_lsap_batch_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),
     "dpft_assign_loss_f32": (_I, [_P] * 11 + [_F] + [_P] * 8 + [_I] * 4 + [_P]),
+    "dpft_lsap_batch_dev_f32": (_I, [_P] * 5 + [_I] * 3 + [_P]),
+    "dpft_assign_loss_dev_f32": (_I, [_P] * 11 + [_F] + [_P] * 8 + [_I] * 4 + [_P]),
     "dpft_add_many_f32": (_I, [_I, _P, _P]),
     "dpft_i64_add_many": (_I, [_I, _P, _L, _P]),
     "dpft_seed_advance": (_I, [_P, _P, _L, _P]),

@@ -51,6 +51,8 @@ class _Replay(torch.autograd.Function):
     @staticmethod
     def forward(ctx, g: "GraphedFuser", *inputs):
         # this step's small inputs (shapes, projection matrices) into the graph's static buffers: one launch for all of them
+        if g.pace_event is not None:
+            g.pace_event.record()                           # (DataParallelTrainer.train_step waits for it on the HOST)
         ops.memops([(s, a) for s, a in zip(g.static_inputs, inputs[:len(g.static_inputs)]) if s.data_ptr() != a.data_ptr()])
         g.fwd_graph.replay()
         ctx.g = g
@@ -78,6 +80,7 @@ class _Replay(torch.autograd.Function):
 class GraphedFuser:
     last_inputs = None
     clone_outputs = True        # False: hand out the graph's static output buffers (DataParallelTrainer.train_step)
+    pace_event = None           # a torch.cuda.Event recorded in front of the decoder's forward graph when the trainer sets one
 
     def level_buffers(self, view: str, feats) -> "Optional[List[torch.Tensor]]":
         """The static pyramid inputs of ``view`` (in the neck's level order) as plain tensors sharing their storage, or None

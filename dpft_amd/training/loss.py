@@ -280,6 +280,32 @@ class Loss(nn.modules.loss._Loss):
                 and isinstance(self.anassigner, HungarianAnassigner) and isinstance(self.criterion, SetCriterion)
                 and set(self.loss_weights) <= set(self._TERMS) and inputs["class"].dtype == torch.float32)
 
+    # Assignments on the device (csrc/lsap.hip) instead of a read-back + host assignment.  Off by default for a stand-alone Loss:
+    # scipy raises ValueError for a cost matrix with NaN / inf entries AT the call, a kernel can only leave a status word; the
+    # trainer switches it on and calls check_assignment_status() where it reads values back anyway (logging, epoch end).
+    assign_on_device = False
+
+    def _status_word(self, dev) -> torch.Tensor:
+        """One page-locked int32 the assignment kernel writes its error code to (device-visible host memory: the host can look at it
+        without a sync; it only ever changes on an error)."""
+        st = self.__dict__.get("_lsap_status")
+        if st is None:
+            st = self.__dict__["_lsap_status"] = torch.zeros(1, dtype=torch.int32).pin_memory()
+        return st
+
+    def check_assignment_status(self, sync: bool = True) -> None:
+        """Raise the ValueError scipy would have raised in the step whose cost matrix was not finite (or infeasible)."""
+        st = self.__dict__.get("_lsap_status")
+        if st is None:
+            return
+        if sync:
+            torch.cuda.synchronize()
+        code = int(st[0])
+        if code:
+            st[0] = 0
+            what = "contains invalid numeric entries" if code < 0x10000 else "is infeasible"
+            raise ValueError(f"matcher: cost matrix of sample {(code & 0xffff) - (1 if code < 0x10000 else 0)} {what}")
+
     def _to_host(self, t: torch.Tensor) -> "np.ndarray":
         """Device tensor -> numpy through a reused pinned buffer (one async copy + one stream sync instead of a pageable
         allocation and a staged copy: this read-back is the step's host sync, the GPU idles until the host moves on)."""
@@ -315,6 +341,9 @@ class Loss(nn.modules.loss._Loss):
             lib.call("dpft_match_cost_f32", cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                      gt_box.data_ptr(), gt_id.data_ptr(), counts_t.data_ptr(), C.byref(cw), cost.data_ptr(), B, N, Mmax,
                      ncls, stream())
+        hook = self.__dict__.get("_cost_hook")      # (bench.py: an event behind the cost kernel, the start of the loss window)
+        if hook is not None:
+            hook()
         # (everything the host window needs is prepared BEFORE the sync, while the GPU still runs the cost kernel: after the
         # read-back only the one C call is left)
         n_pack = B * Mmax * 2 + B
@@ -331,6 +360,7 @@ class Loss(nn.modules.loss._Loss):
         match_t, counts_m = packed_t[:B * Mmax * 2].view(B, Mmax, 2), packed_t[B * Mmax * 2:]
         self.__dict__["_bwd_written"] = None
         use_c = os.environ.get("DPFT_LSAP_C", "1") != "0"
+        on_dev = use_c and self.assign_on_device and os.environ.get("DPFT_LSAP_DEV", "1") != "0"
         if use_c:
             cnt = np.asarray(counts, dtype=np.int32)
             losses5 = torch.empty(5, dtype=torch.float32, device=dev)
@@ -345,14 +375,38 @@ class Loss(nn.modules.loss._Loss):
             ok_t = tg is not None and all(t.shape == r.shape and t.is_contiguous() and t.dtype == torch.float32
                                           for t, r in zip(tg, (center, size, angle, cls)))
             w5 = (C.c_float * 5)(*weights5)
-            c_args = (cnt.ctypes.data, packed.ctypes.data, packed_t.data_ptr(),
+            if on_dev:
+                self.check_assignment_status(sync=False)      # (an error of an earlier step that has finished by now)
+                head = (cost.data_ptr(), counts_t.data_ptr(), packed_t.data_ptr(), self._status_word(dev).data_ptr())
+            else:
+                head = (cnt.ctypes.data, packed.ctypes.data, packed_t.data_ptr())
+            c_args = head + (
                       cls.data_ptr(), center.data_ptr(), size.data_ptr(), angle.data_ptr(),
                       gt_box.data_ptr(), gt_onehot.data_ptr(), C.cast(w5, C.c_void_p), 0.75, sel.data_ptr(),
                       scratch.data_ptr(), losses5.data_ptr(), total.data_ptr(),
                       tg[3].data_ptr() if ok_t else None, tg[0].data_ptr() if ok_t else None,
                       tg[1].data_ptr() if ok_t else None, tg[2].data_ptr() if ok_t else None,
                       B, N, Mmax, ncls, st_)
-            assign_loss = lib.dpft_assign_loss_f32
+            assign_loss = lib.dpft_assign_loss_dev_f32 if on_dev else lib.dpft_assign_loss_f32
+        if on_dev:
+            # No host round trip at all (dpft_assign_loss_dev_f32, csrc/lsap.hip): the assignments are computed by one wavefront per
+            # sample from the cost matrices where the cost kernel left them -- the same step sequence as the host code, the same
+            # pairs (tests/test_gpu_lsap.py) --, criterion and gradient launches follow in the same call.  The step has no host
+            # sync left; a non-finite cost matrix is reported through the status word (check_assignment_status) instead of here.
+            try:
+                rc = assign_loss(*c_args)
+            except Exception:
+                scratch.zero_()
+                raise
+            if rc != 0:
+                scratch.zero_()
+                raise ValueError("assignment / loss failed: " + lib.dpft_last_error().decode())
+            if ok_t:
+                self.__dict__["_bwd_written"] = tuple(tg)
+            losses5, total = _SetLossFn.apply(cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel,
+                                              (losses5, total))
+            self.__dict__["_last"] = (cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel, total)
+            return total, {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}
         host = self._to_host(cost)                                                            # the one sync of the step
         if use_c:
             # The whole host window in ONE C call (dpft_assign_loss_f32, csrc/cabi.cpp): the batch's assignments (scipy's algorithm

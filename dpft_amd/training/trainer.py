@@ -68,6 +68,10 @@ class DataParallelTrainer:
             _ops.conv_set_compute(config.get("computing", {}).get("conv_compute") or os.environ.get("DPFT_CONV_COMPUTE", "fp32"))
         train = config["train"]
         self.loss_fn = build_loss(train)
+        if self.device.type == "cuda" and hasattr(self.loss_fn, "assign_on_device"):
+            # assignments on the device (csrc/lsap.hip): the step has no host sync; a non-finite cost matrix surfaces as the
+            # ValueError scipy raises, at the next place this class reads values back (_check_matcher)
+            self.loss_fn.assign_on_device = True
         # the reference evaluates mAP3D / mGIoU3D in every training step (trainer.py:134); optional here
         self.eval_fn = None
         if config.get("evaluate", {}).get("metrics"):
@@ -170,6 +174,8 @@ class DataParallelTrainer:
         g = self.model.__dict__.get("_graphed_fuser")
         if g is not None:
             g.clone_outputs = False                        # loss, metrics and the backward below are done with them in time
+            if self.pace_host and g.pace_event is None:
+                g.pace_event = torch.cuda.Event()
         try:
             output = self.model(data)
         finally:
@@ -184,23 +190,40 @@ class DataParallelTrainer:
         elif hasattr(self.loss_fn, "__dict__"):
             self.loss_fn.__dict__["fused_grad_targets"] = None
         loss, losses = self.loss_fn(output, labels)
+        if g is not None and g.pace_event is not None and self.pace_host:
+            # Pacing, not a data dependency: with the assignments on the device nothing in the step makes the host wait, and a host
+            # that enqueues the whole backward while the GPU is still in the encoders' forward costs 0.3 ms a step (measured,
+            # profiles/r05_loss_window_ab.txt: 24.33 ms unpaced, 24.05 ms with a host sync behind the loss launches, 24.1 ms
+            # like this).  The host waits until the GPU has REACHED the decoder's forward graph (an event in front of it), with
+            # the matcher / assignment / criterion launches already queued behind that graph: the GPU never idles (the loss
+            # window stays ~50 us) and the backward is enqueued into nearly empty queues.
+            g.pace_event.synchronize()
         gate = None
         if self._exp_local_decision and self.world > 1:
             raise RuntimeError("_exp_local_decision is a one-rank timing experiment switch")
+        known = getattr(self.loss_fn, "last_has_targets", None)
         if self.collective and not self._exp_local_decision:
             # The global batch steps if ANY shard has a loss (MAX): a rank whose label shard is empty then runs the same
             # backward over a zero-valued loss, so it contributes zero gradients, issues its bucket collectives in the
             # same order and reports the same set of parameters-with-gradient as every other rank.
-            # [local, any-rank] are read back together: still ONE host sync per step (trainer.py:131 has one).
-            flag = (loss.detach() > 0).to(torch.int32).reshape(1).repeat(2)
-            dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
-            local, stepped = (bool(v) for v in flag.tolist())
+            if known is not None and isinstance(self.optimizer, FusedAdamW) and self.sync_free_decision:
+                # No read-back: every rank ALWAYS runs its backward (over a zero-valued loss where its own shard has no target:
+                # known on the host from the label dicts) and the any-rank flag stays on the device as the optimizer's gate --
+                # in the rare step in which NO rank has a target the backward is wasted work and the gate keeps every
+                # parameter and moment as it was, which is what skipping the step does.
+                any_rank = (loss.detach() > 0).to(torch.float32).reshape(1)
+                dist.all_reduce(any_rank, op=dist.ReduceOp.MAX)
+                local, stepped, gate = bool(known), True, any_rank
+            else:
+                # [local, any-rank] are read back together: ONE host sync per step (trainer.py:131 has one).
+                flag = (loss.detach() > 0).to(torch.int32).reshape(1).repeat(2)
+                dist.all_reduce(flag[1:], op=dist.ReduceOp.MAX)
+                local, stepped = (bool(v) for v in flag.tolist())
         else:
             # trainer.py:131 `if loss > 0`: the loss is exactly 0 when the batch has no target and positive otherwise (the focal term
             # alone) -- the host knows which from the label dicts, so it launches backward and optimizer WITHOUT reading the loss
             # back (the read-back was the second host sync inside the window in which the GPU waits for the host); the comparison
             # itself is done on the device by the optimizer launch (FusedAdamW.set_gate: nothing is updated unless loss > 0).
-            known = getattr(self.loss_fn, "last_has_targets", None)
             if known is not None and isinstance(self.optimizer, FusedAdamW):
                 stepped = local = bool(known)
                 gate = loss.detach()
@@ -250,6 +273,15 @@ class DataParallelTrainer:
     def _dict_to(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
 
+    pace_host = os.environ.get("DPFT_PACE_HOST", "1") != "0"      # train_step: host waits for the GPU to reach the decoder (see there)
+    sync_free_decision = True      # multi-rank step decision without a read-back (train_step); False = the round-4 form
+
+    def _check_matcher(self) -> None:
+        """Deferred error of the on-device assignment (Loss.check_assignment_status): called where values are read back anyway."""
+        chk = getattr(self.loss_fn, "check_assignment_status", None)
+        if chk is not None and self.device.type == "cuda":
+            chk(sync=True)
+
     def _rank_mean(self, scalars: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         """Mean over ranks of every scalar (ONE collective).  Every rank calls it with the same keys -- checked: a rank whose
         loader yielded nothing (tiny validation split, drop_last) would otherwise skip the collective the others enter and
@@ -260,6 +292,7 @@ class DataParallelTrainer:
             if int(n[0]) != -int(n[1]):
                 raise RuntimeError(f"rank {self.rank}: {len(scalars)} epoch scalars, another rank has {int(n[0])} / {-int(n[1])}: "
                                    "a rank saw no batches (sampler / drop_last leave it an empty shard)")
+        self._check_matcher()
         if not scalars:
             return scalars
         keys = sorted(scalars)

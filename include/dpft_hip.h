@@ -601,6 +601,23 @@ int dpft_assign_loss_f32(const float* cost_host, const int32_t* counts_host, int
                          float* losses5, float* total, float* dcls, float* dcenter, float* dsize, float* dangle, int32_t B,
                          int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
 
+/* The same assignments ON THE DEVICE (round 5; dpft_amd/csrc/lsap.hip): one wavefront per sample runs the step sequence of
+ * dpft_lsap_batch_f32 (double precision duals, scipy's tie rule as an associative reduction over the 64 lanes) on the cost
+ * matrices dpft_match_cost_f32 left in HBM: cost (B,N,Mmax), counts (B), match (B,Mmax,2), n_matched (B) all DEVICE memory; the
+ * same pairs in the same order as the host function.  A kernel cannot return an error: status (one int32 in device or
+ * page-locked host memory, zero before the first call, may be NULL) receives 1 + b for a non-finite entry / 0x10000 + b for an
+ * infeasible problem of sample b, and that sample gets no pairs.  With it the training step has no host round trip between the
+ * matcher and the criterion (src/dprt/training/loss.py:296-373: scipy on a .cpu() copy per sample). */
+int dpft_lsap_batch_dev_f32(const float* cost, const int32_t* counts, int32_t* match, int32_t* n_matched, int32_t* status,
+                            int32_t B, int32_t N, int32_t Mmax, dpft_stream_t stream);
+/* dpft_assign_loss_f32 without the host: dpft_lsap_batch_dev_f32 -> dpft_set_loss_fwd_total_f32 -> (dcls != NULL)
+ * dpft_set_loss_bwd_f32, three launches from one call.  packed_dev (B * Mmax * 2 + B) int32 = assignments | matched counts. */
+int dpft_assign_loss_dev_f32(const float* cost, const int32_t* counts, int32_t* packed_dev, int32_t* status, const float* cls,
+                             const float* center, const float* size, const float* angle, const float* gt_box,
+                             const float* gt_onehot, const float* weights5, float alpha, const float* sel, float* scratch,
+                             float* losses5, float* total, float* dcls, float* dcenter, float* dsize, float* dangle, int32_t B,
+                             int32_t N, int32_t Mmax, int32_t C, dpft_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * SetCriterion + batch reduction 'mean' (src/dprt/training/loss.py:17-60 focal loss with the raw-logit p_t,
  * :176-373 criterion, :486-564 weighting / reduction) for given assignments.

@@ -401,7 +401,7 @@ def test_fpn_data_gradients_land_in_the_launch_plans_buffers_and_no_vendor_glue_
     with Spy():
         tr.train_step(batch, labels)
     torch.cuda.synchronize()
-    # round 5: ONE ATen op left -- the cost matrix to the host.  The assignments go back inside dpft_assign_loss_f32 (hipMemcpyAsync
-    # from the pinned buffer), and the loss is not read back any more (the step decision is taken from the label dicts, the
-    # `loss > 0` comparison by the optimizer launch on the device)
-    assert sorted(seen) == ["copy_"], seen
+    # round 5: NO ATen op left.  The assignments are computed on the device (dpft_assign_loss_dev_f32: no cost matrix to the
+    # host, no upload), and the loss is not read back (the step decision is taken from the label dicts, the `loss > 0`
+    # comparison by the optimizer launch on the device)
+    assert seen == [], seen

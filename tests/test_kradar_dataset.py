@@ -105,11 +105,15 @@ def test_folder_reader_equals_the_reference_dataset(tmp_path):
     assert len(ref) == len(ours) == 6
     fov_t = {k: torch.tensor(v) for k, v in FOV.items()}
     ref.fov = fov_t
+    # upstream walks the sequences in os.listdir order (file-system dependent), this repo in sorted order (every rank must see
+    # the same index -> sample map): pair the items by their sample folder, and check that both hold the same set
+    where = {os.path.dirname(f["description"]): j for j, f in enumerate(ours.samples)}
+    assert sorted(where) == sorted(os.path.dirname(f["description"]) for f in ref.dataset_paths)
     for i in range(len(ref)):
         np.random.seed(i)
         item_r, label_r = ref[i]
         np.random.seed(i)
-        item_o, label_o = ours[i]
+        item_o, label_o = ours[where[os.path.dirname(ref.dataset_paths[i]["description"])]]
         assert list(item_r.keys()) == list(item_o.keys())
         for k in item_r:
             assert item_r[k].dtype == item_o[k].dtype and torch.equal(item_r[k], item_o[k]), k
@@ -124,6 +128,6 @@ def test_folder_reader_equals_the_reference_dataset(tmp_path):
         np.random.seed(100 + i)
         item_r, _ = ref2[i]
         np.random.seed(100 + i)
-        item_o, _ = ours2[i]
+        item_o, _ = ours2[where[os.path.dirname(ref2.dataset_paths[i]["description"])]]
         for k in item_r:
             assert torch.equal(item_r[k], item_o[k]), k
