@@ -41,6 +41,24 @@ for step in range(3):
     loss, _ = tr.train_step(data, labels)
     torch.cuda.synchronize()
     same_on_all_ranks(checksum(), f"parameters after step {step}")
+# the step decision without a read-back (trainer.sync_free_decision): a rank whose shard has no target runs its backward over a
+# zero-valued loss; when NO rank has a target the optimizer's device-side gate keeps every parameter as it was
+empty = [{k: v[:0] for k, v in l.items()} for l in labels]
+before = checksum()
+tr.train_step(data, empty if rank == 1 else labels)
+torch.cuda.synchronize()
+after = checksum()
+same_on_all_ranks(after, "parameters after the step with an empty shard on rank 1")
+assert not torch.equal(before, after), "the step with one empty shard must still update"
+tr.train_step(data, empty)
+torch.cuda.synchronize()
+assert torch.equal(checksum(), after), "no rank has a target: nothing may change"
+same_on_all_ranks(checksum(), "parameters after the all-empty step")
+tr.train_step(data, labels)
+torch.cuda.synchronize()
+same_on_all_ranks(checksum(), "parameters after the step behind the all-empty one")
+assert not torch.equal(checksum(), after)
+tr._check_matcher()
 # reduced gradients are identical on every rank
 g = torch.stack([b["flat"].double().sum() for b in tr.reducer.buckets]).cpu()
 same_on_all_ranks(g, "reduced gradient buckets")
