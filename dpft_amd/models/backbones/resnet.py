@@ -312,11 +312,6 @@ class _BodyFn(torch.autograd.Function):
                      ptr(st["arena"]), ptr(d), int(st["mode"] == 2), stream())
             if direct is not None:                       # this stage's gradients are in the DP buckets: release them
                 direct.mark_ready_many(stage_params[li])
-            if __import__("os").environ.get("DPFT_EXP_PACE2") == str(li):
-                ev = owner.__dict__.get("_pace2")
-                if ev is None:
-                    ev = owner.__dict__["_pace2"] = torch.cuda.Event()
-                ev.record()
         grads = {}
         if direct is None:
             for c, g in zip(st["convs"], st["conv_g"]):

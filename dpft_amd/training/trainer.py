@@ -164,11 +164,6 @@ class DataParallelTrainer:
                     first = self.model.backbones[self.model.inputs[0]]
                     self.reducer.comm_stream = views[-1] if self.comm_placement == "front" or first.side_stream is None \
                         else first.side_stream
-        if os.environ.get("DPFT_EXP_PACE2") and hasattr(self.model, "backbones"):
-            for b in self.model.backbones.values():
-                ev = b.__dict__.get("_pace2")
-                if ev is not None and (os.environ.get("DPFT_EXP_PACE2_ALL") or b is self.model.backbones[self.model.inputs[0]]):
-                    ev.synchronize()
         self.reducer.reset()                               # zero_grad (grads live in the buckets)
         if self.early_adamw and not self.collective and self.reducer.opt_stream is None:
             first = self.model.backbones[self.model.inputs[0]] if hasattr(self.model, "backbones") else None
