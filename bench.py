@@ -592,6 +592,7 @@ def main():
                                             trainer.comm_placement, trainer.comm_placement)},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
+            "host_pacing": trainer.pace_host,      # "1": DataParallelTrainer._pace (opt-in, DPFT_PACE_HOST=1); "0": the host is never held back
             "loss_window_us": loss_window_us,
             "loss_window_is": "median GPU time from the end of the matcher's cost kernel to the start of the decoder's backward graph "
                               "(assignment kernel -- one wavefront per sample, no host round trip --, criterion + gradient kernels; "

@@ -234,7 +234,14 @@ def ptr(t: Optional[torch.Tensor]):
     return C.c_void_p(t.data_ptr())
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """The current HIP stream of the current device as a C pointer (asked ~100 times per training step: the raw query, not a
+    torch.cuda.Stream object per call -- 0.3 vs 8 us)."""
+    if _raw_stream is not None:
+        return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -191,13 +191,29 @@ class _BodyFn(torch.autograd.Function):
             arena = torch.empty(plan.arena_bytes, dtype=torch.uint8, device=x.device)
         # inference: the pointer tables only depend on where the parameters live -- rebuilt when a tensor moved
         # (building them costs ~0.4 ms of host time per backbone, in front of the forward's first kernel)
-        sig = None if need_grad else (weights_generation(), tuple(c.weight.data_ptr() for c in convs),
-                                      tuple(m.running_var.data_ptr() for m in bns),
-                                      tuple(m.weight.data_ptr() for m in bns), tuple(m.bias.data_ptr() for m in bns))
-        cached = owner.__dict__.get("_infer_tables") if sig is not None else None
-        if cached is not None and cached[0] == sig:
+        sig = (weights_generation(), tuple(c.weight.data_ptr() for c in convs),
+               tuple(m.running_var.data_ptr() for m in bns), tuple(m.running_mean.data_ptr() for m in bns),
+               tuple(m.weight.data_ptr() for m in bns), tuple(m.bias.data_ptr() for m in bns))
+        cached = owner.__dict__.get("_infer_tables") if not need_grad else None
+        # training with direct-to-bucket gradients: the tables also name the reducer's bucket views -- the same every step for the
+        # life of the reducer (its arena): rebuilt when a parameter, a buffer or the arena moved (~1.1 ms of host time per
+        # backbone and step otherwise, on a step whose launch work takes the host 15+ ms)
+        tsig = None
+        if need_grad and owner.grad_direct is not None:
+            tsig = (sig, id(owner.grad_direct), owner.grad_direct.arena.data_ptr(), len(params))
+            tc = owner.__dict__.get("_train_tables")
+            if tc is not None and tc[0] == tsig:
+                prev = owner.__dict__.get("_direct_lease")
+                if prev is not None and prev() is not None:
+                    raise RuntimeError("dpft_amd backbone: a second grad-enabled forward while the previous one's backward "
+                                       "is outstanding is not supported with direct-to-bucket gradients (grad_direct)")
+                cached = tc
+        if cached is not None and not need_grad and cached[0] == sig:
             _, t, keep, weights = cached
             conv_g = bn_g = bn_b = flat = direct = None
+        elif cached is not None and need_grad:
+            _, t, keep, weights, conv_g, bn_g, bn_b = cached
+            flat, direct = None, owner.grad_direct
         else:
             weights = [khwc(c.weight) for c in convs]                       # physical [K][kh][kw][C]
             # gradient buffers: straight into the DP buckets when a reducer is attached, else one flat buffer
@@ -240,8 +256,11 @@ class _BodyFn(torch.autograd.Function):
                 [C.cast(k, C.POINTER(C.c_void_p)) for k in keep]
             # cached only if every table entry aliases its parameter: khwc() COPIES a weight that is not physically
             # [K][kh][kw][C] (p.data reassigned, load_state_dict(assign=True)), and a cached copy would go stale
-            if sig is not None and all(wk.data_ptr() == c.weight.data_ptr() for wk, c in zip(weights, convs)):
-                owner.__dict__["_infer_tables"] = (sig, t, keep, weights)
+            if all(wk.data_ptr() == c.weight.data_ptr() for wk, c in zip(weights, convs)):
+                if not need_grad:
+                    owner.__dict__["_infer_tables"] = (sig, t, keep, weights)
+                elif tsig is not None and direct is not None:
+                    owner.__dict__["_train_tables"] = (tsig, t, keep, weights, conv_g, bn_g, bn_b)
         lib.call("dpft_resnet_forward", plan.handle, ptr(x), C.byref(t), ptr(arena), mode, stream())
         if train:      # num_batches_tracked += 1 of every BatchNorm: one launch per 256 counters
             ptrs = tuple(m.num_batches_tracked.data_ptr() for m in bns)
@@ -287,14 +306,19 @@ class _BodyFn(torch.autograd.Function):
             af = st["arena"].view(torch.float32)
             for off, shape in plan.outs:
                 ops.drop_grad_sink(af[off:off + 1])
-        # stage -> parameters whose gradients are complete after that stage's call
-        stage_params = {li: [] for li in range(body.n_layers)}
-        for li in range(body.n_layers):
-            for blk in getattr(body, f"layer{li + 1}"):
-                stage_params[li] += list(blk.parameters())
-        stage_params[0] += [body.conv1.weight, body.bn1.weight, body.bn1.bias]
-        if owner.adjustment_layer is not None:
-            stage_params[0].append(owner.adjustment_layer.weight)
+        # stage -> parameters whose gradients are complete after that stage's call (the module tree is fixed: built once)
+        stage_params = owner.__dict__.get("_stage_params")
+        if stage_params is None or any(a is not b for a, b in zip(stage_params[-1], st["params"])) \
+                or len(stage_params[-1]) != len(st["params"]):
+            stage_params = {li: [] for li in range(body.n_layers)}
+            for li in range(body.n_layers):
+                for blk in getattr(body, f"layer{li + 1}"):
+                    stage_params[li] += list(blk.parameters())
+            stage_params[0] += [body.conv1.weight, body.bn1.weight, body.bn1.bias]
+            if owner.adjustment_layer is not None:
+                stage_params[0].append(owner.adjustment_layer.weight)
+            stage_params[-1] = tuple(st["params"])         # (the parameter objects the lists were built from)
+            owner.__dict__["_stage_params"] = stage_params
         keep_alive = []
         for li in range(body.n_layers - 1, -1, -1):
             d = douts[li]
@@ -393,7 +417,7 @@ class BackboneBase(nn.Module):
         st["_plans"] = {}
         st["grad_direct"] = None
         st["side_stream"] = None
-        for k in ("_ordered", "_infer_tables", "_plist", "_direct_lease", "_nbt_ptrs"):
+        for k in ("_ordered", "_infer_tables", "_train_tables", "_stage_params", "_plist", "_direct_lease", "_nbt_ptrs"):
             st.pop(k, None)
         return st
 

@@ -151,7 +151,8 @@ class DataParallelTrainer:
     def train_step(self, data: Dict[str, torch.Tensor], labels: List[Dict[str, torch.Tensor]], with_metrics: bool = False):
         """One step of CentralizedTrainer.train_one_epoch (trainer.py:122-136).  ``with_metrics`` also evaluates the
         configured detection metrics on the step's outputs (two more launches) and returns them as a third value."""
-        self.model.train()
+        if not self.model.training:                        # (Module.train() walks ~1 000 modules: 2-4 ms of host time per call;
+            self.model.train()                             # the epoch loop calls it once per epoch like trainer.py:113)
         if self.collective and self.reducer.comm_stream is None and self.comm_placement != "pg" and self.device.type == "cuda" \
                 and dist.get_backend() == "nccl":
             if self.comm_placement == "own":
@@ -174,7 +175,7 @@ class DataParallelTrainer:
         g = self.model.__dict__.get("_graphed_fuser")
         if g is not None:
             g.clone_outputs = False                        # loss, metrics and the backward below are done with them in time
-            if self.pace_host and g.pace_event is None:
+            if self.pace_host != "0" and g.pace_event is None:
                 g.pace_event = torch.cuda.Event()
         try:
             output = self.model(data)
@@ -190,14 +191,8 @@ class DataParallelTrainer:
         elif hasattr(self.loss_fn, "__dict__"):
             self.loss_fn.__dict__["fused_grad_targets"] = None
         loss, losses = self.loss_fn(output, labels)
-        if g is not None and g.pace_event is not None and self.pace_host:
-            # Pacing, not a data dependency: with the assignments on the device nothing in the step makes the host wait, and a host
-            # that enqueues the whole backward while the GPU is still in the encoders' forward costs 0.3 ms a step (measured,
-            # profiles/r05_loss_window_ab.txt: 24.33 ms unpaced, 24.05 ms with a host sync behind the loss launches, 24.1 ms
-            # like this).  The host waits until the GPU has REACHED the decoder's forward graph (an event in front of it), with
-            # the matcher / assignment / criterion launches already queued behind that graph: the GPU never idles (the loss
-            # window stays ~50 us) and the backward is enqueued into nearly empty queues.
-            g.pace_event.synchronize()
+        if g is not None and g.pace_event is not None and self.pace_host != "0":
+            self._pace(g)
         gate = None
         if self._exp_local_decision and self.world > 1:
             raise RuntimeError("_exp_local_decision is a one-rank timing experiment switch")
@@ -273,7 +268,22 @@ class DataParallelTrainer:
     def _dict_to(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
 
-    pace_host = os.environ.get("DPFT_PACE_HOST", "1") != "0"      # train_step: host waits for the GPU to reach the decoder (see there)
+    # Pacing of the host (train_step -> _pace): off by default, DPFT_PACE_HOST=1 / trainer.pace_host = "1" switches it on.
+    pace_host = os.environ.get("DPFT_PACE_HOST", "0")
+
+    def _pace(self, g) -> None:
+        """Pacing, not a data dependency (OPT-IN).  With the assignments on the device nothing in the step makes the host wait.
+        On a clearly GPU-bound step a host that is never held back costs 0-0.4 ms per step (kradar.json at batch 4: 24.3-24.5 ms
+        unpaced, 24.0-24.4 paced; bf16 at batch 8: 23.7 vs 23.3; on some boxes nothing -- profiles/r05_loss_window_ab.txt): it
+        enqueues the whole backward while the GPU is still in the encoders' forward.  Paced, the host waits until the GPU has
+        REACHED the decoder's forward graph (an event in front of it), with the matcher / assignment / criterion launches
+        already queued behind that graph: the GPU never idles (the loss window stays ~50 us) and the backward is enqueued into
+        nearly empty queues.  On a step whose launch work takes the host about as long as the kernels take the GPU (bf16 at
+        batch 4: host 13-18 ms, GPU 15 ms) the same wait removes the lead that absorbs the host's jitter and costs 1-6 ms
+        (15.3 -> 18.7-19.4 ms).  Two automatic choosers (host / GPU period ratio; an in-situ A/B over 6 + 6 steps) were tried and
+        both mis-picked on noisy boxes, so the safe mode is the default and the gain stays an explicit switch."""
+        g.pace_event.synchronize()
+
     sync_free_decision = True      # multi-rank step decision without a read-back (train_step); False = the round-4 form
 
     def _check_matcher(self) -> None:
