@@ -200,7 +200,8 @@ class _BodyFn(torch.autograd.Function):
         # backbone and step otherwise, on a step whose launch work takes the host 15+ ms)
         tsig = None
         if need_grad and owner.grad_direct is not None:
-            tsig = (sig, id(owner.grad_direct), owner.grad_direct.arena.data_ptr(), len(params))
+            # (pointers only: the tables alias the parameters, an optimizer step does not invalidate them)
+            tsig = (sig[1:], id(owner.grad_direct), owner.grad_direct.arena.data_ptr(), len(params))
             tc = owner.__dict__.get("_train_tables")
             if tc is not None and tc[0] == tsig:
                 prev = owner.__dict__.get("_direct_lease")
