@@ -592,7 +592,10 @@ def main():
                                             trainer.comm_placement, trainer.comm_placement)},
             "dp_comm_dtype": trainer.comm_dtype,
             "loss": float(loss),
-            "host_pacing": trainer.pace_host,      # "1": DataParallelTrainer._pace (opt-in, DPFT_PACE_HOST=1); "0": the host is never held back
+            "host_pacing": dict(mode=trainer.pace_host, **{k: v for k, v in trainer.__dict__.get("_pace_state", {}).items()
+                                                           if k in ("decided", "host_ms", "gpu_ms")}),
+            "host_pacing_is": "DataParallelTrainer._pace: the host waits for the GPU to reach the decoder's forward graph before it enqueues "
+                              "the backward; 'auto' does so when four measured steps say the host's own period is < 0.8 x the GPU's",
             "loss_window_us": loss_window_us,
             "loss_window_is": "median GPU time from the end of the matcher's cost kernel to the start of the decoder's backward graph "
                               "(assignment kernel -- one wavefront per sample, no host round trip --, criterion + gradient kernels; "

@@ -176,7 +176,7 @@ class DataParallelTrainer:
         if g is not None:
             g.clone_outputs = False                        # loss, metrics and the backward below are done with them in time
             if self.pace_host != "0" and g.pace_event is None:
-                g.pace_event = torch.cuda.Event()
+                g.pace_event = torch.cuda.Event(enable_timing=self.pace_host == "auto")
         try:
             output = self.model(data)
         finally:
@@ -268,21 +268,48 @@ class DataParallelTrainer:
     def _dict_to(self, data: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
         return {k: (v.to(self.device, non_blocking=True) if isinstance(v, torch.Tensor) else v) for k, v in data.items()}
 
-    # Pacing of the host (train_step -> _pace): off by default, DPFT_PACE_HOST=1 / trainer.pace_host = "1" switches it on.
-    pace_host = os.environ.get("DPFT_PACE_HOST", "0")
+    # Pacing of the host (train_step -> _pace): "auto" (default) | "1" on | "0" off  (DPFT_PACE_HOST).
+    pace_host = os.environ.get("DPFT_PACE_HOST", "auto")
+    pace_ratio = 0.8               # auto: pace when the host's own step period is below this fraction of the GPU's
 
     def _pace(self, g) -> None:
-        """Pacing, not a data dependency (OPT-IN).  With the assignments on the device nothing in the step makes the host wait.
-        On a clearly GPU-bound step a host that is never held back costs 0-0.4 ms per step (kradar.json at batch 4: 24.3-24.5 ms
-        unpaced, 24.0-24.4 paced; bf16 at batch 8: 23.7 vs 23.3; on some boxes nothing -- profiles/r05_loss_window_ab.txt): it
-        enqueues the whole backward while the GPU is still in the encoders' forward.  Paced, the host waits until the GPU has
-        REACHED the decoder's forward graph (an event in front of it), with the matcher / assignment / criterion launches
-        already queued behind that graph: the GPU never idles (the loss window stays ~50 us) and the backward is enqueued into
-        nearly empty queues.  On a step whose launch work takes the host about as long as the kernels take the GPU (bf16 at
-        batch 4: host 13-18 ms, GPU 15 ms) the same wait removes the lead that absorbs the host's jitter and costs 1-6 ms
-        (15.3 -> 18.7-19.4 ms).  Two automatic choosers (host / GPU period ratio; an in-situ A/B over 6 + 6 steps) were tried and
-        both mis-picked on noisy boxes, so the safe mode is the default and the gain stays an explicit switch."""
-        g.pace_event.synchronize()
+        """Pacing, not a data dependency.  With the assignments on the device nothing in the step makes the host wait.  On a
+        GPU-bound step a host that is never held back costs 0-0.4 ms per step (kradar.json at batch 4: 24.3-24.9 ms unpaced,
+        24.0-24.4 paced; bf16 at batch 8: 23.7 vs 23.3 -- profiles/r05_loss_window_ab.txt): it enqueues the whole backward while the
+        GPU is still in the encoders' forward.  Paced, the host waits until the GPU has REACHED the decoder's forward graph (an
+        event in front of it), with the matcher / assignment / criterion launches already queued behind that graph: the GPU
+        never idles (the loss window stays ~50 us) and the backward is enqueued into nearly empty queues.  On a step whose launch
+        work takes the host about as long as the kernels take the GPU (bf16 at batch 4: host 13-18 ms, GPU 15 ms) the same wait
+        removes the lead that absorbs the host's jitter and costs 1-6 ms (15.3 -> 18.7-22.7 ms).  "auto" tells the two apart from
+        four unpaced steps: the host's period between two pace points (it runs free: its own launch work) against the GPU's
+        period between the two events; the observed ratios are 0.35-0.73 where pacing gains (fp32 batch 4 / 8, bf16 batch 8) and
+        0.97-1.0 where it loses (bf16 batch 4): paced below pace_ratio = 0.8."""
+        if self.pace_host == "1":
+            g.pace_event.synchronize()
+            return
+        st = self.__dict__.setdefault("_pace_state", {"events": [], "host": [], "t": None, "decided": None})
+        if st["decided"] is not None:
+            if st["decided"]:
+                g.pace_event.synchronize()
+            return
+        import time
+        now = time.perf_counter()
+        if st["t"] is not None:
+            st["host"].append(now - st["t"])
+        st["t"] = now
+        st["events"].append(g.pace_event)                  # this step's (recorded) event; the next step records a fresh one
+        if len(st["events"]) < 5:
+            g.pace_event = torch.cuda.Event(enable_timing=True)
+            return
+        ev = st["events"]
+        ev[-1].synchronize()                               # (once: the measurement needs the last event's time stamp)
+        try:
+            gpu_ms = min(ev[i].elapsed_time(ev[i + 1]) for i in range(1, 4))
+            host_ms = min(st["host"][1:]) * 1e3
+            st.update(decided=host_ms < self.pace_ratio * gpu_ms, host_ms=host_ms, gpu_ms=gpu_ms, events=[])
+        except RuntimeError:                               # (an event of a step that did not replay the decoder graph)
+            st.update(decided=False, host_ms=None, gpu_ms=None, events=[])
+        g.pace_event = torch.cuda.Event()
 
     sync_free_decision = True      # multi-rank step decision without a read-back (train_step); False = the round-4 form
 
