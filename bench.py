@@ -295,7 +295,8 @@ def main():
         marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
-    step_ms = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
+    step_ms = sorted(step_ms_order)
     # None at one rank without forced collectives: there is no exchange to expose (0.0 would read like a measurement)
     exposed_ms = trainer.reducer.exposed_ms() if collective else None
     if collective:
@@ -552,6 +553,7 @@ def main():
         line = {
             "metric": f"training samples/sec (K-Radar C+R, bs{B}/GPU)", "value": value, "unit": "samples/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "step_ms_first8": [round(v, 2) for v in step_ms_order[:8]],      # (in order: the steps right behind the sync at the start)
             "step_ms_min": step_ms[0], "step_ms_median": step_ms[len(step_ms) // 2], "step_ms_max": step_ms[-1],
             "step_ms_is": "rank 0, per step: HIP events on the main stream at every step boundary of the timed region",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",

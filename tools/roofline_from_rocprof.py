@@ -21,7 +21,7 @@ MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "igemm_x3_k
         "conv16_", "wgrad16_", "thin_wgrad", "wgrad_stem7_kernel", "conv1x1_to16_kernel", "wgrad1x1_")
 AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel", "zero_fill_kernel")
 GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", "pack_"),
-          "decoder_infer": ("decoder_selfattn", "decoder_xattn"), "loss": ("match_cost", "set_loss", "giou3d"),
+          "decoder_infer": ("decoder_selfattn", "decoder_xattn"), "loss": ("match_cost", "set_loss", "giou3d", "lsap_batch"),
           "optimizer": ("adamw",), "weight_transpose": ("weight_transpose",), "fpn_misc": ("fpn_topdown", "add_pos", "add_inplace", "relu_bwd"),
           "vendor_aten": ("at::native", "Cijk_", "__amd_rocclr", "rocclr")}
 
