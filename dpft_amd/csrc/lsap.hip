@@ -13,7 +13,7 @@
 // doubles in the same order as the host code (no products: nothing to contract), so pairs AND their order are identical
 // (tests/test_gpu_lsap.py: the host function on the same matrices, ties included).
 // Errors (a non-finite cost, an infeasible problem) cannot be returned by a kernel: status[0] receives 1 + b (non-finite) or
-// 0x10000 + b (infeasible) of an offending sample, the sample gets no pairs, and the host raises when it next looks
+// 0x10000 + b (infeasible) / 0x20000 + b (count above Mmax) of an offending sample, the sample gets no pairs, and the host raises when it next looks
 // (Loss.check_assignment_status: the trainer's logging / epoch sync points).
 #include "common.h"
 
@@ -60,6 +60,10 @@ __global__ __launch_bounds__(64) void lsap_batch_kernel(LsapArgs a) {
     for (int k = lane; k < 2 * Mmax; k += 64) mb[k] = -1;
     if (lane == 0) a.n_matched[b] = 0;
     if (m <= 0) return;
+    if (m > Mmax) {      // (the host function refuses it as an argument error; here: no pairs + the status word)
+        if (lane == 0 && a.status) report(a.status, 0x20000 + b);
+        return;
+    }
     const float* cb = a.cost + (size_t)b * N * Mmax;
     // rows = the narrower side (scipy transposes a tall problem)
     const bool tall = N > m;

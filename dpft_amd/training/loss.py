@@ -303,7 +303,8 @@ class Loss(nn.modules.loss._Loss):
         code = int(st[0])
         if code:
             st[0] = 0
-            what = "contains invalid numeric entries" if code < 0x10000 else "is infeasible"
+            what = "contains invalid numeric entries" if code < 0x10000 else ("is infeasible" if code < 0x20000 else
+                                                                              "has more targets than the packed width")
             raise ValueError(f"matcher: cost matrix of sample {(code & 0xffff) - (1 if code < 0x10000 else 0)} {what}")
 
     def _to_host(self, t: torch.Tensor) -> "np.ndarray":

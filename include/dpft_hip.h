@@ -606,7 +606,7 @@ int dpft_assign_loss_f32(const float* cost_host, const int32_t* counts_host, int
  * matrices dpft_match_cost_f32 left in HBM: cost (B,N,Mmax), counts (B), match (B,Mmax,2), n_matched (B) all DEVICE memory; the
  * same pairs in the same order as the host function.  A kernel cannot return an error: status (one int32 in device or
  * page-locked host memory, zero before the first call, may be NULL) receives 1 + b for a non-finite entry / 0x10000 + b for an
- * infeasible problem of sample b, and that sample gets no pairs.  With it the training step has no host round trip between the
+ * infeasible problem / 0x20000 + b for counts[b] > Mmax of sample b, and that sample gets no pairs.  With it the training step has no host round trip between the
  * matcher and the criterion (src/dprt/training/loss.py:296-373: scipy on a .cpu() copy per sample). */
 int dpft_lsap_batch_dev_f32(const float* cost, const int32_t* counts, int32_t* match, int32_t* n_matched, int32_t* status,
                             int32_t B, int32_t N, int32_t Mmax, dpft_stream_t stream);

@@ -102,6 +102,9 @@ def test_non_finite_costs_are_reported_through_the_status_word():
     good = cost.copy()
     good[1] = 0
     _check_against_scipy(good, [7, 0, 0, 1], match, nm, "the other samples")
+    cost[1, 5, 2] = 0.0
+    match, nm, st = _device_assign(cost, [7, 3, 9, 1])       # more targets than the packed width: refused, no pairs
+    assert st == 0x20000 + 2 and nm[2] == 0 and (match[2] == -1).all() and nm[0] == 7
     pinned = torch.zeros(1, dtype=torch.int32).pin_memory()
     cost[1, 5, 2] = -np.inf
     _device_assign(cost, counts, status=pinned)

@@ -382,8 +382,12 @@ def test_fpn_data_gradients_land_in_the_launch_plans_buffers_and_no_vendor_glue_
     assert n_copies == 0, f"{n_copies} gradient copies into the plans' static buffers with sinks on"
     _, losses_off, n_copies_off, _ = run(False)
     assert n_copies_off > 0, "switching the sinks off must bring the copies back (the test can fail)"
-    for a, b in zip(losses, losses_off):
-        assert abs(a - b) <= 2e-3 * max(abs(b), 1.0), (losses, losses_off)      # same trajectory (atomics-order noise only)
+    # same trajectory: the only run-to-run difference is the summation order of the decoder's fp32 atomics, 1e-7 after the first
+    # update -- which this small configuration amplifies by ~1e3 per step up to ~2e-3 (tools/determinism_probe.py: two identically
+    # seeded runs differ by 0 / 3e-7 / 1e-4 / 2e-3 / 4e-3 over steps 1-5 at worst).  A sink that delivered a wrong gradient would
+    # show in the step right behind the first update.
+    for k, (a, b) in enumerate(zip(losses, losses_off)):
+        assert abs(a - b) <= (1e-5, 1e-5, 1e-3, 1e-2, 1e-2)[k] * max(abs(b), 1.0), (k, losses, losses_off)
 
     seen = []
 
