@@ -136,3 +136,7 @@ bash /root/repo/tools/step_vendor_rows.sh > $OUT/r05_step_vendor_rows.txt 2>&1
 # (11) the loader rate again with the sample files read from disk (KRadarFolderDataset over a generated folder tree)
 FILES=1 timeout 600 python /root/repo/tools/loader_rate.py > /dev/null 2>&1      # (first run on a fresh box: the tree is written, the workers' imports are cold -- 134 vs 152 samples/s)
 FILES=1 timeout 600 python /root/repo/tools/loader_rate.py > $OUT/r05_loader_rate_files.json 2>> $OUT/r05_loader_rate.err
+# (12) the driver's own command under the kernel trace: python bench.py --steps 20 --warmup 5 (CPU leg off: it is host work)
+cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_benchcmd -- python /root/repo/bench.py --steps 20 --warmup 5 --no-cpu-baseline </dev/null > $OUT/r05_bench_cmd_under_rocprof.json 2> $OUT/r05_bench_cmd.err
+f=$(find /tmp/p_benchcmd -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/r05_bench_cmd_kernel_stats.csv
+cd /root/repo
