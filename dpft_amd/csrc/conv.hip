@@ -1797,8 +1797,10 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);
     if (d->act16) t.splits = 1;
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
-    if (t.x3 && t.splits > 1 && (a.N & 3) == 0 && workspace && sk_fixup_ok(a, t.splits, 1)) {
-        // split kernels with a K split: the last workgroup of a tile runs the whole inference epilogue (in-launch fix-up)
+    static const bool fix_all = getenv("DPFT_BNACT_FIXUP") == nullptr || atoi(getenv("DPFT_BNACT_FIXUP")) != 0;      // A/B switch
+    if ((t.x3 || (fix_all && t.vec && !conv16_matches(d))) && t.splits > 1 && (a.N & 3) == 0 && workspace && sk_fixup_ok(a, t.splits, 1)) {
+        // a K split (the latency-sized problems: batch-1 inference, the radar encoders' maps; the split kernels): the last
+        // workgroup of a tile runs the whole inference epilogue (in-launch fix-up) -- no reduction launch, no elementwise pass
         ProfScope prof(0, d, st);
         a.x = x; a.w = w; a.y = y;
         a.partial = ws_slabs(workspace);
