@@ -1310,6 +1310,17 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
             const int64_t nwg = (int64_t)cdiv(M, 128) * cdiv(N, 128);
             int sp = (int)std::max<int64_t>(1, std::min<int64_t>(8, kNumCU / nwg));      // at most one workgroup per CU: one round
             while (sp > 1 && ksteps / sp < 4) --sp;
+            // Few row tiles (batch-1 inference: 15 at layer 3; layer 4 in training): a deep K split of 128 x 128 tiles ends in a
+            // fix-up over 4-8 slabs of 64 KB read by ONE workgroup per tile -- 128 x 64 tiles reach the same workgroup count with
+            // half the split and quarter-size fix-ups: batch-1 forward 3.50 -> 3.10-3.24 ms, training step unchanged
+            // (tools/infer_ab.sh; DPFT_X3_NARROW=0 switches it off, =4 moves the threshold)
+            static const int narrow = getenv("DPFT_X3_NARROW") ? atoi(getenv("DPFT_X3_NARROW")) : 2;
+            if (narrow && sp > narrow) {
+                t.bn = 64;
+                const int64_t nwg64 = (int64_t)cdiv(M, 128) * cdiv(N, 64);
+                sp = (int)std::max<int64_t>(1, std::min<int64_t>(8, kNumCU / nwg64));
+                while (sp > 1 && ksteps / sp < 4) --sp;
+            }
             t.splits = sp;
             // (measured, tools/x3_unsplit.sh: 128 x 64 tiles without the K split -- which would keep the data gradients' epilogue
             // operand prefetch -- lose: layer-3 forward 82 vs 70 us per call, data gradient 70 vs 68.5)
