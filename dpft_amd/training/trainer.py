@@ -410,6 +410,9 @@ class DataParallelTrainer:
         BackboneBase / FPN) is not part of the pickle, so the live model keeps training afterwards."""
         if self.device.type == "cuda":
             torch.cuda.synchronize(self.device)
+            chk = getattr(self.loss_fn, "check_assignment_status", None)
+            if chk is not None:
+                chk(sync=False)      # (a step with a non-finite cost matrix must not end up in a checkpoint unnoticed)
         if self.rank == 0:
             tmp = path + ".tmp"
             torch.save(self.model, tmp)
