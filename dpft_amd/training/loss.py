@@ -408,7 +408,7 @@ class Loss(nn.modules.loss._Loss):
                                               (losses5, total))
             self.__dict__["_last"] = (cls, center, size, angle, gt_box, gt_onehot, match_t, counts_m, weights5, 0.75, sel, total)
             return total, {k: losses5[self._TERMS.index(k)] for k in self.loss_weights}
-        host = self._to_host(cost)                                                            # the one sync of the step
+        host = self._to_host(cost)                                         # the host path's sync (assign_on_device has none)
         if use_c:
             # The whole host window in ONE C call (dpft_assign_loss_f32, csrc/cabi.cpp): the batch's assignments (scipy's algorithm
             # restated in C, same pairs in the same order -- tests/test_host.py), their upload from the pinned buffer (rewritten only
