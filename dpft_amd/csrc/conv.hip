@@ -1354,6 +1354,10 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
     if (shortk_rule && (int64_t)ksteps * BKV <= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 768) {
         eff[0] = 0.88; eff[1] = 1.0; eff[2] = 0.85;
     }
+    if (const char* e = getenv("DPFT_TILE_EFF")) {      // tuning aid: "e128x128,e128x64,e64x64[,max row tiles it applies to]"
+        double a0, a1, a2; int rows = 1 << 30;
+        if (sscanf(e, "%lf,%lf,%lf,%d", &a0, &a1, &a2, &rows) >= 3 && cdiv(M, 128) <= rows) { eff[0] = a0; eff[1] = a1; eff[2] = a2; }
+    }
     double best = -1;
     t.bm = 64; t.bn = 64;
     for (int i = 0; i < 3; ++i) {

@@ -1,11 +1,6 @@
 #!/bin/bash
 {
-for r in 1 2 3; do for v in 0 4 2; do for b in 1 4; do
-  echo "narrow=$v batch=$b $(DPFT_X3_NARROW=$v BATCH=$b REPS=200 python tools/infer_only.py 2>/dev/null | tail -1)"
-done; done; done
-for v in 0 4 2; do
-  echo "== train narrow=$v"; DPFT_X3_NARROW=$v timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --latency-reps 5 2>/dev/null | grep "^{" | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print({k:d.get(k) for k in ('value','ms_per_step','step_ms_median')})"
-done
+for r in 1 2; do for v in "" "1,1,0.8,16" "1,1.1,0.8,16" "1,0.92,0.6,16" "0.8,1,0.9,16" "1,0.92,1.0,16"; do
+  echo "eff=[$v] batch=1 $(DPFT_TILE_EFF=$v BATCH=1 REPS=300 python tools/infer_only.py 2>/dev/null | tail -1)"
+done; done
 } > gpurun_out/infer_ab.txt 2>&1
