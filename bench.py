@@ -57,6 +57,9 @@ def parse():
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = all host cores (BASELINE.md section 3)")
     ap.add_argument("--cpu-timeout", type=int, default=120, help="wall-clock budget of the CPU baseline leg in s")
     ap.add_argument("--cpu-baseline-only", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary legs (BASELINE.json configs[1] radar-BEV batch 4 and configs[4] bf16 batch 8)")
+    ap.add_argument("--leg", action="store_true", help=argparse.SUPPRESS)      # child mode of secondary_legs(): compact line
     return ap.parse_args()
 
 
@@ -191,6 +194,40 @@ def cpu_baseline_subprocess(args):
                 "sample": f"timed out after {args.cpu_timeout}s"}
 
 
+SECONDARY_LEGS = {
+    # BASELINE.json configs[1]: radar-only BEV backbone, batch 4, 1 GPU  |  configs[4]: bf16 mixed precision, its per-GPU share (batch 8)
+    "radar_bev_b4": ["--config", "kradar_radar_bev", "--batch", "4"],
+    "bf16_b8": ["--config", "kradar", "--dtype", "bf16", "--batch", "8"],
+}
+
+
+def secondary_legs(args):
+    """Driver-clocked numbers for the configurations the headline line is not quoted on: each leg is this
+    script again in a child process (`--leg`: the same trainer step, 5 warm-up + 12 timed steps, its own serialized-step
+    conv roofline, 30 eval forwards), run AFTER and OUTSIDE the headline's timed region while this process idles."""
+    import subprocess
+    out = {}
+    for name, flags in SECONDARY_LEGS.items():
+        cmd = [sys.executable, os.path.abspath(__file__), "--leg", "--steps", "12", "--warmup", "5", "--latency-reps", "30",
+               "--no-cpu-baseline"] + flags
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            leg = None
+            for ln in reversed(r.stdout.strip().splitlines()):
+                if ln.startswith("{"):
+                    leg = json.loads(ln)
+                    break
+            out[name] = leg if leg is not None else {"error": (r.stderr or "no output")[-300:]}
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "timed out after 240 s"}
+        except Exception as e:      # a failed leg must not take the headline line with it
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        out[name]["wall_s"] = round(time.perf_counter() - t0, 1)
+        out[name]["cmd"] = "python bench.py " + " ".join(cmd[2:])
+    return out
+
+
 def decoder_runner(m, data):
     """-> (run, feats): ``run()`` = exactly one dpft_decoder_forward_f32 call (the fused inference decoder of one
     IMPFusion.forward) on the encoded pyramids of ``data``.  Also used by tools/decoder_only.py for the PMC passes."""
@@ -321,17 +358,23 @@ def main():
     if rank == 0:
         tot_f, tot_t = 0.0, 0.0
         shapes = {}
-        for kind, flops, dt, shape in recs:
+        fam_f, fam_t, fam_n = {}, {}, {}      # per kernel family, as tagged by the library's dispatch code at the launch
+        shape_fam = {}
+        for kind, flops, dt, shape, fam in recs:
             sh = shapes.setdefault((kind,) + shape, [0.0, 0.0, 0])
             sh[0] += flops; sh[1] += dt; sh[2] += 1
+            shape_fam[(kind,) + shape] = fam
+            fam_f[fam] = fam_f.get(fam, 0.0) + flops
+            fam_t[fam] = fam_t.get(fam, 0.0) + dt
+            fam_n[fam] = fam_n.get(fam, 0) + 1
             k = per_kind.setdefault(kind, [0.0, 0.0, 0])
             k[0] += flops; k[1] += dt; k[2] += 1
             tot_f += flops; tot_t += dt
         if os.environ.get("DPFT_CONV_TABLE"):
             with open(os.environ["DPFT_CONV_TABLE"], "w") as f:
-                f.write("kind B H W C K k s calls total_us TFLOPs\n")
+                f.write("kind B H W C K k s calls total_us TFLOPs family\n")
                 for key, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
-                    f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f}\n")
+                    f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f} {shape_fam[key]}\n")
         n_launch = sum(k[2] for k in per_kind.values())
         # algorithmic HBM bytes of the same calls: every conv call (fwd / dgrad / wgrad alike) touches its input map, its
         # output map and its weights once -- x + y + w fp32 elements (shape key = kind, B, H, W, C, K, k, s; H x W = the
@@ -352,7 +395,7 @@ def main():
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
         prof_dir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-        for name in ("r05_conv_traffic_pmc.json", "r04_conv_traffic_pmc.json", "r03_conv_traffic_pmc.json"):
+        for name in ("r06_conv_traffic_pmc.json", "r05_conv_traffic_pmc.json", "r04_conv_traffic_pmc.json", "r03_conv_traffic_pmc.json"):
             if os.path.exists(os.path.join(prof_dir, name)):
                 with open(os.path.join(prof_dir, name)) as f:
                     traffic = json.load(f).get("traffic_bytes_per_launch")
@@ -362,11 +405,13 @@ def main():
         # path (global loads -> LDS -> fragments, two barriers per 64-deep K-step), not by the matrix pipe
         peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_F32_MFMA_TFLOPS
         split = args.dtype == "f32" and ops.conv_get_split()
-        # share of the conv flops that ran as split products: forward / stride-1 data gradient of multi-tap filters, >= 2 GFLOP,
-        # C % 64 == 0 (conv.hip: choose_tile) -- shape key = kind, B, H, W, C, K, k, s
-        split_f = sum(v[0] for key, v in shapes.items()
-                      if key[0] in ("fwd", "dgrad") and key[6] > 1 and key[4] % 64 == 0 and (key[0] == "fwd" or key[7] == 1)
-                      and v[0] / max(v[2], 1) >= 2e9) if split else 0.0
+        # share of the conv flops that ran as split products: what the library's dispatch tagged 'x3' at the launch (forward,
+        # data gradient AND weight gradient kernels of conv_x3.hip) -- not a shape predicate
+        split_f = fam_f.get("x3", 0.0)
+        # pipe-correct pricing: every launch against the peak of the pipe that ran it -- fp32 MFMA 157.3 TF,
+        # six-product split 2500 / 6 = 416.7 TF, bf16 operands 2500 TF, vector-ALU kernels 157.3 TF (fp32 FMA rate)
+        fam_peak = {"f32": PEAK_F32_MFMA_TFLOPS, "x3": PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16": PEAK_BF16_MFMA_TFLOPS, "vector": PEAK_F32_MFMA_TFLOPS}
+        ideal_s = sum(fam_f[k] / (fam_peak[k] * 1e12) for k in fam_f)
         family = {"f32": "fp32 MFMA (v_mfma_f32_32x32x2_f32)" + ("; multi-tap filters >= 2 GFLOP: 3 x bf16 split, six v_mfma_f32_32x32x16_bf16 "
                          "term products per fp32 product, fp32 accumulation (conv_x3.hip)" if split else ""), "bf16": "bf16 MFMA (v_mfma_f32_32x32x16_bf16, fp32 accumulation)",
                   "f32x3": "3 x bf16 split products on the bf16 MFMA, fp32 accumulation"}[args.dtype]
@@ -379,6 +424,15 @@ def main():
         # reduction kernels and the ~4.5 us an empty event bracket costs, i.e. what round 1 reported as `frac`.
         ovh = float(ops.lib.dpft_profile_overhead_ms()) * 1e-3
         raw_t = tot_t + ovh * n_launch
+        # committed rocprofv3 summaries of this step (newest round first): the serialized one the line must agree with, and the
+        # plain (concurrent-stream) one that gives the conv kernels' durations inside the real step
+        rnd = next((r for r in ("r06", "r05") if os.path.exists(os.path.join(prof_dir, r + "_serialized_step_kernel_stats.csv"))), "r05")
+        in_step = {}
+        try:
+            with open(os.path.join(prof_dir, rnd + "_roofline_from_rocprof_plain_steps.json")) as f:
+                in_step = json.load(f)
+        except Exception:
+            in_step = {}
         roof = {"bound": "mfma", "achieved": tot_f / raw_t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": tot_f / raw_t / 1e12 / peak,
                 "traffic": traffic if args.dtype == "f32" else None, "traffic_is": "HBM bytes per conv launch", "traffic_source": traffic_src,
@@ -393,18 +447,30 @@ def main():
                 "timing": "HIP events around every conv call of one serialized step, on the launch stream (raw bracket time)",
                 "frac_main_kernels_only": tot_f / tot_t / 1e12 / peak,
                 "event_bracket_overhead_us": 1e6 * ovh,
-                "rocprof_summary": ("profiles/r05_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py -> "
-                                    "profiles/r05_roofline_from_rocprof.json)" if args.dtype == "f32" and B == 4 else None),
+                "rocprof_summary": (f"profiles/{rnd}_serialized_step_kernel_stats.csv (tools/roofline_from_rocprof.py -> "
+                                    f"profiles/{rnd}_roofline_from_rocprof.json)" if args.dtype == "f32" and B == 4 else None),
+                "frac_in_step": in_step.get("frac") if args.dtype == "f32" and B == 4 else None,
+                "frac_in_step_source": (f"profiles/{rnd}_roofline_from_rocprof_plain_steps.json <- {rnd}_train_step_kernel_stats.csv (rocprofv3 "
+                                        "--kernel-trace --stats over plain, un-serialized steps; a constant of the committed profile, "
+                                        "not of this run)") if in_step else None,
                 "precision": ("fp32 (3 x bf16 split, 6 products) on the multi-tap conv GEMMs >= 2 GFLOP, fp32 MFMA elsewhere: fp32 tensors "
                               "in and out, error vs fp64 below the fp32 MFMA path's on every conv of the step "
                               "(tests/test_gpu_conv_table.py)" if split else
                               {"f32": "fp32 MFMA", "bf16": "bf16 operands, fp32 accumulation", "f32x3": "3 x bf16 split"}[args.dtype]),
                 "split_share_of_conv_flops": (split_f / tot_f) if tot_f > 0 else None,
+                "split_share_is": "flops of the launches the library's dispatch code tagged as conv_x3.hip kernels (igemm_x3 forward / data "
+                                  "gradient AND wgrad_x3) / all conv flops (dpft_profile_get_family; not a shape predicate)",
                 "split_peak_tflops": PEAK_BF16_MFMA_TFLOPS / 6.0,
-                "frac_of_split_peak": tot_f / raw_t / 1e12 / (PEAK_BF16_MFMA_TFLOPS / 6.0),
+                "frac_blended": ideal_s / raw_t if raw_t > 0 else None,
+                "frac_blended_is": "sum_i(flops_i / peak_i) / conv time of the serialized step, peak_i of the pipe that ran launch i: "
+                                   "fp32 MFMA 157.3 TF | six-product bf16 split 416.7 TF | bf16 operands 2500 TF | vector-ALU kernels 157.3 TF",
+                "by_family": {k: {"gflop_per_step": fam_f[k] / 1e9, "ms_per_step": 1e3 * (fam_t[k] + ovh * fam_n[k]), "launches": fam_n[k],
+                                  "tflops": fam_f[k] / (fam_t[k] + ovh * fam_n[k]) / 1e12, "peak_tflops": fam_peak[k],
+                                  "frac_of_own_peak": fam_f[k] / (fam_t[k] + ovh * fam_n[k]) / 1e12 / fam_peak[k]} for k in sorted(fam_f)},
                 "frac_note": "frac prices ALL conv flops of the step against the fp32 MFMA peak (157.3 TF), whichever pipe ran them; "
-                             "frac_of_split_peak prices the same flops against 2500 / 6 = 416.7 TF, what six bf16 term products per "
-                             "fp32 product could deliver",
+                             "frac_blended prices every launch against its own pipe (by_family); frac_in_step is the same ratio as "
+                             "frac with the conv kernels' durations INSIDE the real, un-serialized step (they share CUs with the other "
+                             "streams there), from the committed kernel trace",
                 "peak_note": "157.3 TF = 2.4 GHz nominal; under sustained fp32 MFMA load the chip clocks ~2.16 GHz "
                              "(64-cycle MFMA measured at 71 nominal cycles, tools/probes/mfma_valu_overlap.hip), i.e. ~142 TF "
                              "is what the matrix pipe delivers; frac is priced against the nominal peak",
@@ -412,6 +478,17 @@ def main():
                 "conv_frac_camera_only": (cam_f / cam_t / 1e12 / peak) if cam_t > 0 else None,
                 "camera_encoder_share_of_conv_time": (cam_t / tot_t) if tot_t > 0 else None}
 
+    if args.leg:      # child of secondary_legs(): one compact line, nothing else
+        fwd_mean, fwd_std = trainer.inference_time(data, warmup=5, reps=args.latency_reps)
+        if rank == 0:
+            print(json.dumps({
+                "samples_per_s": value, "ms": ms_per_step, "step_ms_median": step_ms[len(step_ms) // 2], "steps": args.steps,
+                "batch": B, "dtype": args.dtype, "config": args.config, "fwd_ms_per_frame": fwd_mean / B,
+                "frac": roof["frac"] if roof else None, "peak_tflops": roof["peak"] if roof else None,
+                "frac_blended": roof["frac_blended"] if roof else None,
+                "conv_ms_per_step": roof["conv_ms_per_step"] if roof else None,
+                "conv_gflop_per_step": roof["algorithmic_gflop_per_step"] if roof else None, "loss": float(loss)}))
+        return
     # ---- the step's host window: GPU time between the matcher's cost kernel and the start of the decoder's backward graph ------
     # (the one place where the GPU waits for the host: read-back of the cost matrices, assignments, upload, criterion + gradient
     # launches, graph launch).  Events recorded by wrapping the two call sites; median over 12 extra steps after the timed region.
@@ -548,6 +625,11 @@ def main():
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline_subprocess(args)
+    secondary = None
+    # (--no-cpu-baseline is what the A/B scripts under tools/ pass for a quick line: no child processes at all then)
+    if rank == 0 and world == 1 and not collective and not args.no_secondary and not args.no_cpu_baseline and args.config == "kradar" and args.dtype == "f32":
+        torch.cuda.synchronize()
+        secondary = secondary_legs(args)
 
     if rank == 0:
         line = {
@@ -605,6 +687,11 @@ def main():
             "loss_window_assignments": "device" if getattr(trainer.loss_fn, "assign_on_device", False)
                                        and os.environ.get("DPFT_LSAP_DEV", "1") != "0" else "host",
             "roofline": roof, "roofline_decoder": dec, "roofline_decoder_train": dec_train, "cpu_baseline": cpu,
+            "secondary": secondary,
+            "secondary_is": "BASELINE.json configs[1] (kradar_radar_bev.json, batch 4) and configs[4]'s per-GPU share (kradar.json, bf16 "
+                            "mixed precision, batch 8): this script as a child process per leg, after and outside the headline's timed "
+                            "region -- 5 warm-up + 12 timed steps, barrier + device sync on both sides; frac = that leg's conv family "
+                            "against its own peak (fp32 MFMA 157.3 TF | bf16 2500 TF), serialized-step event brackets",
         }
         print(json.dumps(line))
     if collective:

@@ -105,6 +105,22 @@ bool profiling_active();      // conv.hip: true between dpft_profile_start / dpf
 int zero_fill(void* ptr, size_t bytes, dpft_stream_t stream);
 int bias_grad_ws(const float* dy, float* db, int64_t M, int32_t K, void* workspace, dpft_stream_t stream);
 
+// Dynamic-LDS cap of a kernel above 64 KiB (hipFuncAttributeMaxDynamicSharedMemorySize): the attribute is PER DEVICE, so the
+// "largest size granted so far" cache is keyed by the current device -- one process driving several GPUs must not skip the
+// call on the second one.  One LdsGrant per kernel instantiation (a function-local static at the launch site).
+struct LdsGrant {
+    size_t granted[16] = {};
+};
+inline bool lds_grant(LdsGrant& g, const void* fn, size_t lds) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    size_t& have = g.granted[dev & 15];
+    if (lds <= have) return true;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return false;
+    have = lds;
+    return true;
+}
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

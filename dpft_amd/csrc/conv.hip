@@ -1221,7 +1221,14 @@ struct ProfRec {
     double flops;
     hipEvent_t e0, e1;
     int shape[7];        // B,H,W,C,K,k,stride
+    int family;          // which pipe the launch ran on (kFam*), written by the dispatch code, not derived from the shape
 };
+// kernel family of the conv launch being dispatched (bench.py prices each against ITS pipe's peak):
+//   0 fp32 MFMA (v_mfma_f32_32x32x2_f32: igemm_pipe / igemm_vec / wgrad_pipe / wgrad_vec), 1 three-term bf16 split, six
+//   v_mfma_f32_32x32x16_bf16 per fp32 product (conv_x3.hip), 2 bf16 operands on the bf16 MFMA (mixed precision),
+//   3 no matrix core: thin-channel / 16-channel / generic vector-ALU kernels
+enum { kFamF32 = 0, kFamX3 = 1, kFamBf16 = 2, kFamVector = 3 };
+static int g_prof_family = kFamVector;
 static bool g_prof_on = false;
 static bool g_serialize = false;                   // dpft_profile_serialize: one stream, no event brackets
 bool profiling_active() { return g_prof_on || g_serialize; }   // resnet_plan: keep everything on one stream while timing
@@ -1240,9 +1247,11 @@ struct ProfScope {
         (void)hipEventCreate(&r.e0);
         (void)hipEventCreate(&r.e1);
         (void)hipEventRecord(r.e0, st);
+        g_prof_family = kFamVector;      // the early-return paths (conv16, thin-channel) launch no MFMA kernel
     }
     ~ProfScope() {
         if (!on) return;
+        r.family = g_prof_family;
         (void)hipEventRecord(r.e1, st);
         g_prof.push_back(r);
     }
@@ -1415,11 +1424,8 @@ static void fill_igemm(IgemmArgs& a, const dpft_conv_desc* d, bool dgrad) {
 // launch with dynamic LDS; raises the per-kernel dynamic-LDS cap once (tiles above 64 KiB)
 template <typename K, typename A>
 static void launch_lds(K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t st, const A& args) {
-    static size_t configured = 0;       // one static per kernel instantiation: the largest size allowed so far
-    if (lds > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
-    }
+    static LdsGrant grant;      // one per kernel instantiation: the largest size allowed so far, per device
+    (void)lds_grant(grant, reinterpret_cast<const void*>(kernel), lds);
     hipLaunchKernelGGL(kernel, grid, block, lds, st, args);
 }
 
@@ -1442,6 +1448,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     const int nwg = a.mtiles * a.ntiles * a.splits;
     DPFT_REQUIRE(!a.sk_ticket || a.mtiles * a.ntiles <= kWsTickets, "conv: %d output tiles exceed the split-K ticket header", a.mtiles * a.ntiles);
     dim3 grid(nwg), block(256);
+    g_prof_family = !t.vec ? kFamVector : (g_conv_bf16 == 1 ? kFamBf16 : kFamF32);      // (the x3 branches below override)
     if (nonlin) {
         if constexpr (DGRAD) {
             constexpr size_t lds = (size_t)(64 + 64) * LDK * sizeof(float);
@@ -1452,6 +1459,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     // bf16 activations AND bf16 weights (act16 = 2): both operands go to the matrix cores untouched -- the pipelined kernel
     // with 2-byte elements, everything by LDS-DMA
     if (t.vec && a.w16 && a.x16 && !pro && !nonlin) {
+        g_prof_family = kFamBf16;
         auto go16 = [&](auto kernel, int pbk, size_t lds) {
             a.ksteps = a.ksteps * BKV / pbk;      // (a parity class of a strided data gradient covers a subset of the taps)
             a.ksteps_per_split = cdiv(a.ksteps, a.splits);
@@ -1476,18 +1484,23 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     }
     // operands given as three bf16 planes (dpft_conv_desc::a_planes / w_planes): the copy-only split kernel of conv_x3.hip
     if (t.vec && a.x3 && a.w3 && !pro && !a.x16 && !a.y16 && !a.w16 &&
-        ((t.bm == 128 && (t.bn == 128 || t.bn == 64)) || (t.bm == 64 && t.bn == 64)))
+        ((t.bm == 128 && (t.bn == 128 || t.bn == 64)) || (t.bm == 64 && t.bn == 64))) {
+        g_prof_family = kFamX3;
         return launch_igemm_x3(a, t.bm, t.bn, DGRAD, false, st);
+    }
     a.x3 = a.w3 = nullptr;
     // fp32 results from the bf16 matrix cores (compute mode 2, conv_x3.hip): three-term split of both operands, six MFMAs
     static const bool x3_all = getenv("DPFT_X3_ALL") != nullptr && atoi(getenv("DPFT_X3_ALL")) != 0;      // tuning aid: 1x1 convs too
     if (t.vec && (t.x3 || (g_conv_bf16 == 2 && (x3_all || getenv("DPFT_FORCE_TILE")))) && g_conv_bf16 != 1 && !a.x16 && !a.y16 && !a.w16 && (!pro || a.pro_relu) &&
-        ((t.bm == 128 && (t.bn == 128 || t.bn == 64)) || (t.bm == 64 && t.bn == 64)))
+        ((t.bm == 128 && (t.bn == 128 || t.bn == 64)) || (t.bm == 64 && t.bn == 64))) {
+        g_prof_family = kFamX3;
         return launch_igemm_x3(a, t.bm, t.bn, DGRAD, pro, st);
+    }
     // fp32, linear taps: the software-pipelined kernel (conv_pipe.h) -- LDS-DMA operands, one barrier per K-step.
     // DPFT_PIPE=0 keeps igemm_vec_kernel (A/B measurements).
     static const int pipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;      // bit 0: igemm, bit 1: wgrad
     if (t.vec && g_conv_bf16 != 1 && (pipe_env & 1) && !a.x16 && !a.y16 && (!pro || a.pro_relu)) {
+        g_prof_family = kFamF32;
         static const int shortk_env = getenv("DPFT_SHORTK") ? atoi(getenv("DPFT_SHORTK")) : 0;      // tuning aid
         const bool short_k = shortk_env > 0 && a.Ktot <= shortk_env;
         auto go = [&](auto kernel, int pbk, size_t lds) {
@@ -2104,6 +2117,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         a.psteps = cdiv(a.M, pk);
         a.psteps_per_split = cdiv(a.psteps, splits);
         const size_t lds = (size_t)2 * pk * (bmn + bnc) * 2 + (size_t)a.psteps_per_split * pk * 4;
+        g_prof_family = kFamBf16;
         if (bmn == 128) launch_lds(wgrad_pipe16_kernel<128, 128, 2, 2, 64>, grid, block, lds, st, a);
         else launch_lds(wgrad_pipe16_kernel<64, 64, 2, 2, 128>, grid, block, lds, st, a);
     } else if (vec && (wpipe_env & 2) && g_conv_bf16 != 1 && !d->act16 && (!pro || pro_relu) && (bmn == 128 || bmn == 64)) {
@@ -2112,10 +2126,12 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
         a.psteps = cdiv(a.M, pk);
         a.psteps_per_split = cdiv(a.psteps, splits);
         const size_t tbl = (size_t)a.psteps_per_split * pk * 4;      // per-workgroup input-pixel offset table
+        g_prof_family = kFamF32;
         static const bool wx3 = getenv("DPFT_WGRAD_X3") == nullptr || atoi(getenv("DPFT_WGRAD_X3")) != 0;      // A/B switch
         static const bool wx3_1x1 = getenv("DPFT_WGRAD_X3_1X1") == nullptr || atoi(getenv("DPFT_WGRAD_X3_1X1")) != 0;      // A/B switch
         if (bmn == 128 && wx3 && split_on() && (a.taps > 1 || wx3_1x1) && 2.0 * a.M * (double)d->K * a.J >= 2e9) {
             // the big multi-tap weight gradients on the split kernels (conv_x3.hip), like their forward / data gradient
+            g_prof_family = kFamX3;
             rc = launch_wgrad_x3(a, pro, grid, st);
             if (rc) return rc;
         } else if (bmn == 128) {
@@ -2128,6 +2144,7 @@ extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* 
             else launch_lds(wgrad_pipe_kernel<64, 64, 2, 2, 64, false>, grid, block, lds, st, a);
         }
     } else if (vec) {
+        g_prof_family = g_conv_bf16 == 1 && (bmn == 128 || bmn == 64) ? kFamBf16 : kFamF32;
 #define LAUNCH_WG(BM_, BN_, WGM_, WGN_)                                                           \
     do {                                                                                          \
         if (pro) hipLaunchKernelGGL((wgrad_vec_kernel<BM_, BN_, WGM_, WGN_, true>), grid, block, 0, st, a);  \
@@ -2299,6 +2316,12 @@ extern "C" int dpft_profile_serialize(int32_t on) {
 extern "C" int32_t dpft_profile_stop(void) {
     g_prof_on = false;
     return (int32_t)g_prof.size();
+}
+
+extern "C" int dpft_profile_get_family(int32_t i, int32_t* family) {
+    DPFT_REQUIRE(i >= 0 && i < (int32_t)g_prof.size() && family, "profile_get_family: bad index");
+    *family = g_prof[i].family;
+    return DPFT_OK;
 }
 
 extern "C" int dpft_profile_get(int32_t i, int32_t* kind, double* flops, float* ms, int32_t* shape7) {

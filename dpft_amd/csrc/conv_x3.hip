@@ -1117,11 +1117,8 @@ int launch_wgrad_x3(const WgradArgs& a, bool pro, dim3 grid, hipStream_t st) {
     const size_t lds = (size_t)2 * 3 * 32 * (128 + 128) * 2 + (size_t)a.psteps_per_split * 32 * 4;
     const bool padded = a.kh * a.kw > 1 || a.pad > 0;
     auto go = [&](auto kernel) {
-        static size_t configured = 0;
-        if (lds > configured) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            configured = lds;
-        }
+        static LdsGrant grant;
+        (void)lds_grant(grant, reinterpret_cast<const void*>(kernel), lds);
         hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, a);
     };
     if (pro && padded) go(wgrad_x3_kernel<2>);
@@ -1132,11 +1129,8 @@ int launch_wgrad_x3(const WgradArgs& a, bool pro, dim3 grid, hipStream_t st) {
 
 template <typename K>
 static void launch_x3(K kernel, dim3 grid, size_t lds, hipStream_t st, const IgemmArgs& args) {
-    static size_t configured = 0;       // one static per kernel instantiation
-    if (lds > configured) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        configured = lds;
-    }
+    static LdsGrant grant;      // one per kernel instantiation
+    (void)lds_grant(grant, reinterpret_cast<const void*>(kernel), lds);
     hipLaunchKernelGGL(kernel, grid, dim3(256), lds, st, args);
 }
 

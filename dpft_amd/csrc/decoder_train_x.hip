@@ -713,12 +713,8 @@ extern "C" int dpft_xattn_ffn_train_bwd_f32(const dpft_pyramid* pyr, const dpft_
     xs.scratch = scratch; xs.B = B; xs.Q = Q; xs.qchunk = cdiv(Q, nchunk); xs.exp = exp;
     nchunk = cdiv(Q, xs.qchunk);
     const size_t lds = (size_t)max_px * DC * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(xf_scatter_small_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, XC_MAX_PIXELS * DC * (int)sizeof(float));
-        attr_set = true;
-    }
+    static LdsGrant grant;      // (per device)
+    (void)lds_grant(grant, reinterpret_cast<const void*>(xf_scatter_small_kernel), (size_t)XC_MAX_PIXELS * DC * sizeof(float));
     hipLaunchKernelGGL(xf_scatter_small_kernel, dim3(nchunk, n_maps, B), dim3(512), lds, (hipStream_t)stream, xs);
     return check_launch("xattn_ffn_train_bwd (small-map scatter)");
 }

@@ -200,14 +200,10 @@ extern "C" int dpft_lsap_batch_dev_f32(const float* cost, const int32_t* counts,
     a.cost_in_lds = work + mat <= 150 * 1024;
     const size_t lds = work + (a.cost_in_lds ? mat : 0);
     if (lds > 64 * 1024) {
-        static size_t granted = 0;
-        if (lds > granted) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(dpft::lsap_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds) != hipSuccess) {
-                dpft::set_error("lsap_batch_dev: cannot reserve %zu bytes of LDS", lds);
-                return DPFT_ERR_LAUNCH;
-            }
-            granted = lds;
+        static dpft::LdsGrant grant;
+        if (!dpft::lds_grant(grant, reinterpret_cast<const void*>(dpft::lsap_batch_kernel), lds)) {
+            dpft::set_error("lsap_batch_dev: cannot reserve %zu bytes of LDS", lds);
+            return DPFT_ERR_LAUNCH;
         }
     }
     hipLaunchKernelGGL(dpft::lsap_batch_kernel, dim3(B), dim3(64), lds, (hipStream_t)stream, a);

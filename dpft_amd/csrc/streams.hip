@@ -8,6 +8,8 @@
 // candidate streams and keeps one per hardware queue other than the caller's, found by observation: a spin kernel on
 // stream A, an event on stream B -- the event completing while A still spins means different queues.
 #include <chrono>
+#include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -65,9 +67,22 @@ extern "C" int32_t dpft_stream_set(dpft_stream_t main_stream, int32_t n, dpft_st
     // i.e. the one a stream destroyed a moment ago has just left
     std::vector<hipStream_t> chosen, rejected;
     const hipStream_t mainq = (hipStream_t)main_stream;
+    // Priority of the side streams (DPFT_STREAM_PRIORITY=low|normal|high, default normal): everything on them -- the radar
+    // encoders, the camera's weight gradients -- is off the step's critical chain (the camera encoder on the caller's stream),
+    // so "low" lets the dispatcher hand freed CUs to the chain's kernels first.
+    int prio = 0;
+    bool with_prio = false;
+    if (const char* e = getenv("DPFT_STREAM_PRIORITY")) {
+        int least = 0, greatest = 0;
+        if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest) {
+            if (!strcmp(e, "low")) { prio = least; with_prio = true; }
+            else if (!strcmp(e, "high")) { prio = greatest; with_prio = true; }
+        }
+    }
     for (int attempt = 0; attempt < 24 && (int)chosen.size() < n; ++attempt) {
         hipStream_t s;
-        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) break;
+        if ((with_prio ? hipStreamCreateWithPriority(&s, hipStreamNonBlocking, prio)
+                       : hipStreamCreateWithFlags(&s, hipStreamNonBlocking)) != hipSuccess) break;
         (void)hipEventRecord(eb, s);      // first use of a stream creates its hardware queue (milliseconds): not inside a probe
         (void)hipStreamSynchronize(s);
         bool fresh = runs_beside(mainq, s, eb, flag);

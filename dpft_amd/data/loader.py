@@ -214,6 +214,11 @@ class PrefetchLoader:
     def __len__(self):
         return len(self.source)
 
+    @property
+    def sampler(self):
+        """The wrapped DataLoader's sampler (DataParallelEvaluator reads ``sampler.start`` of an evaluation block)."""
+        return getattr(self.source, "sampler", None)
+
     def _producer(self, q: "queue.Queue", stop: threading.Event):
         try:
             up = torch.cuda.Stream(self.device) if self.device.type == "cuda" else None
@@ -316,3 +321,18 @@ def load_listed(dataset: Dataset, config: Dict[str, Any], device="cpu", rank: in
     dl = DataLoader(dataset, batch_size=config["train"]["batch_size"], sampler=sampler, num_workers=workers,
                     collate_fn=slots if slots is not None else listed_collating, drop_last=True, persistent_workers=False)
     return PrefetchLoader(dl, device, preprocessor, slots=slots), sampler
+
+
+
+def load_listed_eval(dataset: Dataset, config: Dict[str, Any], device="cpu", rank: int = 0, world: int = 1,
+                     preprocessor=None) -> Tuple[PrefetchLoader, BlockShardedSampler]:
+    """``load_listed`` for EVALUATION over several ranks: rank r reads the contiguous block of the split a
+    ``BlockShardedSampler`` gives it, in order, nothing shuffled, nothing dropped (``drop_last=False``) -- every sample is
+    scored and exported exactly once and keeps the file index it has in a one-process run.  The returned loader exposes
+    ``.sampler`` (``.start`` = the block's first global index, which ``DataParallelEvaluator.evaluate_one_epoch`` numbers the
+    export files from)."""
+    sampler = BlockShardedSampler(len(dataset), rank, world)
+    workers = config.get("computing", {}).get("workers", 0)
+    dl = DataLoader(dataset, batch_size=config["train"]["batch_size"], sampler=sampler, num_workers=workers,
+                    collate_fn=listed_collating, drop_last=False, persistent_workers=False)
+    return PrefetchLoader(dl, device, preprocessor), sampler

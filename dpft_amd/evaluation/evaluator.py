@@ -25,9 +25,14 @@ from dpft_amd.evaluation.exporters import build as build_exporter
 from dpft_amd.evaluation.metric import build_metric
 
 
+APPENDED_LISTS = ("val.txt",)      # the split lists the exporter appends one line per sample to (exporters: kitti)
+
+
 def merge_rank_exports(dst: str, world: int) -> None:
-    """``<dst>/_rank<r>/exports/...`` of ranks 0 .. world-1 -> ``<dst>/exports/...``.  Files that exist in several rank trees are
-    the appended lists (``val.txt``): concatenated in rank order; everything else is moved."""
+    """``<dst>/_rank<r>/exports/...`` of ranks 0 .. world-1 -> ``<dst>/exports/...``.  Only the appended split lists
+    (``APPENDED_LISTS``) may exist in several rank trees: they are concatenated in rank order.  Any OTHER name collision
+    means two ranks numbered their per-sample files from the same index (a missing ``shard_start``): that raises instead of
+    silently gluing two samples' predictions into one file."""
     for r in range(world):
         root = osp.join(dst, f"_rank{r}")
         if not osp.isdir(root):
@@ -39,6 +44,9 @@ def merge_rank_exports(dst: str, world: int) -> None:
             for f in sorted(files):
                 src, out = osp.join(cur, f), osp.join(out_dir, f)
                 if osp.exists(out):
+                    if f not in APPENDED_LISTS:
+                        raise RuntimeError(f"merge_rank_exports: rank {r} wrote {osp.join(rel, f)}, which another rank wrote too -- "
+                                           "the ranks' blocks overlap (evaluate_one_epoch needs each rank's shard_start)")
                     with open(out, "a") as fo, open(src) as fi:
                         shutil.copyfileobj(fi, fo)
                 else:
@@ -93,7 +101,15 @@ class DataParallelEvaluator:
         rank = self.rank if rank is None else rank
         world = self.world if world is None else world
         if shard_start is None:
-            shard_start = int(getattr(getattr(data_loader, "sampler", None), "start", 0))
+            sampler = getattr(data_loader, "sampler", None)
+            if sampler is None:      # PrefetchLoader / DataLoader wrappers: the loader they wrap
+                sampler = getattr(getattr(data_loader, "source", None), "sampler", None)
+            start = getattr(sampler, "start", None)
+            if start is None and world > 1 and dst is not None and self.export_fn is not None:
+                raise ValueError("evaluate_one_epoch: with more than one rank the exporter needs the global index of this rank's "
+                                 "first sample: pass shard_start= or a loader over a BlockShardedSampler "
+                                 "(dpft_amd.data.loader.load_listed_eval)")
+            shard_start = int(start or 0)
         model.eval()
         root = osp.join(dst, f"_rank{rank}") if (dst is not None and world > 1) else dst
         sums: Dict[str, torch.Tensor] = {}
@@ -160,8 +176,13 @@ class DataParallelEvaluator:
 
     @torch.no_grad()
     def evaluate_complexity(self, epoch: int, model: torch.nn.Module, data_loader: Iterable, writer=None) -> Dict[str, float]:
-        """evaluator.py:67-93 minus deepspeed's profiler (absent): the parameter count."""
-        out = {"Parameters": float(sum(p.numel() for p in model.parameters()))}
+        """evaluator.py:70-94: FLOPS, MACS and Parameters of one forward on the first batch.  deepspeed's profiler is absent
+        (and blind to launch plans): the counts come from the library's conv launch log + the decoder's analytic table
+        (dpft_amd/evaluation/complexity.py)."""
+        from dpft_amd.evaluation.complexity import model_complexity
+        data, _ = next(iter(data_loader))
+        c = model_complexity(model, self._dict_to(data))
+        out = {k: c[k] for k in ("FLOPS", "MACS", "Parameters")}
         if self.rank == 0:
             self.log_scalars(writer, out, epoch, "test")
         return out

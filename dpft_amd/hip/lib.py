@@ -170,6 +170,7 @@ SIGNATURES = {
     "dpft_profile_serialize": (_I, [_I]),
     "dpft_profile_overhead_ms": (_F, []),
     "dpft_profile_get": (_I, [_I, C.POINTER(_I), C.POINTER(C.c_double), C.POINTER(_F), C.POINTER(_I * 7)]),
+    "dpft_profile_get_family": (_I, [_I, C.POINTER(_I)]),
     "dpft_rows_outer_f32": (_I, [_P, _I, _I, _I, _P, _I, _P, _L, _P]),
     "dpft_memops": (_I, [_I, _P, _P]),
     "dpft_lsap_batch_f32": (_I, [_P, _I, _I, _I, _P, _P, _P]),

@@ -40,16 +40,22 @@ def profile_start():
     lib.call("dpft_profile_start")
 
 
+CONV_FAMILIES = ("f32", "x3", "bf16", "vector")      # dpft_profile_get_family: the pipe the library launched the conv on
+
+
 def profile_collect():
-    """-> list of (kind, flops, seconds, shape7) for every conv launch since profile_start() (syncs)."""
+    """-> list of (kind, flops, seconds, shape7, family) for every conv launch since profile_start() (syncs).
+    family: 'f32' fp32 MFMA | 'x3' three-term bf16 split on the bf16 MFMA | 'bf16' bf16 operands | 'vector' no matrix core
+    -- written by the library's dispatch code at the launch, not derived from the shape."""
     n = int(lib.dpft_profile_stop())
     torch.cuda.synchronize()
     out = []
-    kind, flops, ms, shape = C.c_int32(), C.c_double(), C.c_float(), (C.c_int32 * 7)()
+    kind, flops, ms, shape, fam = C.c_int32(), C.c_double(), C.c_float(), (C.c_int32 * 7)(), C.c_int32()
     names = ("fwd", "dgrad", "wgrad")
     for i in range(n):
         lib.call("dpft_profile_get", i, C.byref(kind), C.byref(flops), C.byref(ms), C.byref(shape))
-        out.append((names[kind.value], flops.value, ms.value * 1e-3, tuple(shape)))
+        lib.call("dpft_profile_get_family", i, C.byref(fam))
+        out.append((names[kind.value], flops.value, ms.value * 1e-3, tuple(shape), CONV_FAMILIES[fam.value]))
     return out
 
 

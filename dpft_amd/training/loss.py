@@ -293,19 +293,30 @@ class Loss(nn.modules.loss._Loss):
             st = self.__dict__["_lsap_status"] = torch.zeros(1, dtype=torch.int32).pin_memory()
         return st
 
-    def check_assignment_status(self, sync: bool = True) -> None:
-        """Raise the ValueError scipy would have raised in the step whose cost matrix was not finite (or infeasible)."""
+    def assignment_status(self, sync: bool = True) -> int:
+        """The on-device assignment's status word (0 = fine), read and cleared.  ``check_assignment_status`` raises from it; the
+        trainer MAX-reduces it over the ranks first so that all of them raise in the same place."""
         st = self.__dict__.get("_lsap_status")
         if st is None:
-            return
+            return 0
         if sync:
             torch.cuda.synchronize()
         code = int(st[0])
         if code:
             st[0] = 0
-            what = "contains invalid numeric entries" if code < 0x10000 else ("is infeasible" if code < 0x20000 else
-                                                                              "has more targets than the packed width")
-            raise ValueError(f"matcher: cost matrix of sample {(code & 0xffff) - (1 if code < 0x10000 else 0)} {what}")
+        return code
+
+    @staticmethod
+    def describe_assignment_status(code: int) -> str:
+        what = "contains invalid numeric entries" if code < 0x10000 else ("is infeasible" if code < 0x20000 else
+                                                                          "has more targets than the packed width")
+        return f"matcher: cost matrix of sample {(code & 0xffff) - (1 if code < 0x10000 else 0)} {what}"
+
+    def check_assignment_status(self, sync: bool = True) -> None:
+        """Raise the ValueError scipy would have raised in the step whose cost matrix was not finite (or infeasible)."""
+        code = self.assignment_status(sync)
+        if code:
+            raise ValueError(self.describe_assignment_status(code))
 
     def _to_host(self, t: torch.Tensor) -> "np.ndarray":
         """Device tensor -> numpy through a reused pinned buffer (one async copy + one stream sync instead of a pageable

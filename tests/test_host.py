@@ -412,3 +412,24 @@ def test_c_assignment_solver_returns_scipys_pairs_in_scipys_order():
     cost[1, 5, 2] = 0.0
     cost[3, 7, 6] = np.inf                                               # beyond the sample's count: not looked at
     assert run(cost, [7, 3, 0, 1])[0] == 0
+
+
+def test_integration_shim_loads_the_library_and_exposes_the_extension_api():
+    """integration/MultiScaleDeformableAttention.py: the module name and the two callables the reference imports
+    (ms_deform_attn.py:24,32,58), bound to the C-ABI symbols of include/dpft_hip.h (no compute without a GPU)."""
+    import importlib.util
+    import inspect
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("MultiScaleDeformableAttention",
+                                                  os.path.join(root, "integration", "MultiScaleDeformableAttention.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert list(inspect.signature(m.ms_deform_attn_forward).parameters) == [
+        "value", "spatial_shapes", "level_start_index", "sampling_loc", "attn_weight", "im2col_step"]
+    assert list(inspect.signature(m.ms_deform_attn_backward).parameters) == [
+        "value", "spatial_shapes", "level_start_index", "sampling_loc", "attn_weight", "grad_output", "im2col_step"]
+    assert m._lib.dpft_msda_fwd_f32 and m._lib.dpft_msda_bwd_f32
+    import torch
+    with pytest.raises(RuntimeError):      # CPU tensors are refused, not computed on some fallback
+        m.ms_deform_attn_forward(torch.zeros(1, 4, 2, 2), torch.tensor([[2, 2]]), torch.tensor([0]),
+                                 torch.zeros(1, 3, 2, 1, 1, 2), torch.zeros(1, 3, 2, 1, 1), 64)
