@@ -228,6 +228,33 @@ def secondary_legs(args):
     return out
 
 
+def exchange_diagnostics(trainer, bucket_trace, last_step_ms):
+    """What a reader needs to judge the gradient exchange of an N > 1 run from the line alone: the collective library and its
+    knobs, and for every bucket of the last timed step when its gradients were complete (`ready_ms`), when its collective started
+    and ended (ms after the step's start on this rank).  A bucket whose `end_ms` is close to the step's end is exposed; gaps between
+    one bucket's `end` and the next one's `start` that exceed `ready` spacing mean the exchange stream idles on dependencies."""
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        ver = None
+    env = {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_")) or k in ("HSA_ENABLE_IPC_MODE_LEGACY", "GPU_MAX_HW_QUEUES")}
+    rows = sorted(bucket_trace or [], key=lambda r: r["start_ms"])
+    total_mb = sum(r["mb"] for r in rows)
+    busy = sum(r["end_ms"] - r["start_ms"] for r in rows)
+    return {"library": "RCCL (torch.distributed backend 'nccl')", "rccl_version": ver, "env": env,
+            "channels": os.environ.get("NCCL_MAX_NCHANNELS") or os.environ.get("NCCL_MIN_NCHANNELS") or
+                        "library default (not exposed through torch; NCCL_DEBUG=INFO prints it at init)",
+            "comm_stream": trainer.comm_placement, "collective_op": trainer.reducer.collective_op, "wire_dtype": trainer.comm_dtype,
+            "buckets": len(rows), "exchanged_mb_per_step": round(total_mb, 1),
+            "sum_of_collective_ms": round(busy, 3), "last_step_ms": last_step_ms,
+            "first_ready_ms": rows[0]["ready_ms"] if rows else None, "last_end_ms": max((r["end_ms"] for r in rows), default=None),
+            "bus_gb_per_s_while_busy": round(total_mb * 2 ** 20 / 1e9 / (busy * 1e-3), 1) if busy > 0 else None,
+            "per_bucket": rows,
+            "is": "rank 0, last timed step, ms after that step's first launch: ready = the bucket's last gradient written (firing "
+                  "stream), start / end = its collective (a comm stream of our own: events around the call; the process group's own "
+                  "stream: start = issue point, end = an event on a helper stream that waits for the work)"}
+
+
 def decoder_runner(m, data):
     """-> (run, feats): ``run()`` = exactly one dpft_decoder_forward_f32 call (the fused inference decoder of one
     IMPFusion.forward) on the encoded pyramids of ``data``.  Also used by tools/decoder_only.py for the PMC passes."""
@@ -328,10 +355,13 @@ def main():
     t0 = time.perf_counter()
     marks[0].record()
     for i in range(args.steps):
+        if collective and i == args.steps - 1:
+            trainer.reducer.trace_begin()      # per-bucket ready / start / end marks of the LAST timed step (~3 event records per bucket)
         loss, _ = trainer.train_step(data, labels)
         marks[i + 1].record()
     sync()
     elapsed = time.perf_counter() - t0
+    bucket_trace = trainer.reducer.trace_report() if collective else None
     step_ms_order = [marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps)]
     step_ms = sorted(step_ms_order)
     # None at one rank without forced collectives: there is no exchange to expose (0.0 would read like a measurement)
@@ -666,6 +696,7 @@ def main():
                                     "backward work to the completion of the last bucket's collective, bracketed by events on "
                                     "that stream; collectives of view-stream buckets that finish earlier are not in it",
             "dp_bucket_mb": trainer.bucket_mb,
+            "dp_exchange": exchange_diagnostics(trainer, bucket_trace, step_ms_order[-1] if step_ms_order else None) if collective else None,
             "hardware_queues": {"distinct_besides_main": trainer.model.__dict__.get("_queues_found"),
                                 "placement": os.environ.get("DPFT_STREAM_PLACEMENT", "probe"),
                                 "note": "views and the camera's weight-gradient stream sit on probed, distinct hardware queues "

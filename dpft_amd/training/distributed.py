@@ -113,6 +113,7 @@ class GradBucketReducer:
                 self._index[id(p)] = bi
         self._bucket_index = {id(b["flat"]): bi for bi, b in enumerate(self.buckets)}
         self._in_finish = False
+        self._trace = None               # trace_begin(): per-bucket ready / start / end marks of the next step's exchange
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in self.params]
         self._pending: List = []
         self.reset()
@@ -298,7 +299,19 @@ class GradBucketReducer:
                 if b["stage"] is not None:
                     wire = b["stage"]
                     wire.copy_(b["flat"])                             # round to the wire dtype (RNE)
-                self._pending.append((dist.all_reduce(wire, op=op, group=self.group, async_op=True), b))
+                ready = self._trace_mark() if self._trace is not None else None
+                work = dist.all_reduce(wire, op=op, group=self.group, async_op=True)
+                self._pending.append((work, b))
+                if ready is not None:
+                    tr = self._trace
+                    if tr["cuda"]:
+                        with torch.cuda.stream(tr["helper"]):      # the helper stream waits for the collective, nothing else does
+                            work.wait()
+                            end = self._trace_mark(tr["helper"])
+                    else:
+                        work.wait()
+                        end = self._trace_mark()
+                    tr["rows"].append((self._bucket_index[id(b["flat"])], wire.numel() * wire.element_size(), len(b["params"]), ready, ready, end))
                 if GradBucketReducer.exp_after_collective is not None:
                     GradBucketReducer.exp_after_collective(wire)
             else:
@@ -307,6 +320,7 @@ class GradBucketReducer:
                 # all-reduce, widening -- is one in-order sequence there, fenced by two events
                 # the COMMUNICATION stream waits for every producer of the bucket; no compute stream waits for another
                 cur = torch.cuda.current_stream(b["flat"].device)
+                ready = self._trace_mark(cur) if self._trace is not None else None
                 if cur.cuda_stream != comm.cuda_stream:
                     comm.wait_stream(cur)
                 for sid, st in b["streams"].items():
@@ -319,13 +333,56 @@ class GradBucketReducer:
                     if b["stage"] is not None:
                         wire = b["stage"]
                         wire.copy_(b["flat"])
+                    start = self._trace_mark(comm) if ready is not None else None
                     dist.all_reduce(wire, op=op, group=self.group, async_op=False)
+                    if ready is not None:
+                        self._trace["rows"].append((self._bucket_index[id(b["flat"])], wire.numel() * wire.element_size(),
+                                                    len(b["params"]), ready, start, self._trace_mark(comm)))
                     if GradBucketReducer.exp_after_collective is not None:
                         GradBucketReducer.exp_after_collective(wire)
                     if b["stage"] is not None:
                         b["flat"].copy_(b["stage"])
                     self._final(b)                                    # (on the communication stream, behind the collective)
                     self._pending.append((comm.record_event(), None))
+
+    # ---- per-bucket timeline of one step's exchange (bench.py, N > 1: the line explains itself the day a node exists) ----
+    def trace_begin(self) -> None:
+        """Mark the buckets of the step that starts now: `ready` (the bucket's last gradient is written: recorded on the firing
+        stream), `start` / `end` of its collective (comm stream of our own: events around the call on that stream; the process
+        group's stream: `start` = the issue point, `end` = an event on a helper stream that waits for the work).  ~3 event
+        records per bucket; off unless called."""
+        cuda = self.arena.is_cuda
+        t0 = None
+        if cuda:
+            t0 = torch.cuda.Event(enable_timing=True)
+            t0.record()
+        else:
+            import time
+            t0 = time.perf_counter()
+        self._trace = {"t0": t0, "rows": [], "cuda": cuda, "helper": torch.cuda.Stream(self.arena.device) if cuda else None}
+
+    def _trace_mark(self, stream=None):
+        tr = self._trace
+        if tr["cuda"]:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream(self.arena.device))
+            return ev
+        import time
+        return time.perf_counter()
+
+    def trace_report(self):
+        """-> rows {bucket, mb, params, ready_ms, start_ms, end_ms} relative to trace_begin() (synchronises); ends the trace."""
+        tr, self._trace = self._trace, None
+        if tr is None:
+            return None
+        if tr["cuda"]:
+            torch.cuda.synchronize(self.arena.device)
+        rel = (lambda e: tr["t0"].elapsed_time(e)) if tr["cuda"] else (lambda t: (t - tr["t0"]) * 1e3)
+        rows = []
+        for bi, nbytes, n_params, ready, start, end in tr["rows"]:
+            rows.append({"bucket": bi, "bytes": int(nbytes), "mb": round(nbytes / 2 ** 20, 2), "params": n_params, "ready_ms": round(rel(ready), 3),
+                         "start_ms": round(rel(start), 3), "end_ms": round(rel(end), 3)})
+        return rows
 
     def seen_ids(self):
         """ids of the parameters that received a gradient since the last reset()."""

@@ -51,11 +51,17 @@ def _worker(rank, world, port, q, wire=None):
     xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
     for step in range(2):                      # second pass checks reset()
         red.reset()
+        if step == 1:
+            red.trace_begin()                  # the per-bucket timeline bench.py prints for N > 1
         loss = ((model(xs) - ys) ** 2).sum(1).mean()       # per-sample mean => averaging = global-batch grad
         loss.backward()
         # one gradient is delivered through the direct sink path as the hand-scheduled backward does
         red.finish()
         assert red.exposed_ms() >= 0.0
+    rows = red.trace_report()
+    assert red.trace_report() is None          # the trace ended with its report
+    assert len(rows) == len(red.buckets) and sorted(r["bucket"] for r in rows) == list(range(len(red.buckets)))
+    assert all(0.0 <= r["ready_ms"] <= r["start_ms"] <= r["end_ms"] and r["bytes"] > 0 and r["params"] >= 1 for r in rows), rows
     grads = {n: p.grad.clone() for n, p in model.named_parameters()}
     q.put((rank, {k: v.numpy() for k, v in grads.items()}))
     dist.destroy_process_group()

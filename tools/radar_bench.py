@@ -12,8 +12,14 @@ torch.cuda.synchronize(); e0.record()
 for _ in range(10): radar_projection(td)
 e1.record(); torch.cuda.synchronize()
 dt = e0.elapsed_time(e1) / 10 * 1e-3
+# yardstick: one streaming read of the same cube by the vendor's reduction kernel (what "HBM-bound" means on this box)
+for _ in range(3): td.sum()
+torch.cuda.synchronize(); e0.record()
+for _ in range(10): td.sum()
+e1.record(); torch.cuda.synchronize()
+dt_sum = e0.elapsed_time(e1) / 10 * 1e-3
 byts = t.nbytes
 a = time.perf_counter(); RO.radar_projection(t, np.linspace(-1.9, 1.9, 64)); cpu = time.perf_counter() - a
 print(json.dumps({"cube_mb": byts / 1e6, "gpu_ms_per_cube": dt * 1e3, "cubes_per_s": 1 / dt,
                   "achieved_GBs_algorithmic": byts / dt / 1e9, "frac_of_8TBs": byts / dt / 8e12,
-                  "numpy_reference_s_per_cube": cpu, "host_threads": torch.get_num_threads()}))
+                  "torch_sum_one_read_us": dt_sum * 1e6, "torch_sum_GBs": byts / dt_sum / 1e9, "numpy_reference_s_per_cube": cpu, "host_threads": torch.get_num_threads()}))
