@@ -405,6 +405,12 @@ def main():
                 f.write("kind B H W C K k s calls total_us TFLOPs family\n")
                 for key, v in sorted(shapes.items(), key=lambda kv: -kv[1][1]):
                     f.write(" ".join(str(x) for x in key) + f" {v[2]} {v[1] * 1e6:.1f} {v[0] / v[1] / 1e12:.1f} {shape_fam[key]}\n")
+            # algorithmic flops per kernel family of this step (what tools/roofline_from_rocprof.py --families prices the
+            # committed kernel-trace summary with: time per family from the kernel names, flops from here)
+            with open(os.path.splitext(os.environ["DPFT_CONV_TABLE"])[0] + "_families.json", "w") as f:
+                json.dump({"gflop_per_step": {k: v / 1e9 for k, v in fam_f.items()}, "launches_per_step": fam_n,
+                           "batch": B, "dtype": args.dtype, "config": args.config,
+                           "source": "bench.py: dpft_profile_get_family tags of one serialized step"}, f, indent=1)
         n_launch = sum(k[2] for k in per_kind.values())
         # algorithmic HBM bytes of the same calls: every conv call (fwd / dgrad / wgrad alike) touches its input map, its
         # output map and its weights once -- x + y + w fp32 elements (shape key = kind, B, H, W, C, K, k, s; H x W = the
@@ -420,7 +426,7 @@ def main():
         cam_w = {910, 455, 228, 114, 57, 29}          # widths of the camera feature maps (input of the conv)
         cam = [v for key, v in shapes.items() if key[3] in cam_w]
         cam_f, cam_t = sum(v[0] for v in cam), sum(v[1] for v in cam)
-        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/r03_profile.sh: FETCH_SIZE and
+        # HBM bytes per conv LAUNCH from the committed PMC passes of this round (tools/r06_profile.sh: FETCH_SIZE and
         # WRITE_SIZE in separate rocprofv3 runs, FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md).  It is a
         # constant read from profiles/, not a measurement of this run: the file is named in the line.
         traffic, traffic_src = None, None
@@ -579,7 +585,7 @@ def main():
         fcfg = cfg["model"]["fuser"]
         n_calls = fcfg["i_iter"] * len(m.inputs)
         dec_bytes = fcfg["i_iter"] * B * tokens * 64 + n_calls * B * fcfg["n_queries"] * (16 + 16 + 2 + 16) * 4 + 0.42e6
-        # counter traffic of the decoder kernels (tools/r03_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
+        # counter traffic of the decoder kernels (tools/r06_profile.sh: FETCH_SIZE x 2 + WRITE_SIZE per forward, committed)
         dec_traffic, dec_src = None, None
         for pname in ("r05_decoder_traffic_pmc.json", "r04_decoder_traffic_pmc.json", "r03_decoder_traffic_pmc.json"):
             pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", pname)

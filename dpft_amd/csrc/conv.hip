@@ -1331,7 +1331,7 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
                 while (sp > 1 && ksteps / sp < 4) --sp;
             }
             t.splits = sp;
-            // (measured, tools/x3_unsplit.sh: 128 x 64 tiles without the K split -- which would keep the data gradients' epilogue
+            // (measured, round-5 A/B, docs/history: 128 x 64 tiles without the K split -- which would keep the data gradients' epilogue
             // operand prefetch -- lose: layer-3 forward 82 vs 70 us per call, data gradient 70 vs 68.5)
         } else {
             t.bm = 64; t.bn = 64; t.splits = 1;
@@ -1357,7 +1357,7 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
     double eff[3] = {1.0, 0.92, 0.80};
     // Short reductions over many row tiles (the 1x1 convs of camera layers 1-2, K <= 256): the kernel is its epilogue
     // (statistics / residual / BatchNorm-reduction operands, staged stores), and with 128 x 128 tiles all workgroups of a
-    // wave reach it together; 128 x 64 measured 10-25 % faster there (tools/r03_tile_ab.sh: 176 -> 129 us on the
+    // wave reach it together; 128 x 64 measured 10-25 % faster there (round-3 tile A/B, docs/history: 176 -> 129 us on the
     // 128x228 256<-64 data gradient), not on the 57-row-tile grids of layer 3.
     static const bool shortk_rule = getenv("DPFT_SHORTK_TILE") == nullptr || atoi(getenv("DPFT_SHORTK_TILE")) != 0;      // A/B switch
     if (shortk_rule && (int64_t)ksteps * BKV <= 256 && (int64_t)cdiv(M, 128) * cdiv(N, 128) >= 768) {
@@ -1389,12 +1389,12 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
     const int64_t nwg = (int64_t)cdiv(M, t.bm) * cdiv(N, t.bn);
     t.splits = 1;
     // DPFT_SPLIT_BELOW (tuning aid): the isolated 232-tile layer-4 1x1 forward runs 52.9 us split in three vs 35.9 us
-    // unsplit (tools/r03_tile_ab.sh), but over the whole step 128 / 192 / 256 are within run-to-run noise (conv time 28.2 /
+    // unsplit (round-3 tile A/B, docs/history), but over the whole step 128 / 192 / 256 are within run-to-run noise (conv time 28.2 /
     // 27.9 / 28.0 ms): the threshold stays at one workgroup per CU.
     static const int split_below = getenv("DPFT_SPLIT_BELOW") ? atoi(getenv("DPFT_SPLIT_BELOW")) : kNumCU;
     // (round 4) 200 ... 255 tiles with a SHALLOW reduction (<= 32 K-steps: the 1x1 convs of camera layer 4, 232 tiles)
     // stay unsplit: the split's slab round trip + reduction launch cost more than the idle tenth of the chip
-    // (tools/r03_tile_ab.sh: 16x29 2048->512 forward 53.7 -> 36.9 us, 512->2048 data gradient 55.1 -> 40.1 us)
+    // (round-3 tile A/B, docs/history: 16x29 2048->512 forward 53.7 -> 36.9 us, 512->2048 data gradient 55.1 -> 40.1 us)
     const bool shallow_nearly_full = nwg >= 200 && ksteps <= 32;
     if (nwg < split_below && ksteps >= 8 && !shallow_nearly_full) {
         int s = (int)((kNumCU * 2 + nwg - 1) / nwg);

@@ -50,7 +50,7 @@ class GradBucketReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = self.world > 1 or (bool(force_collectives) and dist.is_initialized())
         if self.world > 1:
-            # the one-rank timing switches of tools/r03_forced_breakdown.sh would let ranks diverge (no gradient exchange) or
+            # the one-rank timing switches of the round-3 forced-collectives breakdown, docs/history would let ranks diverge (no gradient exchange) or
             # hang (ranks disagreeing on the step decision mismatch their collectives): refused outside one-rank runs
             if GradBucketReducer.exp_skip_bucket_collectives:
                 raise RuntimeError(f"exp_skip_bucket_collectives: one-rank timing experiment switches are not allowed with "
@@ -60,7 +60,7 @@ class GradBucketReducer:
         # One rank (bench.py --force-collectives, tests): the average over one rank IS the sum, and RCCL implements a one-rank
         # AVG as a pre-multiply kernel over the whole bucket (oneRankReduce<FuncPreMulSum>: 20 launches, 0.5 ms of memory
         # passes per step that the all-reduce kernel of N > 1 ranks does not add) but a one-rank SUM as nothing -- so SUM
-        # there.  DPFT_COLLECTIVE_OP=avg|sum forces either (A/B, tools/r03_forced_breakdown.sh).
+        # there.  DPFT_COLLECTIVE_OP=avg|sum forces either (A/B, the round-3 forced-collectives breakdown, docs/history).
         self.collective_op = "avg" if self._avg_op else "sum"
         forced_op = __import__("os").environ.get("DPFT_COLLECTIVE_OP")
         if self._avg_op and (forced_op == "sum" or (forced_op is None and self.world == 1)):

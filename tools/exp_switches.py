@@ -3,7 +3,7 @@ package and the library: this wrapper flips the two switches
 usage: python tools/exp_switches.py [--skip-bucket-collectives] [--local-decision] [--standin-collective] -- <bench.py arguments>
 --standin-collective: behind every bucket's (one-rank, forced) collective a kernel with the footprint of an 8-rank ring
 all-reduce runs on the same stream (tools/probes/comm_standin.hip; STANDIN_BLOCKS=32, STANDIN_PASSES=2)
-(tools/r03_forced_breakdown.sh used DPFT_EXP_* environment variables for the same; those are gone.)"""
+(the round-3 forced-collectives breakdown, docs/history used DPFT_EXP_* environment variables for the same; those are gone.)"""
 import os
 import runpy
 import sys

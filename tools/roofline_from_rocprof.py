@@ -1,7 +1,14 @@
 """Conv-family roofline recomputed from a rocprofv3 --kernel-trace --stats summary (the bench line's
 `roofline.frac` must follow from what is committed under profiles/).
 
-    python tools/roofline_from_rocprof.py <kernel_stats.csv> <steps> [algorithmic_gflop_per_step] [peak_tflops]
+    python tools/roofline_from_rocprof.py <kernel_stats.csv> <steps> [algorithmic_gflop_per_step] [peak_tflops] [--families <conv_table>_families.json]
+
+--families (round 6): the pipe-correct pricing of the bench line reproduced from the committed summary.  Every conv kernel NAME
+belongs to one family -- x3 (conv_x3.hip: igemm_x3 / igemm_x3p / wgrad_x3), bf16 (igemm_pipe_kernel with its B16 template flag,
+wgrad_pipe16, the BF16 instantiations of the vec kernels), vector (thin-channel / 16-channel / generic kernels: no matrix core),
+f32 (everything else of the conv family: v_mfma_f32_32x32x2_f32) -- its time comes from the CSV, its algorithmic flops from the
+JSON bench.py writes next to DPFT_CONV_TABLE (dpft_profile_get_family tags of the launches).  Output adds by_family,
+split_share_of_conv_flops and frac_blended = sum_i(flops_i / peak_i) / conv time (peaks 157.3 | 416.7 | 2500 | 157.3 TF).
 
     python tools/roofline_from_rocprof.py --decoder <decoder_kernel_stats.csv> [iterations_per_forward] [algorithmic_MB]
 
@@ -47,20 +54,50 @@ def decoder_main(argv):
     print(json.dumps(out, indent=1))
 
 
+FAM_PEAK = {"f32": 157.3, "x3": 2500.0 / 6.0, "bf16": 2500.0, "vector": 157.3}
+
+
+def family_of(name: str) -> str:
+    """Kernel name (with template arguments) -> the pipe it runs on."""
+    if "_x3_kernel" in name or "_x3p_kernel" in name:
+        return "x3"
+    if "wgrad_pipe16" in name:
+        return "bf16"
+    m = re.search(r"igemm_pipe_kernel<([^>]*)>", name)
+    if m:
+        a = [t.strip() for t in m.group(1).split(",")]
+        return "bf16" if len(a) >= 8 and a[7] == "true" else "f32"
+    m = re.search(r"(igemm_vec_kernel|wgrad_vec_kernel)<([^>]*)>", name)
+    if m:
+        a = [t.strip() for t in m.group(2).split(",")]
+        idx = 7 if m.group(1) == "igemm_vec_kernel" else 5      # the BF16 template flag
+        return "bf16" if len(a) > idx and a[idx] == "true" else "f32"
+    if any(t in name for t in ("conv16_", "wgrad16_", "thin_", "igemm_gen", "wgrad_gen", "wgrad_stem7", "conv1x1_to16", "wgrad1x1_")):
+        return "vector"
+    return "f32"
+
+
 def main():
     if sys.argv[1] == "--decoder":
         return decoder_main(sys.argv[2:])
+    fam_json = None
+    if "--families" in sys.argv:
+        i = sys.argv.index("--families")
+        fam_json = json.load(open(sys.argv[i + 1]))
+        del sys.argv[i:i + 2]
     path, steps = sys.argv[1], int(sys.argv[2])
     gflop = float(sys.argv[3]) if len(sys.argv) > 3 else 1839.439164384       # kradar, B=4: 3 x 4 x 153.29 (bench.py log)
     peak = float(sys.argv[4]) if len(sys.argv) > 4 else 157.3      # fp32 MFMA; 2500 for the bf16 mode's summaries
     t = {"conv_main": 0.0, "conv_aux": 0.0, "other_dpft": 0.0}
     t.update({k: 0.0 for k in GROUPS})
     n = dict.fromkeys(t, 0)
+    fam_ns = {}
     for r in csv.DictReader(open(path)):
         name = re.sub(r"\(.*", "", r["Name"])
         ns, calls = float(r["TotalDurationNs"]), int(r["Calls"])
         if any(m in name for m in MAIN):
             key = "conv_main"
+            fam_ns[family_of(name)] = fam_ns.get(family_of(name), 0.0) + ns
         elif any(m in name for m in AUX):
             key = "conv_aux"
         else:
@@ -77,6 +114,16 @@ def main():
            "total_kernel_ms_per_step": round(sum(ms.values()), 3),
            "note_vendor_aten": "whole-run launches / steps: contains the set-up copies and fills (parameter flattening, bucket / arena "
                                "initialisation, warm-up); inside one steady-state step: profiles/r04_step_vendor_rows.txt (tools/step_vendor_rows.sh)"}
+    if fam_json is not None:
+        gf = fam_json["gflop_per_step"]
+        ideal_ms = sum(gf[k] / FAM_PEAK[k] for k in gf)      # GFLOP / (TFLOP/s) = ms
+        out["by_family"] = {k: {"gflop_per_step": gf.get(k, 0.0), "kernel_ms_per_step": round(fam_ns.get(k, 0.0) / 1e6 / steps, 3),
+                                "tflops": (gf.get(k, 0.0) / (fam_ns[k] / 1e6 / steps)) if fam_ns.get(k) else None,
+                                "peak_tflops": FAM_PEAK[k]} for k in sorted(set(gf) | set(fam_ns))}
+        out["split_share_of_conv_flops"] = gf.get("x3", 0.0) / sum(gf.values())
+        out["frac_blended"] = ideal_ms / conv
+        out["frac_blended_main_only"] = ideal_ms / ms["conv_main"]
+        out["families_source"] = fam_json.get("source")
     print(json.dumps(out, indent=1))
 
 
