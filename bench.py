@@ -212,7 +212,8 @@ def secondary_legs(args):
                "--no-cpu-baseline"] + flags
         t0 = time.perf_counter()
         try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240)
+            env = {k: v for k, v in os.environ.items() if k != "DPFT_CONV_TABLE"}      # (the table is the headline step's)
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
             leg = None
             for ln in reversed(r.stdout.strip().splitlines()):
                 if ln.startswith("{"):
