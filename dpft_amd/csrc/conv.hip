@@ -1405,6 +1405,42 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
     return t;
 }
 
+// act16 = 2 (bf16 activations and bf16 weights): the 256-row tiles of conv_b16w.hip (eight waves, 64 x 128 / 64 x 64 outputs
+// per wave); the tile may carry a K split (in-launch fix-up).  The tile height must not depend on the workspace:
+// dpft_conv2d_stats_tiles answers without one.  OFF by default (DPFT_B16W=1 switches it on): alone, the 256 x 256 tiles win
+// on the wide short-K 1x1 convs (batch 8, 256 -> 1024 forward + statistics 30.9 -> 22.7 us, its data gradient 28.0 -> 19.3,
+// 128 -> 512 forward 46.1 -> 35.8), lose on N = 256 problems (57 row tiles: a K split's slab round trip costs more than the
+// idle CUs) -- and INSIDE the training step they lose overall (bf16 batch 8, same box, two pairs: 24.8 vs 23.5 ms): a
+// 512-thread workgroup that owns a CU's whole LDS cannot share the CU with the weight-gradient stream's workgroups the way
+// three 48 KB workgroups do (profiles/r06_b16w_*.txt).
+static bool big16_tile(const dpft_conv_desc* d, const IgemmArgs& a, bool dgrad, bool has_ws, TileChoice& t) {
+    static const int on = getenv("DPFT_B16W") ? atoi(getenv("DPFT_B16W")) : 0;
+    if (!on || d->act16 != 2 || (a.C % BKV) != 0 || (a.N % 128) != 0 || getenv("DPFT_FORCE_TILE") != nullptr) return false;
+    if (dgrad && d->stride > 1) return false;      // (parity classes / the all-tap form keep their kernels)
+    if ((int64_t)a.B * a.H * a.W * a.C >= (1ll << 29) || (int64_t)a.N * a.Ktot >= (1ll << 29)) return false;
+    const int64_t mt = cdiv(a.M, 256);
+    static const int min256 = getenv("DPFT_B16W_MIN256") ? atoi(getenv("DPFT_B16W_MIN256")) : 100;
+    static const int min128 = getenv("DPFT_B16W_MIN128") ? atoi(getenv("DPFT_B16W_MIN128")) : (1 << 30);      // 256 x 128 tiles: measured at par or behind the four-wave kernels (profiles/r06_b16w_*.txt): off
+    const int ksteps = a.Ktot / BKV;
+    if ((a.N % 256) == 0 && mt * (a.N / 256) >= min256) {
+        t.bm = 256; t.bn = 256; t.splits = 1; t.vec = true; t.x3 = false;
+        return true;
+    }
+    const int64_t n128 = mt * (a.N / 128);
+    if (n128 >= min128) {
+        t.bm = 256; t.bn = 128; t.vec = true; t.x3 = false;
+        int sp = 1;
+        static const int max_split = getenv("DPFT_B16W_SPLIT") ? atoi(getenv("DPFT_B16W_SPLIT")) : 4;      // tuning aid
+        if (has_ws && n128 < 200 && max_split > 1) {
+            sp = (int)std::min<int64_t>(max_split, (kNumCU + n128 / 2) / n128);
+            while (sp > 1 && ksteps / sp < 8) --sp;
+        }
+        t.splits = sp < 1 ? 1 : sp;
+        return true;
+    }
+    return false;
+}
+
 static void fill_igemm(IgemmArgs& a, const dpft_conv_desc* d, bool dgrad) {
     a.obn = nullptr; a.oadd = nullptr; a.orelu = 0;
     memset(&a, 0, sizeof(a));
@@ -1460,6 +1496,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     // with 2-byte elements, everything by LDS-DMA
     if (t.vec && a.w16 && a.x16 && !pro && !nonlin) {
         g_prof_family = kFamBf16;
+        if (t.bm == 256) return launch_igemm_b16w(a, t.bm, t.bn, DGRAD, st);      // conv_b16w.hip: 256-row tiles, eight waves
         auto go16 = [&](auto kernel, int pbk, size_t lds) {
             a.ksteps = a.ksteps * BKV / pbk;      // (a parity class of a strided data gradient covers a subset of the taps)
             a.ksteps_per_split = cdiv(a.ksteps, a.splits);
@@ -1689,6 +1726,8 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
         for (int dg = 0; dg < 2; ++dg) {
             IgemmArgs a; fill_igemm(a, d, dg != 0);
             TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->kh * d->kw);
+            if (d->act16) t.splits = 1;
+            (void)big16_tile(d, a, dg != 0, true, t);
             if (t.splits > 1) best = std::max<int64_t>(best, (int64_t)t.splits * a.M * a.N * 4);
         }
     }
@@ -1735,6 +1774,7 @@ extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* til
     if (check_desc(d) != DPFT_OK) return -1;
     IgemmArgs a; fill_igemm(a, d, false);
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);      // (as conv_fwd_bnfinal asks)
+    (void)big16_tile(d, a, false, false, t);
     if (tile_rows) *tile_rows = t.bm;
     return cdiv(a.M, t.bm);
 }
@@ -1769,7 +1809,9 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     DPFT_REQUIRE(!(a.w16 && (pro_bn || bias)), "conv fwd: act16 = 2 (bf16 weights) takes no operand prologue and no bias");
     const bool pro = pro_bn != nullptr;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || (pro && !pro_relu)) ? 1 : d->kh * d->kw);
-    if (d->act16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors
+    const bool big16 = !pro && !bias && big16_tile(d, a, false, workspace != nullptr, t);
+    if (d->act16 && !big16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors (big16: in-launch fix-up only)
+    if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 1)) t.splits = 1;
     DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 64 == 0 (C=%d)", d->C);
     bool fixup = false;
     if (t.splits > 1) {
@@ -1928,7 +1970,9 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
         return DPFT_OK;
     }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || d->stride > 1) ? 1 : d->kh * d->kw);
-    if (d->act16) t.splits = 1;
+    const bool big16 = big16_tile(d, a, true, workspace != nullptr, t);
+    if (d->act16 && !big16) t.splits = 1;
+    if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 2)) t.splits = 1;
     bool fixup = false;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
@@ -1974,7 +2018,9 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     if (d->a_planes && d->w_planes && !d->act16) { a.x3 = d->a_planes; a.w3 = d->w_planes; }
     if (res_mask8 && (a.N & 3) == 0) a.res_mask8 = res_mask8;      // (the split-K reduction and the scalar tail read res_mask)
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
-    if (d->act16) t.splits = 1;
+    const bool big16 = big16_tile(d, a, true, workspace != nullptr, t);
+    if (d->act16 && !big16) t.splits = 1;
+    if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 4)) t.splits = 1;
     bool fixup = false;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv dgrad: split-K selected but no workspace given");
@@ -1991,7 +2037,7 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     // takes the kernel when the operand types allow the pipelined path).  DPFT_EPF=0: the plain epilogue, A/B switch.
     static const int epf_on = getenv("DPFT_EPF") == nullptr ? 3 : atoi(getenv("DPFT_EPF"));      // bit 0: this form, bit 1: mode 2
     if ((epf_on & 1) && t.splits == 1 && a.bnr_sums && a.bnr_mask8 && a.res_mask8 && t.vec && (int64_t)a.M * a.N < (1ll << 29) &&
-        (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) >= kNumCU && getenv("DPFT_FORCE_TILE") == nullptr) {
+        (int64_t)cdiv(a.M, 128) * cdiv(a.N, 64) >= kNumCU && getenv("DPFT_FORCE_TILE") == nullptr && !big16) {
         a.epf = 1;
         t.bm = 128; t.bn = 64;
     }

@@ -1423,3 +1423,19 @@ def test_msda_module_reference_signature_matches_reference_golden(tag, geom):
     out4 = mod(q, t("ref4").to(DEV), src, shapes, start, None)
     close(out2, t("out2"), rtol=1e-4, atol_scale=1e-5, what="reference-signature forward, 2-d reference points + padding mask")
     close(out4, t("out4"), rtol=1e-4, atol_scale=1e-5, what="reference-signature forward, 4-d reference boxes")
+
+
+@pytest.mark.gpu
+def test_conv_bf16_large_tile_kernels_vs_fp64():
+    """conv_b16w.hip (256 x 256 / 256 x 128 tiles on eight waves, act16 = 2; off by default -- DESIGN.md section 3 has the measured
+    reason): every epilogue form the mixed-precision plan launches (forward + BatchNorm tile statistics, plain / accumulating
+    data gradient, the fused BatchNorm-backward reduction with both mask sources, the residual form, the in-launch split-K
+    fix-up run twice over the same tickets) against fp64 on the same bf16-valued operands, ragged row / tap / stride cases
+    included.  Own process: the tile thresholds are read once per process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPFT_B16W="1", DPFT_B16W_MIN256="1", DPFT_B16W_MIN128="1")
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "b16w_check.py"), "check"], env=env, capture_output=True,
+                       text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
+    assert r.stdout.count("rows/tile 256") >= 20 and "MISS" not in r.stdout, r.stdout[-3000:]
