@@ -1560,6 +1560,15 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
             else took = false;
             if (took) return check_launch("conv igemm (pipelined, epilogue prefetch)");
         }
+        if constexpr (!DGRAD) {      // inference epilogue with a residual: the residual is requested with the first tile (EpiPrefetch mode 3)
+            bool took = !pro && a.epf == 3;
+            if (!took) {}
+            else if (t.bm == 128 && t.bn == 128) go(igemm_pipe_kernel<128, 128, 2, 2, 32, false, false, false, 3>, 32, PIPE_LDS(128, 128, 32));
+            else if (t.bm == 128 && t.bn == 64) go(igemm_pipe_kernel<128, 64, 2, 2, 32, false, false, false, 3>, 32, PIPE_LDS(128, 64, 32));
+            else if (t.bm == 64 && t.bn == 64 && !short_k) go(igemm_pipe_kernel<64, 64, 2, 2, 64, false, false, false, 3>, 64, PIPE_LDS(64, 64, 64));
+            else took = false;
+            if (took) return check_launch("conv igemm (pipelined, inference epilogue, residual prefetch)");
+        }
         if (t.bm == 128 && t.bn == 128) LAUNCH_PIPE(128, 128, 32);
         else if (t.bm == 128 && t.bn == 64) LAUNCH_PIPE(128, 64, 32);
         else if (t.bm == 64 && t.bn == 128) LAUNCH_PIPE(64, 128, 32);
@@ -1888,6 +1897,9 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
     a.x16 = a.y16 = d->act16 != 0;
     if (d->a_planes && d->w_planes && !d->act16) { a.x3 = d->a_planes; a.w3 = d->w_planes; }
     a.obn = out_bn; a.oadd = residual; a.orelu = relu;
+    // unsplit fp32 launch with a residual: the residual is read during the main loop instead of after it (DPFT_EPF bit 2)
+    static const int epf_on = getenv("DPFT_EPF") == nullptr ? 7 : atoi(getenv("DPFT_EPF"));
+    if ((epf_on & 4) && residual && !d->act16 && !a.x3 && !t.x3 && (int64_t)a.M * a.N < (1ll << 29) && d->stride == 1 && g_conv_bf16 != 1) a.epf = 3;
     return launch_igemm<false>(a, t, false, st);
 }
 

@@ -147,12 +147,14 @@ __device__ __forceinline__ size_t out_pixel(const IgemmArgs& a, int m) {
 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
 // MODE 1: the residual form above (bnr_y, res_src, both mask bytes).  MODE 2: a plain data gradient that carries a BatchNorm-
 // backward reduction (conv2 / conv3 of a bottleneck): bnr_y, and the mask byte where that layer's ReLU mask is a byte mask.
+// MODE 3 (round 6, FORWARD): the inference epilogue y = relu(bn(conv) + residual) of a bottleneck's last conv
+// (dpft_conv2d_nhwc_fwd_bnact_f32): the residual (IgemmArgs::oadd) is the prefetched operand, in g[].
 template <int ITER, bool H16, int MODE_>
 struct EpiPrefetch {
     static constexpr int MODE = MODE_;
     using Q = typename std::conditional<H16, u32x2_t, f32x4>::type;      // 4 channels as stored (bf16 / fp32), not widened:
-    Q y[ITER], g[MODE_ == 1 ? ITER : 1];                                  // a conversion would be a use of the load
-    unsigned mk[ITER], rm[MODE_ == 1 ? ITER : 1];
+    Q y[MODE_ == 3 ? 1 : ITER], g[(MODE_ == 1 || MODE_ == 3) ? ITER : 1];  // a conversion would be a use of the load
+    unsigned mk[MODE_ == 3 ? 1 : ITER], rm[MODE_ == 1 ? ITER : 1];
 };
 template <bool H16> __device__ __forceinline__ f32x4 pf_widen(f32x4 v) { return v; }
 template <bool H16> __device__ __forceinline__ f32x4 pf_widen(u32x2_t v) {
@@ -362,11 +364,11 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         static_assert(BM * C4 % NT == 0, "tile / thread count");
         f32x4 old[ITER];
         // operands of the fused BatchNorm-backward reduction: requested here, consumed in the store loop below
-        const bool bnr_pre = HAS_PF || ((a.bnr_sums != nullptr) && !part);
+        const bool bnr_pre = (HAS_PF && PFM != 3) || (!HAS_PF && (a.bnr_sums != nullptr) && !part);
         f32x4 bnr_yv[ITER];
         unsigned bnr_mk[ITER];
         if (bnr_pre && HAS_PF) {
-            if constexpr (HAS_PF) {
+            if constexpr (HAS_PF && PFM != 3) {
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
                     bnr_yv[it] = pf_widen<true>(pf->y[it]);
@@ -388,9 +390,14 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
             }
         }
         const bool resid = PFM == 1 || (PFM == 0 && (a.res_src != nullptr) && !part);
-        const bool obn = !HAS_PF && (a.obn != nullptr) && !part;
-        const bool oadd = obn && a.oadd != nullptr;
-        if (PFM == 1) {
+        const bool obn = PFM == 3 || (!HAS_PF && (a.obn != nullptr) && !part);
+        const bool oadd = PFM == 3 || (obn && a.oadd != nullptr);
+        if (PFM == 3) {
+            if constexpr (PFM == 3) {
+#pragma unroll
+                for (int it = 0; it < ITER; ++it) old[it] = pf_widen<true>(pf->g[it]);
+            }
+        } else if (PFM == 1) {
             if constexpr (PFM == 1) {
 #pragma unroll
                 for (int it = 0; it < ITER; ++it) {
@@ -429,7 +436,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         }
         // fused BatchNorm-backward reduction (see IgemmArgs::bnr_*): a thread owns ONE 4-channel chunk (NT % C4 == 0)
         static_assert(NT % C4 == 0, "a thread's channel chunk must not depend on the pass");
-        const bool bnr = HAS_PF || ((a.bnr_sums != nullptr) && !part);
+        const bool bnr = (HAS_PF && PFM != 3) || (!HAS_PF && (a.bnr_sums != nullptr) && !part);
         f32x4 bs0 = {0.f, 0.f, 0.f, 0.f}, bs1 = {0.f, 0.f, 0.f, 0.f}, bmu = bs0, bis = bs0, bsc = bs0, bbe = bs0;
         const int bc = n0 + (tid % C4) * 4;
         if (bnr && bc < a.N) {

@@ -41,7 +41,7 @@ namespace dpft {
 template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO, bool B16 = false, int EPF = 0>
 __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     static_assert(!(B16 && PRO), "bf16 operands: no fused prologue");
-    static_assert(EPF == 0 || (DGRAD && !PRO), "epilogue prefetch: data gradients only");      // EPF = EpiPrefetch::MODE
+    static_assert(EPF == 0 || (EPF == 3 ? (!DGRAD && !PRO) : (DGRAD && !PRO)), "epilogue prefetch: data gradients (1, 2) / inference forward (3)");      // EPF = EpiPrefetch::MODE
     constexpr int EB = B16 ? 2 : 4;         // bytes per element
     constexpr int EPC = 16 / EB;            // elements per 16-byte chunk
     constexpr int RB = BM / WGM / 32, CB = BN / WGN / 32;
@@ -241,7 +241,9 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
             const unsigned el = ok ? (unsigned)(m0 + row) * (unsigned)a.N + (unsigned)(n0 + c4 * 4)      // (stride-1 data gradient: output pixel = row)
                                    : (unsigned)m0 * (unsigned)a.N + (unsigned)n0;
             using Q = typename PFT::Q;
-            if constexpr (kind == 0) pf.y[it] = *reinterpret_cast<const Q*>(reinterpret_cast<const char*>(a.bnr_y) + (size_t)el * EB);
+            if constexpr (EPF == 3) {      // forward: the residual of the inference epilogue
+                if constexpr (kind == 1) pf.g[it] = *reinterpret_cast<const Q*>(reinterpret_cast<const char*>(a.oadd) + (size_t)el * EB);
+            } else if constexpr (kind == 0) pf.y[it] = *reinterpret_cast<const Q*>(reinterpret_cast<const char*>(a.bnr_y) + (size_t)el * EB);
             else if constexpr (kind == 1) { if constexpr (EPF == 1) pf.g[it] = *reinterpret_cast<const Q*>(reinterpret_cast<const char*>(a.res_src) + (size_t)el * EB); }
             else if constexpr (kind == 2) { if (EPF == 1 || a.bnr_mask8) pf.mk[it] = a.bnr_mask8[el >> 2]; }
             else { if constexpr (EPF == 1) pf.rm[it] = a.res_mask8[el >> 2]; }

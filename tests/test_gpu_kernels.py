@@ -1138,6 +1138,10 @@ def test_bf16_plan_bn_reduce_in_dgrad_epilogue_equals_separate_pass(tmp_path):
 @pytest.mark.parametrize("B,H,W,Cin,K,k,stride,res,relu", [
     (2, 32, 57, 256, 256, 3, 1, False, True),      # vector path, epilogue form
     (2, 32, 57, 256, 1024, 1, 1, True, True),      # conv3 + identity + ReLU
+    (4, 32, 57, 256, 1024, 1, 1, True, True),      # the same at the bench batch: 128 x 128 tiles, residual prefetched (EpiPrefetch mode 3)
+    (3, 33, 57, 128, 512, 1, 1, True, False),      # ragged last row tile, no ReLU
+    (4, 128, 228, 64, 256, 1, 1, True, True),      # layer-1 shape (K = 64: one K-step)
+    (2, 16, 29, 512, 2048, 1, 1, True, True),      # layer-4 shape
     (2, 64, 114, 256, 512, 1, 2, False, False),    # downsample branch: BN only
     (1, 8, 4, 256, 256, 3, 1, True, True),         # small map: split-K -> convolution + elementwise pass
     (2, 16, 29, 6, 16, 1, 1, False, True),         # thin channels: generic path -> convolution + elementwise pass
