@@ -1782,6 +1782,13 @@ int dpft::conv_mode_key() { return dpft::g_conv_bf16 * 2 + (dpft::g_conv_split ?
 extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows) {
     if (check_desc(d) != DPFT_OK) return -1;
     IgemmArgs a; fill_igemm(a, d, false);
+    {
+        int tr = 0;
+        if (g_conv_bf16 != 1 && stream1x1_match(d, &tr)) {      // conv_stream.hip: tile = the rows of one workgroup
+            if (tile_rows) *tile_rows = tr;
+            return cdiv(a.M, tr);
+        }
+    }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);      // (as conv_fwd_bnfinal asks)
     (void)big16_tile(d, a, false, false, t);
     if (tile_rows) *tile_rows = t.bm;
@@ -1809,6 +1816,10 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     if (conv16_matches(d) && !pro_bn && !stats) return conv16_forward(d, x, w, bias, y, st);
     static const bool thin_fwd = getenv("DPFT_THIN_FWD") == nullptr || atoi(getenv("DPFT_THIN_FWD")) != 0;      // A/B switch
     if (thin_fwd && conv1x1_to16_matches(d) && !pro_bn && !stats) return conv1x1_to16_forward(d, x, w, bias, y, st);
+    if (g_conv_bf16 != 1 && !bias && (!pro_bn || pro_relu) && !(fuse && fuse->acc) && stream1x1_match(d, nullptr)) {
+        g_prof_family = kFamF32;      // short reduction, wide output, large map: the streaming kernel (conv_stream.hip)
+        return launch_stream1x1(d, x, w, pro_bn, y, stats, nullptr, nullptr, 0, st);
+    }
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
     a.pro = pro_bn; a.pro_relu = pro_relu;
@@ -1872,6 +1883,11 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
     if (rc) return rc;
     DPFT_REQUIRE(x && w && y && out_bn, "conv fwd_bnact: null tensor");
     hipStream_t st = (hipStream_t)stream;
+    if (g_conv_bf16 != 1 && stream1x1_match(d, nullptr)) {      // conv_stream.hip
+        ProfScope prof(0, d, st);
+        g_prof_family = kFamF32;
+        return launch_stream1x1(d, x, w, nullptr, y, nullptr, out_bn, residual, relu, st);
+    }
     IgemmArgs a; fill_igemm(a, d, false);
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);
     if (d->act16) t.splits = 1;

@@ -671,6 +671,10 @@ struct WgradArgs {
 // conv_x3.hip: the 3 x bf16 split main loop (fp32 results from the bf16 matrix cores); `a` prepared as for igemm_pipe_kernel
 int launch_igemm_x3(IgemmArgs& a, int bm, int bn, bool dgrad, bool pro, hipStream_t st);
 int split_planes(const float* src, void* dst, int64_t n, hipStream_t st);
+// conv_stream.hip: 1x1 convs with 64 / 128 input channels and K % 256 == 0 on large maps (weights in LDS, rows private to a wave)
+bool stream1x1_match(const dpft_conv_desc* d, int* tile_rows);
+int launch_stream1x1(const dpft_conv_desc* d, const float* x, const float* w, const float* pro_bn, float* y, float* stats,
+                     const float* out_bn, const float* residual, int relu, hipStream_t st);
 // conv_b16w.hip: bf16 operands on 256-row tiles, eight waves (act16 = 2); `a` prepared as for igemm_pipe_kernel<bm, bn, .., B16>
 int launch_igemm_b16w(IgemmArgs& a, int bm, int bn, bool dgrad, hipStream_t st);      // fp32 -> three bf16 planes
 // weight gradient on the split kernels: 128 x 128 tiles, 32 pixels per step; `a` as for wgrad_pipe_kernel<128, 128, 2, 2, 32, *>

@@ -1443,3 +1443,61 @@ def test_conv_bf16_large_tile_kernels_vs_fp64():
                        text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
     assert r.stdout.count("rows/tile 256") >= 20 and "MISS" not in r.stdout, r.stdout[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,K", [(2, 96, 171, 64, 256),      # M = 32 832: ragged last row block (M % 32 = 0, % 128 != 0)
+                                         (1, 129, 131, 64, 256),     # M = 16 899: ragged inside a 32-row block
+                                         (4, 64, 114, 128, 512),     # layer-2 conv3 shape: two column slices, C = 128
+                                         (1, 127, 141, 128, 256)])
+def test_conv1x1_streaming_kernel_forward_forms_vs_fp64(B, H, W, Cin, K):
+    """conv_stream.hip (1x1 convs with a short reduction on large maps: weights in LDS, rows private to a wave, accumulators
+    stored straight from the MFMA layout): training forms -- raw output + BatchNorm tile statistics, with and without the
+    BatchNorm + ReLU operand prologue -- and inference forms -- relu(bn(conv) [+ residual]) -- against fp64."""
+    import ctypes as C
+    from dpft_amd.hip import ops
+    from dpft_amd.hip.lib import lib
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B * 1000 + H + K)
+    cv = ops.conv_problem(B, H, W, Cin, K, 1, 1, 1, 0)
+    tr = C.c_int32(0)
+    tiles = int(lib.dpft_conv2d_stats_tiles(C.byref(cv.desc), C.byref(tr)))
+    M = B * H * W
+    assert tr.value % 128 == 0 and tiles == -(-M // tr.value) and tiles == cv.tiles      # the streaming kernel's row tiling
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.3 + 0.2)
+    w = torch.randn(K, 1, 1, Cin, generator=g) / Cin ** 0.5
+    mean, invstd = torch.randn(Cin, generator=g) * 0.4, torch.rand(Cin, generator=g) + 0.5
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    block = torch.stack((mean, gamma * invstd, beta, invstd)).contiguous()
+    xd, wd = x.to(dev), w.to(dev)
+    w64 = w.double().reshape(K, Cin)
+    for pro in (None, (block.to(dev), True)):
+        y, stats = ops.conv_fwd(cv, xd, wd, pro=pro, want_stats=True)
+        a64 = x.double().reshape(M, Cin)
+        if pro is not None:
+            a64 = ((a64 - mean.double()) * (gamma * invstd).double() + beta.double()).relu()
+        ref = a64 @ w64.t()
+        got = y.double().cpu().reshape(M, K)
+        assert float((got - ref).abs().max()) < 2e-6 * float(ref.abs().max()), ("prologue" if pro else "plain")
+        cnt = torch.full((tiles,), float(tr.value), dtype=torch.float64)
+        cnt[-1] = M - tr.value * (tiles - 1)
+        st = stats.double().cpu()
+        mu = (st[:, 0] * cnt[:, None]).sum(0) / M
+        m2 = st[:, 1].sum(0) + (cnt[:, None] * (st[:, 0] - mu) ** 2).sum(0)
+        assert float((mu - ref.mean(0)).abs().max()) < 2e-6 * float(ref.abs().max())
+        assert float((m2 / M - ref.var(0, unbiased=False)).abs().max()) < 1e-5 * float(ref.var(0).max())
+        # per-tile pairs, not only their merge
+        t0 = ref[: tr.value]
+        assert float((st[0, 0] - t0.mean(0)).abs().max()) < 2e-6 * float(ref.abs().max())
+        assert float((st[0, 1] - ((t0 - t0.mean(0)) ** 2).sum(0)).abs().max()) < 1e-5 * float(((t0 - t0.mean(0)) ** 2).sum(0).max())
+    og, ob = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g) * 0.3
+    orm, orv = torch.randn(K, generator=g) * 0.2, torch.rand(K, generator=g) + 0.3
+    bnp = ops.bn_eval_params(og.to(dev), ob.to(dev), orm.to(dev), orv.to(dev), 1e-5)
+    res = torch.randn(B, H, W, K, generator=g)
+    conv = x.double().reshape(M, Cin) @ w64.t()
+    bn = (conv - orm.double()) / (orv.double() + 1e-5).sqrt() * og.double() + ob.double()
+    for r, relu in ((None, True), (res, True), (res, False)):
+        y = ops.conv_fwd_bnact(cv, xd, wd, bnp, relu=relu, residual=None if r is None else r.to(dev))
+        ref = bn if r is None else bn + r.double().reshape(M, K)
+        ref = ref.relu() if relu else ref
+        torch.testing.assert_close(y.double().cpu().reshape(M, K), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()) + 1e-6)
