@@ -31,12 +31,13 @@ struct StreamArgs {
     int orelu;
     int M, N;
     int rbw;             // 32-row blocks per wave
-    int nslices;         // N / 256
+    int nslices;         // N / (columns per workgroup)
 };
 
-template <int KC, bool PRO, bool EVAL>
-__global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
-    constexpr int NB = 256, CHK = KC / 4, NJ = KC / 8;      // chunks (16 B) per row; chunk pairs (one per lane half)
+// KC input channels; NB output columns per workgroup (its weight slice [NB][KC] lives in LDS); NW waves per workgroup
+template <int KC, int NB, int NW, bool PRO, bool EVAL>
+__global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(StreamArgs a) {
+    constexpr int NT = NW * 64, NCB = NB / 32, CHK = KC / 4, NJ = KC / 8;      // chunks (16 B) per row; chunk pairs (one per lane half)
     extern __shared__ __attribute__((aligned(16))) float smem[];      // weights [256][KC] | prologue table [3][KC]; at the end: statistics merge
     DPFT_SETPRIO_IGEMM();
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -44,15 +45,15 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
     const int n0 = slice * NB;
     // ---- weights of the slice -> LDS (chunk c of row r at position c ^ (r & 15)) ----
 #pragma unroll 4
-    for (int i = 0; i < CHK; ++i) {
-        const int idx = tid + i * 256;
+    for (int i = 0; i < NB * CHK / NT; ++i) {
+        const int idx = tid + i * NT;
         const int row = idx / CHK, c = idx - row * CHK;
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.w + (size_t)(n0 + row) * KC + c * 4);
         *reinterpret_cast<f32x4*>(smem + row * KC + ((c ^ (row & 15)) << 2)) = v;
     }
     float* ptab = smem + NB * KC;
     if constexpr (PRO) {
-        for (int i = tid; i < 3 * KC; i += 256) ptab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
+        for (int i = tid; i < 3 * KC; i += NT) ptab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
     }
     __syncthreads();
     // (restrict: without it every block's residual loads wait for the previous block's stores -- s_waitcnt vmcnt(0) -- because
@@ -63,11 +64,11 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
     const float* __restrict__ const obnp = a.obn;
     const int r32 = lane & 31, h = lane >> 5;
     const int nrb = (a.M + 31) / 32;
-    const int rb0 = (wg * 4 + wave) * a.rbw, rb1 = min(nrb, rb0 + a.rbw);
+    const int rb0 = (wg * NW + wave) * a.rbw, rb1 = min(nrb, rb0 + a.rbw);
     // running per-column statistics of this wave (column = n0 + cb * 32 + r32; both lane halves hold the same values)
-    float s_n = 0.f, s_mean[8], s_m2[8];
+    float s_n = 0.f, s_mean[NCB], s_m2[NCB];
 #pragma unroll
-    for (int cb = 0; cb < 8; ++cb) { s_mean[cb] = 0.f; s_m2[cb] = 0.f; }
+    for (int cb = 0; cb < NCB; ++cb) { s_mean[cb] = 0.f; s_m2[cb] = 0.f; }
     typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
     const unsigned lds_base = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
     // fragment address of (column block 0, chunk pair j): row r32, chunk (2 j + h) ^ (r32 & 15)
@@ -81,15 +82,20 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
         f32x4 af[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) af[j] = *reinterpret_cast<const f32x4*>(xp + (size_t)row * KC + (2 * j + h) * 4);
-        if constexpr (PRO) {
+        if constexpr (PRO) {      // (four chunk pairs at a time: all NJ parameter triples in flight at once spilled at C = 256)
+            static_for<NJ / 4>([&](auto G) {
+                constexpr int g = decltype(G)::value;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const f32x4 mu = *reinterpret_cast<const f32x4*>(ptab + (2 * j + h) * 4);
-                const f32x4 sc = *reinterpret_cast<const f32x4*>(ptab + KC + (2 * j + h) * 4);
-                const f32x4 sh = *reinterpret_cast<const f32x4*>(ptab + 2 * KC + (2 * j + h) * 4);
+                for (int jj = 0; jj < 4; ++jj) {
+                    const int j = g * 4 + jj;
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(ptab + (2 * j + h) * 4);
+                    const f32x4 sc = *reinterpret_cast<const f32x4*>(ptab + KC + (2 * j + h) * 4);
+                    const f32x4 sh = *reinterpret_cast<const f32x4*>(ptab + 2 * KC + (2 * j + h) * 4);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) af[j][e] = fmaxf(fmaf(af[j][e] - mu[e], sc[e], sh[e]), 0.f);
-            }
+                    for (int e = 0; e < 4; ++e) af[j][e] = fmaxf(fmaf(af[j][e] - mu[e], sc[e], sh[e]), 0.f);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
         }
         // Output / residual addressing: one per-lane base (row m0 + 4 h, this lane's column) per block; the 16 rows of an
         // accumulator are wave-uniform multiples of N away from it -- scalar offsets, no vector address arithmetic beside the
@@ -116,13 +122,13 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
             }
         };
         load_res(std::integral_constant<int, 0>{});
-        static_for<8>([&](auto CB_) {
+        static_for<NCB>([&](auto CB_) {
             constexpr int cb = decltype(CB_)::value;
             const int col = n0 + cb * 32 + r32;
             float* __restrict__ const yb = yp + lane_off + cb * 32;
             float omu = 0.f, osc = 1.f, obe = 0.f;
             if constexpr (EVAL) { omu = obnp[col]; osc = obnp[a.N + col]; obe = obnp[2 * a.N + col]; }
-            if constexpr (cb + 1 < 8) load_res(std::integral_constant<int, (cb + 1 < 8 ? cb + 1 : 0)>{});
+            if constexpr (cb + 1 < NCB) load_res(std::integral_constant<int, (cb + 1 < NCB ? cb + 1 : 0)>{});
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -180,20 +186,20 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
     if constexpr (!EVAL) {
         if (a.stats) {      // the four waves' pairs -> one (mean, M2) per column of the workgroup's rows
             __syncthreads();      // every wave is done with the weights
-            float* sm = smem;     // [4][3][256]
+            float* sm = smem;     // [NW][3][NB]
             if (h == 0) {
 #pragma unroll
-                for (int cb = 0; cb < 8; ++cb) {
+                for (int cb = 0; cb < NCB; ++cb) {
                     sm[(wave * 3 + 0) * NB + cb * 32 + r32] = s_n;
                     sm[(wave * 3 + 1) * NB + cb * 32 + r32] = s_mean[cb];
                     sm[(wave * 3 + 2) * NB + cb * 32 + r32] = s_m2[cb];
                 }
             }
             __syncthreads();
-            {
+            if (tid < NB) {
                 float n = 0.f, mean = 0.f, m2 = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < 4; ++wv) {
+                for (int wv = 0; wv < NW; ++wv) {
                     const float nb = sm[(wv * 3 + 0) * NB + tid], mb = sm[(wv * 3 + 1) * NB + tid], qb = sm[(wv * 3 + 2) * NB + tid];
                     if (nb > 0.f) {
                         const float nn = n + nb, dl = mb - mean;
@@ -214,49 +220,59 @@ __global__ __launch_bounds__(256) void conv1x1_stream_kernel(StreamArgs a) {
 // ---- host side -------------------------------------------------------------------------------------------------------
 // Which problems take the kernel, and its row tiling (the statistics tile = the rows of one workgroup = 128 * rbw): decided
 // from the descriptor alone so that dpft_conv2d_stats_tiles and the launch agree.  DPFT_STREAM1X1=0: off (A/B switch).
+// geometry per input-channel count: columns per workgroup (its weight slice: NB x C x 4 bytes of LDS) and waves per workgroup
+static bool stream_geom(int C, int& nb, int& nw) {
+    // (C = 256 with 128-column slices on eight waves -- a 128 KB slice, 128 fragment registers per lane -- measured 54 us against
+    // the tiled kernel's 48.9 on the layer-3 conv3 shape: one workgroup per CU, and every wave starts behind a 128 KB weight load)
+    if (C == 64 || C == 128) { nb = 256; nw = 4; return true; }      // 64 / 128 KB: two / one workgroup(s) per CU
+    return false;
+}
+
 bool stream1x1_match(const dpft_conv_desc* d, int* tile_rows) {
     static const int on = getenv("DPFT_STREAM1X1") ? atoi(getenv("DPFT_STREAM1X1")) : 1;
-    static const int min_rows = getenv("DPFT_STREAM1X1_MINROWS") ? atoi(getenv("DPFT_STREAM1X1_MINROWS")) : 16384;
+    static const int min_rows = getenv("DPFT_STREAM1X1_MINROWS") ? atoi(getenv("DPFT_STREAM1X1_MINROWS")) : 4096;
     if (!on || d->act16 || d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0) return false;
-    if ((d->C != 64 && d->C != 128) || (d->K % 256) != 0 || d->a_planes || d->w_planes) return false;
+    int nb = 0, nw = 0;
+    if (!stream_geom(d->C, nb, nw) || (d->K % 256) != 0 || d->a_planes || d->w_planes) return false;
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
-    if (M < min_rows || M * std::max(d->C, d->K) >= (1ll << 31)) return false;
+    // enough row blocks to give every wave of a chip-filling grid one: the latency-sized problems keep the tiled kernels
+    if (M < min_rows || (M / 32) * (d->K / nb) < 2 * kNumCU || M * std::max(d->C, d->K) >= (1ll << 31)) return false;
     if (tile_rows) {
         const int64_t nrb = (M + 31) / 32;
-        int rbw = (int)((nrb + 4 * 2048 - 1) / (4 * 2048));      // at most ~2048 workgroups per column slice
-        *tile_rows = 128 * (rbw < 1 ? 1 : rbw);
+        int rbw = (int)((nrb + nw * 2048 - 1) / (nw * 2048));      // at most ~2048 workgroups per column slice
+        *tile_rows = 32 * nw * (rbw < 1 ? 1 : rbw);
     }
     return true;
 }
 
 int launch_stream1x1(const dpft_conv_desc* d, const float* x, const float* w, const float* pro_bn, float* y, float* stats,
                      const float* out_bn, const float* residual, int relu, hipStream_t st) {
-    int tile_rows = 0;
-    DPFT_REQUIRE(stream1x1_match(d, &tile_rows), "conv 1x1 (streaming): problem not supported");
+    int tile_rows = 0, nb = 0, nw = 0;
+    DPFT_REQUIRE(stream1x1_match(d, &tile_rows) && stream_geom(d->C, nb, nw), "conv 1x1 (streaming): problem not supported");
     DPFT_REQUIRE(!(out_bn && (stats || pro_bn)), "conv 1x1 (streaming): inference epilogue takes no prologue / statistics");
     StreamArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = w; a.y = y; a.pro = pro_bn; a.stats = stats; a.obn = out_bn; a.oadd = residual; a.orelu = relu;
     a.M = d->B * d->OH * d->OW; a.N = d->K;
-    a.rbw = tile_rows / 128;
-    a.nslices = d->K / 256;
+    a.rbw = tile_rows / (32 * nw);
+    a.nslices = d->K / nb;
     const int wgs = cdiv(a.M, tile_rows);
-    const dim3 grid(wgs * a.nslices), block(256);
-    const size_t lds = (size_t)256 * d->C * 4 + (size_t)3 * d->C * 4;
+    const dim3 grid(wgs * a.nslices), block(nw * 64);
+    const size_t lds = (size_t)nb * d->C * 4 + (size_t)3 * d->C * 4;
     auto go = [&](auto kernel) {
         static LdsGrant grant;
         (void)lds_grant(grant, reinterpret_cast<const void*>(kernel), lds);
         hipLaunchKernelGGL(kernel, grid, block, lds, st, a);
     };
-    if (d->C == 64) {
-        if (out_bn) go(conv1x1_stream_kernel<64, false, true>);
-        else if (pro_bn) go(conv1x1_stream_kernel<64, true, false>);
-        else go(conv1x1_stream_kernel<64, false, false>);
-    } else {
-        if (out_bn) go(conv1x1_stream_kernel<128, false, true>);
-        else if (pro_bn) go(conv1x1_stream_kernel<128, true, false>);
-        else go(conv1x1_stream_kernel<128, false, false>);
-    }
+#define STREAM_FORMS(KC_, NB_, NW_)                                                          \
+    do {                                                                                     \
+        if (out_bn) go(conv1x1_stream_kernel<KC_, NB_, NW_, false, true>);                   \
+        else if (pro_bn) go(conv1x1_stream_kernel<KC_, NB_, NW_, true, false>);              \
+        else go(conv1x1_stream_kernel<KC_, NB_, NW_, false, false>);                         \
+    } while (0)
+    if (d->C == 64) STREAM_FORMS(64, 256, 4);
+    else STREAM_FORMS(128, 256, 4);
+#undef STREAM_FORMS
     return check_launch("conv 1x1 (streaming, short reduction)");
 }
 
