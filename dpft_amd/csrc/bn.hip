@@ -200,6 +200,63 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
     }
 }
 
+// bn_act_kernel<float> for launches whose grid stride is a multiple of K / 4 (round 6, as bn_bwd_apply_fixc_kernel): the
+// thread's parameter quads are loaded once, two element quads per tensor in flight.  Same expression per element.
+template <int U>
+__global__ __launch_bounds__(256) void bn_act_fixc_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
+                                                           const float* __restrict__ res, const float* __restrict__ rbnp,
+                                                           int relu, float* __restrict__ out, int64_t n4, int K4,
+                                                           unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
+    const int K = K4 * 4;
+    const unsigned stride = gridDim.x * blockDim.x;      // % K4 == 0, n4 < 2^30 (host)
+    const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(first % (unsigned)K4) * 4;
+    const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + K + c);
+    const f32x4 be = *reinterpret_cast<const f32x4*>(bnp + 2 * K + c);
+    f32x4 rmu = mu, rsc = sc, rbe = be;
+    if (rbnp) {
+        rmu = *reinterpret_cast<const f32x4*>(rbnp + c);
+        rsc = *reinterpret_cast<const f32x4*>(rbnp + K + c);
+        rbe = *reinterpret_cast<const f32x4*>(rbnp + 2 * K + c);
+    }
+    const unsigned n = (unsigned)n4;
+    for (unsigned i0 = first; i0 < n; i0 += U * stride) {
+        f32x4 yv[U], rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i < n) {
+                yv[u] = reinterpret_cast<const f32x4*>(y)[i];
+                if (res) rv[u] = reinterpret_cast<const f32x4*>(res)[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i >= n) break;
+            f32x4 v = yv[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaf(v[e] - mu[e], sc[e], be[e]);
+            if (res) {
+                f32x4 r = rv[u];
+                if (rbnp) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) r[e] = fmaf(r[e] - rmu[e], rsc[e], rbe[e]);
+                }
+                v += r;
+            }
+            if (relu) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            reinterpret_cast<f32x4*>(out)[i] = v;
+            if (mask8) mask8[i] = (unsigned char)((v[0] > 0.f ? 1 : 0) | (v[1] > 0.f ? 2 : 0) | (v[2] > 0.f ? 4 : 0) | (v[3] > 0.f ? 8 : 0));
+        }
+    }
+}
+
 // bf16 storage with 16-byte accesses (round 4): a lane handles 8 consecutive channels per access (the 4-channel form above
 // moves 8 bytes per lane and access; these passes are pure HBM streaming and ran at 2.8 TB/s), two accesses per tensor in
 // flight.  K % 8 == 0; same arithmetic per element as bn_act_kernel<__bf16>.
@@ -602,6 +659,86 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// BN backward pass 2, fp32, for launches whose grid stride is a multiple of K / 4 (round 6): a thread then meets the SAME four
+// channels in every trip -- its five parameter quads are loaded once -- and keeps U element quads of both tensors in flight.
+// Why: inside the training step this pass shares its CUs with the weight-gradient stream's workgroups (the split kernels hold
+// 456 of a SIMD's 512 registers: ONE wave of this kernel fits beside them), and with one trip's two loads per wave in flight
+// it ran 2.3x slower there than alone (3.5 ms of the main queue, profiles/r06_bn_in_step.txt).  Stays within 56 registers so
+// that it still fits beside such a wave.  Same expression per element as bn_bwd_apply_kernel.
+template <int U>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_num_vgpr(56)))
+void bn_bwd_apply_fixc_kernel(const float* __restrict__ y, const float* __restrict__ dout, const float* __restrict__ outp,
+                              const float* __restrict__ mbnp, const float* __restrict__ bnp, const float* __restrict__ gamma,
+                              const float* __restrict__ sums, float* __restrict__ dy, float* __restrict__ dgamma,
+                              float* __restrict__ dbeta, int64_t n4, int K, float invM, float* __restrict__ zero_buf, int zero_n,
+                              const unsigned char* __restrict__ mask8) {
+    DPFT_SETPRIO_BN();
+    const int K4 = K / 4;
+    if (blockIdx.x == 0) {
+        for (int c = threadIdx.x; c < K; c += blockDim.x) {
+            if (dbeta) dbeta[c] = sums[c];
+            if (dgamma) dgamma[c] = sums[K + c];
+        }
+        for (int c = threadIdx.x; c < zero_n; c += blockDim.x) zero_buf[c] = 0.f;
+    }
+    const unsigned stride = gridDim.x * blockDim.x;      // % K4 == 0 (host); n4 < 2^31 (host)
+    const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(first % (unsigned)K4) * 4;
+    // r = ga is (d - s0 / M - xhat s1 / M),  xhat = (y - mu) is   ==   A d + P + Q y  with three constants per channel
+    // (12 registers instead of 20 for the five parameter quads: the kernel has to stay within 56)
+    f32x4 A, P, Q;
+    {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
+        const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            A[e] = ga[e] * is[e];
+            Q[e] = -A[e] * is[e] * (s1[e] * invM);
+            P[e] = -A[e] * (s0[e] * invM) - Q[e] * mu[e];
+        }
+    }
+    const unsigned n = (unsigned)n4;
+    for (unsigned i0 = first; i0 < n; i0 += U * stride) {
+        f32x4 dq[U], yq[U];
+        unsigned mq[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i < n) {
+                dq[u] = reinterpret_cast<const f32x4*>(dout)[i];
+                yq[u] = reinterpret_cast<const f32x4*>(y)[i];
+                if (mask8) mq[u] = mask8[i];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const unsigned i = i0 + u * stride;
+            if (i >= n) break;
+            f32x4 d = dq[u];
+            const f32x4 yv = yq[u];
+            if (mask8) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = ((mq[u] >> e) & 1u) ? d[e] : 0.f;
+            } else if (outp) {
+                const f32x4 o = reinterpret_cast<const f32x4*>(outp)[i];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = o[e] > 0.f ? d[e] : 0.f;
+            } else if (mbnp) {
+                const f32x4 a = bn_apply4(yv, mbnp, K, c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = a[e] > 0.f ? d[e] : 0.f;
+            }
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = fmaf(A[e], d[e], fmaf(Q[e], yv[e], P[e]));
+            reinterpret_cast<f32x4*>(dy)[i] = r;
+        }
+    }
+}
+
 // BN backward pass 2, bf16 storage with 16-byte accesses (see bn_act16_kernel); K % 8 == 0
 __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                               const float* __restrict__ outp, const float* __restrict__ mbnp,
@@ -844,9 +981,26 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
     else if (act16)
         hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
                            res_bnp, relu, out, out32, n4, K / 4, mask8);
-    else
-        hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
-                           res_bnp, relu, out, out32, n4, K / 4, mask8);
+    else {
+        static const int fixc = getenv("DPFT_BN_FIXC") ? atoi(getenv("DPFT_BN_FIXC")) : 2;      // see bn_bwd_apply_zeroing
+        const int K4 = K / 4;
+        int blocks = ew_blocks(n4);
+        bool ok = fixc > 0 && !out32 && n4 >= 4096 && n4 < (1ll << 30);
+        if (ok && (256 % K4) != 0) {
+            const int f = K4 / 256;
+            ok = (K4 % 256) == 0 && blocks >= f;
+            if (ok) blocks -= blocks % f;
+        }
+        if (ok && fixc >= 2)
+            hipLaunchKernelGGL(bn_act_fixc_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
+                               K4, mask8);
+        else if (ok)
+            hipLaunchKernelGGL(bn_act_fixc_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
+                               K4, mask8);
+        else
+            hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
+                               res_bnp, relu, out, out32, n4, K / 4, mask8);
+    }
     return check_launch("bn_act");
 }
 
@@ -965,9 +1119,30 @@ int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* o
     else if (act16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
                            mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
-    else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
-                           mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
+    else {
+        // fixed-channel form (see bn_bwd_apply_fixc_kernel): the grid stride must be a multiple of K / 4.  DPFT_BN_FIXC=0: off; =U: quads in flight
+        static const int fixc = getenv("DPFT_BN_FIXC") ? atoi(getenv("DPFT_BN_FIXC")) : 2;
+        const int K4 = K / 4;
+        int blocks = ew_blocks(n4);
+        bool ok = fixc > 0 && n4 >= 4096 && n4 < (1ll << 30);
+        if (ok && (256 % K4) != 0) {      // K4 = 512 ...: the block count itself must carry the remaining factor
+            const int f = K4 / 256;
+            ok = (K4 % 256) == 0 && blocks >= f;
+            if (ok) blocks -= blocks % f;
+        }
+        if (ok && fixc >= 3)
+            hipLaunchKernelGGL(bn_bwd_apply_fixc_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
+                               gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
+        else if (ok && fixc == 2)
+            hipLaunchKernelGGL(bn_bwd_apply_fixc_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
+                               gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
+        else if (ok)
+            hipLaunchKernelGGL(bn_bwd_apply_fixc_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
+                               gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
+                               mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);
+    }
     return check_launch("bn_bwd_apply");
 }
 
