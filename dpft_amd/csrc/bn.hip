@@ -274,6 +274,9 @@ __device__ __forceinline__ u32x4_t narrow8(f32x4 lo, f32x4 hi) {
 __device__ __forceinline__ unsigned relu_bits(f32x4 v) {
     return (v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u);
 }
+// FIXC (round 6): the grid stride is a multiple of K / 8 -- a thread meets the same 8 channels in every trip and loads their
+// parameters once (as bn_act_fixc_kernel)
+template <bool FIXC>
 __global__ __launch_bounds__(256) void bn_act16_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
                                                         const float* __restrict__ res, const float* __restrict__ rbnp,
                                                         int relu, float* __restrict__ out, float* __restrict__ out32,
@@ -284,6 +287,22 @@ __global__ __launch_bounds__(256) void bn_act16_kernel(const float* __restrict__
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const u32x4_t* __restrict__ y8 = reinterpret_cast<const u32x4_t*>(y);
     const u32x4_t* __restrict__ r8 = reinterpret_cast<const u32x4_t*>(res);
+    const int cfix = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % K8) * 8;
+    f32x4 pmu[2], psc[2], pbe[2], qmu[2], qsc[2], qbe[2];
+    if constexpr (FIXC) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            pmu[hh] = *reinterpret_cast<const f32x4*>(bnp + cfix + 4 * hh);
+            psc[hh] = *reinterpret_cast<const f32x4*>(bnp + K + cfix + 4 * hh);
+            pbe[hh] = *reinterpret_cast<const f32x4*>(bnp + 2 * K + cfix + 4 * hh);
+            qmu[hh] = pmu[hh]; qsc[hh] = psc[hh]; qbe[hh] = pbe[hh];
+            if (rbnp) {
+                qmu[hh] = *reinterpret_cast<const f32x4*>(rbnp + cfix + 4 * hh);
+                qsc[hh] = *reinterpret_cast<const f32x4*>(rbnp + K + cfix + 4 * hh);
+                qbe[hh] = *reinterpret_cast<const f32x4*>(rbnp + 2 * K + cfix + 4 * hh);
+            }
+        }
+    }
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n8; i0 += U * stride) {
         u32x4_t yv[U], rv[U];
 #pragma unroll
@@ -298,16 +317,28 @@ __global__ __launch_bounds__(256) void bn_act16_kernel(const float* __restrict__
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i >= n8) break;
-            const int c = (int)(i % K8) * 8;
+            const int c = FIXC ? cfix : (int)(i % K8) * 8;
             f32x4 v[2], r[2];
             widen8(yv[u], v[0], v[1]);
             if (res) widen8(rv[u], r[0], r[1]);
             unsigned bits = 0;
 #pragma unroll
             for (int hh = 0; hh < 2; ++hh) {
-                v[hh] = bn_apply4(v[hh], bnp, K, c + 4 * hh);
+                if constexpr (FIXC) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[hh][e] = fmaf(v[hh][e] - pmu[hh][e], psc[hh][e], pbe[hh][e]);
+                } else {
+                    v[hh] = bn_apply4(v[hh], bnp, K, c + 4 * hh);
+                }
                 if (res) {
-                    if (rbnp) r[hh] = bn_apply4(r[hh], rbnp, K, c + 4 * hh);
+                    if (rbnp) {
+                        if constexpr (FIXC) {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) r[hh][e] = fmaf(r[hh][e] - qmu[hh][e], qsc[hh][e], qbe[hh][e]);
+                        } else {
+                            r[hh] = bn_apply4(r[hh], rbnp, K, c + 4 * hh);
+                        }
+                    }
                     v[hh] += r[hh];
                 }
                 if (relu) {
@@ -740,6 +771,7 @@ void bn_bwd_apply_fixc_kernel(const float* __restrict__ y, const float* __restri
 }
 
 // BN backward pass 2, bf16 storage with 16-byte accesses (see bn_act16_kernel); K % 8 == 0
+template <bool FIXC>      // FIXC: as bn_act16_kernel (three precombined constants per channel, see bn_bwd_apply_fixc_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const float* __restrict__ y, const float* __restrict__ dout,
                                                               const float* __restrict__ outp, const float* __restrict__ mbnp,
                                                               const float* __restrict__ bnp, const float* __restrict__ gamma,
@@ -761,6 +793,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const float* __rest
     const u32x4_t* __restrict__ d8 = reinterpret_cast<const u32x4_t*>(dout);
     const u32x4_t* __restrict__ y8 = reinterpret_cast<const u32x4_t*>(y);
     const u32x4_t* __restrict__ o8 = reinterpret_cast<const u32x4_t*>(outp);
+    const int cfix = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % K8) * 8;
+    f32x4 cA[2], cP[2], cQ[2];
+    if constexpr (FIXC) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+            const int c = cfix + 4 * hh;
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+            const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c);
+            const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
+            const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                cA[hh][e] = ga[e] * is[e];
+                cQ[hh][e] = -cA[hh][e] * is[e] * (s1[e] * invM);
+                cP[hh][e] = -cA[hh][e] * (s0[e] * invM) - cQ[hh][e] * mu[e];
+            }
+        }
+    }
     for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i0 < n8; i0 += U * stride) {
         u32x4_t dq[U], yq[U], oq[U];
         unsigned mq[U];
@@ -778,7 +829,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const float* __rest
         for (int u = 0; u < U; ++u) {
             const int64_t i = i0 + u * stride;
             if (i >= n8) break;
-            const int c0 = (int)(i % K8) * 8;
+            const int c0 = FIXC ? cfix : (int)(i % K8) * 8;
             f32x4 d[2], yv[2], o[2], r[2];
             widen8(dq[u], d[0], d[1]);
             widen8(yq[u], yv[0], yv[1]);
@@ -798,15 +849,20 @@ __global__ __launch_bounds__(256) void bn_bwd_apply16_kernel(const float* __rest
 #pragma unroll
                     for (int e = 0; e < 4; ++e) d[hh][e] = a[e] > 0.f ? d[hh][e] : 0.f;
                 }
-                const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
-                const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c);
-                const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
-                const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
-                const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
+                if constexpr (FIXC) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float xh = (yv[hh][e] - mu[e]) * is[e];
-                    r[hh][e] = ga[e] * is[e] * (d[hh][e] - s0[e] * invM - xh * s1[e] * invM);
+                    for (int e = 0; e < 4; ++e) r[hh][e] = fmaf(cA[hh][e], d[hh][e], fmaf(cQ[hh][e], yv[hh][e], cP[hh][e]));
+                } else {
+                    const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
+                    const f32x4 is = *reinterpret_cast<const f32x4*>(bnp + 3 * K + c);
+                    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c);
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(sums + c);
+                    const f32x4 s1 = *reinterpret_cast<const f32x4*>(sums + K + c);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (yv[hh][e] - mu[e]) * is[e];
+                        r[hh][e] = ga[e] * is[e] * (d[hh][e] - s0[e] * invM - xh * s1[e] * invM);
+                    }
                 }
             }
             reinterpret_cast<u32x4_t*>(dy)[i] = narrow8(r[0], r[1]);
@@ -919,6 +975,19 @@ __global__ __launch_bounds__(256) void add_pos_kernel(float* __restrict__ x, con
     }
 }
 
+// fixed-channel forms (round 6): can the launch's grid stride (blocks x 256) be a multiple of `kq` channel groups?  May lower
+// `blocks` to make it so.  DPFT_BN_FIXC=0: off (A/B switch).
+static inline bool fixc_grid(int kq, int64_t items, int& blocks) {
+    static const int fixc = getenv("DPFT_BN_FIXC") ? atoi(getenv("DPFT_BN_FIXC")) : 2;
+    if (fixc <= 0 || items < 4096 || items >= (1ll << 30) || kq <= 0) return false;
+    if ((256 % kq) == 0) return true;
+    if ((kq % 256) != 0) return false;
+    const int f = kq / 256;
+    if (blocks < f) return false;
+    blocks -= blocks % f;
+    return true;
+}
+
 static inline int ew_blocks(int64_t work_items) {
     return (int)std::max<int64_t>(1, std::min<int64_t>((work_items + 255) / 256, (int64_t)kNumCU * 8));
 }
@@ -976,8 +1045,15 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
     static const bool wide16 = getenv("DPFT_BN_WIDE16") == nullptr || atoi(getenv("DPFT_BN_WIDE16")) != 0;      // A/B switch
     if (act16 && wide16 && K % 8 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)res & 15) == 0 &&
         ((uintptr_t)mask8 & 1) == 0)
-        hipLaunchKernelGGL(bn_act16_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
-                           out32, n4 / 2, K / 8, mask8);
+    {
+        int blocks = ew_blocks(n4 / 2);
+        if (fixc_grid(K / 8, n4 / 2, blocks))
+            hipLaunchKernelGGL(bn_act16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
+                               out32, n4 / 2, K / 8, mask8);
+        else
+            hipLaunchKernelGGL(bn_act16_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
+                               out32, n4 / 2, K / 8, mask8);
+    }
     else if (act16)
         hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
                            res_bnp, relu, out, out32, n4, K / 4, mask8);
@@ -1114,8 +1190,15 @@ int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* o
     static const bool wide16 = getenv("DPFT_BN_WIDE16") == nullptr || atoi(getenv("DPFT_BN_WIDE16")) != 0;      // A/B switch
     if (act16 && wide16 && K % 8 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)dout & 15) == 0 && ((uintptr_t)dy & 15) == 0 &&
         ((uintptr_t)out & 15) == 0 && ((uintptr_t)mask8 & 1) == 0)
-        hipLaunchKernelGGL(bn_bwd_apply16_kernel, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
-                           gamma, sums, dy, dgamma, dbeta, n4 / 2, K, invM, zero_buf, (int)zero_n, mask8);
+    {
+        int blocks = ew_blocks(n4 / 2);
+        if (fixc_grid(K / 8, n4 / 2, blocks))
+            hipLaunchKernelGGL(bn_bwd_apply16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
+                               gamma, sums, dy, dgamma, dbeta, n4 / 2, K, invM, zero_buf, (int)zero_n, mask8);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply16_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, dout, out, mask_bnp, bnp,
+                               gamma, sums, dy, dgamma, dbeta, n4 / 2, K, invM, zero_buf, (int)zero_n, mask8);
+    }
     else if (act16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, dout, out,
                            mask_bnp, bnp, gamma, sums, dy, dgamma, dbeta, n4, K, invM, zero_buf, (int)zero_n, mask8);

@@ -30,7 +30,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
         for r in csv.DictReader(open(f[0])):
             if r.get("Counter_Name") != c: continue
             n = r["Kernel_Name"]
-            key = "igemm" if ("igemm" in n or "conv16_" in n or "thin_dgrad" in n) else "wgrad" if ("wgrad" in n) else "splitk" if ("splitk" in n or "slab_reduce" in n) else None
+            key = "igemm" if ("igemm" in n or "conv16_" in n or "thin_dgrad" in n or "conv1x1_stream" in n) else "wgrad" if ("wgrad" in n) else "splitk" if ("splitk" in n or "slab_reduce" in n) else None
             if key is None: continue
             agg[key][0] += float(r["Counter_Value"]); agg[key][1] += 1
     raw[c] = {k: {"sum": v[0], "launches": v[1]} for k, v in agg.items()}

@@ -25,7 +25,7 @@ import re
 import sys
 
 MAIN = ("igemm_vec_kernel", "igemm_gen_kernel", "igemm_pipe_kernel", "igemm_x3_kernel", "igemm_x3p_kernel", "wgrad_x3_kernel", "wgrad_pipe_kernel", "wgrad_pipe16_kernel", "wgrad_vec_kernel", "wgrad_gen_kernel", "thin_dgrad_kernel",
-        "conv16_", "wgrad16_", "thin_wgrad", "wgrad_stem7_kernel", "conv1x1_to16_kernel", "wgrad1x1_")
+        "conv16_", "wgrad16_", "thin_wgrad", "wgrad_stem7_kernel", "conv1x1_to16_kernel", "wgrad1x1_", "conv1x1_stream_kernel", "igemm_b16w_kernel")
 AUX = ("splitk_reduce", "slab_reduce", "bias_grad_kernel", "zero_fill_kernel")
 GROUPS = {"bn": ("bn_",), "decoder_train": ("sa_train", "xf_train", "hd_train", "pack_"),
           "decoder_infer": ("decoder_selfattn", "decoder_xattn"), "loss": ("match_cost", "set_loss", "giou3d", "lsap_batch"),
@@ -61,7 +61,7 @@ def family_of(name: str) -> str:
     """Kernel name (with template arguments) -> the pipe it runs on."""
     if "_x3_kernel" in name or "_x3p_kernel" in name:
         return "x3"
-    if "wgrad_pipe16" in name:
+    if "wgrad_pipe16" in name or "igemm_b16w_kernel" in name:
         return "bf16"
     m = re.search(r"igemm_pipe_kernel<([^>]*)>", name)
     if m:
