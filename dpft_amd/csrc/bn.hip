@@ -989,7 +989,8 @@ static inline bool fixc_grid(int kq, int64_t items, int& blocks) {
 }
 
 static inline int ew_blocks(int64_t work_items) {
-    return (int)std::max<int64_t>(1, std::min<int64_t>((work_items + 255) / 256, (int64_t)kNumCU * 8));
+    static const int per_cu = getenv("DPFT_EW_BLOCKS_PER_CU") ? atoi(getenv("DPFT_EW_BLOCKS_PER_CU")) : 8;      // tuning aid
+    return (int)std::max<int64_t>(1, std::min<int64_t>((work_items + 255) / 256, (int64_t)kNumCU * per_cu));
 }
 
 }  // namespace dpft
@@ -1206,7 +1207,10 @@ int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* o
         // fixed-channel form (see bn_bwd_apply_fixc_kernel): the grid stride must be a multiple of K / 4.  DPFT_BN_FIXC=0: off; =U: quads in flight
         static const int fixc = getenv("DPFT_BN_FIXC") ? atoi(getenv("DPFT_BN_FIXC")) : 2;
         const int K4 = K / 4;
-        int blocks = ew_blocks(n4);
+        // U quads per thread and trip: a grid of n4 / (256 U) workgroups (inside the step a CU that also holds a split weight-gradient
+        // workgroup has room for ONE wave of this kernel per SIMD: the pass runs as rounds of 256 workgroups, so fewer, fatter ones)
+        static const int fat = getenv("DPFT_BN_FAT") ? atoi(getenv("DPFT_BN_FAT")) : 1;      // A/B switch
+        int blocks = ew_blocks(fat && fixc >= 2 ? (n4 + 1) / 2 : n4);
         bool ok = fixc > 0 && n4 >= 4096 && n4 < (1ll << 30);
         if (ok && (256 % K4) != 0) {      // K4 = 512 ...: the block count itself must carry the remaining factor
             const int f = K4 / 256;
