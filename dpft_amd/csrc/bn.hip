@@ -1185,6 +1185,10 @@ int dpft::bn_bwd_apply_zeroing(const float* y, const float* dout, const float* o
                                dpft_stream_t stream, const unsigned char* mask8, bool frozen) {
     DPFT_REQUIRE(y && dout && bnp && gamma && sums && dy && M > 0 && K % 4 == 0, "bn_bwd_apply: bad arguments");
     const int64_t n4 = M * K / 4;
+    {      // timing experiment (wrong gradients): what the pass costs on the step's critical path = the step time without it
+        static const bool skip = getenv("DPFT_BN_SKIP_APPLY") != nullptr && atoi(getenv("DPFT_BN_SKIP_APPLY")) != 0;
+        if (skip) return DPFT_OK;
+    }
     // frozen (running-statistics) BatchNorm: mean and variance do not depend on the batch, so dy = gamma invstd d -- the
     // batch form with its two mean terms weighted by 1/M = 0; dgamma = sum d xhat and dbeta = sum d are the same sums
     const float invM = frozen ? 0.f : 1.0f / (float)M;

@@ -1811,6 +1811,10 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
+    {
+        static const char* skip = getenv("DPFT_SKIP");      // timing experiments (see dpft_conv2d_nhwc_wgrad_f32)
+        if (skip && ((strstr(skip, "fwd3x3") && d->kh == 3) || (strstr(skip, "fwd1x1") && d->kh == 1)) && (int64_t)d->B * d->OH * d->OW >= 4096) return DPFT_OK;
+    }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(0, d, st);
     if (conv16_matches(d) && !pro_bn && !stats) return conv16_forward(d, x, w, bias, y, st);
@@ -1937,6 +1941,13 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(dy && w_t && dx, "conv dgrad: null tensor");
+    {
+        static const char* skip = getenv("DPFT_SKIP");      // timing experiments (see dpft_conv2d_nhwc_wgrad_f32)
+        if (skip && ((strstr(skip, "dgrad3x3") && d->kh == 3) || (strstr(skip, "dgrad1x1") && d->kh == 1)) && (int64_t)d->B * d->H * d->W >= 4096) {
+            if (fuse && fuse->sums) fuse->applied = true;
+            return DPFT_OK;
+        }
+    }
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(1, d, st);
     if (conv16_matches(d)) return conv16_dgrad(d, dy, w_t, dx, accumulate, st);
@@ -2036,6 +2047,14 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(dy && w_t && dx && res_src && res_mask, "conv dgrad residual: null tensor");
+    {
+        static const char* skip = getenv("DPFT_SKIP");      // timing experiments (see dpft_conv2d_nhwc_wgrad_f32)
+        if (skip && ((strstr(skip, "dgrad3x3") && d->kh == 3) || (strstr(skip, "dgrad1x1") && d->kh == 1)) && (int64_t)d->B * d->H * d->W >= 4096) {
+            if (fuse && fuse->sums) fuse->applied = true;
+            return DPFT_OK;
+        }
+    }
+
     DPFT_REQUIRE(d->stride == 1 && !conv16_matches(d), "conv dgrad residual: stride-1 bottleneck convs only");
     hipStream_t st = (hipStream_t)stream;
     ProfScope prof(1, d, st);
@@ -2103,6 +2122,10 @@ extern "C" int dpft_conv2d_nhwc_dgrad_bn_reduce_f32(const dpft_conv_desc* d, con
 extern "C" int dpft_conv2d_nhwc_wgrad_f32(const dpft_conv_desc* d, const float* x, const float* dy,
                                           const float* pro_bn, int32_t pro_relu, float* dw,
                                           void* workspace, dpft_stream_t stream) {
+    {      // timing experiments (wrong gradients, DPFT_SKIP=...): the step time without a family = its cost on the critical path
+        static const char* skip = getenv("DPFT_SKIP");
+        if (skip && strstr(skip, "wgrad")) return DPFT_OK;
+    }
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(x && dy && dw, "conv wgrad: null tensor");
