@@ -670,6 +670,8 @@ struct WgradArgs {
 
 // conv_x3.hip: the 3 x bf16 split main loop (fp32 results from the bf16 matrix cores); `a` prepared as for igemm_pipe_kernel
 int launch_igemm_x3(IgemmArgs& a, int bm, int bn, bool dgrad, bool pro, hipStream_t st);
+// conv_x3w.hip: the same arithmetic on eight waves per 128 x 128 tile (`a` as launch_igemm_x3 prepared it)
+int launch_igemm_x3w(IgemmArgs& a, bool dgrad, bool pro, hipStream_t st);
 int split_planes(const float* src, void* dst, int64_t n, hipStream_t st);
 // conv_stream.hip: 1x1 convs with 64 / 128 input channels and K % 256 == 0 on large maps (weights in LDS, rows private to a wave)
 bool stream1x1_match(const dpft_conv_desc* d, int* tile_rows);

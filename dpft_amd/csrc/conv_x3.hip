@@ -1172,6 +1172,10 @@ int launch_igemm_x3(IgemmArgs& a, int bm, int bn, bool dgrad, bool pro, hipStrea
 #undef X3P_GO
         return check_launch("conv igemm (3 x bf16 planes)");
     }
+    // 128 x 128 tiles on eight waves, two per SIMD (conv_x3w.hip, DPFT_X3W=1): the plain form measures within 3 % of this file's
+    // hand-pipelined four-wave kernel on every 128 x 128 problem of the step (profiles/r06_x3w.txt) -- the plateau is not latency.  Off.
+    static const int x3w = getenv("DPFT_X3W") ? atoi(getenv("DPFT_X3W")) : 0;
+    if (x3w && bm == 128 && bn == 128 && !a.bnf_acc && !a.bnf_slab && (a.N & 3) == 0) return launch_igemm_x3w(a, dgrad, pro, st);
     auto lds_of = [&](int BM_, int BN_) {
         return std::max((size_t)2 * 3 * (BM_ + BN_) * 64 + (pro ? (size_t)12 * a.C : 0), (size_t)BM_ * (BN_ + 4) * 4 + (size_t)3 * BN_ * 4);
     };

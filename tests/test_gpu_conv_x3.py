@@ -138,3 +138,16 @@ def test_planes_operands_forward_and_data_gradient_vs_fp64(shape, tile, monkeypa
     # the planes path is deterministic: a second launch gives the same bits
     y2, _ = ops.conv_fwd(cv, xg, wg, want_stats=True, planes=(xp, wp))
     assert torch.equal(y, y2)
+
+
+@pytest.mark.gpu
+def test_eight_wave_split_kernel_passes_the_same_cases():
+    """conv_x3w.hip (the split GEMM on eight waves per 128 x 128 tile, off by default: DESIGN.md section 3): every case of this file
+    again in a process that has it switched on."""
+    import os, subprocess, sys
+    if os.environ.get("DPFT_X3W") == "1":
+        pytest.skip("already the eight-wave run")
+    env = dict(os.environ, DPFT_X3W="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k", "not eight_wave"],
+                       env=env, capture_output=True, text=True, timeout=1200)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
