@@ -1069,7 +1069,8 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
     else {
         static const int fixc = getenv("DPFT_BN_FIXC") ? atoi(getenv("DPFT_BN_FIXC")) : 2;      // see bn_bwd_apply_zeroing
         const int K4 = K / 4;
-        int blocks = ew_blocks(n4);
+        static const int fat = getenv("DPFT_BN_FAT") ? atoi(getenv("DPFT_BN_FAT")) : 1;      // two quads per thread and trip (as bn_bwd_apply)
+        int blocks = ew_blocks(fat && fixc >= 2 ? (n4 + 1) / 2 : n4);
         bool ok = fixc > 0 && !out32 && n4 >= 4096 && n4 < (1ll << 30);
         if (ok && (256 % K4) != 0) {
             const int f = K4 / 256;
