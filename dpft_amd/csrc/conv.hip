@@ -1407,15 +1407,17 @@ static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
 
 // act16 = 2 (bf16 activations and bf16 weights): the 256-row tiles of conv_b16w.hip (eight waves, 64 x 128 / 64 x 64 outputs
 // per wave); the tile may carry a K split (in-launch fix-up).  The tile height must not depend on the workspace:
-// dpft_conv2d_stats_tiles answers without one.  OFF by default (DPFT_B16W=1 switches it on): alone, the 256 x 256 tiles win
-// on the wide short-K 1x1 convs (batch 8, 256 -> 1024 forward + statistics 30.9 -> 22.7 us, its data gradient 28.0 -> 19.3,
-// 128 -> 512 forward 46.1 -> 35.8), lose on N = 256 problems (57 row tiles: a K split's slab round trip costs more than the
-// idle CUs) -- and INSIDE the training step they lose overall (bf16 batch 8, same box, two pairs: 24.8 vs 23.5 ms): a
-// 512-thread workgroup that owns a CU's whole LDS cannot share the CU with the weight-gradient stream's workgroups the way
-// three 48 KB workgroups do (profiles/r06_b16w_*.txt).
+// dpft_conv2d_stats_tiles answers without one.  Alone, the 256 x 256 tiles win on the wide short-K 1x1 convs (batch 8,
+// 256 -> 1024 forward + statistics 30.9 -> 22.7 us, its data gradient 28.0 -> 19.3, 128 -> 512 forward 46.1 -> 35.8) and lose on
+// N = 256 problems (57 row tiles: a K split's slab round trip costs more than the idle CUs).  INSIDE the training step the data
+// gradients lose -- a 512-thread workgroup that owns a CU's whole LDS cannot share the CU with the weight-gradient stream's
+// workgroups the way three 48 KB workgroups do -- but the FORWARD has no weight-gradient stream beside it: bf16 batch 8, same box,
+// two rounds: off 22.91 / 22.78 ms, forward only 22.60 / 22.60, forward + data gradients 24.14 / 24.21 (profiles/r06_b16w_*.txt).
+// Default: forward only (DPFT_B16W=2); =1 both, =0 off.
 static bool big16_tile(const dpft_conv_desc* d, const IgemmArgs& a, bool dgrad, bool has_ws, TileChoice& t) {
-    static const int on = getenv("DPFT_B16W") ? atoi(getenv("DPFT_B16W")) : 0;
+    static const int on = getenv("DPFT_B16W") ? atoi(getenv("DPFT_B16W")) : 2;      // 0 off | 1 forward + data gradients | 2 forward only (default)
     if (!on || d->act16 != 2 || (a.C % BKV) != 0 || (a.N % 128) != 0 || getenv("DPFT_FORCE_TILE") != nullptr) return false;
+    if (on == 2 && dgrad) return false;      // 2: forward convs only (no weight-gradient stream beside them)
     if (dgrad && d->stride > 1) return false;      // (parity classes / the all-tap form keep their kernels)
     if ((int64_t)a.B * a.H * a.W * a.C >= (1ll << 29) || (int64_t)a.N * a.Ktot >= (1ll << 29)) return false;
     const int64_t mt = cdiv(a.M, 256);
