@@ -1496,6 +1496,28 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
     }
     // bf16 activations AND bf16 weights (act16 = 2): both operands go to the matrix cores untouched -- the pipelined kernel
     // with 2-byte elements, everything by LDS-DMA
+    if (t.vec && a.w16 && a.x16 && pro && !DGRAD && a.pro_relu && !nonlin) {
+        // bf16 operands WITH the producer's BatchNorm + ReLU (round 6): the A operand on the register route, its parameters from an
+        // LDS table; weights by LDS-DMA.  Tiles as the prologue-free form (a 256-row choice falls back to 128 x 128).
+        g_prof_family = kFamBf16;
+        if constexpr (!DGRAD) {
+            const int pbm = t.bm == 64 ? 64 : 128, pbn = (t.bm == 64 || t.bn == 64) ? 64 : 128;
+            a.mtiles = cdiv(a.M, pbm); a.ntiles = cdiv(a.N, pbn);
+            const dim3 pgrid(a.mtiles * a.ntiles * a.splits);
+            auto gop = [&](auto kernel, int pbk, size_t lds) {
+                a.ksteps = a.ksteps * BKV / pbk;
+                a.ksteps_per_split = cdiv(a.ksteps, a.splits);
+                launch_lds(kernel, pgrid, block, lds + (size_t)12 * a.C, st, a);
+            };
+#define PIPE16P_LDS(BM_, BN_, PBK_) std::max((size_t)2 * (BM_ + BN_) * PBK_ * 2, (size_t)BM_ * (BN_ + 4) * 4 + (size_t)3 * BN_ * 4)
+            if (pbm == 128 && pbn == 128) gop(igemm_pipe_kernel<128, 128, 2, 2, 64, false, true, true>, 64, PIPE16P_LDS(128, 128, 64));
+            else if (pbm == 128) gop(igemm_pipe_kernel<128, 64, 2, 2, 64, false, true, true>, 64, PIPE16P_LDS(128, 64, 64));
+            else if (a.C % 128 == 0) gop(igemm_pipe_kernel<64, 64, 2, 2, 128, false, true, true>, 128, PIPE16P_LDS(64, 64, 128));
+            else gop(igemm_pipe_kernel<64, 64, 2, 2, 64, false, true, true>, 64, PIPE16P_LDS(64, 64, 64));
+#undef PIPE16P_LDS
+        }
+        return check_launch("conv igemm (pipelined, bf16 operands, BatchNorm + ReLU prologue)");
+    }
     if (t.vec && a.w16 && a.x16 && !pro && !nonlin) {
         g_prof_family = kFamBf16;
         if (t.bm == 256) return launch_igemm_b16w(a, t.bm, t.bn, DGRAD, st);      // conv_b16w.hip: 256-row tiles, eight waves
@@ -1782,6 +1804,11 @@ extern "C" int32_t dpft_conv_get_split() { return dpft::g_conv_split; }
 int dpft::conv_mode_key() { return dpft::g_conv_bf16 * 2 + (dpft::g_conv_split ? 1 : 0); }
 
 extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows) {
+    return dpft_conv2d_stats_tiles_pro(d, 0, tile_rows);
+}
+
+// `pro`: the launch will carry a BatchNorm + ReLU operand prologue (bf16 operands: the 256-row tiles have none)
+extern "C" int32_t dpft_conv2d_stats_tiles_pro(const dpft_conv_desc* d, int32_t pro, int32_t* tile_rows) {
     if (check_desc(d) != DPFT_OK) return -1;
     IgemmArgs a; fill_igemm(a, d, false);
     {
@@ -1792,7 +1819,8 @@ extern "C" int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* til
         }
     }
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);      // (as conv_fwd_bnfinal asks)
-    (void)big16_tile(d, a, false, false, t);
+    if (!pro) (void)big16_tile(d, a, false, false, t);
+    if (pro && d->act16 == 2 && t.bm != 64) t.bm = 128;      // (launch_igemm: the bf16 prologue kernels' tiles)
     if (tile_rows) *tile_rows = t.bm;
     return cdiv(a.M, t.bm);
 }
@@ -1832,7 +1860,7 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     a.x16 = a.y16 = d->act16 != 0;
     a.w16 = d->act16 == 2;
     if (d->a_planes && d->w_planes && !pro_bn && !d->act16) { a.x3 = d->a_planes; a.w3 = d->w_planes; }
-    DPFT_REQUIRE(!(a.w16 && (pro_bn || bias)), "conv fwd: act16 = 2 (bf16 weights) takes no operand prologue and no bias");
+    DPFT_REQUIRE(!(a.w16 && (bias || (pro_bn && !pro_relu))), "conv fwd: act16 = 2 (bf16 weights) takes no bias and only the BatchNorm + ReLU prologue");
     const bool pro = pro_bn != nullptr;
     TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || (pro && !pro_relu)) ? 1 : d->kh * d->kw);
     const bool big16 = !pro && !bias && big16_tile(d, a, false, workspace != nullptr, t);

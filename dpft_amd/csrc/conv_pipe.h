@@ -34,13 +34,14 @@ namespace dpft {
 // B16: BOTH operands are bf16 in memory (activations in bf16 storage, dpft_conv_desc.act16 = 2: the caller also passes
 // bf16 weights) -- the same kernel with 2-byte elements: a 16-byte chunk is 8 reduction indices, a K-group is 16 of them
 // and one v_mfma_f32_32x32x16_bf16 (fp32 accumulation) per 32x32 block and group.  No arithmetic touches an operand on
-// its way to the matrix cores, so nothing but LDS-DMA feeds the stages (PRO is not available: the mixed-precision plan
-// materialises BatchNorm+ReLU outputs instead).
+// its way to the matrix cores, so nothing but LDS-DMA feeds the stages -- unless the conv carries the producer's BatchNorm + ReLU
+// (PRO, round 6): then the A operand takes the register route as in fp32 (8 bf16 per 16-byte quad: widened, normalised, rounded
+// back to bf16 -- the value a materialising pass would have stored), its parameters from a [3][C] table in LDS behind the
+// stages; the bf16 MFMA does not share the vector ALUs, so the prologue's arithmetic rides beside it.
 // EPF: the epilogue's operands (residual data gradient with the fused BatchNorm-backward reduction, both byte masks) are
 // requested behind the MFMAs of selected K-steps (EpiPrefetch, conv.hip) instead of after the last one.
 template <int BM, int BN, int WGM, int WGN, int PBK, bool DGRAD, bool PRO, bool B16 = false, int EPF = 0>
 __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
-    static_assert(!(B16 && PRO), "bf16 operands: no fused prologue");
     static_assert(EPF == 0 || (EPF == 3 ? (!DGRAD && !PRO) : (DGRAD && !PRO)), "epilogue prefetch: data gradients (1, 2) / inference forward (3)");      // EPF = EpiPrefetch::MODE
     constexpr int EB = B16 ? 2 : 4;         // bytes per element
     constexpr int EPC = 16 / EB;            // elements per 16-byte chunk
@@ -168,13 +169,20 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
 
     // register route of the A operand (PRO only)
     f32x4 ra[PRO ? AP : 1], p_mu, p_sc, p_sh;
+    f32x4 q_mu = {0.f, 0.f, 0.f, 0.f}, q_sc = q_mu, q_sh = q_mu;      // B16: channels 4..7 of the lane's 8-channel quad
+    const float* const ptab16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + 2 * STAGE);      // B16 + PRO: [3][C]
+    if constexpr (PRO && B16) {
+        float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE);
+        for (int i = tid; i < 3 * a.C; i += 256) tab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
+        __syncthreads();
+    }
     unsigned ra_valid = 0;
     unsigned long long ra_inv[PRO ? AP : 1] = {};      // wave-uniform copies of a_inv_tap for the tile in the registers
 
     // The loads of a tile as NOPS separately placeable operations (the main loop puts one behind each of the first MFMAs
     // of a step: a vector-memory instruction takes tens of cycles to issue, which an MFMA in the pipe hides and an idle
     // pipe does not).  Order: A operand, [prologue parameters], weights.
-    constexpr int NPAR = PRO ? 3 : 0;
+    constexpr int NPAR = (PRO && !B16) ? 3 : 0;      // fp32: three parameter quads per tile from global memory; bf16: the LDS table
     constexpr int NOPS = AP + NPAR + BP;
     auto vmem_op = [&](auto STG, auto K) {
         constexpr int stg = decltype(STG)::value, k = decltype(K)::value;
@@ -183,6 +191,12 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
                 ra[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsrc_a, (int)a_off[k], so_a, 0));
                 if constexpr (k == 0) ra_valid = a_valid_tap;
                 ra_inv[k] = a_inv_tap[k];
+                if constexpr (B16 && k == 0) {      // this tile's parameters (channels so_a / 2 + 8 chunk .. + 7): consumed at the end of the step
+                    const float* t = ptab16 + (so_a >> 1) + chunk * 8;
+                    p_mu = *reinterpret_cast<const f32x4*>(t);          q_mu = *reinterpret_cast<const f32x4*>(t + 4);
+                    p_sc = *reinterpret_cast<const f32x4*>(t + a.C);    q_sc = *reinterpret_cast<const f32x4*>(t + a.C + 4);
+                    p_sh = *reinterpret_cast<const f32x4*>(t + 2 * a.C); q_sh = *reinterpret_cast<const f32x4*>(t + 2 * a.C + 4);
+                }
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, lds0 + stg * STAGE + (RPP * k + RW * wave) * ROWB, 16,
                                                          (int)a_off[k], so_a, 0, 0);
@@ -206,8 +220,21 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     auto consume = [&](auto STG, auto I) {
         constexpr int stg = decltype(STG)::value, i = decltype(I)::value;
         f32x4 val = ra[i];
+        if constexpr (B16) {      // 8 bf16: widen, BatchNorm + ReLU in fp32, round back (RNE) -- what the materialising pass stores
+            const u32x4 raw = __builtin_bit_cast(u32x4, val);
+            f32x4 lo = {__uint_as_float(raw[0] << 16), __uint_as_float(raw[0] & 0xffff0000u), __uint_as_float(raw[1] << 16), __uint_as_float(raw[1] & 0xffff0000u)};
+            f32x4 hi = {__uint_as_float(raw[2] << 16), __uint_as_float(raw[2] & 0xffff0000u), __uint_as_float(raw[3] << 16), __uint_as_float(raw[3] & 0xffff0000u)};
 #pragma unroll
-        for (int e = 0; e < 4; ++e) val[e] = fmaxf(fmaf(val[e] - p_mu[e], p_sc[e], p_sh[e]), 0.f);
+            for (int e = 0; e < 4; ++e) {
+                lo[e] = fmaxf(fmaf(lo[e] - p_mu[e], p_sc[e], p_sh[e]), 0.f);
+                hi[e] = fmaxf(fmaf(hi[e] - q_mu[e], q_sc[e], q_sh[e]), 0.f);
+            }
+            const u32x2 pl = __builtin_bit_cast(u32x2, __builtin_convertvector(lo, bf16x4)), ph = __builtin_bit_cast(u32x2, __builtin_convertvector(hi, bf16x4));
+            val = __builtin_bit_cast(f32x4, u32x4{pl[0], pl[1], ph[0], ph[1]});
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) val[e] = fmaxf(fmaf(val[e] - p_mu[e], p_sc[e], p_sh[e]), 0.f);
+        }
         if (ra_inv[i] != 0ull) {
             asm volatile("" ::: "memory");      // keeps this a branch (the compiler would turn it back into selects)
             if (!((ra_valid >> i) & 1u)) val = f32x4{0.f, 0.f, 0.f, 0.f};

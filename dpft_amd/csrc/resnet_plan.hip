@@ -14,6 +14,16 @@
 
 namespace dpft {
 
+// bf16 plan (act16 = 2), round 6 experiment (DPFT_PRO16=1): conv2 / conv3 read the RAW bf16 outputs y1 / y2 through the BatchNorm + ReLU
+// operand prologue of the bf16 pipelined kernel (conv_pipe.h) instead of materialised a1 / a2 -- two elementwise launches per bottleneck
+// leave the forward's chain; the weight gradients, which still want the materialised operand, get it on the side stream right before
+// they run.  Measured at bf16 batch 8 (same box, two rounds): 22.75 / 22.51 ms materialising vs 22.81 / 22.70 with the prologues -- the
+// register-route GEMMs (and conv3 losing its 256-row tiles) cost what the 66 launches cost.  Off.
+static bool pro16_on() {
+    static const bool on = getenv("DPFT_PRO16") != nullptr && atoi(getenv("DPFT_PRO16")) != 0;
+    return on;
+}
+
 struct ConvRef {
     dpft_conv_desc d{};
     int w;  // index into the conv table
@@ -133,9 +143,9 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     };
     size_t gmax = 0;
     auto track_g = [&](size_t n) { if (n > gmax) gmax = n; };
-    auto stats_of = [&](const dpft_conv_desc& d, int& tiles, int& rows) {
+    auto stats_of = [&](const dpft_conv_desc& d, int& tiles, int& rows, bool pro = false) {
         int32_t r = 0;
-        tiles = dpft_conv2d_stats_tiles(&d, &r);
+        tiles = dpft_conv2d_stats_tiles_pro(&d, pro ? 1 : 0, &r);
         rows = r;
         return (size_t)tiles * 2 * d.K;
     };
@@ -195,8 +205,8 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
                 if (bp.has_ds) bp.cd.w16 = take((nelem_w(bp.cd.d) + 1) / 2);
             }
             bp.y1 = take(nelem_out(bp.c1.d));  bp.p1 = take(4 * planes);  bp.s1 = take(stats_of(bp.c1.d, bp.t1, bp.r1));
-            bp.y2 = take(nelem_out(bp.c2.d));  bp.p2 = take(4 * planes);  bp.s2 = take(stats_of(bp.c2.d, bp.t2, bp.r2));
-            bp.y3 = take(nelem_out(bp.c3.d));  bp.p3 = take(4 * planes * 4);  bp.s3 = take(stats_of(bp.c3.d, bp.t3, bp.r3));
+            bp.y2 = take(nelem_out(bp.c2.d));  bp.p2 = take(4 * planes);  bp.s2 = take(stats_of(bp.c2.d, bp.t2, bp.r2, desc->act16 == 2 && pro16_on()));
+            bp.y3 = take(nelem_out(bp.c3.d));  bp.p3 = take(4 * planes * 4);  bp.s3 = take(stats_of(bp.c3.d, bp.t3, bp.r3, desc->act16 == 2 && pro16_on()));
             if (bp.has_ds) {
                 bp.yd = take(nelem_out(bp.cd.d));  bp.pd = take(4 * planes * 4);  bp.sd = take(stats_of(bp.cd.d, bp.td, bp.rd));
                 track_ws(bp.cd.d);
@@ -308,6 +318,7 @@ struct Tables {
         int rc_ = (call);     \
         if (rc_) return rc_;  \
     } while (0)
+
 
 // act16: the last block of a stage also writes the fp32 copy of its output that the neck reads
 static float* stage_out32(const ResnetPlan* p, const BlockPlan& b, float* A) {
@@ -457,10 +468,15 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
             // bf16 weights: no operand prologues -- relu(bn(y)) is materialised (bf16) by one elementwise pass per layer and
             // every GEMM is the LDS-DMA kernel
             RC(conv_bn_train(p, T, b.c1, b.bn1, A + b.x, nullptr, A, A + b.y1, A + b.s1, b.t1, b.r1, M1, A + b.p1, ws, st, A + b.c1.w16));
+            if (pro16_on()) {
+                RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st, A + b.c2.w16));
+                RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.y2, A + b.p2, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st, A + b.c3.w16));
+            } else {
             RC(bn_act_any(A + b.y1, A + b.p1, nullptr, nullptr, 1, A + b.a1, nullptr, M1, b.c1.d.K, true, st));
             RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.a1, nullptr, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st, A + b.c2.w16));
             RC(bn_act_any(A + b.y2, A + b.p2, nullptr, nullptr, 1, A + b.a2, nullptr, M2, b.c2.d.K, true, st));
             RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.a2, nullptr, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st, A + b.c3.w16));
+            }
         } else {
         RC(conv_bn_train(p, T, b.c1, b.bn1, A + b.x, nullptr, A, A + b.y1, A + b.s1, b.t1, b.r1, M1, A + b.p1, ws, st));
         RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st));
@@ -553,11 +569,17 @@ struct SideCtx {
         return DPFT_OK;
     }
     // dy buffer `slot` is complete on the main stream: launch the weight gradient that reads it on the side stream
-    int wgrad(int slot, const dpft_conv_desc* d, const float* x, const float* dy, const float* pro, int relu, float* dw) {
-        if (profiling_active())      // per-launch event timing wants each kernel alone on the device
+    // `mat_y` (bf16 plan with operand prologues in the forward): x is relu(bn(mat_y)) and has not been materialised yet -- the
+    // elementwise pass runs here, on the stream of the weight gradient that wants it
+    int wgrad(int slot, const dpft_conv_desc* d, const float* x, const float* dy, const float* pro, int relu, float* dw,
+              const float* mat_y = nullptr, const float* mat_bnp = nullptr, int64_t mat_M = 0, int mat_K = 0) {
+        if (profiling_active()) {      // per-launch event timing wants each kernel alone on the device
+            if (mat_y) RC(bn_act_any(mat_y, mat_bnp, nullptr, nullptr, 1, const_cast<float*>(x), nullptr, mat_M, mat_K, true, (dpft_stream_t)main));
             return dpft_conv2d_nhwc_wgrad_f32(d, x, dy, pro, relu, dw, ws2, (dpft_stream_t)main);
+        }
         DPFT_REQUIRE(hipEventRecord(p->ev_ready, main) == hipSuccess, "resnet_backward: record event");
         DPFT_REQUIRE(hipStreamWaitEvent(p->side, p->ev_ready, 0) == hipSuccess, "resnet_backward: wait event");
+        if (mat_y) RC(bn_act_any(mat_y, mat_bnp, nullptr, nullptr, 1, const_cast<float*>(x), nullptr, mat_M, mat_K, true, (dpft_stream_t)p->side));
         RC(dpft_conv2d_nhwc_wgrad_f32(d, x, dy, pro, relu, dw, ws2, (dpft_stream_t)p->side));
         DPFT_REQUIRE(hipEventRecord(p->ev_done[slot], p->side) == hipSuccess, "resnet_backward: record event");
         p->ev_valid[slot] = true;
@@ -625,7 +647,7 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     const unsigned char* m8 = (const unsigned char*)(A + b.mask);      // ReLU mask of the block output (written by the forward)
     RC(bn_backward(A + b.y3, gp, nullptr, nullptr, A + b.p3, T.gamma(b.bn3), sums, dyv[cur], T.dgamma(b.bn3), T.dbeta(b.bn3), M2, K3, st, a16, m8, bn3_reduced));
     const bool w16 = p->desc.act16 == 2;      // materialised activations a1 / a2: no prologue in the weight gradients either
-    if (w16) RC(sc.wgrad(cur, &b.c3.d, A + b.a2, dyv[cur], nullptr, 0, T.dw(b.c3.w)));
+    if (w16) RC(sc.wgrad(cur, &b.c3.d, A + b.a2, dyv[cur], nullptr, 0, T.dw(b.c3.w), pro16_on() ? A + b.y2 : nullptr, A + b.p2, M2, planes));
     else RC(sc.wgrad(cur, &b.c3.d, A + b.y2, dyv[cur], A + b.p2, 1, T.dw(b.c3.w)));
     // the data gradient of conv3 produces bn2's dout: bn2's reduction rides in its epilogue (mask = bn2(y2) > 0)
     BnReduceFuse f2{A + b.y2, A + b.p2, nullptr, 1, fuse_on ? sums.buf[sums.cur] : nullptr, false};
@@ -634,7 +656,7 @@ static int block_backward(ResnetPlan* p, const BlockPlan& b, const Tables& T, fl
     // bn2 (fused-ReLU mask recomputed from its BN block)
     RC(sc.acquire(cur));
     RC(bn_backward(A + b.y2, dab, nullptr, A + b.p2, A + b.p2, T.gamma(b.bn2), sums, dyv[cur], T.dgamma(b.bn2), T.dbeta(b.bn2), M2, planes, st, a16, nullptr, f2.applied));
-    if (w16) RC(sc.wgrad(cur, &b.c2.d, A + b.a1, dyv[cur], nullptr, 0, T.dw(b.c2.w)));
+    if (w16) RC(sc.wgrad(cur, &b.c2.d, A + b.a1, dyv[cur], nullptr, 0, T.dw(b.c2.w), pro16_on() ? A + b.y1 : nullptr, A + b.p1, M1, planes));
     else RC(sc.wgrad(cur, &b.c2.d, A + b.y1, dyv[cur], A + b.p1, 1, T.dw(b.c2.w)));
     BnReduceFuse f1{A + b.y1, A + b.p1, nullptr, 1, fuse_on ? sums.buf[sums.cur] : nullptr, false};
     RC(conv_dgrad_fused(&b.c2.d, dyv[cur], wt + b.c2.wt, dab, 0, ws, st, &f1));

@@ -86,6 +86,9 @@ int dpft_split_planes_f32(const float* src, void* planes, int64_t n, dpft_stream
  * (rows of the `stats` buffer: stats is [mtiles][2][K] floats = per-tile mean and M2);
  * *tile_rows receives the tile height so the caller can recover per-tile counts. */
 int32_t dpft_conv2d_stats_tiles(const dpft_conv_desc* d, int32_t* tile_rows);
+/* the same for a launch that carries the BatchNorm + ReLU operand prologue (pro_bn != NULL in dpft_conv2d_nhwc_fwd_f32): with bf16
+ * operands (act16 = 2) such a launch takes other tiles than the prologue-free one */
+int32_t dpft_conv2d_stats_tiles_pro(const dpft_conv_desc* d, int32_t pro, int32_t* tile_rows);
 
 /* Arithmetic of the forward / data-gradient GEMMs of every conv with C % 64 == 0 and of the 128 x 128-tiled weight
  * gradients (process-wide; call between launches):

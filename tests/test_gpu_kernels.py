@@ -1501,3 +1501,55 @@ def test_conv1x1_streaming_kernel_forward_forms_vs_fp64(B, H, W, Cin, K):
         ref = bn if r is None else bn + r.double().reshape(M, K)
         ref = ref.relu() if relu else ref
         torch.testing.assert_close(y.double().cpu().reshape(M, K), ref, rtol=1e-4, atol=1e-5 * float(ref.abs().max()) + 1e-6)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,Cin,K,k,stride", [(2, 32, 57, 256, 256, 3, 1), (4, 32, 57, 256, 1024, 1, 1), (2, 24, 40, 64, 128, 3, 1),
+                                                    (1, 9, 7, 128, 64, 3, 1), (1, 33, 29, 64, 128, 3, 2), (3, 17, 23, 128, 512, 1, 1)])
+def test_conv_bf16_operands_with_batchnorm_relu_prologue(B, H, W, Cin, K, k, stride):
+    """act16 = 2 forward WITH the producer's BatchNorm + ReLU on the A operand (igemm_pipe_kernel<.., PRO, B16>, round 6): the kernel
+    widens the bf16 input, normalises in fp32, rounds back to bf16 (what the materialising pass stores) and multiplies -- against
+    fp64 on exactly those rounded operands; padding stays zero; the BatchNorm tile statistics come from the fp32 accumulators, in
+    the tiling dpft_conv2d_stats_tiles_pro reports."""
+    import ctypes as C
+    from dpft_amd.hip import ops
+    from dpft_amd.hip.lib import lib, make_desc, ptr, stream
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B * 31 + K + k)
+    pad = k // 2
+    d = make_desc(B, H, W, Cin, K, k, k, stride, pad)
+    d.act16 = 2
+    x = (torch.randn(B, H, W, Cin, generator=g) * 1.5 + 0.2).bfloat16()
+    w = (torch.randn(K, k, k, Cin, generator=g) / (Cin * k * k) ** 0.5).bfloat16()
+    mean, invstd = torch.randn(Cin, generator=g) * 0.4, torch.rand(Cin, generator=g) + 0.5
+    gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
+    block = torch.stack((mean, gamma * invstd, beta, invstd)).contiguous()
+    lib.dpft_conv2d_stats_tiles_pro.restype = C.c_int32
+    tr = C.c_int32(0)
+    tiles = int(lib.dpft_conv2d_stats_tiles_pro(C.byref(d), 1, C.byref(tr)))
+    ws = torch.zeros(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (1 << 20), dtype=torch.uint8, device=dev)
+    y = torch.empty(B, d.OH, d.OW, K, dtype=torch.bfloat16, device=dev)
+    stats = torch.empty(tiles, 2, K, dtype=torch.float32, device=dev)
+    xd, wd, bd = x.to(dev), w.to(dev), block.to(dev)
+    ops.conv_set_compute("bf16")
+    try:
+        lib.call("dpft_conv2d_nhwc_fwd_f32", C.byref(d), ptr(xd), ptr(wd), None, ptr(bd), 1, ptr(y), ptr(stats), ptr(ws), stream())
+        torch.cuda.synchronize()
+    finally:
+        ops.conv_set_compute("fp32")
+    a = (torch.fma(x.float() - mean, gamma * invstd, beta) if hasattr(torch, "fma") else (x.float() - mean) * (gamma * invstd) + beta).relu().bfloat16()
+    ref = F.conv2d(a.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    got = y.double().cpu()
+    rel = float((got - ref).norm() / ref.norm())
+    # an operand element that sits on a bf16 rounding boundary may round the other way in the kernel's fmaf: 2^-8 of ONE operand
+    assert rel < 3e-3, rel
+    assert float(((got - ref).abs() - 2.0 ** -8 * ref.abs()).max()) < 2e-3 * float(ref.abs().max())
+    M = B * d.OH * d.OW
+    cnt = torch.full((tiles,), float(tr.value), dtype=torch.float64)
+    cnt[-1] = M - tr.value * (tiles - 1)
+    st = stats.double().cpu()
+    mu = (st[:, 0] * cnt[:, None]).sum(0) / M
+    m2 = st[:, 1].sum(0) + (cnt[:, None] * (st[:, 0] - mu) ** 2).sum(0)
+    yr = ref.reshape(-1, K)
+    assert float((mu - yr.mean(0)).abs().max()) < 2e-3 * float(yr.abs().max())
+    assert float((m2 / M - yr.var(0, unbiased=False)).abs().max()) < 1e-2 * float(yr.var(0).max())
