@@ -99,6 +99,7 @@ SIGNATURES = {
     "dpft_conv2d_workspace_init": (_I, [_P, _P]),
     "dpft_split_planes_f32": (_I, [_P, _P, _L, _P]),
     "dpft_conv2d_stats_tiles": (_I, [_DESC, C.POINTER(_I)]),
+    "dpft_conv2d_stats_tiles_pro": (_I, [_DESC, _I, C.POINTER(_I)]),
     "dpft_conv_set_compute": (_I, [_I]),
     "dpft_conv_get_compute": (_I, []),
     "dpft_conv_set_split": (_I, [_I]),

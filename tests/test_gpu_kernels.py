@@ -1524,7 +1524,6 @@ def test_conv_bf16_operands_with_batchnorm_relu_prologue(B, H, W, Cin, K, k, str
     mean, invstd = torch.randn(Cin, generator=g) * 0.4, torch.rand(Cin, generator=g) + 0.5
     gamma, beta = torch.rand(Cin, generator=g) + 0.5, torch.randn(Cin, generator=g) * 0.3
     block = torch.stack((mean, gamma * invstd, beta, invstd)).contiguous()
-    lib.dpft_conv2d_stats_tiles_pro.restype = C.c_int32
     tr = C.c_int32(0)
     tiles = int(lib.dpft_conv2d_stats_tiles_pro(C.byref(d), 1, C.byref(tr)))
     ws = torch.zeros(max(int(lib.dpft_conv2d_workspace_bytes(C.byref(d))), 16) + (1 << 20), dtype=torch.uint8, device=dev)
