@@ -1305,13 +1305,19 @@ static bool split_on() {
 // deep reductions -- take the 3 x bf16 split kernels (conv_x3.hip), whose best tiles differ: their operand stream
 // (6 bytes per element through L2 -> LDS) is what bounds them (tools/x3_abl.sh), so 128 x 128 tiles with a K split
 // that brings the grid to about one workgroup per CU; the 1x1 convs stay on the fp32 MFMA (measured at par there).
+static inline int taps_of(const dpft_conv_desc* d) { return (d->kh * d->kw == 1 && d->stride == 1) ? -1 : d->kh * d->kw; }
 static TileChoice choose_tile(int M, int N, int C, int ksteps, int taps = 1) {
     TileChoice t;
     t.vec = (C % BKV) == 0;
     t.x3 = false;
     // (only where the GEMM is big enough to be bound by the matrix pipe: the latency-sized problems of the radar encoders
     // measured 2x SLOWER on the 128-row tiles, profiles/r05_x3_table.txt)
-    if (split_on() && taps > 1 && t.vec && getenv("DPFT_FORCE_TILE") == nullptr &&
+    // taps = -1: a 1x1 stride-1 conv on fp32 operands; DPFT_X3_1X1_MINK (tuning aid, 0 = off) sends those with a reduction of at
+    // least that many channels to the split kernels too.  Measured in the step (same box, two rounds): off 24.18 / 24.23 ms,
+    // >= 1024 channels 24.66 / 24.71, >= 512 24.68 / 24.90, >= 256 27.5 / 25.8 -- the forward loses as well (1.78 -> 1.81 ms per frame)
+    static const int x1k = getenv("DPFT_X3_1X1_MINK") ? atoi(getenv("DPFT_X3_1X1_MINK")) : 0;
+    const bool deep1x1 = taps == -1 && x1k > 0 && (int64_t)ksteps * BKV >= x1k;
+    if (split_on() && (taps > 1 || deep1x1) && t.vec && getenv("DPFT_FORCE_TILE") == nullptr &&
         2.0 * M * N * (double)ksteps * BKV >= 2e9) {
         t.x3 = true;
         if (N >= 128) {
@@ -1758,7 +1764,7 @@ extern "C" int64_t dpft_conv2d_workspace_bytes(const dpft_conv_desc* d) {
         g_split_override = mode;
         for (int dg = 0; dg < 2; ++dg) {
             IgemmArgs a; fill_igemm(a, d, dg != 0);
-            TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->kh * d->kw);
+            TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : taps_of(d));
             if (d->act16) t.splits = 1;
             (void)big16_tile(d, a, dg != 0, true, t);
             if (t.splits > 1) best = std::max<int64_t>(best, (int64_t)t.splits * a.M * a.N * 4);
@@ -1818,7 +1824,7 @@ extern "C" int32_t dpft_conv2d_stats_tiles_pro(const dpft_conv_desc* d, int32_t 
             return cdiv(a.M, tr);
         }
     }
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);      // (as conv_fwd_bnfinal asks)
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : taps_of(d));      // (as conv_fwd_bnfinal asks)
     if (!pro) (void)big16_tile(d, a, false, false, t);
     if (pro && d->act16 == 2 && t.bm != 64) t.bm = 128;      // (launch_igemm: the bf16 prologue kernels' tiles)
     if (tile_rows) *tile_rows = t.bm;
@@ -1862,7 +1868,7 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     if (d->a_planes && d->w_planes && !pro_bn && !d->act16) { a.x3 = d->a_planes; a.w3 = d->w_planes; }
     DPFT_REQUIRE(!(a.w16 && (bias || (pro_bn && !pro_relu))), "conv fwd: act16 = 2 (bf16 weights) takes no bias and only the BatchNorm + ReLU prologue");
     const bool pro = pro_bn != nullptr;
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || (pro && !pro_relu)) ? 1 : d->kh * d->kw);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || (pro && !pro_relu)) ? 1 : taps_of(d));
     const bool big16 = !pro && !bias && big16_tile(d, a, false, workspace != nullptr, t);
     if (d->act16 && !big16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors (big16: in-launch fix-up only)
     if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 1)) t.splits = 1;
@@ -1923,7 +1929,7 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
         return launch_stream1x1(d, x, w, nullptr, y, nullptr, out_bn, residual, relu, st);
     }
     IgemmArgs a; fill_igemm(a, d, false);
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : d->kh * d->kw);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : taps_of(d));
     if (d->act16) t.splits = 1;
     const int64_t M = (int64_t)d->B * d->OH * d->OW;
     static const bool fix_all = getenv("DPFT_BNACT_FIXUP") == nullptr || atoi(getenv("DPFT_BNACT_FIXUP")) != 0;      // A/B switch
@@ -2038,7 +2044,7 @@ int dpft::conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float
         if (fuse_ok && !empty_class) fuse->applied = true;
         return DPFT_OK;
     }
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || d->stride > 1) ? 1 : d->kh * d->kw);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, (d->act16 || d->stride > 1) ? 1 : taps_of(d));
     const bool big16 = big16_tile(d, a, true, workspace != nullptr, t);
     if (d->act16 && !big16) t.splits = 1;
     if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 2)) t.splits = 1;
@@ -2094,7 +2100,7 @@ int dpft::conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const fl
     a.w16 = d->act16 == 2;
     if (d->a_planes && d->w_planes && !d->act16) { a.x3 = d->a_planes; a.w3 = d->w_planes; }
     if (res_mask8 && (a.N & 3) == 0) a.res_mask8 = res_mask8;      // (the split-K reduction and the scalar tail read res_mask)
-    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps);
+    TileChoice t = choose_tile(a.M, a.N, a.C, a.ksteps, d->act16 ? 1 : taps_of(d));
     const bool big16 = big16_tile(d, a, true, workspace != nullptr, t);
     if (d->act16 && !big16) t.splits = 1;
     if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 4)) t.splits = 1;
