@@ -202,24 +202,44 @@ __global__ __launch_bounds__(256) void bn_act_kernel(const float* __restrict__ y
 
 // bn_act_kernel<float> for launches whose grid stride is a multiple of K / 4 (round 6, as bn_bwd_apply_fixc_kernel): the
 // thread's parameter quads are loaded once, two element quads per tensor in flight.  Same expression per element.
-template <int U>
+// SUMS: either BatchNorm may come as fp64 column sums (common.h: BnSumsRef; .sums null = its BN block) -- the thread derives its
+// four channels' parameters itself, once.
+template <int U, bool SUMS = false>
 __global__ __launch_bounds__(256) void bn_act_fixc_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
-                                                           const float* __restrict__ res, const float* __restrict__ rbnp,
+                                                           const float* __restrict__ res, const float* __restrict__ rbnp_,
                                                            int relu, float* __restrict__ out, int64_t n4, int K4,
-                                                           unsigned char* __restrict__ mask8) {
+                                                           unsigned char* __restrict__ mask8, BnSumsRef ys, BnSumsRef rs) {
     DPFT_SETPRIO_BN();
     const int K = K4 * 4;
     const unsigned stride = gridDim.x * blockDim.x;      // % K4 == 0, n4 < 2^30 (host)
     const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(first % (unsigned)K4) * 4;
-    const f32x4 mu = *reinterpret_cast<const f32x4*>(bnp + c);
-    const f32x4 sc = *reinterpret_cast<const f32x4*>(bnp + K + c);
-    const f32x4 be = *reinterpret_cast<const f32x4*>(bnp + 2 * K + c);
+    f32x4 mu, sc, be;
+    if (SUMS && ys.sums) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float m_, s_, b_, is_;
+            bn_from_sums(ys, c + e, m_, s_, b_, is_);
+            mu[e] = m_; sc[e] = s_; be[e] = b_;
+        }
+    } else {
+        mu = *reinterpret_cast<const f32x4*>(bnp + c);
+        sc = *reinterpret_cast<const f32x4*>(bnp + K + c);
+        be = *reinterpret_cast<const f32x4*>(bnp + 2 * K + c);
+    }
     f32x4 rmu = mu, rsc = sc, rbe = be;
-    if (rbnp) {
-        rmu = *reinterpret_cast<const f32x4*>(rbnp + c);
-        rsc = *reinterpret_cast<const f32x4*>(rbnp + K + c);
-        rbe = *reinterpret_cast<const f32x4*>(rbnp + 2 * K + c);
+    const bool rbnp = rbnp_ != nullptr || (SUMS && rs.sums != nullptr);      // the residual has a BatchNorm of its own (downsample branch)
+    if (SUMS && rs.sums) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float m_, s_, b_, is_;
+            bn_from_sums(rs, c + e, m_, s_, b_, is_);
+            rmu[e] = m_; rsc[e] = s_; rbe[e] = b_;
+        }
+    } else if (rbnp_) {
+        rmu = *reinterpret_cast<const f32x4*>(rbnp_ + c);
+        rsc = *reinterpret_cast<const f32x4*>(rbnp_ + K + c);
+        rbe = *reinterpret_cast<const f32x4*>(rbnp_ + 2 * K + c);
     }
     const unsigned n = (unsigned)n4;
     for (unsigned i0 = first; i0 < n; i0 += U * stride) {
@@ -1078,16 +1098,78 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
             if (ok) blocks -= blocks % f;
         }
         if (ok && fixc >= 2)
-            hipLaunchKernelGGL(bn_act_fixc_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
-                               K4, mask8);
+            hipLaunchKernelGGL((bn_act_fixc_kernel<2, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
+                               K4, mask8, BnSumsRef{}, BnSumsRef{});
         else if (ok)
-            hipLaunchKernelGGL(bn_act_fixc_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
-                               K4, mask8);
+            hipLaunchKernelGGL((bn_act_fixc_kernel<1, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
+                               K4, mask8, BnSumsRef{}, BnSumsRef{});
         else
             hipLaunchKernelGGL(bn_act_kernel<float>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
                                res_bnp, relu, out, out32, n4, K / 4, mask8);
     }
     return check_launch("bn_act");
+}
+
+int dpft::bn_act_sums(const float* y, const float* bnp, const BnSumsRef& ys, const float* res, const float* res_bnp, const BnSumsRef& rs,
+                      int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream, unsigned char* mask8, bool* used) {
+    DPFT_REQUIRE(y && out && used && M > 0 && K > 0 && K % 4 == 0 && (bnp || ys.sums), "bn_act (column sums): bad arguments (K=%d)", K);
+    DPFT_REQUIRE(res || !(res_bnp || rs.sums), "bn_act (column sums): a residual BatchNorm without a residual");
+    *used = false;
+    {
+        static const char* skip = getenv("DPFT_SKIP");
+        if (skip && strstr(skip, "bnact")) { *used = true; return DPFT_OK; }
+    }
+    static const int fixc = getenv("DPFT_BN_FIXC") ? atoi(getenv("DPFT_BN_FIXC")) : 2;
+    static const int fat = getenv("DPFT_BN_FAT") ? atoi(getenv("DPFT_BN_FAT")) : 1;
+    const int64_t n4 = M * K / 4;
+    const int K4 = K / 4;
+    int blocks = ew_blocks(fat && fixc >= 2 ? (n4 + 1) / 2 : n4);
+    bool ok = fixc > 0 && n4 >= 4096 && n4 < (1ll << 30);
+    if (ok && (256 % K4) != 0) {
+        const int f = K4 / 256;
+        ok = (K4 % 256) == 0 && blocks >= f;
+        if (ok) blocks -= blocks % f;
+    }
+    if (!ok) return DPFT_OK;      // (the generic kernel reads BN blocks only: the caller finalizes first)
+    if (fixc >= 2)
+        hipLaunchKernelGGL((bn_act_fixc_kernel<2, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
+                           K4, mask8, ys, rs);
+    else
+        hipLaunchKernelGGL((bn_act_fixc_kernel<1, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
+                           K4, mask8, ys, rs);
+    *used = true;
+    return check_launch("bn_act (column sums)");
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_sums_multi_kernel(BnSumsBatch a) {
+    const int i = blockIdx.y;
+    const int K = a.K[i];
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= K) return;
+    const BnSumsRef r{a.sums[i], a.gamma[i], a.beta[i], a.invn[i], a.eps, K};
+    float mean, scale, beta, invstd;
+    bn_from_sums(r, c, mean, scale, beta, invstd);      // what every forward consumer of the layer computed
+    float* bnp = a.out[i];
+    bnp[c] = mean;
+    bnp[K + c] = scale;
+    bnp[2 * K + c] = beta;
+    bnp[3 * K + c] = invstd;
+    if (a.rm[i]) {
+        const double m = bn_sums_get(r.sums, K, c, 0) * r.invn;
+        const double var = fmax(bn_sums_get(r.sums, K, c, 1) * r.invn - m * m, 0.0);
+        const long long M = a.M[i];
+        const float unbiased = (float)(M > 1 ? var * ((double)M / (double)(M - 1)) : var);
+        a.rm[i][c] = (1.f - a.momentum) * a.rm[i][c] + a.momentum * mean;
+        a.rv[i][c] = (1.f - a.momentum) * a.rv[i][c] + a.momentum * unbiased;
+    }
+}
+
+int dpft::bn_finalize_sums_batch(const BnSumsBatch& batch, dpft_stream_t stream) {
+    DPFT_REQUIRE(batch.n >= 1 && batch.n <= BnSumsBatch::MAX, "bn_finalize_sums_batch: 1..%d layers per launch (n=%d)", BnSumsBatch::MAX, batch.n);
+    int kmax = 0;
+    for (int i = 0; i < batch.n; ++i) kmax = std::max(kmax, batch.K[i]);
+    hipLaunchKernelGGL(bn_finalize_sums_multi_kernel, dim3(cdiv(kmax, 256), batch.n), dim3(256), 0, (hipStream_t)stream, batch);
+    return check_launch("bn_finalize (column sums, batched)");
 }
 
 extern "C" int dpft_bn_act_f32(const float* y, const float* bnp, const float* res, const float* res_bnp,

@@ -28,6 +28,56 @@ struct BnReduceFuse {
 int conv_dgrad_residual(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, const float* res_src,
                         const float* res_mask, void* workspace, dpft_stream_t stream, BnReduceFuse* fuse = nullptr,
                         const unsigned char* res_mask8 = nullptr);      // conv.hip
+// Train-mode BatchNorm statistics as COLUMN SUMS ("sums" form, round 6): the producing conv adds n * mean and M2 + n * mean^2 of
+// every tile to per-channel accumulators, and every forward CONSUMER -- the next conv's operand prologue, the block-closing
+// elementwise pass -- derives (mean, scale, beta) for its channels itself (bn_from_sums below, the same arithmetic everywhere):
+// no finalize launch between a conv and its consumer.  The BN blocks the backward reads and the running statistics come from
+// ONE batched launch at the end of the forward (bn_finalize_sums_batch, bn.hip).
+// The accumulators are 96-bit FIXED-POINT numbers in two 64-bit words (units of 2^-46: a high word counting fours, a low word of
+// 48 bits per addend), added to with INTEGER atomics: integer addition is associative, so the totals -- and with them every BN block
+// -- are the same bits whatever order the tiles arrive in (a floating-point atomic would move them from run to run), and exact to
+// 2^-46 absolute per addend (the addends come from fp32 tile statistics).  Layout [4][K] words: sum 1 high, low, sum 2 high, low;
+// room for 65 536 tiles per launch and |sum| < 2^65.
+struct BnSumsRef {
+    const unsigned long long* sums;      // [4][K]; null = off
+    const float* gamma;
+    const float* beta;
+    double invn;             // 1 / (B * OH * OW)
+    float eps;
+    int K;
+};
+__device__ __forceinline__ void bn_sums_add(unsigned long long* acc, int K, int c, double s1, double s2) {
+    const double h1 = floor(s1 * 0.25), h2 = floor(s2 * 0.25);
+    const unsigned long long l1 = (unsigned long long)((s1 - h1 * 4.0) * 0x1p46), l2 = (unsigned long long)((s2 - h2 * 4.0) * 0x1p46);
+    atomicAdd(acc + c, (unsigned long long)(long long)h1);      // (two's complement: the wrap-around add is the signed add)
+    atomicAdd(acc + K + c, l1);
+    atomicAdd(acc + 2 * K + c, (unsigned long long)(long long)h2);
+    atomicAdd(acc + 3 * K + c, l2);
+}
+__device__ __forceinline__ double bn_sums_get(const unsigned long long* acc, int K, int c, int which) {
+    return (double)(long long)acc[(2 * which) * K + c] * 4.0 + (double)acc[(2 * which + 1) * K + c] * 0x1p-46;
+}
+__device__ __forceinline__ void bn_from_sums(const BnSumsRef& r, int c, float& mean, float& scale, float& beta, float& invstd) {
+    const double m = bn_sums_get(r.sums, r.K, c, 0) * r.invn;
+    const double var = fmax(bn_sums_get(r.sums, r.K, c, 1) * r.invn - m * m, 0.0);
+    mean = (float)m;
+    invstd = 1.0f / sqrtf((float)var + r.eps);
+    scale = r.gamma[c] * invstd;
+    beta = r.beta[c];
+}
+// rows mean | scale | beta of a prologue table [3][K] in LDS, from a BN block or from the sums (all threads of the workgroup; the
+// caller synchronises)
+__device__ __forceinline__ void fill_pro_table(float* tab, const float* bnp, const BnSumsRef& r, int K, int tid, int nt) {
+    if (r.sums) {
+        for (int c = tid; c < K; c += nt) {
+            float mean, scale, beta, invstd;
+            bn_from_sums(r, c, mean, scale, beta, invstd);
+            tab[c] = mean; tab[K + c] = scale; tab[2 * K + c] = beta;
+        }
+    } else {
+        for (int i = tid; i < 3 * K; i += nt) tab[i] = bnp[i];
+    }
+}
 // Train-mode BatchNorm finalize folded into the producing forward conv: tiles add pivoted sums to `acc` [2][K] (zero
 // before the launch, like `ticket`), the workgroup with the last ticket writes the BN block `bnp` [4][K] and updates the
 // running statistics.  `applied` (out) as in BnReduceFuse.
@@ -42,9 +92,13 @@ struct BnFinalFuse {
     float eps, momentum;
     bool applied;
     int slab = 0;      // > 0: deterministic form for launches of at most `slab` row tiles (statistics slab + per-column-tile tickets)
+    unsigned long long* sums = nullptr;      // the "sums" form (BnSumsRef): [4][K] words, zero before the launch; no ticket, nothing finalized here
 };
+// `pro_sums` (may be null): the prologue's BatchNorm comes as column sums; *pro_sums_used tells whether the kernel taken derives
+// its table from them (otherwise NOTHING was launched: the caller finalizes the layer into `pro_bn` and calls again without)
 int conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* pro_bn,
-                     int32_t pro_relu, float* y, float* stats, void* workspace, dpft_stream_t stream, BnFinalFuse* fuse);
+                     int32_t pro_relu, float* y, float* stats, void* workspace, dpft_stream_t stream, BnFinalFuse* fuse,
+                     const BnSumsRef* pro_sums = nullptr, bool* pro_sums_used = nullptr);
 int conv_dgrad_fused(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, int32_t accumulate,
                      void* workspace, dpft_stream_t stream, BnReduceFuse* fuse);
 // bn.hip -- `act16`: the activation / gradient tensors (y, dout, out, dy, res) are bf16 in memory (the pointers keep
@@ -60,6 +114,22 @@ int bn_bwd_apply_zeroing(const float* y, const float* dout, const float* out, co
                          const unsigned char* mask8 = nullptr, bool frozen = false);      // frozen: running-statistics BN (no mean terms)
 int bn_act_any(const float* y, const float* bnp, const float* res, const float* res_bnp, int32_t relu, float* out,
                float* out32, int64_t M, int32_t K, bool act16, dpft_stream_t stream, unsigned char* mask8 = nullptr);
+// the same pass with one or both BatchNorms given as column sums (ys / rs: .sums null = take the BN block); *used = false (and
+// nothing launched) where only the generic kernel fits the shape
+int bn_act_sums(const float* y, const float* bnp, const BnSumsRef& ys, const float* res, const float* res_bnp, const BnSumsRef& rs,
+                int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream, unsigned char* mask8, bool* used);
+struct BnSumsBatch {      // sums -> BN block [4][K] + running statistics of up to MAX layers in one launch (bn.hip)
+    static constexpr int MAX = 48;      // (kernel arguments: 68 bytes per layer)
+    const unsigned long long* sums[MAX];
+    const float *gamma[MAX], *beta[MAX];
+    float *rm[MAX], *rv[MAX], *out[MAX];
+    double invn[MAX];
+    long long M[MAX];
+    int K[MAX];
+    int n;
+    float eps, momentum;
+};
+int bn_finalize_sums_batch(const BnSumsBatch& batch, dpft_stream_t stream);
 int bn_relu_maxpool_any(const float* y, const float* bnp, float* out, int32_t B, int32_t H, int32_t W, int32_t K,
                         int32_t PH, int32_t PW, bool out16, dpft_stream_t stream);
 int bn_relu_maxpool_bwd_any(const float* y, const float* bnp, const float* dout, float* dact, int32_t B, int32_t H,

@@ -1578,7 +1578,7 @@ static int launch_igemm(IgemmArgs& a, const TileChoice& t, bool pro, hipStream_t
 #define PIPE_LDS(BM_, BN_, PBK_) std::max((size_t)2 * (BM_ + BN_) * PBK_ * 4, (size_t)BM_ * (BN_ + 4) * 4 + (size_t)3 * BN_ * 4)
 #define LAUNCH_PIPE(BM_, BN_, PBK_)                                                                       \
     do {                                                                                                  \
-        if (pro) go(igemm_pipe_kernel<BM_, BN_, 2, 2, PBK_, DGRAD, !DGRAD>, PBK_, PIPE_LDS(BM_, BN_, PBK_)); \
+        if (pro) go(igemm_pipe_kernel<BM_, BN_, 2, 2, PBK_, DGRAD, !DGRAD>, PBK_, PIPE_LDS(BM_, BN_, PBK_) + (size_t)12 * a.C); \
         else go(igemm_pipe_kernel<BM_, BN_, 2, 2, PBK_, DGRAD, false>, PBK_, PIPE_LDS(BM_, BN_, PBK_));      \
     } while (0)
         if constexpr (DGRAD) {      // epilogue operands requested with the first tile (EpiPrefetch; a.epf = its MODE)
@@ -1842,8 +1842,11 @@ extern "C" int dpft_conv2d_nhwc_fwd_f32(const dpft_conv_desc* d, const float* x,
 // dpft_bn_finalize_f32 on `stats` as before).
 int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* pro_bn,
                            int32_t pro_relu, float* y, float* stats, void* workspace, dpft_stream_t stream,
-                           BnFinalFuse* fuse) {
+                           BnFinalFuse* fuse, const BnSumsRef* pro_sums, bool* pro_sums_used) {
     if (fuse) fuse->applied = false;
+    if (pro_sums_used) *pro_sums_used = false;
+    if (pro_sums && !pro_sums->sums) pro_sums = nullptr;
+    DPFT_REQUIRE(!pro_sums || (pro_bn && pro_sums_used), "conv fwd: a prologue from column sums needs the BN block's address and the answer slot");
     int rc = check_desc(d);
     if (rc) return rc;
     DPFT_REQUIRE(x && w && y, "conv fwd: null tensor");
@@ -1858,7 +1861,10 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     if (thin_fwd && conv1x1_to16_matches(d) && !pro_bn && !stats) return conv1x1_to16_forward(d, x, w, bias, y, st);
     if (g_conv_bf16 != 1 && !bias && (!pro_bn || pro_relu) && !(fuse && fuse->acc) && stream1x1_match(d, nullptr)) {
         g_prof_family = kFamF32;      // short reduction, wide output, large map: the streaming kernel (conv_stream.hip)
-        return launch_stream1x1(d, x, w, pro_bn, y, stats, nullptr, nullptr, 0, st);
+        unsigned long long* bns = fuse && fuse->sums && stats ? fuse->sums : nullptr;
+        if (bns) fuse->applied = true;
+        if (pro_sums) *pro_sums_used = true;
+        return launch_stream1x1(d, x, w, pro_bn, y, stats, nullptr, nullptr, 0, st, bns, pro_sums);
     }
     IgemmArgs a; fill_igemm(a, d, false);
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.stats = stats;
@@ -1873,6 +1879,13 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     if (d->act16 && !big16) t.splits = 1;      // the split-K reduction kernels write fp32 tensors (big16: in-launch fix-up only)
     if (big16 && t.splits > 1 && !sk_fixup_ok(a, t.splits, 1)) t.splits = 1;
     DPFT_REQUIRE(!(pro && !t.vec), "conv fwd: fused prologue needs C %% 64 == 0 (C=%d)", d->C);
+    if (pro_sums) {
+        // the kernels that build their prologue table from the sums: the split kernels and the pipelined fp32 kernel (launch_igemm)
+        static const int pipe_env = getenv("DPFT_PIPE") ? atoi(getenv("DPFT_PIPE")) : 3;
+        if (!(t.vec && g_conv_bf16 != 1 && !d->act16 && pro_relu && (t.x3 || (pipe_env & 1)) && (int64_t)12 * d->C <= 16384)) return DPFT_OK;
+        a.pro_s = *pro_sums;
+        *pro_sums_used = true;
+    }
     bool fixup = false;
     if (t.splits > 1) {
         DPFT_REQUIRE(workspace, "conv fwd: split-K selected but no workspace given");
@@ -1891,6 +1904,11 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
         a.bnf_acc = fuse->acc; a.bnf_ticket = fuse->ticket; a.bnf_gamma = fuse->gamma; a.bnf_beta = fuse->beta;
         a.bnf_rm = fuse->running_mean; a.bnf_rv = fuse->running_var; a.bnf_bnp = fuse->bnp;
         a.bnf_eps = fuse->eps; a.bnf_mom = fuse->momentum;
+        a.stats = nullptr;
+        fuse->applied = true;
+    }
+    if (fuse && fuse->sums && !fuse->applied && stats && !bias && !d->act16 && t.vec && (a.N & 3) == 0 && (t.splits == 1 || fixup)) {
+        a.bns = fuse->sums;      // column sums instead of the per-tile table; finalized by nobody here
         a.stats = nullptr;
         fuse->applied = true;
     }

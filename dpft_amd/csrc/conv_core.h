@@ -65,6 +65,8 @@ struct IgemmArgs {
     const float* bias;
     const float* pro;      // producer BN block [4][C] = mean, scale, beta, invstd (or null)
     float* stats;     // [mtiles][2][N] or null
+    unsigned long long* bns;      // BatchNorm statistics as column sums [4][N] (common.h: BnSumsRef), added to by every tile; or null
+    BnSumsRef pro_s;  // the prologue's BatchNorm given as column sums (.sums null: `pro` holds the BN block)
     float* partial;   // split-K: [splits][M][N] or null
     int* sk_ticket;   // split-K fix-up (round 4): one zeroed ticket per output tile; the workgroup that draws the last one
                       // sums the partial tiles in split order and runs the normal epilogue -- no reduction launch.  null = the
@@ -272,7 +274,7 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
         __syncthreads();      // the statistics / staging below reuse the same LDS
     }
     const bool part = !HAS_PF && a.partial != nullptr && !fix;      // this launch leaves partial tiles for a reduction kernel
-    if (!HAS_PF && (a.stats != nullptr || a.bnf_acc != nullptr)) {
+    if (!HAS_PF && (a.stats != nullptr || a.bnf_acc != nullptr || a.bns != nullptr)) {
         // ---- per-tile column statistics of the raw conv output (bias-free by construction) ----
         float* red = smem;               // [WGM][BN]
         float* smean = smem + WGM * BN;  // [BN]
@@ -328,6 +330,10 @@ __device__ __forceinline__ void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)
                 float* dst = a.stats + ((size_t)mt * 2 + 1) * a.N + n0 + tid;
                 if (a.bnf_slab) __hip_atomic_store(dst, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 else *dst = s;
+            }
+            if (a.bns) {      // "sums" form: n * mean and M2 + n * mean^2 (fp64: exact products) into the fixed-point accumulators
+                const double m = (double)smean[tid], fc = (double)cnt;
+                bn_sums_add(a.bns, a.N, n0 + tid, fc * m, (double)s + fc * m * m);
             }
             if (a.bnf_acc) {      // fused finalize: this tile's share of the pivoted sums (device-scope atomics)
                 const int n = n0 + tid;
@@ -676,7 +682,8 @@ int split_planes(const float* src, void* dst, int64_t n, hipStream_t st);
 // conv_stream.hip: 1x1 convs with 64 / 128 input channels and K % 256 == 0 on large maps (weights in LDS, rows private to a wave)
 bool stream1x1_match(const dpft_conv_desc* d, int* tile_rows);
 int launch_stream1x1(const dpft_conv_desc* d, const float* x, const float* w, const float* pro_bn, float* y, float* stats,
-                     const float* out_bn, const float* residual, int relu, hipStream_t st);
+                     const float* out_bn, const float* residual, int relu, hipStream_t st, unsigned long long* bns = nullptr,
+                     const BnSumsRef* pro_sums = nullptr);
 // conv_b16w.hip: bf16 operands on 256-row tiles, eight waves (act16 = 2); `a` prepared as for igemm_pipe_kernel<bm, bn, .., B16>
 int launch_igemm_b16w(IgemmArgs& a, int bm, int bn, bool dgrad, hipStream_t st);      // fp32 -> three bf16 planes
 // weight gradient on the split kernels: 128 x 128 tiles, 32 pixels per step; `a` as for wgrad_pipe_kernel<128, 128, 2, 2, 32, *>

@@ -170,10 +170,11 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     // register route of the A operand (PRO only)
     f32x4 ra[PRO ? AP : 1], p_mu, p_sc, p_sh;
     f32x4 q_mu = {0.f, 0.f, 0.f, 0.f}, q_sc = q_mu, q_sh = q_mu;      // B16: channels 4..7 of the lane's 8-channel quad
-    const float* const ptab16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + 2 * STAGE);      // B16 + PRO: [3][C]
-    if constexpr (PRO && B16) {
-        float* tab = reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE);
-        for (int i = tid; i < 3 * a.C; i += 256) tab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
+    // PRO: rows mean, scale, beta of the producer's BatchNorm as a table [3][C] in LDS behind the stages -- copied from the BN block
+    // or derived from the layer's column sums (common.h: fill_pro_table)
+    const float* const ptab16 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(smem) + 2 * STAGE);
+    if constexpr (PRO) {
+        fill_pro_table(reinterpret_cast<float*>(reinterpret_cast<char*>(smem) + 2 * STAGE), a.pro, a.pro_s, a.C, tid, 256);
         __syncthreads();
     }
     unsigned ra_valid = 0;
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
     // The loads of a tile as NOPS separately placeable operations (the main loop puts one behind each of the first MFMAs
     // of a step: a vector-memory instruction takes tens of cycles to issue, which an MFMA in the pipe hides and an idle
     // pipe does not).  Order: A operand, [prologue parameters], weights.
-    constexpr int NPAR = (PRO && !B16) ? 3 : 0;      // fp32: three parameter quads per tile from global memory; bf16: the LDS table
+    constexpr int NPAR = 0;      // (the prologue parameters come from the LDS table, read with the tile's first load)
     constexpr int NOPS = AP + NPAR + BP;
     auto vmem_op = [&](auto STG, auto K) {
         constexpr int stg = decltype(STG)::value, k = decltype(K)::value;
@@ -197,15 +198,16 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
                     p_sc = *reinterpret_cast<const f32x4*>(t + a.C);    q_sc = *reinterpret_cast<const f32x4*>(t + a.C + 4);
                     p_sh = *reinterpret_cast<const f32x4*>(t + 2 * a.C); q_sh = *reinterpret_cast<const f32x4*>(t + 2 * a.C + 4);
                 }
+                if constexpr (!B16 && k == 0) {      // fp32: channels so_a / 4 + 4 chunk .. + 3
+                    const float* t = ptab16 + (so_a >> 2) + chunk * 4;
+                    p_mu = *reinterpret_cast<const f32x4*>(t);
+                    p_sc = *reinterpret_cast<const f32x4*>(t + a.C);
+                    p_sh = *reinterpret_cast<const f32x4*>(t + 2 * a.C);
+                }
             } else {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, lds0 + stg * STAGE + (RPP * k + RW * wave) * ROWB, 16,
                                                          (int)a_off[k], so_a, 0, 0);
             }
-        } else if constexpr (k < AP + NPAR) {
-            const float* src = a.pro + (k - AP) * a.C + (so_a >> 2) + chunk * 4;
-            if constexpr (k - AP == 0) p_mu = *reinterpret_cast<const f32x4*>(src);
-            if constexpr (k - AP == 1) p_sc = *reinterpret_cast<const f32x4*>(src);
-            if constexpr (k - AP == 2) p_sh = *reinterpret_cast<const f32x4*>(src);
         } else {
             constexpr int i = k - AP - NPAR;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, lds0 + stg * STAGE + A_BYTES + (RPP * i + RW * wave) * ROWB, 16,

@@ -26,6 +26,8 @@ struct StreamArgs {
     float* y;            // [M][N]
     const float* pro;    // BN block [4][C] of the input (BatchNorm + ReLU prologue) or null
     float* stats;        // [tiles][2][N] or null (tile = the rows of one workgroup)
+    unsigned long long* bns;   // the statistics as column sums instead (common.h: BnSumsRef), or null
+    BnSumsRef pro_s;     // the prologue's BatchNorm as column sums (.sums null: `pro`)
     const float* obn;    // inference: BN block [4][N] of the output channels, or null
     const float* oadd;   // inference: residual [M][N] or null
     int orelu;
@@ -53,7 +55,7 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(StreamArgs a) {
     }
     float* ptab = smem + NB * KC;
     if constexpr (PRO) {
-        for (int i = tid; i < 3 * KC; i += NT) ptab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
+        fill_pro_table(ptab, a.pro, a.pro_s, KC, tid, NT);      // rows mean, scale, beta (from the BN block or the layer's column sums)
     }
     __syncthreads();
     // (restrict: without it every block's residual loads wait for the previous block's stores -- s_waitcnt vmcnt(0) -- because
@@ -208,7 +210,10 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(StreamArgs a) {
                         n = nn;
                     }
                 }
-                if (n > 0.f) {
+                if (n > 0.f && a.bns) {
+                    const double m = (double)mean, fc = (double)n;
+                    bn_sums_add(a.bns, a.N, n0 + tid, fc * m, (double)m2 + fc * m * m);
+                } else if (n > 0.f) {
                     a.stats[((size_t)wg * 2 + 0) * a.N + n0 + tid] = mean;
                     a.stats[((size_t)wg * 2 + 1) * a.N + n0 + tid] = m2;
                 }
@@ -246,13 +251,15 @@ bool stream1x1_match(const dpft_conv_desc* d, int* tile_rows) {
 }
 
 int launch_stream1x1(const dpft_conv_desc* d, const float* x, const float* w, const float* pro_bn, float* y, float* stats,
-                     const float* out_bn, const float* residual, int relu, hipStream_t st) {
+                     const float* out_bn, const float* residual, int relu, hipStream_t st, unsigned long long* bns,
+                     const BnSumsRef* pro_sums) {
     int tile_rows = 0, nb = 0, nw = 0;
     DPFT_REQUIRE(stream1x1_match(d, &tile_rows) && stream_geom(d->C, nb, nw), "conv 1x1 (streaming): problem not supported");
     DPFT_REQUIRE(!(out_bn && (stats || pro_bn)), "conv 1x1 (streaming): inference epilogue takes no prologue / statistics");
     StreamArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.w = w; a.y = y; a.pro = pro_bn; a.stats = stats; a.obn = out_bn; a.oadd = residual; a.orelu = relu;
+    a.x = x; a.w = w; a.y = y; a.pro = pro_bn; a.stats = stats; a.bns = bns;      /* (bns: `stats` only says that statistics are wanted) */ a.obn = out_bn; a.oadd = residual; a.orelu = relu;
+    if (pro_sums) a.pro_s = *pro_sums;
     a.M = d->B * d->OH * d->OW; a.N = d->K;
     a.rbw = tile_rows / (32 * nw);
     a.nslices = d->K / nb;

@@ -180,7 +180,7 @@ __global__ __launch_bounds__(256) void igemm_x3_kernel(IgemmArgs a) {
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)smem;
     if constexpr (PRO) {
         float* tab = reinterpret_cast<float*>(lds + 2 * STAGE);
-        for (int i = tid; i < 3 * a.C; i += 256) tab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
+        fill_pro_table(tab, a.pro, a.pro_s, a.C, tid, 256);      // rows mean, scale, beta (from the BN block or the layer's column sums)
     }
     const unsigned ptab_ad = lds_base + 2 * STAGE + ch * 16;
 

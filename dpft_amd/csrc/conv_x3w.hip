@@ -141,7 +141,7 @@ __global__ __launch_bounds__(512) void igemm_x3w_kernel(IgemmArgs a) {
     const unsigned lds_base = (unsigned)(size_t)(lds_char*)smem;
     if constexpr (PRO) {
         float* tab = reinterpret_cast<float*>(lds + 2 * STAGE);
-        for (int i = tid; i < 3 * a.C; i += 512) tab[i] = a.pro[i];      // rows mean, scale, beta of the [4][C] block
+        fill_pro_table(tab, a.pro, a.pro_s, a.C, tid, 512);      // rows mean, scale, beta (from the BN block or the layer's column sums)
     }
     const float* const ptab = reinterpret_cast<const float*>(lds + 2 * STAGE) + ch * 4;
 

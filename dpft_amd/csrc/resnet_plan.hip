@@ -67,6 +67,11 @@ struct ResnetPlan {
     size_t o_dy, o_da, o_dd, o_wt, o_sums;   // backward scratch offsets (floats)
     std::vector<size_t> bnacc;      // per BatchNorm: float offset of its fused-finalize accumulators [2][K] + ticket (16 floats)
     size_t o_bnacc = 0, bnacc_floats = 0;
+    // "sums" form of the train-mode statistics (common.h: BnSumsRef): layers whose BN block has not been written yet in THIS forward
+    // (their consumers derive the parameters from the column sums; the batched finalize at the end of the forward writes the blocks)
+    struct PendingBn { int bn, K; long long M; size_t bnp; };
+    std::vector<char> bn_pending;
+    std::vector<PendingBn> pend_list;
     size_t o_dy2;           // second dy buffer: weight gradients run on a side stream while the data path moves on
     int g_cur;
     bool g_valid;
@@ -230,13 +235,14 @@ extern "C" int64_t dpft_resnet_plan_create(const dpft_resnet_desc* desc) {
     {   // accumulators of the fused BatchNorm finalize (conv epilogue): one zero-fill per forward covers them all
         p->bnacc.assign(nbn, 0);
         size_t acc = 0;
-        auto add = [&](int bn, int K) { p->bnacc[bn] = acc; acc += align64((size_t)2 * K + 16); };
+        auto add = [&](int bn, int K) { p->bnacc[bn] = acc; acc += align64((size_t)8 * K + 16); };      // (the sums form: [4][K] 64-bit words)
         add(p->bn0, 64);
         for (const BlockPlan& b : p->blocks) {
             add(b.bn1, b.c1.d.K); add(b.bn2, b.c2.d.K); add(b.bn3, b.c3.d.K);
             if (b.has_ds) add(b.bnd, b.cd.d.K);
         }
         p->bnacc_floats = acc;
+        p->bn_pending.assign(nbn, 0);
         p->o_bnacc = take(acc);
     }
     p->fwd_floats = off;
@@ -345,9 +351,57 @@ static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* 
 //      (28.95 vs 29.0 ms) -- the merger's ~3 us at the end of each conv (one ticket round trip + 64 slab loads in flight; a
 //      first form with the loads one at a time cost 14 us and LOST 0.5 ms) are what the removed kernel boundary cost.
 // Both stay off: neither beats the separate 5 us kernel by enough to carry the extra memory-ordering argument.
-static int conv_bn_train(const ResnetPlan* p, const Tables& T, const ConvRef& c, int bn, const float* x, const float* pro,
+// The "sums" form (DPFT_BN_SUMS, fp32 tensors): no finalize launch between a conv and its consumer at all -- see common.h: BnSumsRef.
+static bool bn_sums_on(const ResnetPlan* p) {
+    static const int on = getenv("DPFT_BN_SUMS") ? atoi(getenv("DPFT_BN_SUMS")) : 1;      // A/B switch: 0 = per-tile tables + one bn_finalize launch per layer
+    static const int fuse_mode = getenv("DPFT_BN_FINAL_FUSE") ? atoi(getenv("DPFT_BN_FINAL_FUSE")) : 0;
+    return on != 0 && fuse_mode == 0 && p->desc.act16 == 0 && !p->frozen;
+}
+static BnSumsRef bn_sums_ref(const ResnetPlan* p, const Tables& T, float* A, int bn, int K, int64_t M) {
+    return BnSumsRef{(const unsigned long long*)(A + p->o_bnacc + p->bnacc[bn]), T.gamma(bn), T.beta(bn), 1.0 / (double)M, p->desc.eps, K};
+}
+// the BN blocks + running statistics of the pending layers [from, end of the list) -- BnSumsBatch::MAX per launch
+static int bn_finalize_pending(ResnetPlan* p, const Tables& T, float* A, size_t from, dpft_stream_t st) {
+    BnSumsBatch batch;
+    memset(&batch, 0, sizeof(batch));
+    batch.eps = p->desc.eps; batch.momentum = p->desc.momentum;
+    for (size_t i = from; i < p->pend_list.size(); ++i) {
+        const ResnetPlan::PendingBn& e = p->pend_list[i];
+        if (!p->bn_pending[e.bn]) continue;      // (finalized on its own already: a consumer without the sums form)
+        const int j = batch.n++;
+        batch.sums[j] = (const unsigned long long*)(A + p->o_bnacc + p->bnacc[e.bn]);
+        batch.gamma[j] = T.gamma(e.bn); batch.beta[j] = T.beta(e.bn); batch.rm[j] = T.rm(e.bn); batch.rv[j] = T.rv(e.bn);
+        batch.out[j] = A + e.bnp; batch.invn[j] = 1.0 / (double)e.M; batch.M[j] = e.M; batch.K[j] = e.K;
+        p->bn_pending[e.bn] = 0;
+        if (batch.n == BnSumsBatch::MAX) {
+            RC(bn_finalize_sums_batch(batch, st));
+            batch.n = 0;
+        }
+    }
+    if (batch.n > 0) RC(bn_finalize_sums_batch(batch, st));
+    return DPFT_OK;
+}
+static int bn_finalize_one(ResnetPlan* p, const Tables& T, float* A, int bn, dpft_stream_t st) {
+    for (size_t i = 0; i < p->pend_list.size(); ++i)
+        if (p->pend_list[i].bn == bn) {
+            BnSumsBatch batch;
+            memset(&batch, 0, sizeof(batch));
+            const ResnetPlan::PendingBn& e = p->pend_list[i];
+            batch.eps = p->desc.eps; batch.momentum = p->desc.momentum; batch.n = 1;
+            batch.sums[0] = (const unsigned long long*)(A + p->o_bnacc + p->bnacc[bn]);
+            batch.gamma[0] = T.gamma(bn); batch.beta[0] = T.beta(bn); batch.rm[0] = T.rm(bn); batch.rv[0] = T.rv(bn);
+            batch.out[0] = A + e.bnp; batch.invn[0] = 1.0 / (double)e.M; batch.M[0] = e.M; batch.K[0] = e.K;
+            p->bn_pending[bn] = 0;
+            return bn_finalize_sums_batch(batch, st);
+        }
+    set_error("resnet plan: BatchNorm %d is not pending", bn);
+    return DPFT_ERR_ARG;
+}
+
+// `pro_bn` / `pro_K` / `pro_M`: the BatchNorm layer behind the prologue block `pro` (its index, channels, rows), for the sums form
+static int conv_bn_train(ResnetPlan* p, const Tables& T, const ConvRef& c, int bn, const float* x, const float* pro,
                          float* A, float* y, float* stats, int tiles, int rows, int64_t M, float* bnp, void* ws,
-                         dpft_stream_t st, const float* w = nullptr) {
+                         dpft_stream_t st, const float* w = nullptr, int pro_bn = -1, int pro_K = 0, int64_t pro_M = 0) {
     if (!w) w = T.w(c.w);
     if (p->frozen)      // the BN block comes from the running statistics (eval_bn_blocks): no statistics, no finalize
         return conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, nullptr, ws, st, nullptr);
@@ -356,7 +410,22 @@ static int conv_bn_train(const ResnetPlan* p, const Tables& T, const ConvRef& c,
     float* acc = A + p->o_bnacc + p->bnacc[bn];
     BnFinalFuse f{acc, (int*)(acc + 2 * c.d.K), T.gamma(bn), T.beta(bn), T.rm(bn), T.rv(bn), bnp, p->desc.eps, p->desc.momentum, false,
                   fuse_mode == 2 ? slab_tiles : 0};
-    RC(conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, stats, ws, st, fuse_mode ? &f : nullptr));
+    const bool sums = bn_sums_on(p);
+    if (sums) { f.acc = nullptr; f.ticket = nullptr; f.sums = (unsigned long long*)acc; }
+    bool launched = false;
+    if (sums && pro && pro_bn >= 0 && p->bn_pending[pro_bn]) {
+        const BnSumsRef ps = bn_sums_ref(p, T, A, pro_bn, pro_K, pro_M);
+        bool used = false;
+        RC(conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, 1, y, stats, ws, st, &f, &ps, &used));
+        launched = used;
+        if (!used) RC(bn_finalize_one(p, T, A, pro_bn, st));      // this conv's kernel reads BN blocks only
+    }
+    if (!launched) RC(conv_fwd_bnfinal(&c.d, x, w, nullptr, pro, pro ? 1 : 0, y, stats, ws, st, (fuse_mode || sums) ? &f : nullptr));
+    if (f.applied && f.sums) {
+        p->bn_pending[bn] = 1;
+        p->pend_list.push_back(ResnetPlan::PendingBn{bn, c.d.K, (long long)M, (size_t)(bnp - A)});
+        return DPFT_OK;
+    }
     if (f.applied) return DPFT_OK;
     return dpft_bn_finalize_f32(stats, tiles, rows, M, c.d.K, T.gamma(bn), T.beta(bn), p->desc.eps, p->desc.momentum, T.rm(bn),
                                 T.rv(bn), bnp, st);
@@ -407,7 +476,9 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
         xa = A + p->xa;
     }
     static const bool final_fuse = getenv("DPFT_BN_FINAL_FUSE") != nullptr && atoi(getenv("DPFT_BN_FINAL_FUSE")) != 0;
-    if (tr && final_fuse) RC(zero_fill(A + p->o_bnacc, p->bnacc_floats * sizeof(float), st));
+    if (tr && (final_fuse || bn_sums_on(p))) RC(zero_fill(A + p->o_bnacc, p->bnacc_floats * sizeof(float), st));
+    p->pend_list.clear();
+    std::fill(p->bn_pending.begin(), p->bn_pending.end(), 0);
     RC(dpft_conv2d_nhwc_fwd_f32(&p->c0.d, xa, T.w(p->c0.w), nullptr, nullptr, 0, A + p->y0, tr && !p->frozen ? A + p->s0 : nullptr, ws, st));
     RC(bn_params(p, T, p->bn0, A + p->s0, p->t0, p->r0, (int64_t)p->c0.d.B * p->c0.d.OH * p->c0.d.OW, 64, A + p->p0, tr && !p->frozen, st));
     const bool a16 = p->desc.act16 != 0;
@@ -479,19 +550,28 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
             }
         } else {
         RC(conv_bn_train(p, T, b.c1, b.bn1, A + b.x, nullptr, A, A + b.y1, A + b.s1, b.t1, b.r1, M1, A + b.p1, ws, st));
-        RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st));
-        RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.y2, A + b.p2, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st));
+        RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st, nullptr, b.bn1, b.c1.d.K, M1));
+        RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.y2, A + b.p2, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st, nullptr, b.bn2, b.c2.d.K, M2));
         }
-        if (b.has_ds) {
+        if (b.has_ds)
             RC(conv_bn_train(p, T, b.cd, b.bnd, A + b.x, nullptr, A, A + b.yd, A + b.sd, b.td, b.rd, M2, A + b.pd, ws, st,
                              w16 ? A + b.cd.w16 : nullptr));
-            RC(bn_act_any(A + b.y3, A + b.p3, A + b.yd, A + b.pd, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st,
-                          tr ? (unsigned char*)(A + b.mask) : nullptr));
-        } else {
-            RC(bn_act_any(A + b.y3, A + b.p3, A + b.x, nullptr, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st,
-                          tr ? (unsigned char*)(A + b.mask) : nullptr));
+        const float* identity = b.has_ds ? A + b.yd : A + b.x;
+        const float* id_bnp = b.has_ds ? A + b.pd : nullptr;
+        unsigned char* mask = tr ? (unsigned char*)(A + b.mask) : nullptr;
+        bool closed = false;
+        if (p->bn_pending[b.bn3] || (b.has_ds && p->bn_pending[b.bnd])) {      // the sums form: the pass derives its parameters itself
+            const BnSumsRef ys = p->bn_pending[b.bn3] ? bn_sums_ref(p, T, A, b.bn3, b.c3.d.K, M2) : BnSumsRef{};
+            const BnSumsRef rs = b.has_ds && p->bn_pending[b.bnd] ? bn_sums_ref(p, T, A, b.bnd, b.cd.d.K, M2) : BnSumsRef{};
+            RC(bn_act_sums(A + b.y3, A + b.p3, ys, identity, id_bnp, rs, 1, A + b.out, M2, b.c3.d.K, st, mask, &closed));
+            if (!closed) {
+                if (p->bn_pending[b.bn3]) RC(bn_finalize_one(p, T, A, b.bn3, st));
+                if (b.has_ds && p->bn_pending[b.bnd]) RC(bn_finalize_one(p, T, A, b.bnd, st));
+            }
         }
+        if (!closed) RC(bn_act_any(A + b.y3, A + b.p3, identity, id_bnp, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st, mask));
     }
+    RC(bn_finalize_pending(p, T, A, 0, st));      // the sums form: every BN block the backward reads + the running statistics, 48 layers per launch
     p->g_valid = false;
     return DPFT_OK;
 }

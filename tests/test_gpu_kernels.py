@@ -1446,6 +1446,59 @@ def test_conv_bf16_large_tile_kernels_vs_fp64():
 
 
 @pytest.mark.gpu
+def test_batchnorm_statistics_as_column_sums_equal_the_tile_tables_and_repeat_bit_for_bit(tmp_path):
+    """csrc/common.h: BnSumsRef -- the train-mode statistics as fixed-point column sums (integer atomics in the conv epilogues, no
+    finalize launch: the next conv's prologue table and the block-closing pass derive mean / scale themselves; BN blocks for the
+    backward + running statistics from one batched launch) against the per-tile (mean, M2) tables + bn_finalize per layer, on a
+    ResNet-50 body at 2 x 512 x 256 (layer 1 has 16 384 rows: pipelined, split, streaming and elementwise consumers all take
+    part): outputs, every parameter gradient and the running statistics agree to fp32 rounding of the statistics, and two runs
+    of the sums form give the same bits (integer accumulation does not depend on the order the tiles arrive in)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = {}
+    for tag, mode in (("tables", "0"), ("sums_a", "1"), ("sums_b", "1")):
+        files[tag] = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, os.path.join(root, "tools", "bn_sums_check.py"), files[tag]],
+                           env=dict(os.environ, DPFT_BN_SUMS=mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    t, a, b = (torch.load(files[k]) for k in ("tables", "sums_a", "sums_b"))
+    assert all(torch.equal(t["sd"][k], a["sd"][k]) for k in t["sd"]) and torch.equal(t["x"], a["x"])      # same problem
+    for rep in (0, 1):
+        for kind in ("out", "buf"):
+            for n in t[rep][kind]:
+                assert torch.equal(a[rep][kind][n], b[rep][kind][n]), (rep, kind, n)      # the forward, run to run: the same bits
+    # (the backward reorders fp32 sums from run to run in either form: weight-gradient slabs, atomics of the stem -- test_gpu_model's
+    # repeatability property bounds that)
+    worst = {"out": 0.0, "grad": 0.0, "buf": 0.0}
+    for rep in (0, 1):
+        for kind in worst:
+            for n, ref in t[rep][kind].items():
+                if not ref.is_floating_point() or float(ref.double().norm()) == 0.0:
+                    continue
+                e = float((a[rep][kind][n].double() - ref.double()).norm() / ref.double().norm())
+                worst[kind] = max(worst[kind], e)
+    num = sum(float((a[0]["grad"][n].double() - t[0]["grad"][n].double()).norm()) ** 2 for n in t[0]["grad"])
+    den = sum(float(t[0]["grad"][n].double().norm()) ** 2 for n in t[0]["grad"])
+    print("column sums vs tile tables, worst rel-L2:", worst, "whole gradient", (num / den) ** 0.5)
+    # the two forms differ in how the statistics are SUMMED (fp32 pivoted merge vs exact): 1e-7-level differences of the BN blocks,
+    # amplified by a 50-layer train-mode chain on raw 0..255 inputs and, for single gradient tensors, by ReLU-mask flips at
+    # near-zero pre-activations (test_gpu_model.test_backbone_train_fwd_bwd: the same sensitivity against fp64)
+    assert worst["out"] < 5e-4 and worst["buf"] < 5e-5 and worst["grad"] < 0.1 and (num / den) ** 0.5 < 2e-2, (worst, (num / den) ** 0.5)
+    # which one is right: the fp64 oracle on the same weights -- the sums form must not be further from it than the tables form
+    from oracle import dprt_oracle as O
+    sd64 = {"bb." + k: (v.double() if v.is_floating_point() else v) for k, v in t["sd"].items()}
+    ref = O.backbone(t["x"].double(), sd64, "bb", t["name"], train=True, multi_scale=4)
+    for k, r in ref.items():
+        e_t = float((t[0]["out"][k].double() - r).norm() / r.norm())
+        e_s = float((a[0]["out"][k].double() - r).norm() / r.norm())
+        print(f"layer{k} vs fp64: tile tables {e_t:.2e}  column sums {e_s:.2e}")
+        assert e_s < max(1.5 * e_t, 1e-5) and e_s < 2e-4, (k, e_t, e_s)
+    # the second forward of a run repeats the first (same input, same weights; only the running statistics moved on)
+    for k in t[0]["out"]:
+        assert torch.equal(a[0]["out"][k], a[1]["out"][k]), k
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("B,H,W,Cin,K", [(2, 96, 171, 64, 256),      # M = 32 832: ragged last row block (M % 32 = 0, % 128 != 0)
                                          (1, 129, 131, 64, 256),     # M = 16 899: ragged inside a 32-row block
                                          (4, 64, 114, 128, 512),     # layer-2 conv3 shape: two column slices, C = 128

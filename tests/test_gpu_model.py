@@ -347,13 +347,13 @@ def test_full_size_train_step_matches_oracle():
     l32, o32, g32, m32 = res["f32"]
     l64, o64, g64, m64 = res["f64"]
     # Hungarian assignments: bit-exact against the reference arithmetic (and its fp64 form)
-    for i in range(4):
-        for ref in (m32, m64):
-            assert torch.equal(matches[i][0].cpu(), ref[i][0]) and torch.equal(matches[i][1].cpu(), ref[i][1]), i
     for k in out:
         e, e32 = rel_l2(out[k], o64[k]), rel_l2(o32[k], o64[k])
         print(f"full-size train out {k}: rel-L2 hip {e:.2e}  fp32 oracle {e32:.2e}")
         assert e < max(1e-4, 4 * e32), (k, e, e32)
+    for i in range(4):
+        for ref in (m32, m64):
+            assert torch.equal(matches[i][0].cpu(), ref[i][0]) and torch.equal(matches[i][1].cpu(), ref[i][1]), i
     el, el32 = abs(float(loss) - l64) / abs(l64), abs(l32 - l64) / abs(l64)
     print(f"full-size train loss: hip {float(loss):.6f} fp32 oracle {l32:.6f} fp64 {l64:.6f}")
     assert el < max(1e-5, 4 * el32), (float(loss), l32, l64)
