@@ -1861,7 +1861,7 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
     if (thin_fwd && conv1x1_to16_matches(d) && !pro_bn && !stats) return conv1x1_to16_forward(d, x, w, bias, y, st);
     if (g_conv_bf16 != 1 && !bias && (!pro_bn || pro_relu) && !(fuse && fuse->acc) && stream1x1_match(d, nullptr)) {
         g_prof_family = kFamF32;      // short reduction, wide output, large map: the streaming kernel (conv_stream.hip)
-        unsigned long long* bns = fuse && fuse->sums && stats ? fuse->sums : nullptr;
+        unsigned long long* bns = fuse && fuse->sums && stats && (int64_t)d->B * d->OH * d->OW < (1 << 22) ? fuse->sums : nullptr;
         if (bns) fuse->applied = true;
         if (pro_sums) *pro_sums_used = true;
         return launch_stream1x1(d, x, w, pro_bn, y, stats, nullptr, nullptr, 0, st, bns, pro_sums);
@@ -1907,7 +1907,9 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
         a.stats = nullptr;
         fuse->applied = true;
     }
-    if (fuse && fuse->sums && !fuse->applied && stats && !bias && !d->act16 && t.vec && (a.N & 3) == 0 && (t.splits == 1 || fixup)) {
+    // (the accumulators' low words hold 65 536 addends: tiles of >= 64 rows)
+    if (fuse && fuse->sums && !fuse->applied && stats && !bias && !d->act16 && t.vec && (a.N & 3) == 0 && (t.splits == 1 || fixup) &&
+        a.M < (1 << 22)) {
         a.bns = fuse->sums;      // column sums instead of the per-tile table; finalized by nobody here
         a.stats = nullptr;
         fuse->applied = true;
