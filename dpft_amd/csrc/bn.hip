@@ -214,14 +214,38 @@ __global__ __launch_bounds__(256) void bn_act_fixc_kernel(const float* __restric
     const unsigned stride = gridDim.x * blockDim.x;      // % K4 == 0, n4 < 2^30 (host)
     const unsigned first = blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(first % (unsigned)K4) * 4;
+    // K4 < 256: the block's 256 threads meet only K4 distinct channel quads -- thread j < K4 derives quad (first_of_block + j) % K4
+    // into LDS, everybody reads slot tid % K4 (the fp64 derivation is ~40 instructions per channel; a small-K pass over a large
+    // map would otherwise repeat it 256 / K4 times per block)
+    extern __shared__ float sums_tab[];      // [2][3][K] when shared (host: 24 K bytes), else nothing
+    const bool share = SUMS && K4 < 256;
+    const int slot = share ? ((int)threadIdx.x % K4) * 4 : 0;
+    auto derive = [&](const BnSumsRef& r, int which, f32x4& o_mu, f32x4& o_sc, f32x4& o_be) {
+        if (share) {
+            if ((int)threadIdx.x < K4) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    float m_, s_, b_, is_;
+                    bn_from_sums(r, c + e, m_, s_, b_, is_);
+                    sums_tab[(which * 3 + 0) * K + slot + e] = m_; sums_tab[(which * 3 + 1) * K + slot + e] = s_; sums_tab[(which * 3 + 2) * K + slot + e] = b_;
+                }
+            }
+            __syncthreads();
+            o_mu = *reinterpret_cast<const f32x4*>(sums_tab + (which * 3 + 0) * K + slot);
+            o_sc = *reinterpret_cast<const f32x4*>(sums_tab + (which * 3 + 1) * K + slot);
+            o_be = *reinterpret_cast<const f32x4*>(sums_tab + (which * 3 + 2) * K + slot);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float m_, s_, b_, is_;
+                bn_from_sums(r, c + e, m_, s_, b_, is_);
+                o_mu[e] = m_; o_sc[e] = s_; o_be[e] = b_;
+            }
+        }
+    };
     f32x4 mu, sc, be;
     if (SUMS && ys.sums) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float m_, s_, b_, is_;
-            bn_from_sums(ys, c + e, m_, s_, b_, is_);
-            mu[e] = m_; sc[e] = s_; be[e] = b_;
-        }
+        derive(ys, 0, mu, sc, be);
     } else {
         mu = *reinterpret_cast<const f32x4*>(bnp + c);
         sc = *reinterpret_cast<const f32x4*>(bnp + K + c);
@@ -230,12 +254,7 @@ __global__ __launch_bounds__(256) void bn_act_fixc_kernel(const float* __restric
     f32x4 rmu = mu, rsc = sc, rbe = be;
     const bool rbnp = rbnp_ != nullptr || (SUMS && rs.sums != nullptr);      // the residual has a BatchNorm of its own (downsample branch)
     if (SUMS && rs.sums) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float m_, s_, b_, is_;
-            bn_from_sums(rs, c + e, m_, s_, b_, is_);
-            rmu[e] = m_; rsc[e] = s_; rbe[e] = b_;
-        }
+        derive(rs, 1, rmu, rsc, rbe);
     } else if (rbnp_) {
         rmu = *reinterpret_cast<const f32x4*>(rbnp_ + c);
         rsc = *reinterpret_cast<const f32x4*>(rbnp_ + K + c);
@@ -296,11 +315,15 @@ __device__ __forceinline__ unsigned relu_bits(f32x4 v) {
 }
 // FIXC (round 6): the grid stride is a multiple of K / 8 -- a thread meets the same 8 channels in every trip and loads their
 // parameters once (as bn_act_fixc_kernel)
-template <bool FIXC>
+// SUMS (FIXC only): either BatchNorm may come as column sums (common.h: BnSumsRef), as in bn_act_fixc_kernel
+template <bool FIXC, bool SUMS = false>
 __global__ __launch_bounds__(256) void bn_act16_kernel(const float* __restrict__ y, const float* __restrict__ bnp,
-                                                        const float* __restrict__ res, const float* __restrict__ rbnp,
+                                                        const float* __restrict__ res, const float* __restrict__ rbnp_,
                                                         int relu, float* __restrict__ out, float* __restrict__ out32,
-                                                        int64_t n8, int K8, unsigned char* __restrict__ mask8) {
+                                                        int64_t n8, int K8, unsigned char* __restrict__ mask8, BnSumsRef ys, BnSumsRef rs) {
+    static_assert(FIXC || !SUMS, "column sums: fixed-channel form only");
+    const bool rbnp_on = rbnp_ != nullptr || (SUMS && rs.sums != nullptr);
+    const float* const rbnp = rbnp_on ? (rbnp_ ? rbnp_ : bnp) : nullptr;      // (non-null = the residual has a BatchNorm; FIXC reads the registers)
     DPFT_SETPRIO_BN();
     const int K = K8 * 8;
     constexpr int U = 2;
@@ -310,16 +333,52 @@ __global__ __launch_bounds__(256) void bn_act16_kernel(const float* __restrict__
     const int cfix = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) % K8) * 8;
     f32x4 pmu[2], psc[2], pbe[2], qmu[2], qsc[2], qbe[2];
     if constexpr (FIXC) {
+        // (K8 < 256: the block's distinct channel octets are derived once, into LDS -- see bn_act_fixc_kernel)
+        extern __shared__ float sums_tab[];      // [2][3][K] when shared (host: 24 K bytes)
+        const bool share = SUMS && K8 < 256;
+        const int slot = share ? ((int)threadIdx.x % K8) * 8 : 0;
+        auto derive = [&](const BnSumsRef& r, int which, f32x4* o_mu, f32x4* o_sc, f32x4* o_be) {
+            if (share) {
+                if ((int)threadIdx.x < K8) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float m_, s_, b_, is_;
+                        bn_from_sums(r, cfix + e, m_, s_, b_, is_);
+                        sums_tab[(which * 3 + 0) * K + slot + e] = m_; sums_tab[(which * 3 + 1) * K + slot + e] = s_; sums_tab[(which * 3 + 2) * K + slot + e] = b_;
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    o_mu[hh] = *reinterpret_cast<const f32x4*>(sums_tab + (which * 3 + 0) * K + slot + 4 * hh);
+                    o_sc[hh] = *reinterpret_cast<const f32x4*>(sums_tab + (which * 3 + 1) * K + slot + 4 * hh);
+                    o_be[hh] = *reinterpret_cast<const f32x4*>(sums_tab + (which * 3 + 2) * K + slot + 4 * hh);
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float m_, s_, b_, is_;
+                    bn_from_sums(r, cfix + e, m_, s_, b_, is_);
+                    o_mu[e >> 2][e & 3] = m_; o_sc[e >> 2][e & 3] = s_; o_be[e >> 2][e & 3] = b_;
+                }
+            }
+        };
+        if (SUMS && ys.sums) derive(ys, 0, pmu, psc, pbe);
+        if (SUMS && rs.sums) derive(rs, 1, qmu, qsc, qbe);
 #pragma unroll
         for (int hh = 0; hh < 2; ++hh) {
-            pmu[hh] = *reinterpret_cast<const f32x4*>(bnp + cfix + 4 * hh);
-            psc[hh] = *reinterpret_cast<const f32x4*>(bnp + K + cfix + 4 * hh);
-            pbe[hh] = *reinterpret_cast<const f32x4*>(bnp + 2 * K + cfix + 4 * hh);
-            qmu[hh] = pmu[hh]; qsc[hh] = psc[hh]; qbe[hh] = pbe[hh];
-            if (rbnp) {
-                qmu[hh] = *reinterpret_cast<const f32x4*>(rbnp + cfix + 4 * hh);
-                qsc[hh] = *reinterpret_cast<const f32x4*>(rbnp + K + cfix + 4 * hh);
-                qbe[hh] = *reinterpret_cast<const f32x4*>(rbnp + 2 * K + cfix + 4 * hh);
+            if (SUMS && ys.sums) {
+            } else {
+                pmu[hh] = *reinterpret_cast<const f32x4*>(bnp + cfix + 4 * hh);
+                psc[hh] = *reinterpret_cast<const f32x4*>(bnp + K + cfix + 4 * hh);
+                pbe[hh] = *reinterpret_cast<const f32x4*>(bnp + 2 * K + cfix + 4 * hh);
+            }
+            if (!(SUMS && rs.sums)) { qmu[hh] = pmu[hh]; qsc[hh] = psc[hh]; qbe[hh] = pbe[hh]; }
+            if (SUMS && rs.sums) {
+            } else if (rbnp_) {
+                qmu[hh] = *reinterpret_cast<const f32x4*>(rbnp_ + cfix + 4 * hh);
+                qsc[hh] = *reinterpret_cast<const f32x4*>(rbnp_ + K + cfix + 4 * hh);
+                qbe[hh] = *reinterpret_cast<const f32x4*>(rbnp_ + 2 * K + cfix + 4 * hh);
             }
         }
     }
@@ -1077,11 +1136,11 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
     {
         int blocks = ew_blocks(n4 / 2);
         if (fixc_grid(K / 8, n4 / 2, blocks))
-            hipLaunchKernelGGL(bn_act16_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
-                               out32, n4 / 2, K / 8, mask8);
+            hipLaunchKernelGGL((bn_act16_kernel<true, false>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
+                               out32, n4 / 2, K / 8, mask8, BnSumsRef{}, BnSumsRef{});
         else
-            hipLaunchKernelGGL(bn_act16_kernel<false>, dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
-                               out32, n4 / 2, K / 8, mask8);
+            hipLaunchKernelGGL((bn_act16_kernel<false, false>), dim3(ew_blocks(n4 / 2)), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out,
+                               out32, n4 / 2, K / 8, mask8, BnSumsRef{}, BnSumsRef{});
     }
     else if (act16)
         hipLaunchKernelGGL(bn_act_kernel<__bf16>, dim3(ew_blocks(n4)), dim3(256), 0, (hipStream_t)stream, y, bnp, res,
@@ -1111,7 +1170,8 @@ int dpft::bn_act_any(const float* y, const float* bnp, const float* res, const f
 }
 
 int dpft::bn_act_sums(const float* y, const float* bnp, const BnSumsRef& ys, const float* res, const float* res_bnp, const BnSumsRef& rs,
-                      int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream, unsigned char* mask8, bool* used) {
+                      int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream, unsigned char* mask8, bool* used,
+                      bool act16, float* out32) {
     DPFT_REQUIRE(y && out && used && M > 0 && K > 0 && K % 4 == 0 && (bnp || ys.sums), "bn_act (column sums): bad arguments (K=%d)", K);
     DPFT_REQUIRE(res || !(res_bnp || rs.sums), "bn_act (column sums): a residual BatchNorm without a residual");
     *used = false;
@@ -1123,6 +1183,18 @@ int dpft::bn_act_sums(const float* y, const float* bnp, const BnSumsRef& ys, con
     static const int fat = getenv("DPFT_BN_FAT") ? atoi(getenv("DPFT_BN_FAT")) : 1;
     const int64_t n4 = M * K / 4;
     const int K4 = K / 4;
+    if (act16) {      // bf16 storage: the 16-byte fixed-channel form (bn_act_any's conditions)
+        static const bool wide16 = getenv("DPFT_BN_WIDE16") == nullptr || atoi(getenv("DPFT_BN_WIDE16")) != 0;
+        if (!(wide16 && K % 8 == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)out & 15) == 0 && ((uintptr_t)res & 15) == 0 && ((uintptr_t)mask8 & 1) == 0))
+            return DPFT_OK;
+        int blocks = ew_blocks(n4 / 2);
+        if (!fixc_grid(K / 8, n4 / 2, blocks)) return DPFT_OK;
+        hipLaunchKernelGGL((bn_act16_kernel<true, true>), dim3(blocks), dim3(256), K / 8 < 256 ? (size_t)24 * K : 0, (hipStream_t)stream, y, bnp,
+                           res, res_bnp, relu, out, out32, n4 / 2, K / 8, mask8, ys, rs);
+        *used = true;
+        return check_launch("bn_act (bf16 storage, column sums)");
+    }
+    if (out32) return DPFT_OK;
     int blocks = ew_blocks(fat && fixc >= 2 ? (n4 + 1) / 2 : n4);
     bool ok = fixc > 0 && n4 >= 4096 && n4 < (1ll << 30);
     if (ok && (256 % K4) != 0) {
@@ -1132,11 +1204,11 @@ int dpft::bn_act_sums(const float* y, const float* bnp, const BnSumsRef& ys, con
     }
     if (!ok) return DPFT_OK;      // (the generic kernel reads BN blocks only: the caller finalizes first)
     if (fixc >= 2)
-        hipLaunchKernelGGL((bn_act_fixc_kernel<2, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
-                           K4, mask8, ys, rs);
+        hipLaunchKernelGGL((bn_act_fixc_kernel<2, true>), dim3(blocks), dim3(256), K4 < 256 ? (size_t)24 * K : 0, (hipStream_t)stream, y, bnp, res,
+                           res_bnp, relu, out, n4, K4, mask8, ys, rs);
     else
-        hipLaunchKernelGGL((bn_act_fixc_kernel<1, true>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, bnp, res, res_bnp, relu, out, n4,
-                           K4, mask8, ys, rs);
+        hipLaunchKernelGGL((bn_act_fixc_kernel<1, true>), dim3(blocks), dim3(256), K4 < 256 ? (size_t)24 * K : 0, (hipStream_t)stream, y, bnp, res,
+                           res_bnp, relu, out, n4, K4, mask8, ys, rs);
     *used = true;
     return check_launch("bn_act (column sums)");
 }

@@ -117,7 +117,8 @@ int bn_act_any(const float* y, const float* bnp, const float* res, const float* 
 // the same pass with one or both BatchNorms given as column sums (ys / rs: .sums null = take the BN block); *used = false (and
 // nothing launched) where only the generic kernel fits the shape
 int bn_act_sums(const float* y, const float* bnp, const BnSumsRef& ys, const float* res, const float* res_bnp, const BnSumsRef& rs,
-                int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream, unsigned char* mask8, bool* used);
+                int32_t relu, float* out, int64_t M, int32_t K, dpft_stream_t stream, unsigned char* mask8, bool* used,
+                bool act16 = false, float* out32 = nullptr);
 struct BnSumsBatch {      // sums -> BN block [4][K] + running statistics of up to MAX layers in one launch (bn.hip)
     static constexpr int MAX = 48;      // (kernel arguments: 68 bytes per layer)
     const unsigned long long* sums[MAX];

@@ -1908,7 +1908,7 @@ int dpft::conv_fwd_bnfinal(const dpft_conv_desc* d, const float* x, const float*
         fuse->applied = true;
     }
     // (the accumulators' low words hold 65 536 addends: tiles of >= 64 rows)
-    if (fuse && fuse->sums && !fuse->applied && stats && !bias && !d->act16 && t.vec && (a.N & 3) == 0 && (t.splits == 1 || fixup) &&
+    if (fuse && fuse->sums && !fuse->applied && stats && !bias && t.vec && (a.N & 3) == 0 && (t.splits == 1 || fixup) &&
         a.M < (1 << 22)) {
         a.bns = fuse->sums;      // column sums instead of the per-tile table; finalized by nobody here
         a.stats = nullptr;

@@ -114,7 +114,7 @@ __device__ __forceinline__ void epilogue_w8(const IgemmArgs& a, f32x16 (&acc)[RB
     }
     const bool part = a.partial != nullptr && !fix;      // partial tiles for a reduction kernel of the caller
     // ---- per-tile column statistics of the raw conv output: (mean, M2) of the tile's rows ----
-    if (a.stats != nullptr && !(a.ablate & 32)) {
+    if ((a.stats != nullptr || a.bns != nullptr) && !(a.ablate & 32)) {
         float* red = smem;               // [WGM][BN]
         float* smean = smem + WGM * BN;  // [BN]
         const int cnt = min(BM, a.M - m0);
@@ -139,7 +139,7 @@ __device__ __forceinline__ void epilogue_w8(const IgemmArgs& a, f32x16 (&acc)[RB
             for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
             const float mean = s / (float)cnt;
             smean[tid] = mean;
-            if (n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
+            if (a.stats && n0 + tid < a.N) a.stats[((size_t)mt * 2 + 0) * a.N + n0 + tid] = mean;
         }
         __syncthreads();
 #pragma unroll
@@ -162,7 +162,11 @@ __device__ __forceinline__ void epilogue_w8(const IgemmArgs& a, f32x16 (&acc)[RB
             float s = 0.f;
 #pragma unroll
             for (int i = 0; i < WGM; ++i) s += red[i * BN + tid];
-            a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+            if (a.stats) a.stats[((size_t)mt * 2 + 1) * a.N + n0 + tid] = s;
+            if (a.bns) {      // the statistics as column sums (common.h: BnSumsRef)
+                const double m = (double)smean[tid], fc = (double)cnt;
+                bn_sums_add(a.bns, a.N, n0 + tid, fc * m, (double)s + fc * m * m);
+            }
         }
         __syncthreads();
     }

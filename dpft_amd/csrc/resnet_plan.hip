@@ -355,7 +355,9 @@ static int bn_params(const ResnetPlan* p, const Tables& T, int bn, const float* 
 static bool bn_sums_on(const ResnetPlan* p) {
     static const int on = getenv("DPFT_BN_SUMS") ? atoi(getenv("DPFT_BN_SUMS")) : 1;      // A/B switch: 0 = per-tile tables + one bn_finalize launch per layer
     static const int fuse_mode = getenv("DPFT_BN_FINAL_FUSE") ? atoi(getenv("DPFT_BN_FINAL_FUSE")) : 0;
-    return on != 0 && fuse_mode == 0 && p->desc.act16 == 0 && !p->frozen;
+    // (bf16 operands, act16 = 2: built and measured -- DPFT_BN_SUMS=2 -- and off: there the consumers are the materialising
+    // elementwise passes, and the step does not gain: batch 8, same box, 22.57 / 22.57 ms with the tables, 22.83 / 22.71 with the sums)
+    return on != 0 && fuse_mode == 0 && (p->desc.act16 == 0 || (on == 2 && p->desc.act16 == 2)) && !p->frozen;
 }
 static BnSumsRef bn_sums_ref(const ResnetPlan* p, const Tables& T, float* A, int bn, int K, int64_t M) {
     return BnSumsRef{(const unsigned long long*)(A + p->o_bnacc + p->bnacc[bn]), T.gamma(bn), T.beta(bn), 1.0 / (double)M, p->desc.eps, K};
@@ -459,6 +461,26 @@ static int eval_bn_blocks(const ResnetPlan* p, const Tables& T, float* A, dpft_s
 
 }  // namespace dpft
 
+// elementwise pass out = relu(bn(y) [+ bn_r(res)]) of the train-mode forward: a BatchNorm whose block is still pending (the sums
+// form) is handed over as its column sums; where only the generic kernel fits, the layer is finalized first
+namespace dpft {
+static int train_act_pass(ResnetPlan* p, const Tables& T, float* A, const float* y, int bn, int K, int64_t M, const float* bnp,
+                          const float* res, int res_bn, const float* res_bnp, float* out, float* out32, bool a16, dpft_stream_t st,
+                          unsigned char* mask) {
+    const bool py = p->bn_pending[bn] != 0, pr = res_bn >= 0 && p->bn_pending[res_bn] != 0;
+    if (py || pr) {
+        const BnSumsRef ys = py ? bn_sums_ref(p, T, A, bn, K, M) : BnSumsRef{};
+        const BnSumsRef rs = pr ? bn_sums_ref(p, T, A, res_bn, K, M) : BnSumsRef{};
+        bool done = false;
+        RC(bn_act_sums(y, bnp, ys, res, res_bnp, rs, 1, out, M, K, st, mask, &done, a16, out32));
+        if (done) return DPFT_OK;
+        if (py) RC(bn_finalize_one(p, T, A, bn, st));
+        if (pr) RC(bn_finalize_one(p, T, A, res_bn, st));
+    }
+    return bn_act_any(y, bnp, res, res_bnp, 1, out, out32, M, K, a16, st, mask);
+}
+}  // namespace dpft
+
 static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables* tables, void* arena, int32_t train,
                         dpft_stream_t st) {
     Tables T{tables};
@@ -543,9 +565,9 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
                 RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.y1, A + b.p1, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st, A + b.c2.w16));
                 RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.y2, A + b.p2, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st, A + b.c3.w16));
             } else {
-            RC(bn_act_any(A + b.y1, A + b.p1, nullptr, nullptr, 1, A + b.a1, nullptr, M1, b.c1.d.K, true, st));
+            RC(train_act_pass(p, T, A, A + b.y1, b.bn1, b.c1.d.K, M1, A + b.p1, nullptr, -1, nullptr, A + b.a1, nullptr, true, st, nullptr));
             RC(conv_bn_train(p, T, b.c2, b.bn2, A + b.a1, nullptr, A, A + b.y2, A + b.s2, b.t2, b.r2, M2, A + b.p2, ws, st, A + b.c2.w16));
-            RC(bn_act_any(A + b.y2, A + b.p2, nullptr, nullptr, 1, A + b.a2, nullptr, M2, b.c2.d.K, true, st));
+            RC(train_act_pass(p, T, A, A + b.y2, b.bn2, b.c2.d.K, M2, A + b.p2, nullptr, -1, nullptr, A + b.a2, nullptr, true, st, nullptr));
             RC(conv_bn_train(p, T, b.c3, b.bn3, A + b.a2, nullptr, A, A + b.y3, A + b.s3, b.t3, b.r3, M2, A + b.p3, ws, st, A + b.c3.w16));
             }
         } else {
@@ -556,20 +578,8 @@ static int forward_impl(ResnetPlan* p, const float* x, const dpft_resnet_tables*
         if (b.has_ds)
             RC(conv_bn_train(p, T, b.cd, b.bnd, A + b.x, nullptr, A, A + b.yd, A + b.sd, b.td, b.rd, M2, A + b.pd, ws, st,
                              w16 ? A + b.cd.w16 : nullptr));
-        const float* identity = b.has_ds ? A + b.yd : A + b.x;
-        const float* id_bnp = b.has_ds ? A + b.pd : nullptr;
-        unsigned char* mask = tr ? (unsigned char*)(A + b.mask) : nullptr;
-        bool closed = false;
-        if (p->bn_pending[b.bn3] || (b.has_ds && p->bn_pending[b.bnd])) {      // the sums form: the pass derives its parameters itself
-            const BnSumsRef ys = p->bn_pending[b.bn3] ? bn_sums_ref(p, T, A, b.bn3, b.c3.d.K, M2) : BnSumsRef{};
-            const BnSumsRef rs = b.has_ds && p->bn_pending[b.bnd] ? bn_sums_ref(p, T, A, b.bnd, b.cd.d.K, M2) : BnSumsRef{};
-            RC(bn_act_sums(A + b.y3, A + b.p3, ys, identity, id_bnp, rs, 1, A + b.out, M2, b.c3.d.K, st, mask, &closed));
-            if (!closed) {
-                if (p->bn_pending[b.bn3]) RC(bn_finalize_one(p, T, A, b.bn3, st));
-                if (b.has_ds && p->bn_pending[b.bnd]) RC(bn_finalize_one(p, T, A, b.bnd, st));
-            }
-        }
-        if (!closed) RC(bn_act_any(A + b.y3, A + b.p3, identity, id_bnp, 1, A + b.out, stage_out32(p, b, A), M2, b.c3.d.K, a16, st, mask));
+        RC(train_act_pass(p, T, A, A + b.y3, b.bn3, b.c3.d.K, M2, A + b.p3, b.has_ds ? A + b.yd : A + b.x, b.has_ds ? b.bnd : -1,
+                          b.has_ds ? A + b.pd : nullptr, A + b.out, stage_out32(p, b, A), a16, st, tr ? (unsigned char*)(A + b.mask) : nullptr));
     }
     RC(bn_finalize_pending(p, T, A, 0, st));      // the sums form: every BN block the backward reads + the running statistics, 48 layers per launch
     p->g_valid = false;
