@@ -182,9 +182,8 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
 
     // The loads of a tile as NOPS separately placeable operations (the main loop puts one behind each of the first MFMAs
     // of a step: a vector-memory instruction takes tens of cycles to issue, which an MFMA in the pipe hides and an idle
-    // pipe does not).  Order: A operand, [prologue parameters], weights.
-    constexpr int NPAR = 0;      // (the prologue parameters come from the LDS table, read with the tile's first load)
-    constexpr int NOPS = AP + NPAR + BP;
+    // pipe does not).  Order: A operand, weights.
+    constexpr int NOPS = AP + BP;      // (the prologue parameters come from the LDS table, read with the tile's first load)
     auto vmem_op = [&](auto STG, auto K) {
         constexpr int stg = decltype(STG)::value, k = decltype(K)::value;
         if constexpr (k < AP) {
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256) void igemm_pipe_kernel(IgemmArgs a) {
                                                          (int)a_off[k], so_a, 0, 0);
             }
         } else {
-            constexpr int i = k - AP - NPAR;
+            constexpr int i = k - AP;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, lds0 + stg * STAGE + A_BYTES + (RPP * i + RW * wave) * ROWB, 16,
                                                      (int)b_off[i], so_b, 0, 0);
         }

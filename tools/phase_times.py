@@ -8,7 +8,7 @@ from dpft_amd.synthetic import make_batch, make_labels
 from dpft_amd.training.trainer import DataParallelTrainer
 
 steps = int(os.environ.get("STEPS", "40"))
-cfg = load_config("kradar")
+cfg = load_config(os.environ.get("CONFIG", "kradar"))
 B = int(os.environ.get("BATCH", "4"))
 torch.manual_seed(0)
 dev = torch.device("cuda", 0)
