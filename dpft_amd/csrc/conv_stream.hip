@@ -229,6 +229,11 @@ __global__ __launch_bounds__(NW * 64) void conv1x1_stream_kernel(StreamArgs a) {
 static bool stream_geom(int C, int& nb, int& nw) {
     // (C = 256 with 128-column slices on eight waves -- a 128 KB slice, 128 fragment registers per lane -- measured 54 us against
     // the tiled kernel's 48.9 on the layer-3 conv3 shape: one workgroup per CU, and every wave starts behind a 128 KB weight load)
+    // tuning aids: C = 128 with 128-column slices (64 KB: two workgroups per CU) and at least DPFT_STREAM_RBW_MIN row blocks per wave --
+    // alone the 128 -> 512 training form (prologue + statistics) goes 62.8 -> 53.5 us with (1, 2), 64 -> 256 60.1 -> 57.1; in the step and
+    // in the inference forward both within the run-to-run spread (23.91 / 23.91 vs 24.00 / 23.92 ms; 1.78 vs 1.77 ms per frame): off
+    static const int nb128 = getenv("DPFT_STREAM_NB128") ? atoi(getenv("DPFT_STREAM_NB128")) : 0;
+    if (C == 128 && nb128) { nb = 128; nw = 4; return true; }
     if (C == 64 || C == 128) { nb = 256; nw = 4; return true; }      // 64 / 128 KB: two / one workgroup(s) per CU
     return false;
 }
@@ -245,6 +250,8 @@ bool stream1x1_match(const dpft_conv_desc* d, int* tile_rows) {
     if (tile_rows) {
         const int64_t nrb = (M + 31) / 32;
         int rbw = (int)((nrb + nw * 2048 - 1) / (nw * 2048));      // at most ~2048 workgroups per column slice
+        static const int rbw_min = getenv("DPFT_STREAM_RBW_MIN") ? atoi(getenv("DPFT_STREAM_RBW_MIN")) : 1;      // (see stream_geom)
+        rbw = std::max(rbw, rbw_min);
         *tile_rows = 32 * nw * (rbw < 1 ? 1 : rbw);
     }
     return true;
@@ -278,6 +285,7 @@ int launch_stream1x1(const dpft_conv_desc* d, const float* x, const float* w, co
         else go(conv1x1_stream_kernel<KC_, NB_, NW_, false, false>);                         \
     } while (0)
     if (d->C == 64) STREAM_FORMS(64, 256, 4);
+    else if (nb == 128) STREAM_FORMS(128, 128, 4);
     else STREAM_FORMS(128, 256, 4);
 #undef STREAM_FORMS
     return check_launch("conv 1x1 (streaming, short reduction)");
