@@ -1979,6 +1979,42 @@ extern "C" int dpft_conv2d_nhwc_fwd_bnact_f32(const dpft_conv_desc* d, const flo
     return launch_igemm<false>(a, t, false, st);
 }
 
+// One level of the FPN neck's forward as two launches (include/dpft_hip.h): the top-down add rides in the lateral's epilogue on
+// the raw-input levels, the positional embedding in the 3x3 conv's; elsewhere conv + the elementwise kernel, same arithmetic.
+extern "C" int dpft_fpn_lateral_f32(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* top,
+                                    int32_t TH, int32_t TW, float* lat, void* workspace, dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(x && w && lat && d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0, "fpn_lateral: a 1x1 conv (stride 1) with its tensors");
+    DPFT_REQUIRE(!top || (TH >= 1 && TW >= 1 && TH <= d->H && TW <= d->W && d->K % 4 == 0), "fpn_lateral: bad top level (%d x %d)", TH, TW);
+    static const bool fuse = getenv("DPFT_FPN_FUSE") == nullptr || atoi(getenv("DPFT_FPN_FUSE")) != 0;      // A/B switch
+    if (top && fuse && conv1x1_to16_top_matches(d)) {
+        ProfScope prof(0, d, (hipStream_t)stream);
+        g_prof_family = kFamVector;
+        return conv1x1_to16_top_forward(d, x, w, bias, top, TH, TW, lat, (hipStream_t)stream);
+    }
+    rc = dpft_conv2d_nhwc_fwd_f32(d, x, w, bias, nullptr, 0, lat, nullptr, workspace, stream);
+    if (rc || !top) return rc;
+    return dpft_fpn_topdown_add_f32(lat, top, d->B, d->H, d->W, TH, TW, d->K, stream);
+}
+
+extern "C" int dpft_fpn_output_f32(const dpft_conv_desc* d, const float* lat, const float* w, const float* bias, const float* pos_x,
+                                   const float* pos_y, float* out, void* workspace, dpft_stream_t stream) {
+    int rc = check_desc(d);
+    if (rc) return rc;
+    DPFT_REQUIRE(lat && w && out && (pos_x == nullptr) == (pos_y == nullptr), "fpn_output: null tensor / one embedding table without the other");
+    DPFT_REQUIRE(d->H == d->OH && d->W == d->OW, "fpn_output: a same-size conv");
+    static const bool fuse = getenv("DPFT_FPN_FUSE") == nullptr || atoi(getenv("DPFT_FPN_FUSE")) != 0;
+    if (pos_x && fuse && conv16_matches(d) && !d->act16) {
+        ProfScope prof(0, d, (hipStream_t)stream);
+        g_prof_family = kFamVector;
+        return conv16_forward(d, lat, w, bias, out, (hipStream_t)stream, pos_x, pos_y);
+    }
+    rc = dpft_conv2d_nhwc_fwd_f32(d, lat, w, bias, nullptr, 0, out, nullptr, workspace, stream);
+    if (rc || !pos_x) return rc;
+    return dpft_add_pos_f32(out, pos_x, pos_y, d->B, d->H, d->W, d->K, stream);
+}
+
 extern "C" int dpft_conv2d_nhwc_dgrad_f32(const dpft_conv_desc* d, const float* dy, const float* w_t,
                                           float* dx, int32_t accumulate, void* workspace,
                                           dpft_stream_t stream) {

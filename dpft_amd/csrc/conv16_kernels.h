@@ -25,6 +25,8 @@ struct Conv16Args {
     float* y;            // (B,H,W,16)
     int B, H, W;
     int accumulate;
+    const float* pos_x;  // fwd only, may be null: y += pos_x[w][16]; y += pos_y[h][16] behind the bias (the neck's sinusoidal
+    const float* pos_y;  // embedding, embeddings/sinusoidal.py: the reference's two fp32 adds in their order)
 };
 
 constexpr int T16H = 8, T16W = 32;
@@ -79,6 +81,10 @@ __global__ __launch_bounds__(256) void conv16_3x3_kernel(Conv16Args a) {
             float* o = a.y + (((size_t)b * a.H + h) * a.W + w) * 16 + n;
             float v = acc[g][i] + bv;
             if (a.accumulate) v += *o;
+            if (!FLIP && a.pos_x) {
+                v += a.pos_x[w * 16 + n];
+                v += a.pos_y[h * 16 + n];
+            }
             *o = v;
         }
     }
@@ -565,9 +571,13 @@ static bool conv16_matches(const dpft_conv_desc* d) {
 // 4 x 512 x 910 pixels, 6 -> 16 on the radar maps): pure streaming, 4 C bytes in and 64 bytes out per pixel.  The generic
 // implicit-GEMM path pads to a 32-wide tile and gathers scalars (92 us = 1.5 TB/s on the camera level); here 4 lanes share
 // a pixel, each computes 4 outputs from the pixel's C inputs and stores one float4 -- a wave writes 1 KiB contiguous.
-template <int C>
+// TOP: + nearest_upsample(top[B][TH][TW][16]) (the neck's top-down path, src = min(floor(dst * in / out), in - 1) as
+// fpn_topdown_add_kernel) behind the bias -- the lateral and the add were two passes over the level's 64 bytes per pixel.
+template <int C, bool TOP = false>
 __global__ __launch_bounds__(256) void conv1x1_to16_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                           const float* __restrict__ bias, float* __restrict__ y, long M) {
+                                                           const float* __restrict__ bias, float* __restrict__ y, long M,
+                                                           const float* __restrict__ top = nullptr, int H = 0, int W = 0, int TH = 0,
+                                                           int TW = 0, float sh = 0.f, float sw = 0.f) {
     const int q = threadIdx.x & 3;      // outputs 4 q .. 4 q + 3
     float wr[4][C], br[4];
 #pragma unroll
@@ -589,6 +599,15 @@ __global__ __launch_bounds__(256) void conv1x1_to16_kernel(const float* __restri
             for (int c = 0; c < C; ++c) s = fmaf(xv[c], wr[k][c], s);
             o[k] = s + br[k];
         }
+        if constexpr (TOP) {
+            const int wq = (int)(p % W);
+            const long bh = p / W;
+            const int h = (int)(bh % H);
+            const long b = bh / H;
+            const int th = (TH == H) ? h : min((int)floorf((float)h * sh), TH - 1);
+            const int tw = (TW == W) ? wq : min((int)floorf((float)wq * sw), TW - 1);
+            o += *reinterpret_cast<const f32x4v*>(top + ((b * TH + th) * TW + tw) * 16 + q * 4);
+        }
         *reinterpret_cast<f32x4v*>(y + p * 16 + q * 4) = o;
     }
 }
@@ -602,20 +621,35 @@ static bool conv1x1_to16_matches(const dpft_conv_desc* d) {
 static int conv1x1_to16_forward(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
     const long M = (long)d->B * d->H * d->W;
     const int blocks = (int)std::max<long>(1, std::min<long>(kNumCU * 16, (M + 63) / 64));
-    if (d->C == 3) hipLaunchKernelGGL(conv1x1_to16_kernel<3>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, M);
-    else hipLaunchKernelGGL(conv1x1_to16_kernel<6>, dim3(blocks), dim3(256), 0, st, x, w, bias, y, M);
+    if (d->C == 3) hipLaunchKernelGGL((conv1x1_to16_kernel<3, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, y, M, (const float*)nullptr, 0, 0, 0, 0, 0.f, 0.f);
+    else hipLaunchKernelGGL((conv1x1_to16_kernel<6, false>), dim3(blocks), dim3(256), 0, st, x, w, bias, y, M, (const float*)nullptr, 0, 0, 0, 0, 0.f, 0.f);
     return check_launch("conv 1x1 -> 16 fwd");
 }
 
-static int conv16_forward(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st) {
-    Conv16Args a{x, w, bias, y, d->B, d->H, d->W, 0};
+// the lateral of a raw-input level with the top-down add in its epilogue (any map size: it replaces two launches)
+static bool conv1x1_to16_top_matches(const dpft_conv_desc* d) {
+    return d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->K == 16 && (d->C == 3 || d->C == 6) && !d->act16;
+}
+static int conv1x1_to16_top_forward(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* top, int TH,
+                                    int TW, float* y, hipStream_t st) {
+    const long M = (long)d->B * d->H * d->W;
+    const int blocks = (int)std::max<long>(1, std::min<long>(kNumCU * 16, (M + 63) / 64));
+    const float sh = (float)TH / (float)d->H, sw = (float)TW / (float)d->W;
+    if (d->C == 3) hipLaunchKernelGGL((conv1x1_to16_kernel<3, true>), dim3(blocks), dim3(256), 0, st, x, w, bias, y, M, top, d->H, d->W, TH, TW, sh, sw);
+    else hipLaunchKernelGGL((conv1x1_to16_kernel<6, true>), dim3(blocks), dim3(256), 0, st, x, w, bias, y, M, top, d->H, d->W, TH, TW, sh, sw);
+    return check_launch("conv 1x1 -> 16 fwd + top-down add");
+}
+
+static int conv16_forward(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, float* y, hipStream_t st,
+                          const float* pos_x = nullptr, const float* pos_y = nullptr) {
+    Conv16Args a{x, w, bias, y, d->B, d->H, d->W, 0, pos_x, pos_y};
     dim3 grid(cdiv(d->W, T16W), cdiv(d->H, T16H), d->B);
     hipLaunchKernelGGL(conv16_3x3_kernel<false>, grid, dim3(256), 0, st, a);
     return check_launch("conv16 fwd");
 }
 
 static int conv16_dgrad(const dpft_conv_desc* d, const float* dy, const float* w_t, float* dx, int accumulate, hipStream_t st) {
-    Conv16Args a{dy, w_t, nullptr, dx, d->B, d->H, d->W, accumulate};
+    Conv16Args a{dy, w_t, nullptr, dx, d->B, d->H, d->W, accumulate, nullptr, nullptr};
     dim3 grid(cdiv(d->W, T16W), cdiv(d->H, T16H), d->B);
     hipLaunchKernelGGL(conv16_3x3_kernel<true>, grid, dim3(256), 0, st, a);
     return check_launch("conv16 dgrad");

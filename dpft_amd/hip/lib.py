@@ -126,6 +126,8 @@ SIGNATURES = {
     "dpft_fpn_topdown_add_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_fpn_topdown_add_bwd_f32": (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_add_pos_f32": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "dpft_fpn_lateral_f32": (_I, [_DESC, _P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "dpft_fpn_output_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P, _P]),
     "dpft_msda_fwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_msda_bwd_f32": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "dpft_xattn_fwd_f32": (_I, [_PYR, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

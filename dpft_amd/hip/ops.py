@@ -217,6 +217,28 @@ def conv_fwd(cv: Conv, x, w, bias=None, pro=None, want_stats=False, out=None, pl
     return y, stats
 
 
+def fpn_lateral(cv: Conv, x, w, bias, top=None, out=None):
+    """lat = conv1x1(x) + bias [+ nearest_upsample(top)] -- the neck's lateral with the top-down add in its epilogue where a
+    thin-channel kernel takes the shape (dpft_fpn_lateral_f32; otherwise conv + fpn_topdown_add, same arithmetic)."""
+    y = out if out is not None else torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=x.device)
+    ws = workspace(cv.ws_bytes, x.device)
+    TH, TW = (top.shape[1], top.shape[2]) if top is not None else (0, 0)
+    lib.call("dpft_fpn_lateral_f32", C.byref(cv.desc), ptr(x), ptr(w), ptr(bias), ptr(top), TH, TW, ptr(y), ptr(ws), stream())
+    return y
+
+
+def fpn_output(cv: Conv, lat, w, bias, pos=None, out=None):
+    """out = conv3x3(lat) + bias [+ pos_x[W]; + pos_y[H]] -- the neck's output conv with the positional embedding in its epilogue
+    (dpft_fpn_output_f32).  ``pos`` = (pos_x (W,K), pos_y (H,K)) or None."""
+    y = out if out is not None else torch.empty((cv.B, cv.OH, cv.OW, cv.K), dtype=torch.float32, device=lat.device)
+    if out is not None and (tuple(out.shape) != (cv.B, cv.OH, cv.OW, cv.K) or not out.is_contiguous() or out.dtype != torch.float32):
+        raise ValueError("fpn_output: the output buffer does not match the problem")
+    ws = workspace(cv.ws_bytes, lat.device)
+    px, py = pos if pos is not None else (None, None)
+    lib.call("dpft_fpn_output_f32", C.byref(cv.desc), ptr(lat), ptr(w), ptr(bias), ptr(px), ptr(py), ptr(y), ptr(ws), stream())
+    return y
+
+
 def conv_fwd_bnact(cv: Conv, x, w, out_bn, relu=True, residual=None):
     """Inference conv + BatchNorm (+ residual) (+ ReLU): [relu](bn(conv(x, w)) [+ residual]); out_bn = BN block (4,K) of
     the output channels (bn_eval_params)."""

@@ -102,9 +102,16 @@ class DPRT(nn.Module):
         graphed = self.__dict__.get("_graphed_fuser")
         if graphed is not None and self.training and torch.is_grad_enabled():
             bufs = graphed.level_buffers(i, f)           # the decoder graph's static inputs: the neck writes them directly
+        # neck -> embedding (:228, :231).  A sinusoidal embedding behind an FPN neck is added by the neck's output convs themselves
+        # (dpft_fpn_output_f32: the level is written once instead of written, read and written again)
+        emb, neck = self.embeddings[i], self.necks[i]
+        pos = emb.level_tables(f, neck.out_channels) if hasattr(emb, "level_tables") and getattr(neck, "channel_last", False) \
+            and hasattr(neck, "fpn") and os.environ.get("DPFT_FPN_FUSE", "1") != "0" else None
+        if pos is not None:
+            return neck(f, out_buffers=bufs, pos=pos)
         if bufs is not None:
-            return self.embeddings[i](self.necks[i](f, out_buffers=bufs))
-        return self.embeddings[i](self.necks[i](f))                             # :228, :231
+            return emb(neck(f, out_buffers=bufs))
+        return emb(neck(f))
 
     def _encode_views(self, batch: Dict[str, torch.Tensor]) -> Dict[str, "OrderedDict[str, torch.Tensor]"]:
         """backbone -> (raw skip link) -> neck -> embedding per input.  On the GPU the views run on separate HIP

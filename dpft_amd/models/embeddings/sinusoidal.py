@@ -95,6 +95,15 @@ class MultiLevelSinusoidalEmbedding(nn.Module):
         it = zip(batches.items(), self.embedding_layers.values())
         return OrderedDict({k: layer(b) for (k, b), layer in it})
 
+    def level_tables(self, batches: "OrderedDict[str, torch.Tensor]", channels: int):
+        """Per level the (pos_x (W,C), pos_y (H,C)) tables ``forward`` would add to NHWC tensors of these maps' sizes with ``channels``
+        channels -- for a producer that adds them itself (necks/fpn.py: the output conv's epilogue); None where that cannot replace
+        ``forward`` exactly."""
+        levels, layers = list(batches.values()), list(self.embedding_layers.values())
+        if len(levels) != len(layers) or any(t.dim() != 4 or channels != l.num_feats for t, l in zip(levels, layers)):
+            return None
+        return [l.tables(t.shape[1], t.shape[2], t.device) for t, l in zip(levels, layers)]
+
 
 def build_sinusoidal_embedding(*args, **kwargs) -> nn.Module:
     return MultiLevelSinusoidalEmbedding.from_config(*args, **kwargs)

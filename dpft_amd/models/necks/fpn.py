@@ -36,7 +36,9 @@ class FeaturePyramidNetwork(nn.Module):
 
 class _FPNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, owner, fpn: FeaturePyramidNetwork, n: int, out_buffers, *tensors: torch.Tensor):
+    def forward(ctx, owner, fpn: FeaturePyramidNetwork, n: int, out_buffers, pos, *tensors: torch.Tensor):
+        # ``pos`` (or None): per level (pos_x (W,K), pos_y (H,K)) -- the positional embedding that follows the neck
+        # (embeddings/sinusoidal.py), added in the epilogue of the level's output conv; its backward is the identity
         xs = [t.contiguous() for t in tensors[:n]]
         K = fpn.out_channels
         lasts, outs, ci, cl = [None] * n, [None] * n, [None] * n, [None] * n
@@ -44,14 +46,12 @@ class _FPNFn(torch.autograd.Function):
             B, H, W, C = xs[i].shape
             ci[i] = ops.conv_problem(B, H, W, C, K, 1, 1, 1, 0)
             conv = fpn.inner_blocks[i][0]
-            lat, _ = ops.conv_fwd(ci[i], xs[i], khwc(conv.weight), bias=conv.bias)
-            if i < n - 1:
-                ops.fpn_topdown_add_(lat, lasts[i + 1])
+            lat = ops.fpn_lateral(ci[i], xs[i], khwc(conv.weight), conv.bias, top=lasts[i + 1] if i < n - 1 else None)
             lasts[i] = lat
             cl[i] = ops.conv_problem(B, H, W, K, K, 3, 3, 1, 1)
             conv = fpn.layer_blocks[i][0]
-            outs[i], _ = ops.conv_fwd(cl[i], lat, khwc(conv.weight), bias=conv.bias,
-                                      out=None if out_buffers is None else out_buffers[i])
+            outs[i] = ops.fpn_output(cl[i], lat, khwc(conv.weight), conv.bias, pos=None if pos is None else pos[i],
+                                     out=None if out_buffers is None else out_buffers[i])
         ctx.fpn, ctx.n, ctx.xs, ctx.lasts, ctx.ci, ctx.cl = fpn, n, xs, lasts, ci, cl
         ctx.params = tensors[n:]
         ctx.x_needs = [t.requires_grad for t in tensors[:n]]
@@ -104,7 +104,7 @@ class _FPNFn(torch.autograd.Function):
             g_prev = g
         if direct is not None:
             direct.mark_ready_many(list(fpn.parameters()))
-        return (None, None, None, None, *dxs, *[grads.get(p) for p in ctx.params])
+        return (None, None, None, None, None, *dxs, *[grads.get(p) for p in ctx.params])
 
 
 class FPN(nn.Module):
@@ -132,15 +132,19 @@ class FPN(nn.Module):
     def from_config(cls, config: Dict[str, Any]):
         return cls(config["in_channels_list"], config["out_channels"], config.get("norm_layer"))
 
-    def forward(self, batch: Dict[str, torch.Tensor], out_buffers: Optional[List[torch.Tensor]] = None) -> Dict[str, torch.Tensor]:
+    def forward(self, batch: Dict[str, torch.Tensor], out_buffers: Optional[List[torch.Tensor]] = None,
+                pos: Optional[List[Any]] = None) -> Dict[str, torch.Tensor]:
         """``out_buffers`` (NHWC, one per level): the pyramid is written there (e.g. the static input buffers of a captured
-        decoder graph: no copy between the neck and the graph)."""
+        decoder graph: no copy between the neck and the graph).  ``pos``: per level the (pos_x, pos_y) tables of the positional
+        embedding that follows the neck -- added by the output convs themselves (the caller then skips the embedding)."""
         keys = list(batch.keys())
         xs = list(batch.values())
         if not self.channel_last:
+            if pos is not None:
+                raise ValueError("FPN: the fused positional embedding needs channel-last tensors")
             xs = [x.movedim(1, -1) for x in xs]
             out_buffers = None
-        outs = _FPNFn.apply(self, self.fpn, len(xs), out_buffers, *xs, *self.fpn.parameters())
+        outs = _FPNFn.apply(self, self.fpn, len(xs), out_buffers, pos, *xs, *self.fpn.parameters())
         if not self.channel_last:
             outs = [o.movedim(-1, 1) for o in outs]
         return OrderedDict(zip(keys, outs))

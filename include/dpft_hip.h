@@ -294,6 +294,17 @@ int dpft_fpn_topdown_add_bwd_f32(const float* dlat, float* dtop, int32_t B, int3
 /* x[B,H,W,K] += pos_x[W][K]; x += pos_y[H][K]  (two fp32 adds in the reference's order) */
 int dpft_add_pos_f32(float* x, const float* pos_x, const float* pos_y, int32_t B, int32_t H,
                      int32_t W, int32_t K, dpft_stream_t stream);
+/* One level of the neck's forward in two launches (src/dprt/models/necks/fpn.py:70-83 -> torchvision FeaturePyramidNetwork.forward;
+ * src/dprt/models/embeddings/sinusoidal.py:107-108):
+ *   lat = conv1x1(x, w, bias) [+ nearest_upsample(top[B,TH,TW,K])]          `d` = the 1x1 lateral conv's descriptor
+ *   out = conv3x3(lat, w, bias) [+ pos_x[W][K]; + pos_y[H][K]]              `d` = the 3x3 output conv's descriptor
+ * The adds ride in the convs' epilogues where a thin-channel kernel takes the shape (raw-input laterals C = 3 / 6 -> 16; the
+ * 16 -> 16 3x3 convs): one pass over the level instead of two.  Everywhere else the function runs the conv followed by
+ * dpft_fpn_topdown_add_f32 / dpft_add_pos_f32 -- the same arithmetic in the same order.  top / pos_x + pos_y may be NULL. */
+int dpft_fpn_lateral_f32(const dpft_conv_desc* d, const float* x, const float* w, const float* bias, const float* top,
+                         int32_t TH, int32_t TW, float* lat, void* workspace, dpft_stream_t stream);
+int dpft_fpn_output_f32(const dpft_conv_desc* d, const float* lat, const float* w, const float* bias, const float* pos_x,
+                        const float* pos_y, float* out, void* workspace, dpft_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Multi-scale deformable attention
