@@ -1446,6 +1446,49 @@ def test_conv_bf16_large_tile_kernels_vs_fp64():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("B,H,W,C,K,TH,TW", [(2, 40, 57, 3, 16, 20, 29),       # raw-input lateral (camera): fused epilogues
+                                             (1, 37, 107, 6, 16, 10, 27),      # radar front level 0, odd upsampling ratios
+                                             (2, 24, 31, 64, 16, 12, 16),      # a lateral the thin kernel does not take: conv + add
+                                             (1, 16, 20, 3, 32, 8, 10)])       # 32-channel neck: both fall back
+def test_fpn_level_in_two_launches_equals_the_separate_calls(B, H, W, C, K, TH, TW):
+    """dpft_fpn_lateral_f32 / dpft_fpn_output_f32 (necks/fpn.py:70-83 + embeddings/sinusoidal.py:107-108): the top-down add and the
+    positional embedding in the convs' epilogues give what conv -> fpn_topdown_add -> conv -> add_pos give -- the 3x3 side bit for bit
+    (same kernel, same order of the adds), the lateral to fp32 rounding of the 1x1 products (thin kernel vs implicit GEMM)."""
+    from dpft_amd.hip import ops
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(B * 100 + H + C)
+    x = (torch.rand(B, H, W, C, generator=g) * 255).to(dev)
+    top = torch.randn(B, TH, TW, K, generator=g).to(dev)
+    w1 = (torch.randn(K, 1, 1, C, generator=g) * 0.05).to(dev)
+    b1 = torch.randn(K, generator=g).to(dev)
+    w3 = (torch.randn(K, 3, 3, K, generator=g) * 0.1).to(dev)
+    b3 = torch.randn(K, generator=g).to(dev)
+    pos = (torch.randn(W, K, generator=g).to(dev), torch.randn(H, K, generator=g).to(dev))
+    c1, c3 = ops.conv_problem(B, H, W, C, K, 1, 1, 1, 0), ops.conv_problem(B, H, W, K, K, 3, 3, 1, 1)
+    lat_ref, _ = ops.conv_fwd(c1, x, w1, bias=b1)
+    ops.fpn_topdown_add_(lat_ref, top)
+    out_ref, _ = ops.conv_fwd(c3, lat_ref, w3, bias=b3)
+    out_ref = out_ref.clone()
+    ops.add_pos_(out_ref, *pos)
+    lat = ops.fpn_lateral(c1, x, w1, b1, top=top)
+    assert float((lat - lat_ref).abs().max()) <= 2e-5 * float(lat_ref.abs().max()), float((lat - lat_ref).abs().max())
+    out = ops.fpn_output(c3, lat_ref, w3, b3, pos=pos)
+    assert torch.equal(out, out_ref)
+    # without the optional operands: the plain convs
+    assert torch.equal(ops.fpn_output(c3, lat_ref, w3, b3), ops.conv_fwd(c3, lat_ref, w3, bias=b3)[0])
+    lat0, _ = ops.conv_fwd(c1, x, w1, bias=b1)
+    assert torch.equal(ops.fpn_lateral(c1, x, w1, b1), lat0)
+    # against fp64
+    xr = x.double().cpu().permute(0, 3, 1, 2)
+    ref = torch.nn.functional.conv2d(xr, w1.double().cpu().permute(0, 3, 1, 2), b1.double().cpu())
+    ih = torch.clamp((torch.arange(H, dtype=torch.float32) * (TH / H)).floor().long(), max=TH - 1)
+    iw = torch.clamp((torch.arange(W, dtype=torch.float32) * (TW / W)).floor().long(), max=TW - 1)
+    ref = ref + top.double().cpu().permute(0, 3, 1, 2)[:, :, ih][:, :, :, iw]
+    e = float((lat.double().cpu().permute(0, 3, 1, 2) - ref).abs().max() / ref.abs().max())
+    assert e < 1e-6, e
+
+
+@pytest.mark.gpu
 def test_batchnorm_statistics_as_column_sums_equal_the_tile_tables_and_repeat_bit_for_bit(tmp_path):
     """csrc/common.h: BnSumsRef -- the train-mode statistics as fixed-point column sums (integer atomics in the conv epilogues, no
     finalize launch: the next conv's prologue table and the block-closing pass derive mean / scale themselves; BN blocks for the
